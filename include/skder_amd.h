@@ -1,0 +1,152 @@
+/*
+ * skder_amd.h -- C ABI of libskder_amd.so, the MI355X (gfx950) all-pairs ANI engine that stands in
+ * for the `skani` sub-processes raufs/skDER spawns.  Plain pointers and sizes only; no torch types.
+ *
+ * The reference has no FFI for this path: it builds shell command lines and checks that the output
+ * file exists (/root/reference/src/skDER/util.py:636-652).  Section A below therefore mirrors those
+ * command lines one entry point per sub-command (file paths in, skani-format TSV out, "no output
+ * file" == failure).  Section B is the device-level interface the same entry points are built from;
+ * bench.py, the parity tests and the multi-GPU driver (skder_amd/multigpu.py) call it with device
+ * pointers they own (torch is used there only as an allocator / RCCL front end).
+ *
+ * Every function returns 0 on success; on failure it returns non-zero and writes a message into
+ * err[0..errlen) -- the Python shim raises RuntimeError from it, as util.runCmd does (util.py:652).
+ * There is NO CPU fallback anywhere behind this header: without a gfx950 device every compute entry
+ * point fails with an error.
+ */
+#ifndef SKDER_AMD_H
+#define SKDER_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ======================================================================================
+ * A. drop-in entry points (one per skani sub-command used by the reference)
+ * ====================================================================================== */
+
+/* `skani triangle -l LISTING --min-af MIN_AF -E -s SCREEN -t T -o OUT`
+ * replaces /root/reference/src/skDER/skder.py:16-26 (runSkaniTriangle).
+ * Writes the 7-column edge table (header, %.2f percentages, first-record>=500bp names, rows kept
+ * iff max(AF_ref,AF_query) >= min_af on unrounded values, skani's row order).  The file is written
+ * to a temporary name and renamed, so it exists only if the call succeeded. */
+int skder_amd_triangle(const char *listing, double min_af_pct, double screen_pct, int device,
+                       const char *out_tsv, char *err, size_t errlen);
+
+/* `skani dist --rl REFS --ql QUERIES [-s SCREEN] -o OUT`
+ * replaces skder.py:58-61 (runSkaniDist) and cidder.py:362-364.  Rows grouped by query in --ql
+ * order, references by ANI descending; skani's dist defaults are min_af 15, screen 80. */
+int skder_amd_dist(const char *ref_listing, const char *query_listing, double min_af_pct,
+                   double screen_pct, int device, const char *out_tsv, char *err, size_t errlen);
+
+/* `skani sketch -l LISTING -o DB` replaces skder.py:103-104: the sketch database stays resident in
+ * HBM behind an opaque handle instead of a directory on disk. NULL on failure. */
+typedef struct skder_db skder_db_t;
+skder_db_t *skder_amd_sketch(const char *listing, int device, char *err, size_t errlen);
+/* `skani search QUERY -d DB -o OUT` replaces skder.py:119-120 (one call per representative).
+ * QUERY may be a path of the listing the DB was built from (its sketch is reused) or any FASTA.
+ * Same 7 columns as triangle; includes the self hit; Ref_file strings equal the listing lines
+ * byte for byte (they are compared with N50-table keys at skder.py:117,129). */
+int skder_amd_search(skder_db_t *db, const char *query_path, double min_af_pct, double screen_pct,
+                     const char *out_tsv, char *err, size_t errlen);
+void skder_amd_db_free(skder_db_t *db);
+
+/* The `-p` free-text skani parameter string (bin/skder:132,199-201): accepts "-s <float>" only and
+ * rejects any other skani flag loudly.  On success *screen_pct is set (unchanged if no -s). */
+int skder_amd_parse_skani_params(const char *params, double *screen_pct, char *err, size_t errlen);
+
+/* ======================================================================================
+ * B. device-level interface
+ * ====================================================================================== */
+
+typedef struct skder_ctx skder_ctx_t;
+skder_ctx_t *skder_amd_ctx_create(int device, char *err, size_t errlen);
+void skder_amd_ctx_destroy(skder_ctx_t *ctx);
+/* stream all kernels of this context are launched on (a hipStream_t) */
+void *skder_amd_ctx_stream(skder_ctx_t *ctx);
+const char *skder_amd_last_error(skder_ctx_t *ctx);
+
+/* Layout of a batch of genomes whose bases are resident in HBM (host arrays, copied by the call):
+ * record r (a kept FASTA record, >= 500 bp) occupies d_bases[rec_off[r] .. rec_off[r]+rec_len[r]),
+ * ASCII, rec_off[r] a multiple of 32, with >= 32 readable bytes in front of the first record and
+ * >= SKDER_TILE+32 readable bytes behind the last; genome g owns records
+ * [genome_rec_begin[g], genome_rec_begin[g+1]). */
+#define SKDER_TILE 8192
+typedef struct {
+    uint32_t n_genomes;
+    uint32_t n_records;
+    const uint64_t *rec_off;
+    const uint32_t *rec_len;
+    const uint32_t *genome_rec_begin;   /* n_genomes + 1 */
+} skder_batch_t;
+
+/* A sketch set: FracMinHash seeds + markers of a list of genomes, resident in HBM. */
+typedef struct skder_sketches skder_sketches_t;
+skder_sketches_t *skder_amd_sketches_new(skder_ctx_t *ctx);
+void skder_amd_sketches_free(skder_sketches_t *s);
+/* HOT KERNEL: sketch `batch` (bases already on the device) and append the genomes to `s`. */
+int skder_amd_sketch_batch(skder_sketches_t *s, const uint8_t *d_bases, const skder_batch_t *batch);
+/* sizes / raw device arrays (position-ordered seeds; sorted unique markers), for all-gather:
+ *   seed_off[n_genomes+1], seed_kmer/gpos/ctg[n_seeds]; marker_off[n_genomes+1], markers[n_markers];
+ *   genome_len[n_genomes] (sum of kept record lengths), genome_nrec[n_genomes],
+ *   rec_goff: per genome record start offsets concatenated (genome_nrec[g]+1 entries each). */
+typedef struct {
+    uint32_t n_genomes;
+    uint64_t n_seeds, n_markers, n_rec_goff;
+    const uint32_t *d_seed_kmer;   /* canonical 15-mer | fwd<<31 */
+    const uint32_t *d_seed_gpos;
+    const uint32_t *d_seed_ctg;
+    const uint64_t *d_markers;
+    const uint64_t *h_seed_off;    /* host */
+    const uint64_t *h_marker_off;  /* host */
+    const uint64_t *h_genome_len;  /* host */
+    const uint32_t *h_genome_nrec; /* host */
+    const uint32_t *h_rec_goff;    /* host */
+} skder_raw_view_t;
+int skder_amd_sketches_view(skder_sketches_t *s, skder_raw_view_t *out);
+/* append genomes from raw arrays (device pointers for seeds/markers, host pointers for the rest) */
+int skder_amd_sketches_append_raw(skder_sketches_t *s, const skder_raw_view_t *raw);
+/* build the per-genome lookup structures (k-mer bucket index, chunk tables, repetitive cut-offs) */
+int skder_amd_sketches_index(skder_sketches_t *s);
+
+/* one reported genome pair */
+typedef struct {
+    uint32_t ref;            /* genome index on the reference side */
+    uint32_t query;          /* genome index on the query side */
+    double ani;              /* fraction, after calibration */
+    double af_ref;
+    double af_query;
+    uint32_t n_chains;
+    uint32_t n_anchors;
+    uint64_t aligned_bases;
+    int64_t ani_fx_sum;
+    uint64_t sum_seeds;
+} skder_edge_t;
+
+/* Upper triangle rows i = row_begin, row_begin+row_stride, ... of `s` against all j > i:
+ * marker screen at screen_pct, anchors, chaining, ANI/AF.  Edges (every screened pair with at least
+ * one chain) are appended to a host buffer owned by the context; the edges pointer and n_edges are valid until the
+ * next call on the same context. */
+int skder_amd_triangle_rows(skder_sketches_t *s, uint32_t row_begin, uint32_t row_stride,
+                            double screen_pct, const skder_edge_t **edges, uint64_t *n_edges);
+/* rectangle: every genome of `refs` against every genome of `queries` (dist / search) */
+int skder_amd_rectangle(skder_sketches_t *refs, skder_sketches_t *queries, double screen_pct,
+                        const skder_edge_t **edges, uint64_t *n_edges);
+
+/* timing of the last triangle_rows/rectangle/sketch_batch call, milliseconds by HIP events on the
+ * context's stream: [0] sketch kernel, [1] sketch post-processing, [2] screen, [3] anchors,
+ * [4] chaining, [5] finalize; counts: [6] pairs screened in, [7] anchors */
+int skder_amd_last_timing(skder_ctx_t *ctx, double *out8);
+
+/* synthetic genomes generated ON the device (SURVEY 8d recipe; bench.py / tests):
+ * fills d_bases for one batch from (seed, species, strain, isolate) lineage ids. See synth.h. */
+int skder_amd_synth_fill(skder_ctx_t *ctx, uint8_t *d_bases, const skder_batch_t *batch,
+                         const uint64_t *genome_lineage /* 3 per genome: species,strain,isolate seeds */,
+                         const uint32_t *genome_params /* 4 per genome, see synth.h */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

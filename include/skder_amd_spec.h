@@ -26,9 +26,10 @@
 #define ANI_PAD            250     /* 2*c bases added to every kept chain's span (G5 fit) */
 #define ANI_SMALL_PASS     20      /* marker sets smaller than this always pass the screen */
 #define ANI_REP_FLOOR      30      /* repetitive-k-mer cut-off is disabled below this multiplicity */
+#define ANI_REP_HIST       4096    /* multiplicities are clamped to REP_HIST-1 when ranking them */
 #define ANI_REF_OVERLAP_NUM 1      /* a chain is dropped if > NUM/DEN of its span on the other   */
 #define ANI_REF_OVERLAP_DEN 2      /* genome is already covered by one better-scoring kept chain */
-#define ANI_ROOT_ITERS     48      /* Newton iterations of the fixed-point k-th root */
+#define ANI_ROOT_ITERS     24      /* Newton iterations of the fixed-point k-th root */
 
 /* "learned ANI" stand-in: piecewise-linear map on d = 100*(1-ANI_raw), fitted to golden table G5
  * by oracle/fit_calibration.py (rms 0.16, max 0.60 ANI points on 561 pairs); slope 1 beyond the

@@ -176,7 +176,7 @@ static void genome_finish(oracle_genome_t *g, sketch_acc *acc, const oracle_para
         for (uint32_t i = 0; i < g->n_seeds;) {
             uint32_t j = i;
             while (j < g->n_seeds && g->s_kmer[g->by_kmer[j]] == g->s_kmer[g->by_kmer[i]]) j++;
-            VPUSH(cnt, uint64_t, (uint64_t)(j - i));
+            VPUSH(cnt, uint64_t, (uint64_t)(j - i < ANI_REP_HIST - 1 ? j - i : ANI_REP_HIST - 1));
             i = j;
         }
         g->rep_cut = UINT32_MAX;

@@ -1,0 +1,78 @@
+"""ctypes loader for libskder_amd.so (the C ABI declared in include/skder_amd.h).
+
+The library is built in-tree by `make -C skder_amd/csrc` (or `__graft_entry__.build()`).  There is no
+Python or CPU fallback: a missing library is an ImportError-like RuntimeError, and every compute
+entry point fails on a machine without a gfx950 device."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libskder_amd.so")
+SKDER_TILE = 8192
+ERRLEN = 2048
+
+
+class Batch(C.Structure):
+    _fields_ = [("n_genomes", C.c_uint32), ("n_records", C.c_uint32), ("rec_off", C.c_void_p),
+                ("rec_len", C.c_void_p), ("genome_rec_begin", C.c_void_p)]
+
+
+class RawView(C.Structure):
+    _fields_ = [("n_genomes", C.c_uint32), ("n_seeds", C.c_uint64), ("n_markers", C.c_uint64),
+                ("n_rec_goff", C.c_uint64), ("d_seed_kmer", C.c_void_p), ("d_seed_gpos", C.c_void_p),
+                ("d_seed_ctg", C.c_void_p), ("d_markers", C.c_void_p), ("h_seed_off", C.c_void_p),
+                ("h_marker_off", C.c_void_p), ("h_genome_len", C.c_void_p), ("h_genome_nrec", C.c_void_p),
+                ("h_rec_goff", C.c_void_p)]
+
+
+class Edge(C.Structure):
+    _fields_ = [("ref", C.c_uint32), ("query", C.c_uint32), ("ani", C.c_double), ("af_ref", C.c_double),
+                ("af_query", C.c_double), ("n_chains", C.c_uint32), ("n_anchors", C.c_uint32),
+                ("aligned_bases", C.c_uint64), ("ani_fx_sum", C.c_int64), ("sum_seeds", C.c_uint64)]
+
+
+# every symbol include/skder_amd.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "skder_amd_triangle": (C.c_int, [C.c_char_p, C.c_double, C.c_double, C.c_int, C.c_char_p, C.c_char_p, C.c_size_t]),
+    "skder_amd_dist": (C.c_int, [C.c_char_p, C.c_char_p, C.c_double, C.c_double, C.c_int, C.c_char_p, C.c_char_p, C.c_size_t]),
+    "skder_amd_sketch": (C.c_void_p, [C.c_char_p, C.c_int, C.c_char_p, C.c_size_t]),
+    "skder_amd_search": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double, C.c_double, C.c_char_p, C.c_char_p, C.c_size_t]),
+    "skder_amd_db_free": (None, [C.c_void_p]),
+    "skder_amd_parse_skani_params": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.c_char_p, C.c_size_t]),
+    "skder_amd_ctx_create": (C.c_void_p, [C.c_int, C.c_char_p, C.c_size_t]),
+    "skder_amd_ctx_destroy": (None, [C.c_void_p]),
+    "skder_amd_ctx_stream": (C.c_void_p, [C.c_void_p]),
+    "skder_amd_last_error": (C.c_char_p, [C.c_void_p]),
+    "skder_amd_sketches_new": (C.c_void_p, [C.c_void_p]),
+    "skder_amd_sketches_free": (None, [C.c_void_p]),
+    "skder_amd_sketch_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Batch)]),
+    "skder_amd_sketches_view": (C.c_int, [C.c_void_p, C.POINTER(RawView)]),
+    "skder_amd_sketches_append_raw": (C.c_int, [C.c_void_p, C.POINTER(RawView)]),
+    "skder_amd_sketches_index": (C.c_int, [C.c_void_p]),
+    "skder_amd_triangle_rows": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_double,
+                                          C.POINTER(C.POINTER(Edge)), C.POINTER(C.c_uint64)]),
+    "skder_amd_rectangle": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.POINTER(C.POINTER(Edge)),
+                                      C.POINTER(C.c_uint64)]),
+    "skder_amd_last_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "skder_amd_synth_fill": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p]),
+    "skder_amd_debug_genome": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                         C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
+_LIB = None
+
+
+def lib():
+    """Load libskder_amd.so; raises RuntimeError if it has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.isfile(LIB_PATH):
+            raise RuntimeError("libskder_amd.so is missing (run `make -C skder_amd/csrc`); "
+                               "skder_amd has no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            f = getattr(L, name)      # AttributeError if a declared symbol is not exported
+            f.restype = res
+            f.argtypes = args
+        _LIB = L
+    return _LIB

@@ -1,0 +1,436 @@
+// api.hip -- the C ABI of include/skder_amd.h.
+#include <algorithm>
+#include <numeric>
+
+#include "device_utils.h"
+#include "engine.h"
+#include "host_io.h"
+#include "synth.h"
+
+static void set_err(char *err, size_t errlen, const std::string &msg)
+{
+    if (err && errlen) snprintf(err, errlen, "%s", msg.c_str());
+}
+
+#define API_TRY try {
+#define API_CATCH_CTX(ctx_, rc_)                                                   \
+    }                                                                              \
+    catch (const std::exception &e) { if (ctx_) (ctx_)->last_error = e.what(); return rc_; }
+
+// ---------------------------------------------------------------------------------------------
+// context
+
+extern "C" skder_ctx_t *skder_amd_ctx_create(int device, char *err, size_t errlen)
+{
+    skder_ctx *ctx = nullptr;
+    try {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
+            throw SkError("no HIP device available: libskder_amd has no CPU fallback");
+        if (device < 0 || device >= n) throw SkError("device index out of range");
+        HIPCHECK(hipSetDevice(device));
+        hipDeviceProp_t prop;
+        HIPCHECK(hipGetDeviceProperties(&prop, device));
+        if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+            throw SkError(std::string("libskder_amd is built for gfx950 (MI355X) only; device is ") + prop.gcnArchName);
+        ctx = new skder_ctx();
+        ctx->device = device;
+        HIPCHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        for (auto &e : ctx->ev) HIPCHECK(hipEventCreate(&e));
+        HIPCHECK(hipMalloc(&ctx->d_flags, 64));
+        HIPCHECK(hipMemset(ctx->d_flags, 0, 64));
+        return ctx;
+    } catch (const std::exception &e) {
+        set_err(err, errlen, e.what());
+        delete ctx;
+        return nullptr;
+    }
+}
+
+extern "C" void skder_amd_ctx_destroy(skder_ctx_t *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto &e : ctx->ev) (void)hipEventDestroy(e);
+    if (ctx->d_flags) (void)hipFree(ctx->d_flags);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" void *skder_amd_ctx_stream(skder_ctx_t *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+extern "C" const char *skder_amd_last_error(skder_ctx_t *ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+extern "C" int skder_amd_last_timing(skder_ctx_t *ctx, double *out8)
+{
+    if (!ctx || !out8) return 1;
+    for (int i = 0; i < 8; i++) out8[i] = ctx->timing[i];
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// sketch sets
+
+extern "C" skder_sketches_t *skder_amd_sketches_new(skder_ctx_t *ctx)
+{
+    if (!ctx) return nullptr;
+    skder_sketches *s = new skder_sketches();
+    s->ctx = ctx;
+    return s;
+}
+extern "C" void skder_amd_sketches_free(skder_sketches_t *s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+    delete s;
+}
+
+extern "C" int skder_amd_sketch_batch(skder_sketches_t *s, const uint8_t *d_bases, const skder_batch_t *batch)
+{
+    if (!s || !batch) return 1;
+    API_TRY
+    HIPCHECK(hipSetDevice(s->ctx->device));
+    sketch_batch_impl(s, d_bases, batch);
+    return 0;
+    API_CATCH_CTX(s->ctx, 2)
+}
+
+extern "C" int skder_amd_sketches_view(skder_sketches_t *s, skder_raw_view_t *out)
+{
+    if (!s || !out) return 1;
+    out->n_genomes = s->n_genomes;
+    out->n_seeds = s->h_seed_off.back();
+    out->n_markers = s->h_marker_off.back();
+    out->n_rec_goff = s->h_rec_goff.size();
+    out->d_seed_kmer = s->seed_kmer.p; out->d_seed_gpos = s->seed_gpos.p; out->d_seed_ctg = s->seed_ctg.p;
+    out->d_markers = s->markers.p;
+    out->h_seed_off = s->h_seed_off.data(); out->h_marker_off = s->h_marker_off.data();
+    out->h_genome_len = s->h_genome_len.data(); out->h_genome_nrec = s->h_genome_nrec.data();
+    out->h_rec_goff = s->h_rec_goff.data();
+    return 0;
+}
+
+extern "C" int skder_amd_sketches_append_raw(skder_sketches_t *s, const skder_raw_view_t *raw)
+{
+    if (!s || !raw) return 1;
+    API_TRY
+    if (s->indexed) throw SkError("sketch set already indexed; cannot append");
+    HIPCHECK(hipSetDevice(s->ctx->device));
+    hipStream_t st = s->ctx->stream;
+    const uint64_t sb = s->seed_kmer.n, mb = s->markers.n;
+    s->seed_kmer.resize(sb + raw->n_seeds, st);
+    s->seed_gpos.resize(sb + raw->n_seeds, st);
+    s->seed_ctg.resize(sb + raw->n_seeds, st);
+    s->markers.resize(mb + raw->n_markers, st);
+    if (raw->n_seeds) {
+        HIPCHECK(hipMemcpyAsync(s->seed_kmer.p + sb, raw->d_seed_kmer, raw->n_seeds * 4, hipMemcpyDeviceToDevice, st));
+        HIPCHECK(hipMemcpyAsync(s->seed_gpos.p + sb, raw->d_seed_gpos, raw->n_seeds * 4, hipMemcpyDeviceToDevice, st));
+        HIPCHECK(hipMemcpyAsync(s->seed_ctg.p + sb, raw->d_seed_ctg, raw->n_seeds * 4, hipMemcpyDeviceToDevice, st));
+    }
+    if (raw->n_markers)
+        HIPCHECK(hipMemcpyAsync(s->markers.p + mb, raw->d_markers, raw->n_markers * 8, hipMemcpyDeviceToDevice, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    size_t rg = 0;
+    for (uint32_t g = 0; g < raw->n_genomes; g++) {
+        s->h_seed_off.push_back(sb + raw->h_seed_off[g + 1] - raw->h_seed_off[0]);
+        s->h_marker_off.push_back(mb + raw->h_marker_off[g + 1] - raw->h_marker_off[0]);
+        s->h_genome_len.push_back(raw->h_genome_len[g]);
+        s->h_genome_nrec.push_back(raw->h_genome_nrec[g]);
+        for (uint32_t r = 0; r <= raw->h_genome_nrec[g]; r++) s->h_rec_goff.push_back(raw->h_rec_goff[rg++]);
+    }
+    s->n_genomes += raw->n_genomes;
+    return 0;
+    API_CATCH_CTX(s->ctx, 2)
+}
+
+extern "C" int skder_amd_sketches_index(skder_sketches_t *s)
+{
+    if (!s) return 1;
+    API_TRY
+    HIPCHECK(hipSetDevice(s->ctx->device));
+    index_impl(s);
+    return 0;
+    API_CATCH_CTX(s->ctx, 2)
+}
+
+// debugging / parity-test accessors: copy a genome's index-stage products to the host
+extern "C" int skder_amd_debug_genome(skder_sketches_t *s, uint32_t g, uint32_t *n_chunks, uint32_t *rep_cut, uint32_t *bucket_bits,
+                                      uint32_t *h_skmer, uint32_t *h_sgpos, uint32_t *h_sctg, uint32_t *h_pchunk)
+{
+    if (!s || g >= s->n_genomes || !s->indexed) return 1;
+    API_TRY
+    HIPCHECK(hipSetDevice(s->ctx->device));
+    const GenomeMeta &m = s->h_meta[g];
+    if (n_chunks) *n_chunks = m.n_chunks;
+    if (rep_cut) *rep_cut = m.rep_cut;
+    if (bucket_bits) *bucket_bits = m.bucket_bits;
+    if (h_skmer) HIPCHECK(hipMemcpy(h_skmer, s->skmer.p + m.seed_off, m.n_seeds * 4ull, hipMemcpyDeviceToHost));
+    if (h_sgpos) HIPCHECK(hipMemcpy(h_sgpos, s->sgpos.p + m.seed_off, m.n_seeds * 4ull, hipMemcpyDeviceToHost));
+    if (h_sctg) HIPCHECK(hipMemcpy(h_sctg, s->sctg.p + m.seed_off, m.n_seeds * 4ull, hipMemcpyDeviceToHost));
+    if (h_pchunk) HIPCHECK(hipMemcpy(h_pchunk, s->pchunk.p + m.seed_off, m.n_seeds * 4ull, hipMemcpyDeviceToHost));
+    return 0;
+    API_CATCH_CTX(s->ctx, 2)
+}
+
+extern "C" int skder_amd_triangle_rows(skder_sketches_t *s, uint32_t row_begin, uint32_t row_stride, double screen_pct,
+                                       const skder_edge_t **edges, uint64_t *n_edges)
+{
+    if (!s) return 1;
+    API_TRY
+    HIPCHECK(hipSetDevice(s->ctx->device));
+    triangle_rows_impl(s, row_begin, row_stride, screen_pct);
+    if (edges) *edges = s->ctx->edges.data();
+    if (n_edges) *n_edges = s->ctx->edges.size();
+    return 0;
+    API_CATCH_CTX(s->ctx, 2)
+}
+
+extern "C" int skder_amd_rectangle(skder_sketches_t *refs, skder_sketches_t *queries, double screen_pct,
+                                   const skder_edge_t **edges, uint64_t *n_edges)
+{
+    if (!refs || !queries || refs->ctx != queries->ctx) return 1;
+    API_TRY
+    HIPCHECK(hipSetDevice(refs->ctx->device));
+    rectangle_impl(refs, queries, screen_pct);
+    if (edges) *edges = refs->ctx->edges.data();
+    if (n_edges) *n_edges = refs->ctx->edges.size();
+    return 0;
+    API_CATCH_CTX(refs->ctx, 2)
+}
+
+// ---------------------------------------------------------------------------------------------
+// synthetic genomes on the device
+
+struct SynthTile { uint64_t base_off; uint32_t genome, gpos0, npos, pad; };
+
+__global__ __launch_bounds__(256) void synth_fill_kernel(uint8_t *__restrict__ bases, const SynthTile *__restrict__ tiles,
+                                                         const uint64_t *__restrict__ lineage, const uint32_t *__restrict__ params)
+{
+    const SynthTile t = tiles[blockIdx.x];
+    const uint64_t sp = lineage[3 * t.genome], stn = lineage[3 * t.genome + 1], iso = lineage[3 * t.genome + 2];
+    const uint32_t acc = params[4 * t.genome], sppm = params[4 * t.genome + 1], ippm = params[4 * t.genome + 2];
+    const uint32_t padded = (t.npos + 31u) & ~31u;
+    for (uint32_t p4 = threadIdx.x * 4; p4 < padded; p4 += 256 * 4) {
+        uint32_t word = 0;
+        for (int k = 0; k < 4; k++) {
+            uint32_t p = p4 + k;
+            uint32_t ch = 'A';
+            if (p < t.npos) ch = "ACGT"[synth_base(sp, stn, iso, acc, sppm, ippm, (uint64_t)t.gpos0 + p)];
+            word |= ch << (8 * k);
+        }
+        *reinterpret_cast<uint32_t *>(bases + t.base_off + p4) = word;
+    }
+}
+
+extern "C" int skder_amd_synth_fill(skder_ctx_t *ctx, uint8_t *d_bases, const skder_batch_t *b, const uint64_t *lineage,
+                                    const uint32_t *params)
+{
+    if (!ctx || !b) return 1;
+    API_TRY
+    HIPCHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    std::vector<SynthTile> tiles;
+    for (uint32_t g = 0; g < b->n_genomes; g++) {
+        uint32_t gpos = 0;
+        for (uint32_t r = b->genome_rec_begin[g]; r < b->genome_rec_begin[g + 1]; r++) {
+            for (uint32_t p = 0; p < b->rec_len[r]; p += SKDER_TILE) {
+                SynthTile t;
+                t.base_off = b->rec_off[r] + p; t.genome = g; t.gpos0 = gpos + p;
+                t.npos = b->rec_len[r] - p < SKDER_TILE ? b->rec_len[r] - p : SKDER_TILE; t.pad = 0;
+                tiles.push_back(t);
+            }
+            gpos += b->rec_len[r];
+        }
+    }
+    DevBuf<SynthTile> d_tiles;
+    DevBuf<uint64_t> d_lin;
+    DevBuf<uint32_t> d_par;
+    d_tiles.resize(tiles.size(), st); d_lin.resize(3ull * b->n_genomes, st); d_par.resize(4ull * b->n_genomes, st);
+    HIPCHECK(hipMemcpyAsync(d_tiles.p, tiles.data(), tiles.size() * sizeof(SynthTile), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(d_lin.p, lineage, 3ull * b->n_genomes * 8, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(d_par.p, params, 4ull * b->n_genomes * 4, hipMemcpyHostToDevice, st));
+    if (!tiles.empty())
+        hipLaunchKernelGGL(synth_fill_kernel, dim3((unsigned)tiles.size()), dim3(256), 0, st, d_bases, d_tiles.p, d_lin.p, d_par.p);
+    HIPCHECK(hipStreamSynchronize(st));
+    return 0;
+    API_CATCH_CTX(ctx, 2)
+}
+
+// ---------------------------------------------------------------------------------------------
+// drop-in entry points
+
+struct skder_db {
+    skder_ctx *ctx = nullptr;
+    skder_sketches *refs = nullptr;
+    GenomeNames names;
+    std::vector<std::pair<std::string, uint32_t>> by_path;   // sorted (path, index)
+};
+
+extern "C" int skder_amd_parse_skani_params(const char *params, double *screen_pct, char *err, size_t errlen)
+{
+    std::string s = params ? params : "";
+    std::vector<std::string> tok;
+    size_t i = 0;
+    while (i < s.size()) {
+        while (i < s.size() && isspace((unsigned char)s[i])) i++;
+        size_t j = i;
+        while (j < s.size() && !isspace((unsigned char)s[j])) j++;
+        if (j > i) tok.push_back(s.substr(i, j - i));
+        i = j;
+    }
+    for (size_t t = 0; t < tok.size(); t++) {
+        if (tok[t] == "-s") {
+            if (t + 1 >= tok.size()) { set_err(err, errlen, "skani parameter -s needs a value"); return 1; }
+            char *end = nullptr;
+            double v = strtod(tok[t + 1].c_str(), &end);
+            if (!end || *end) { set_err(err, errlen, "skani parameter -s: not a number: " + tok[t + 1]); return 1; }
+            if (screen_pct) *screen_pct = v;
+            t++;
+        } else {
+            set_err(err, errlen, "unsupported skani parameter '" + tok[t] + "': this engine implements skani's defaults and -s only");
+            return 1;
+        }
+    }
+    return 0;
+}
+
+static void sorted_unique_listing(const char *listing, std::vector<std::string> &paths)
+{
+    paths = read_listing(listing);
+    std::sort(paths.begin(), paths.end());   // skani indexes genomes by ascending path
+}
+
+extern "C" int skder_amd_triangle(const char *listing, double min_af_pct, double screen_pct, int device, const char *out_tsv,
+                                  char *err, size_t errlen)
+{
+    skder_ctx *ctx = skder_amd_ctx_create(device, err, errlen);
+    if (!ctx) return 1;
+    skder_sketches *s = nullptr;
+    int rc = 0;
+    try {
+        std::vector<std::string> paths;
+        sorted_unique_listing(listing, paths);
+        s = skder_amd_sketches_new(ctx);
+        GenomeNames names;
+        sketch_files(s, paths, names);
+        index_impl(s);
+        triangle_rows_impl(s, 0, 1, screen_pct);
+        write_triangle_tsv(out_tsv, ctx->edges, names, min_af_pct);
+    } catch (const std::exception &e) {
+        set_err(err, errlen, e.what());
+        rc = 2;
+    }
+    skder_amd_sketches_free(s);
+    skder_amd_ctx_destroy(ctx);
+    return rc;
+}
+
+extern "C" int skder_amd_dist(const char *ref_listing, const char *query_listing, double min_af_pct, double screen_pct, int device,
+                              const char *out_tsv, char *err, size_t errlen)
+{
+    skder_ctx *ctx = skder_amd_ctx_create(device, err, errlen);
+    if (!ctx) return 1;
+    skder_sketches *r = nullptr, *q = nullptr;
+    int rc = 0;
+    try {
+        std::vector<std::string> rp = read_listing(ref_listing), qp = read_listing(query_listing);
+        r = skder_amd_sketches_new(ctx);
+        q = skder_amd_sketches_new(ctx);
+        GenomeNames rn, qn;
+        sketch_files(r, rp, rn);
+        sketch_files(q, qp, qn);
+        rectangle_impl(r, q, screen_pct);
+        write_rect_tsv(out_tsv, ctx->edges, rn, qn, min_af_pct);
+    } catch (const std::exception &e) {
+        set_err(err, errlen, e.what());
+        rc = 2;
+    }
+    skder_amd_sketches_free(r);
+    skder_amd_sketches_free(q);
+    skder_amd_ctx_destroy(ctx);
+    return rc;
+}
+
+extern "C" skder_db_t *skder_amd_sketch(const char *listing, int device, char *err, size_t errlen)
+{
+    skder_ctx *ctx = skder_amd_ctx_create(device, err, errlen);
+    if (!ctx) return nullptr;
+    skder_db *db = new skder_db();
+    db->ctx = ctx;
+    try {
+        std::vector<std::string> paths = read_listing(listing);
+        db->refs = skder_amd_sketches_new(ctx);
+        sketch_files(db->refs, paths, db->names);
+        index_impl(db->refs);
+        for (uint32_t i = 0; i < paths.size(); i++) db->by_path.emplace_back(paths[i], i);
+        std::sort(db->by_path.begin(), db->by_path.end());
+        return db;
+    } catch (const std::exception &e) {
+        set_err(err, errlen, e.what());
+        skder_amd_sketches_free(db->refs);
+        skder_amd_ctx_destroy(ctx);
+        delete db;
+        return nullptr;
+    }
+}
+
+// one-genome view of genome g of `src`, sharing nothing: copies its raw sketch into a new set
+static skder_sketches *single_genome_set(skder_sketches *src, uint32_t g)
+{
+    skder_sketches *q = skder_amd_sketches_new(src->ctx);
+    skder_raw_view_t v;
+    skder_amd_sketches_view(src, &v);
+    skder_raw_view_t one = v;
+    uint64_t so[2] = {v.h_seed_off[g], v.h_seed_off[g + 1]}, mo[2] = {v.h_marker_off[g], v.h_marker_off[g + 1]};
+    size_t rg = 0;
+    for (uint32_t i = 0; i < g; i++) rg += v.h_genome_nrec[i] + 1;
+    one.n_genomes = 1;
+    one.n_seeds = so[1] - so[0]; one.n_markers = mo[1] - mo[0];
+    one.d_seed_kmer = v.d_seed_kmer + so[0]; one.d_seed_gpos = v.d_seed_gpos + so[0]; one.d_seed_ctg = v.d_seed_ctg + so[0];
+    one.d_markers = v.d_markers + mo[0];
+    one.h_seed_off = so; one.h_marker_off = mo;
+    one.h_genome_len = v.h_genome_len + g; one.h_genome_nrec = v.h_genome_nrec + g;
+    one.h_rec_goff = v.h_rec_goff + rg;
+    if (skder_amd_sketches_append_raw(q, &one) != 0) {
+        std::string m = src->ctx->last_error;
+        skder_amd_sketches_free(q);
+        throw SkError(m);
+    }
+    return q;
+}
+
+extern "C" int skder_amd_search(skder_db_t *db, const char *query_path, double min_af_pct, double screen_pct, const char *out_tsv,
+                                char *err, size_t errlen)
+{
+    if (!db || !query_path || !out_tsv) { set_err(err, errlen, "null argument"); return 1; }
+    skder_sketches *q = nullptr;
+    int rc = 0;
+    try {
+        HIPCHECK(hipSetDevice(db->ctx->device));
+        GenomeNames qn;
+        auto it = std::lower_bound(db->by_path.begin(), db->by_path.end(), std::make_pair(std::string(query_path), 0u));
+        if (it != db->by_path.end() && it->first == query_path) {
+            q = single_genome_set(db->refs, it->second);
+            qn.path.push_back(db->names.path[it->second]);
+            qn.first_name.push_back(db->names.first_name[it->second]);
+        } else {
+            q = skder_amd_sketches_new(db->ctx);
+            sketch_files(q, {std::string(query_path)}, qn);
+        }
+        rectangle_impl(db->refs, q, screen_pct);
+        write_rect_tsv(out_tsv, db->ctx->edges, db->names, qn, min_af_pct);
+    } catch (const std::exception &e) {
+        set_err(err, errlen, e.what());
+        rc = 2;
+    }
+    skder_amd_sketches_free(q);
+    return rc;
+}
+
+extern "C" void skder_amd_db_free(skder_db_t *db)
+{
+    if (!db) return;
+    skder_amd_sketches_free(db->refs);
+    skder_amd_ctx_destroy(db->ctx);
+    delete db;
+}

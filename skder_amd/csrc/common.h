@@ -1,0 +1,86 @@
+// common.h -- shared declarations of the MI355X ANI engine (libskder_amd.so).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/skder_amd.h"
+#include "../../include/skder_amd_spec.h"
+
+#define SK_SEED_MASK 0x3FFFFFFFu            /* 2*ANI_K bits */
+#define SK_MARK_MASK ((1ULL << 42) - 1)      /* 2*ANI_MARKER_K bits */
+#define SK_FWD_BIT 0x80000000u
+#define SK_SEED_THR (0xFFFFFFFFFFFFFFFFULL / ANI_C)
+#define SK_MARK_THR (0xFFFFFFFFFFFFFFFFULL / ANI_MARKER_C)
+
+#define SK_THREADS 256
+#define SK_POS_PER_THREAD 32
+static_assert(SK_THREADS * SK_POS_PER_THREAD == SKDER_TILE, "tile geometry");
+#define SK_SLOT_SEEDS 512     /* per-tile seed slot capacity (mean 65.5) */
+#define SK_SLOT_MARKS 128     /* per-tile marker slot capacity (mean 8.2) */
+
+struct SkError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+#define HIPCHECK(expr)                                                                           \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            throw SkError(std::string(#expr) + ": " + hipGetErrorString(e_) + " (" + __FILE__ + ":" + \
+                          std::to_string(__LINE__) + ")");                                       \
+    } while (0)
+
+// one 8192-position slice of one kept FASTA record
+struct TileDesc {
+    uint64_t base_off;   // offset in d_bases of the tile's first position (multiple of 32)
+    uint32_t genome;     // index inside the batch
+    uint32_t ctg;        // kept-record index inside the genome
+    uint32_t pos0;       // record-relative position of the tile start
+    uint32_t npos;       // positions in the tile (<= SKDER_TILE)
+    uint32_t gpos0;      // genome-relative gpos of the tile start
+    uint32_t pad;
+};
+
+// device buffer with geometric growth
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0, cap = 0;
+    ~DevBuf() { release(); }
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr; n = cap = 0;
+    }
+    // make room for `want` elements; keeps the first `keep` elements
+    void reserve(size_t want, size_t keep, hipStream_t st) {
+        if (want <= cap) return;
+        size_t nc = cap ? cap : 1024;
+        while (nc < want) nc = nc + nc / 2 + 1024;
+        T *q = nullptr;
+        HIPCHECK(hipMalloc(&q, nc * sizeof(T)));
+        if (keep) HIPCHECK(hipMemcpyAsync(q, p, keep * sizeof(T), hipMemcpyDeviceToDevice, st));
+        if (p) { HIPCHECK(hipStreamSynchronize(st)); (void)hipFree(p); }
+        p = q; cap = nc;
+    }
+    void resize(size_t want, hipStream_t st) { reserve(want, n, st); n = want; }
+};
+
+struct skder_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+    hipEvent_t ev[16];
+    double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<skder_edge_t> edges;
+    uint32_t *d_flags = nullptr;   // [0] overflow / error flags from kernels
+};

@@ -1,0 +1,51 @@
+// engine.h -- internal structures of the ANI engine
+#pragma once
+#include "common.h"
+
+#define IDX_MAX_BUCKET_BITS 14
+#define IDX_REP_HIST ANI_REP_HIST
+
+// per-genome record on the device (index stage)
+struct GenomeMeta {
+    uint64_t seed_off;      // offset of the genome's seeds in the seed arrays
+    uint64_t bucket_off;    // offset of its bucket-offset table (nb+1 entries)
+    uint64_t marker_off;
+    uint64_t total_len;     // sum of kept record lengths
+    uint64_t rec_goff_off;  // offset into d_rec_goff (n_rec+1 entries)
+    uint32_t n_seeds;
+    uint32_t n_markers;
+    uint32_t n_rec;
+    uint32_t bucket_bits;
+    uint32_t n_chunks;      // filled by the index kernel
+    uint32_t rep_cut;       // filled by the index kernel
+};
+
+struct skder_sketches {
+    skder_ctx *ctx = nullptr;
+    uint32_t n_genomes = 0;
+    bool indexed = false;
+    // raw sketches
+    DevBuf<uint32_t> seed_kmer, seed_gpos, seed_ctg;   // position order
+    DevBuf<uint64_t> markers;                          // sorted unique per genome
+    std::vector<uint64_t> h_seed_off{0}, h_marker_off{0}, h_genome_len;
+    std::vector<uint32_t> h_genome_nrec, h_rec_goff;
+    // index
+    DevBuf<GenomeMeta> d_meta;
+    std::vector<GenomeMeta> h_meta;
+    DevBuf<uint32_t> d_rec_goff;
+    DevBuf<uint32_t> skmer, sgpos, sctg;   // by-(kmer,gpos) order inside each genome's hash bucket
+    DevBuf<uint32_t> boff;                 // bucket offset tables
+    DevBuf<uint32_t> pchunk;               // chunk id of every seed (position order)
+};
+
+void sketch_batch_impl(skder_sketches *s, const uint8_t *d_bases, const skder_batch_t *b);
+void index_impl(skder_sketches *s);
+void triangle_rows_impl(skder_sketches *s, uint32_t row_begin, uint32_t row_stride, double screen_pct);
+void rectangle_impl(skder_sketches *refs, skder_sketches *queries, double screen_pct);
+void synth_fill_impl(skder_ctx *ctx, uint8_t *d_bases, const skder_batch_t *b, const uint64_t *lineage,
+                     const uint32_t *params);
+
+__host__ __device__ inline uint32_t kmer_bucket(uint32_t kmer, uint32_t bits)
+{
+    return (kmer * 0x9E3779B1u) >> (32u - bits);
+}

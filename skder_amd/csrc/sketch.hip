@@ -1,0 +1,419 @@
+// sketch.hip -- FracMinHash sketching of genomes resident in HBM (gfx950).
+//
+// Replaces the sketching stage of `skani triangle|sketch|search|dist` as spawned by
+// /root/reference/src/skDER/skder.py:16-26,103,119 (skani itself is an external binary; the
+// algorithm restated here is pinned by oracle/ani_oracle.c sketch_contig()).
+//
+// Data flow (all on one stream):
+//   bases (ASCII, 1 B/base, records 32-B aligned)
+//     -> sketch_tiles_kernel   one workgroup per 8192-position tile: 16-B coalesced loads, 2-bit
+//                              packing into LDS, each thread rolls 32 consecutive positions of the
+//                              15-mer (u32) and 21-mer (u64) forward/reverse registers, hashes both
+//                              canonical k-mers, keeps hash < 2^64/c; ordered compaction through a
+//                              workgroup scan into fixed-capacity per-tile slots
+//     -> scan of per-tile counts, gather_* kernels -> position-ordered seed arrays per genome
+//     -> marker_sort_kernel    per genome: bitonic sort in LDS + dedup -> sorted unique markers
+// HBM traffic per base: 1 B read (+ 32/8192 halo) ; per seed 12 B written twice, 8 B read once.
+#include "common.h"
+#include "device_utils.h"
+#include "engine.h"
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+
+__device__ __forceinline__ uint64_t mm_hash64(uint64_t key)
+{
+    key = ~key + (key << 21);
+    key = key ^ (key >> 24);
+    key = (key + (key << 3)) + (key << 8);
+    key = key ^ (key >> 14);
+    key = (key + (key << 2)) + (key << 4);
+    key = key ^ (key >> 28);
+    key = key + (key << 31);
+    return key;
+}
+
+// 4 ASCII bases in a dword -> 4 two-bit codes in the low byte (A=0 C=1 G=2 T=3, case-insensitive,
+// every other byte = 0), first base in the lowest bits.
+__device__ __forceinline__ uint32_t pack4(uint32_t x)
+{
+    uint32_t u = x & 0xDFDFDFDFu;                       // upper-case
+    uint32_t c = ((u >> 1) ^ (u >> 2)) & 0x03030303u;   // A0 C1 G2 T3 (N happens to give 0 too)
+    // bytes equal to 'C','G','T' (exact zero-byte test, no borrow artefacts)
+    uint32_t vc = u ^ 0x43434343u, vg = u ^ 0x47474747u, vt = u ^ 0x54545454u;
+    uint32_t nzc = (((vc & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | vc) & 0x80808080u;
+    uint32_t nzg = (((vg & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | vg) & 0x80808080u;
+    uint32_t nzt = (((vt & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | vt) & 0x80808080u;
+    uint32_t valid = (~(nzc & nzg & nzt)) & 0x80808080u;   // 0x80 where the byte is C, G or T
+    c &= (valid >> 7) * 3u;
+    uint32_t t = c | (c >> 6);
+    return (t & 0xFu) | ((t >> 12) & 0xF0u);
+}
+
+__device__ __forceinline__ uint32_t pack16(uint4 v)
+{
+    return pack4(v.x) | (pack4(v.y) << 8) | (pack4(v.z) << 16) | (pack4(v.w) << 24);
+}
+
+// reverse complement of a 15-mer held as 30 bits, newest base in the low pair
+__device__ __forceinline__ uint32_t revcomp15(uint32_t f)
+{
+    uint32_t x = __brev(f);
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+    return (~(x >> 2)) & SK_SEED_MASK;
+}
+__device__ __forceinline__ uint64_t revcomp21(uint64_t f)
+{
+    uint64_t x = __brevll(f);
+    x = ((x >> 1) & 0x5555555555555555ULL) | ((x & 0x5555555555555555ULL) << 1);
+    return (~(x >> 22)) & SK_MARK_MASK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// HOT KERNEL
+
+#define PACKED_WORDS ((SKDER_TILE + 32) / 16)   // 514
+
+__global__ __launch_bounds__(SK_THREADS) void sketch_tiles_kernel(
+    const uint8_t *__restrict__ bases, const TileDesc *__restrict__ tiles,
+    uint32_t *__restrict__ slot_kmer, uint32_t *__restrict__ slot_gpos, uint64_t *__restrict__ slot_mark,
+    uint32_t *__restrict__ tile_ns, uint32_t *__restrict__ tile_nm, uint32_t *__restrict__ flags)
+{
+    __shared__ uint32_t packed[PACKED_WORDS + 6];
+    __shared__ uint32_t wsum[SK_THREADS / 64];
+    __shared__ uint32_t out_kmer[SK_SLOT_SEEDS];
+    __shared__ uint32_t out_gpos[SK_SLOT_SEEDS];
+    __shared__ uint64_t out_mark[SK_SLOT_MARKS];
+
+    const uint32_t tid = threadIdx.x;
+    const TileDesc td = tiles[blockIdx.x];
+    const uint8_t *src = bases + td.base_off - 32;   // 32-B aligned; 32 bases of left halo
+
+    for (uint32_t w = tid; w < PACKED_WORDS; w += SK_THREADS) {
+        uint4 v = *reinterpret_cast<const uint4 *>(src + 16ull * w);
+        packed[w] = pack16(v);
+    }
+    if (tid < 6) packed[PACKED_WORDS + tid] = 0;
+    __syncthreads();
+
+    // this thread's 64-base window: tile positions [32*tid - 32, 32*tid + 32)
+    const uint32_t w0 = packed[2 * tid], w1 = packed[2 * tid + 1];
+    const uint32_t w2 = packed[2 * tid + 2], w3 = packed[2 * tid + 3];
+
+    uint32_t fs = 0, rs = 0;
+    uint64_t fm = 0, rm = 0;
+    // warm-up: window bases 12..31 (the 20 positions in front of this thread's first position)
+#pragma unroll
+    for (int n = 12; n < 32; n++) {
+        uint32_t b = ((n < 16 ? w0 : w1) >> (2 * (n & 15))) & 3u;
+        fs = ((fs << 2) | b) & SK_SEED_MASK;
+        rs = (rs >> 2) | ((3u - b) << 28);
+        fm = ((fm << 2) | b) & SK_MARK_MASK;
+        rm = (rm >> 2) | ((uint64_t)(3u - b) << 40);
+    }
+    uint32_t smask = 0, mmask = 0;
+    const uint32_t p0 = tid * SK_POS_PER_THREAD;
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+        uint32_t b = ((j < 16 ? w2 : w3) >> (2 * (j & 15))) & 3u;
+        fs = ((fs << 2) | b) & SK_SEED_MASK;
+        rs = (rs >> 2) | ((3u - b) << 28);
+        fm = ((fm << 2) | b) & SK_MARK_MASK;
+        rm = (rm >> 2) | ((uint64_t)(3u - b) << 40);
+        uint32_t cs = fs < rs ? fs : rs;
+        uint64_t cm = fm < rm ? fm : rm;
+        if (mm_hash64((uint64_t)cs) < SK_SEED_THR) smask |= 1u << j;
+        if (mm_hash64(cm) < SK_MARK_THR) mmask |= 1u << j;
+    }
+    // validity: inside the record, and at least marker_k-1 bases in front (ani_oracle.c sketch_contig)
+    {
+        uint32_t valid = 0xFFFFFFFFu;
+        if (p0 + 32 > td.npos) valid = (p0 >= td.npos) ? 0u : (0xFFFFFFFFu >> (32 - (td.npos - p0)));
+        uint32_t i0 = td.pos0 + p0;   // record position of j = 0
+        if (i0 < ANI_MARKER_K - 1) {
+            uint32_t skip = (ANI_MARKER_K - 1) - i0;
+            valid &= (skip >= 32) ? 0u : (0xFFFFFFFFu << skip);
+        }
+        smask &= valid;
+        mmask &= valid;
+    }
+
+    // ordered compaction: workgroup exclusive scan of (seed count | marker count << 16)
+    uint32_t cnt = __popc(smask) | (__popc(mmask) << 16);
+    uint32_t total;
+    uint32_t excl = block_excl_scan_256(cnt, wsum, total);
+    uint32_t so = excl & 0xFFFFu, mo = excl >> 16;
+    const uint32_t ns = total & 0xFFFFu, nm = total >> 16;
+
+    while (smask) {
+        int j = __ffs(smask) - 1;
+        smask &= smask - 1;
+        // 15-mer ending at window base 32+j: window bases [18+j, 32+j]
+        uint32_t n0 = 18 + j;
+        uint32_t wi = 2 * tid + (n0 >> 4), sh = 2 * (n0 & 15);
+        uint64_t two = ((uint64_t)packed[wi + 1] << 32) | packed[wi];
+        uint32_t f = (uint32_t)(two >> sh) & SK_SEED_MASK;
+        // window order: older bases in lower bits; the rolling register keeps the NEWEST base lowest
+        f = __brev(f);
+        f = ((f >> 1) & 0x55555555u) | ((f & 0x55555555u) << 1);
+        f >>= 2;                                  // now newest base in the low pair, as fs
+        uint32_t r = revcomp15(f);
+        uint32_t fwd = f < r;
+        if (so < SK_SLOT_SEEDS) {
+            out_kmer[so] = (fwd ? f : r) | (fwd ? SK_FWD_BIT : 0u);
+            out_gpos[so] = td.gpos0 + p0 + j;
+        }
+        so++;
+    }
+    while (mmask) {
+        int j = __ffs(mmask) - 1;
+        mmask &= mmask - 1;
+        uint32_t n0 = 12 + j;                     // 21-mer = window bases [12+j, 32+j]
+        uint32_t wi = 2 * tid + (n0 >> 4), sh = 2 * (n0 & 15);
+        uint64_t lo = ((uint64_t)packed[wi + 1] << 32) | packed[wi];
+        uint64_t v = lo >> sh;
+        if (sh > 22) v |= (uint64_t)packed[wi + 2] << (64 - sh);
+        v &= SK_MARK_MASK;
+        // reverse the base order (oldest-lowest -> newest-lowest)
+        uint64_t f = __brevll(v);
+        f = ((f >> 1) & 0x5555555555555555ULL) | ((f & 0x5555555555555555ULL) << 1);
+        f >>= 22;
+        uint64_t r = revcomp21(f);
+        if (mo < SK_SLOT_MARKS) out_mark[mo] = f < r ? f : r;
+        mo++;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        tile_ns[blockIdx.x] = ns;
+        tile_nm[blockIdx.x] = nm;
+        if (ns > SK_SLOT_SEEDS || nm > SK_SLOT_MARKS) atomicOr(&flags[0], 1u);
+    }
+    const uint64_t sbase = (uint64_t)blockIdx.x * SK_SLOT_SEEDS;
+    for (uint32_t t = tid; t < ns && t < SK_SLOT_SEEDS; t += SK_THREADS) {
+        slot_kmer[sbase + t] = out_kmer[t];
+        slot_gpos[sbase + t] = out_gpos[t];
+    }
+    const uint64_t mbase = (uint64_t)blockIdx.x * SK_SLOT_MARKS;
+    for (uint32_t t = tid; t < nm && t < SK_SLOT_MARKS; t += SK_THREADS) slot_mark[mbase + t] = out_mark[t];
+}
+
+// ---------------------------------------------------------------------------------------------
+// gather tile slots into contiguous arrays
+
+__global__ __launch_bounds__(64) void gather_seeds_kernel(
+    const TileDesc *__restrict__ tiles, const uint32_t *__restrict__ tile_ns, const uint32_t *__restrict__ tile_soff,
+    const uint32_t *__restrict__ slot_kmer, const uint32_t *__restrict__ slot_gpos, uint64_t dst_base,
+    uint32_t *__restrict__ seed_kmer, uint32_t *__restrict__ seed_gpos, uint32_t *__restrict__ seed_ctg)
+{
+    const uint32_t t = blockIdx.x;
+    const uint32_t n = tile_ns[t];
+    const uint64_t dst = dst_base + tile_soff[t];
+    const uint64_t src = (uint64_t)t * SK_SLOT_SEEDS;
+    const uint32_t ctg = tiles[t].ctg;
+    for (uint32_t i = threadIdx.x; i < n; i += 64) {
+        seed_kmer[dst + i] = slot_kmer[src + i];
+        seed_gpos[dst + i] = slot_gpos[src + i];
+        seed_ctg[dst + i] = ctg;
+    }
+}
+
+__global__ __launch_bounds__(64) void gather_marks_kernel(
+    const uint32_t *__restrict__ tile_nm, const uint32_t *__restrict__ tile_moff,
+    const uint64_t *__restrict__ slot_mark, uint64_t *__restrict__ raw_marks)
+{
+    const uint32_t t = blockIdx.x;
+    const uint32_t n = tile_nm[t];
+    const uint64_t dst = tile_moff[t];
+    const uint64_t src = (uint64_t)t * SK_SLOT_MARKS;
+    for (uint32_t i = threadIdx.x; i < n; i += 64) raw_marks[dst + i] = slot_mark[src + i];
+}
+
+// per genome: sort the raw markers (bitonic, LDS) and drop duplicates.
+// raw[g_off[g] .. g_off[g+1]) -> sorted unique at the same offset; count to n_unique[g].
+#define MARK_SORT_CAP 16384
+__global__ __launch_bounds__(256) void marker_sort_kernel(uint64_t *__restrict__ raw, const uint32_t *__restrict__ g_off,
+                                                          uint32_t *__restrict__ n_unique, uint32_t *__restrict__ flags)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint64_t *key = reinterpret_cast<uint64_t *>(smem_raw);
+    __shared__ uint32_t wsum[4];
+    const uint32_t g = blockIdx.x;
+    const uint32_t lo = g_off[g], n = g_off[g + 1] - lo;
+    if (n > MARK_SORT_CAP) {
+        if (threadIdx.x == 0) { atomicOr(&flags[0], 2u); n_unique[g] = 0; }
+        return;
+    }
+    uint32_t m = 1;
+    while (m < n) m <<= 1;
+    for (uint32_t i = threadIdx.x; i < m; i += 256) key[i] = i < n ? raw[lo + i] : ~0ULL;
+    __syncthreads();
+    for (uint32_t k = 2; k <= m; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < m; i += 256) {
+                uint32_t ixj = i ^ j;
+                if (ixj > i) {
+                    uint64_t a = key[i], b = key[ixj];
+                    bool up = (i & k) == 0;
+                    if ((a > b) == up) { key[i] = b; key[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // ordered dedup: block scan over "is first of its run" in strips of 256
+    uint32_t running = 0;
+    for (uint32_t base = 0; base < n; base += 256) {
+        uint32_t i = base + threadIdx.x;
+        uint32_t keep = (i < n) && (i == 0 || key[i] != key[i - 1]);
+        uint32_t total;
+        uint32_t ex = block_excl_scan_256(keep, wsum, total);
+        if (keep) raw[lo + running + ex] = key[i];
+        running += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) n_unique[g] = running;
+}
+
+// compact sorted-unique marker runs (still at their raw offsets) to their final offsets
+__global__ __launch_bounds__(256) void marker_compact_kernel(const uint64_t *__restrict__ raw, const uint32_t *__restrict__ g_off,
+                                                             const uint32_t *__restrict__ n_unique,
+                                                             const uint32_t *__restrict__ dst_off, uint64_t dst_base,
+                                                             uint64_t *__restrict__ out)
+{
+    const uint32_t g = blockIdx.x;
+    const uint32_t lo = g_off[g], n = n_unique[g];
+    const uint64_t d = dst_base + dst_off[g];
+    for (uint32_t i = threadIdx.x; i < n; i += 256) out[d + i] = raw[lo + i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+
+static void build_tiles(const skder_batch_t *b, std::vector<TileDesc> &tiles, std::vector<uint32_t> &genome_tile_begin,
+                        std::vector<uint32_t> &rec_goff /* per genome nrec+1 */, std::vector<uint64_t> &genome_len)
+{
+    genome_tile_begin.assign(b->n_genomes + 1, 0);
+    for (uint32_t g = 0; g < b->n_genomes; g++) {
+        genome_tile_begin[g] = (uint32_t)tiles.size();
+        uint32_t gpos = 0;
+        uint32_t r0 = b->genome_rec_begin[g], r1 = b->genome_rec_begin[g + 1];
+        for (uint32_t r = r0; r < r1; r++) {
+            uint32_t len = b->rec_len[r];
+            if (b->rec_off[r] % 32) throw SkError("record offsets must be multiples of 32");
+            if ((uint64_t)gpos + len >= 0x7FFFFFFFull) throw SkError("genome longer than 2^31 bases");
+            rec_goff.push_back(gpos);
+            for (uint32_t p = 0; p < len; p += SKDER_TILE) {
+                TileDesc t;
+                t.base_off = b->rec_off[r] + p;
+                t.genome = g;
+                t.ctg = r - r0;
+                t.pos0 = p;
+                t.npos = len - p < SKDER_TILE ? len - p : SKDER_TILE;
+                t.gpos0 = gpos + p;
+                t.pad = 0;
+                tiles.push_back(t);
+            }
+            gpos += len;
+        }
+        rec_goff.push_back(gpos);
+        genome_len.push_back(gpos);
+    }
+    genome_tile_begin[b->n_genomes] = (uint32_t)tiles.size();
+}
+
+void sketch_batch_impl(skder_sketches *s, const uint8_t *d_bases, const skder_batch_t *b)
+{
+    skder_ctx *ctx = s->ctx;
+    hipStream_t st = ctx->stream;
+    if (s->indexed) throw SkError("sketch set already indexed; cannot append");
+    if (b->n_genomes == 0) return;
+    std::vector<TileDesc> tiles;
+    std::vector<uint32_t> gtb, rec_goff;
+    std::vector<uint64_t> glen;
+    build_tiles(b, tiles, gtb, rec_goff, glen);
+    const uint32_t nt = (uint32_t)tiles.size();
+
+    DevBuf<TileDesc> d_tiles;
+    DevBuf<uint32_t> slot_kmer, slot_gpos, tile_ns, tile_nm, tile_soff, tile_moff;
+    DevBuf<uint64_t> slot_mark;
+    d_tiles.resize(nt, st);
+    HIPCHECK(hipMemcpyAsync(d_tiles.p, tiles.data(), nt * sizeof(TileDesc), hipMemcpyHostToDevice, st));
+    slot_kmer.resize((size_t)nt * SK_SLOT_SEEDS, st);
+    slot_gpos.resize((size_t)nt * SK_SLOT_SEEDS, st);
+    slot_mark.resize((size_t)nt * SK_SLOT_MARKS, st);
+    tile_ns.resize(nt + 1, st); tile_nm.resize(nt + 1, st);
+    tile_soff.resize(nt + 1, st); tile_moff.resize(nt + 1, st);
+    HIPCHECK(hipMemsetAsync(ctx->d_flags, 0, 64, st));
+    HIPCHECK(hipMemsetAsync(tile_ns.p + nt, 0, 4, st));
+    HIPCHECK(hipMemsetAsync(tile_nm.p + nt, 0, 4, st));
+
+    HIPCHECK(hipEventRecord(ctx->ev[0], st));
+    if (nt)
+        hipLaunchKernelGGL(sketch_tiles_kernel, dim3(nt), dim3(SK_THREADS), 0, st, d_bases, d_tiles.p, slot_kmer.p,
+                           slot_gpos.p, slot_mark.p, tile_ns.p, tile_nm.p, ctx->d_flags);
+    HIPCHECK(hipEventRecord(ctx->ev[1], st));
+
+    // offsets
+    ScanWorkspace ws;
+    exclusive_scan_u32(tile_ns.p, tile_soff.p, nt + 1, ws, st);
+    exclusive_scan_u32(tile_nm.p, tile_moff.p, nt + 1, ws, st);
+    std::vector<uint32_t> h_soff(nt + 1), h_moff(nt + 1);
+    uint32_t h_flags = 0;
+    HIPCHECK(hipMemcpyAsync(h_soff.data(), tile_soff.p, (nt + 1) * 4, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipMemcpyAsync(h_moff.data(), tile_moff.p, (nt + 1) * 4, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipMemcpyAsync(&h_flags, ctx->d_flags, 4, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    if (h_flags & 1u) throw SkError("sketch tile slot overflow (more than 512 seeds or 128 markers in 8192 bases)");
+    const uint64_t add_seeds = h_soff[nt], add_raw_marks = h_moff[nt];
+
+    // seeds
+    const uint64_t seed_base = s->seed_kmer.n;
+    s->seed_kmer.resize(seed_base + add_seeds, st);
+    s->seed_gpos.resize(seed_base + add_seeds, st);
+    s->seed_ctg.resize(seed_base + add_seeds, st);
+    if (nt)
+        hipLaunchKernelGGL(gather_seeds_kernel, dim3(nt), dim3(64), 0, st, d_tiles.p, tile_ns.p, tile_soff.p, slot_kmer.p,
+                           slot_gpos.p, seed_base, s->seed_kmer.p, s->seed_gpos.p, s->seed_ctg.p);
+    // markers: raw -> sorted unique per genome -> appended
+    DevBuf<uint64_t> raw_marks;
+    raw_marks.resize(add_raw_marks + 1, st);
+    if (nt)
+        hipLaunchKernelGGL(gather_marks_kernel, dim3(nt), dim3(64), 0, st, tile_nm.p, tile_moff.p, slot_mark.p, raw_marks.p);
+    std::vector<uint32_t> h_goff(b->n_genomes + 1);
+    for (uint32_t g = 0; g <= b->n_genomes; g++) h_goff[g] = h_moff[gtb[g]];
+    DevBuf<uint32_t> d_goff, d_nuniq, d_uoff;
+    d_goff.resize(b->n_genomes + 1, st);
+    d_nuniq.resize(b->n_genomes + 1, st);
+    d_uoff.resize(b->n_genomes + 1, st);
+    HIPCHECK(hipMemcpyAsync(d_goff.p, h_goff.data(), (b->n_genomes + 1) * 4, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemsetAsync(d_nuniq.p, 0, (b->n_genomes + 1) * 4, st));
+    hipLaunchKernelGGL(marker_sort_kernel, dim3(b->n_genomes), dim3(256), MARK_SORT_CAP * 8, st, raw_marks.p, d_goff.p,
+                       d_nuniq.p, ctx->d_flags);
+    exclusive_scan_u32(d_nuniq.p, d_uoff.p, b->n_genomes + 1, ws, st);
+    std::vector<uint32_t> h_uoff(b->n_genomes + 1);
+    HIPCHECK(hipMemcpyAsync(h_uoff.data(), d_uoff.p, (b->n_genomes + 1) * 4, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipMemcpyAsync(&h_flags, ctx->d_flags, 4, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    if (h_flags & 2u) throw SkError("genome with more than 16384 raw markers (> ~16 Mb) is not supported");
+    const uint64_t mark_base = s->markers.n;
+    s->markers.resize(mark_base + h_uoff[b->n_genomes], st);
+    hipLaunchKernelGGL(marker_compact_kernel, dim3(b->n_genomes), dim3(256), 0, st, raw_marks.p, d_goff.p, d_nuniq.p,
+                       d_uoff.p, mark_base, s->markers.p);
+    HIPCHECK(hipEventRecord(ctx->ev[2], st));
+    HIPCHECK(hipStreamSynchronize(st));
+    float ms0 = 0, ms1 = 0;
+    HIPCHECK(hipEventElapsedTime(&ms0, ctx->ev[0], ctx->ev[1]));
+    HIPCHECK(hipEventElapsedTime(&ms1, ctx->ev[1], ctx->ev[2]));
+    ctx->timing[0] = ms0;
+    ctx->timing[1] = ms1;
+
+    // host metadata
+    for (uint32_t g = 0; g < b->n_genomes; g++) {
+        s->h_seed_off.push_back(seed_base + h_soff[gtb[g + 1]]);
+        s->h_marker_off.push_back(mark_base + h_uoff[g + 1]);
+        s->h_genome_len.push_back(glen[g]);
+        s->h_genome_nrec.push_back(b->genome_rec_begin[g + 1] - b->genome_rec_begin[g]);
+    }
+    s->h_rec_goff.insert(s->h_rec_goff.end(), rec_goff.begin(), rec_goff.end());
+    s->n_genomes += b->n_genomes;
+}

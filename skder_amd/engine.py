@@ -1,0 +1,207 @@
+"""Device-level Python view of libskder_amd.so (section B of include/skder_amd.h).
+
+torch is used here ONLY to own device memory and (in multigpu.py) to drive RCCL; every kernel is
+launched by the C library on its own HIP stream."""
+import ctypes as C
+from typing import List, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import Batch, Edge, RawView, SKDER_TILE
+
+EDGE_DTYPE = np.dtype([("ref", "<u4"), ("query", "<u4"), ("ani", "<f8"), ("af_ref", "<f8"), ("af_query", "<f8"),
+                       ("n_chains", "<u4"), ("n_anchors", "<u4"), ("aligned_bases", "<u8"),
+                       ("ani_fx_sum", "<i8"), ("sum_seeds", "<u8")])
+assert EDGE_DTYPE.itemsize == C.sizeof(Edge)
+
+
+class BatchLayout:
+    """Device layout of a batch of genomes: every kept record starts on a 32-byte boundary, 32 readable
+    bytes precede the first record and SKDER_TILE+64 follow the last (include/skder_amd.h)."""
+
+    def __init__(self, rec_lens: Sequence[np.ndarray]):
+        self.n_genomes = len(rec_lens)
+        self.genome_rec_begin = np.zeros(self.n_genomes + 1, np.uint32)
+        lens = []
+        for g, rl in enumerate(rec_lens):
+            rl = np.asarray(rl, np.uint32)
+            if (rl < 500).any():
+                raise ValueError("records shorter than 500 bp must be dropped before layout")
+            lens.append(rl)
+            self.genome_rec_begin[g + 1] = self.genome_rec_begin[g] + len(rl)
+        self.rec_len = np.concatenate(lens) if lens else np.zeros(0, np.uint32)
+        padded = (self.rec_len.astype(np.uint64) + np.uint64(31)) & ~np.uint64(31)
+        self.rec_off = np.zeros(len(self.rec_len), np.uint64)
+        if len(padded):
+            self.rec_off[0] = 32
+            self.rec_off[1:] = 32 + np.cumsum(padded)[:-1]
+        self.payload_end = int(32 + padded.sum())
+        self.total_bytes = self.payload_end + SKDER_TILE + 64
+        self.total_bases = int(self.rec_len.astype(np.uint64).sum())
+
+    def c_batch(self) -> Batch:
+        b = Batch()
+        b.n_genomes = self.n_genomes
+        b.n_records = len(self.rec_len)
+        b.rec_off = self.rec_off.ctypes.data
+        b.rec_len = self.rec_len.ctypes.data
+        b.genome_rec_begin = self.genome_rec_begin.ctypes.data
+        return b
+
+    def pack_host(self, genomes_bases: Sequence[np.ndarray]) -> np.ndarray:
+        """host buffer in device layout from per-genome ASCII bases (records back to back)"""
+        buf = np.full(self.total_bytes, ord("A"), np.uint8)
+        r = 0
+        for g, bases in enumerate(genomes_bases):
+            src = 0
+            for _ in range(self.genome_rec_begin[g], self.genome_rec_begin[g + 1]):
+                l = int(self.rec_len[r])
+                o = int(self.rec_off[r])
+                buf[o:o + l] = bases[src:src + l]
+                src += l
+                r += 1
+        return buf
+
+
+class Context:
+    def __init__(self, device: int = 0):
+        err = C.create_string_buffer(_lib.ERRLEN)
+        self.h = _lib.lib().skder_amd_ctx_create(device, err, _lib.ERRLEN)
+        if not self.h:
+            raise RuntimeError("skder_amd: " + err.value.decode())
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            _lib.lib().skder_amd_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def check(self, rc: int, what: str):
+        if rc != 0:
+            raise RuntimeError("skder_amd %s failed: %s" % (what, _lib.lib().skder_amd_last_error(self.h).decode()))
+
+    @property
+    def stream(self) -> int:
+        return _lib.lib().skder_amd_ctx_stream(self.h)
+
+    def timing(self) -> np.ndarray:
+        out = (C.c_double * 8)()
+        _lib.lib().skder_amd_last_timing(self.h, out)
+        return np.array(out[:])
+
+    def synth_fill(self, d_bases_ptr: int, layout: BatchLayout, lineage: np.ndarray, params: np.ndarray):
+        lineage = np.ascontiguousarray(lineage, np.uint64)
+        params = np.ascontiguousarray(params, np.uint32)
+        b = layout.c_batch()
+        self.check(_lib.lib().skder_amd_synth_fill(self.h, d_bases_ptr, C.byref(b), lineage.ctypes.data,
+                                                   params.ctypes.data), "synth_fill")
+
+
+def _np_from(ptr, n, dtype):
+    if not n:
+        return np.zeros(0, dtype)
+    return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(n * np.dtype(dtype).itemsize,)).view(dtype).copy()
+
+
+class Sketches:
+    """A set of sketched genomes resident in HBM."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self.h = _lib.lib().skder_amd_sketches_new(ctx.h)
+        if not self.h:
+            raise RuntimeError("skder_amd_sketches_new failed")
+
+    def close(self):
+        if getattr(self, "h", None):
+            _lib.lib().skder_amd_sketches_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def sketch_batch(self, d_bases_ptr: int, layout: BatchLayout):
+        b = layout.c_batch()
+        self.ctx.check(_lib.lib().skder_amd_sketch_batch(self.h, d_bases_ptr, C.byref(b)), "sketch_batch")
+
+    def view(self) -> dict:
+        """raw sketch arrays: device pointers for seeds/markers, numpy copies of the host metadata"""
+        v = RawView()
+        self.ctx.check(_lib.lib().skder_amd_sketches_view(self.h, C.byref(v)), "sketches_view")
+        G = v.n_genomes
+        return dict(n_genomes=G, n_seeds=v.n_seeds, n_markers=v.n_markers,
+                    d_seed_kmer=v.d_seed_kmer, d_seed_gpos=v.d_seed_gpos, d_seed_ctg=v.d_seed_ctg, d_markers=v.d_markers,
+                    seed_off=_np_from(v.h_seed_off, G + 1, np.uint64), marker_off=_np_from(v.h_marker_off, G + 1, np.uint64),
+                    genome_len=_np_from(v.h_genome_len, G, np.uint64), genome_nrec=_np_from(v.h_genome_nrec, G, np.uint32),
+                    rec_goff=_np_from(v.h_rec_goff, v.n_rec_goff, np.uint32))
+
+    def append_raw(self, n_genomes, d_seed_kmer, d_seed_gpos, d_seed_ctg, d_markers, seed_off, marker_off, genome_len,
+                   genome_nrec, rec_goff):
+        seed_off = np.ascontiguousarray(seed_off, np.uint64)
+        marker_off = np.ascontiguousarray(marker_off, np.uint64)
+        genome_len = np.ascontiguousarray(genome_len, np.uint64)
+        genome_nrec = np.ascontiguousarray(genome_nrec, np.uint32)
+        rec_goff = np.ascontiguousarray(rec_goff, np.uint32)
+        v = RawView()
+        v.n_genomes = n_genomes
+        v.n_seeds = int(seed_off[-1] - seed_off[0])
+        v.n_markers = int(marker_off[-1] - marker_off[0])
+        v.n_rec_goff = len(rec_goff)
+        v.d_seed_kmer, v.d_seed_gpos, v.d_seed_ctg, v.d_markers = d_seed_kmer, d_seed_gpos, d_seed_ctg, d_markers
+        v.h_seed_off = seed_off.ctypes.data
+        v.h_marker_off = marker_off.ctypes.data
+        v.h_genome_len = genome_len.ctypes.data
+        v.h_genome_nrec = genome_nrec.ctypes.data
+        v.h_rec_goff = rec_goff.ctypes.data
+        self.ctx.check(_lib.lib().skder_amd_sketches_append_raw(self.h, C.byref(v)), "sketches_append_raw")
+
+    def index(self):
+        self.ctx.check(_lib.lib().skder_amd_sketches_index(self.h), "sketches_index")
+
+    def _edges(self, p, n) -> np.ndarray:
+        if not n.value:
+            return np.zeros(0, EDGE_DTYPE)
+        raw = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n.value * EDGE_DTYPE.itemsize,))
+        return raw.view(EDGE_DTYPE).copy()
+
+    def triangle_rows(self, row_begin: int = 0, row_stride: int = 1, screen_pct: float = 80.0) -> np.ndarray:
+        p = C.POINTER(Edge)()
+        n = C.c_uint64(0)
+        self.ctx.check(_lib.lib().skder_amd_triangle_rows(self.h, row_begin, row_stride, screen_pct, C.byref(p), C.byref(n)),
+                       "triangle_rows")
+        return self._edges(p, n)
+
+    def rectangle(self, queries: "Sketches", screen_pct: float = 80.0) -> np.ndarray:
+        p = C.POINTER(Edge)()
+        n = C.c_uint64(0)
+        self.ctx.check(_lib.lib().skder_amd_rectangle(self.h, queries.h, screen_pct, C.byref(p), C.byref(n)), "rectangle")
+        return self._edges(p, n)
+
+    def debug_genome(self, g: int, n_seeds: int) -> dict:
+        nch, rep, bits = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        sk = np.zeros(n_seeds, np.uint32); sg = np.zeros(n_seeds, np.uint32)
+        sc = np.zeros(n_seeds, np.uint32); pc = np.zeros(n_seeds, np.uint32)
+        self.ctx.check(_lib.lib().skder_amd_debug_genome(self.h, g, C.byref(nch), C.byref(rep), C.byref(bits),
+                                                         sk.ctypes.data, sg.ctypes.data, sc.ctypes.data, pc.ctypes.data),
+                       "debug_genome")
+        return dict(n_chunks=nch.value, rep_cut=rep.value, bucket_bits=bits.value, skmer=sk, sgpos=sg, sctg=sc, pchunk=pc)
+
+
+def download(ptr: int, n: int, dtype) -> np.ndarray:
+    """copy n elements from a device pointer (torch as the allocator/copier)"""
+    import torch
+    nbytes = n * np.dtype(dtype).itemsize
+    if not nbytes:
+        return np.zeros(0, dtype)
+    t = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    rc = hip.hipMemcpy(t.data_ptr(), ptr, nbytes, 3)   # device to device
+    if rc != 0:
+        raise RuntimeError("hipMemcpy failed: %d" % rc)
+    return t.cpu().numpy().view(dtype).copy()

@@ -1,0 +1,117 @@
+"""Synthetic genome sets, bit-identical with skder_amd/csrc/synth.h.
+
+`make_recipe(n)` lays out n genomes as species x strains x isolates with record (contig) lengths;
+`bases_numpy(recipe, g)` materialises one genome on the host (tests, CPU baseline);
+the device generator is `Engine.synth_fill` (skder_amd_synth_fill)."""
+from dataclasses import dataclass
+from typing import List
+
+import numpy as np
+
+SEED = 0x5EED5DE22025
+SEG = np.uint64(10000)
+M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def splitmix64(x: np.ndarray) -> np.ndarray:
+    x = (x + np.uint64(0x9E3779B97F4A7C15)) & M64
+    x = ((x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & M64
+    x = ((x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & M64
+    return x ^ (x >> np.uint64(31))
+
+
+def synth_h(seed, x: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        return splitmix64(np.uint64(seed) ^ (x * np.uint64(0xD1342543DE82EF95)))
+
+
+def synth_codes(species, strain, isolate, acc_pct, strain_ppm, iso_ppm, pos: np.ndarray) -> np.ndarray:
+    """2-bit base codes at genome-linear positions `pos` (uint64 array)."""
+    with np.errstate(over="ignore"):
+        pos = pos.astype(np.uint64)
+        b = (synth_h(species, pos) & np.uint64(3)).astype(np.uint32)
+        acc = (synth_h(np.uint64(strain) ^ np.uint64(0xACCE55), pos // SEG) % np.uint64(100)) < np.uint64(acc_pct)
+        b = np.where(acc, (synth_h(np.uint64(strain) ^ np.uint64(0xACC0BA5E), pos) & np.uint64(3)).astype(np.uint32), b)
+        hs = synth_h(np.uint64(strain) ^ np.uint64(0x5B57), pos)
+        sub = (hs % np.uint64(1000000)) < np.uint64(strain_ppm)
+        b = np.where(sub, (b + 1 + ((hs >> np.uint64(32)) % np.uint64(3)).astype(np.uint32)) & 3, b)
+        hi = synth_h(np.uint64(isolate) ^ np.uint64(0x150), pos)
+        sub = (hi % np.uint64(1000000)) < np.uint64(iso_ppm)
+        b = np.where(sub, (b + 1 + ((hi >> np.uint64(32)) % np.uint64(3)).astype(np.uint32)) & 3, b)
+        return b.astype(np.uint8)
+
+
+@dataclass
+class Recipe:
+    n: int
+    lineage: np.ndarray      # (n, 3) uint64: species, strain, isolate seeds
+    params: np.ndarray       # (n, 4) uint32: acc_pct, strain_ppm, iso_ppm, 0
+    rec_lens: List[np.ndarray]   # per genome: record lengths (all >= 500)
+    species: np.ndarray      # (n,) species index
+
+    def total_len(self, g: int) -> int:
+        return int(self.rec_lens[g].sum())
+
+
+def make_recipe(n: int, genome_len: int = 3_000_000, n_species: int = None, strains_per_species: int = 10,
+                seed: int = SEED) -> Recipe:
+    """n genomes: species roots (iid, genome_len +-5 %) x strain ancestors (1-3 % substitutions, 5-10 %
+    accessory segments) x isolates (0.01-0.5 % substitutions); log-normal record lengths."""
+    if n_species is None:
+        n_species = max(1, n // 100)
+    rng = np.random.RandomState(seed & 0x7FFFFFFF)
+    per_species = -(-n // n_species)
+    lineage = np.zeros((n, 3), np.uint64)
+    params = np.zeros((n, 4), np.uint32)
+    species = np.zeros(n, np.int64)
+    rec_lens = []
+    sp_len = (genome_len * (0.95 + 0.10 * rng.rand(n_species))).astype(np.int64)
+    for g in range(n):
+        s = g // per_species
+        within = g % per_species
+        t = within % strains_per_species if per_species >= strains_per_species else within
+        species[g] = s
+        s_seed = int(splitmix64(np.array([seed ^ (s + 1)], np.uint64))[0])
+        t_seed = int(splitmix64(np.array([s_seed ^ (0x1000 + t)], np.uint64))[0])
+        u_seed = int(splitmix64(np.array([t_seed ^ (0x2000000 + within)], np.uint64))[0])
+        lineage[g] = (s_seed, t_seed, u_seed)
+        trng = np.random.RandomState((t_seed ^ (t_seed >> 32)) & 0x7FFFFFFF)
+        urng = np.random.RandomState((u_seed ^ (u_seed >> 32)) & 0x7FFFFFFF)
+        params[g] = (int(trng.randint(5, 11)), int(trng.randint(10000, 30001)), int(urng.randint(100, 5001)), 0)
+        # records: log-normal lengths, median spread so that N50 spans ~10 kb .. whole genome
+        L = int(sp_len[s])
+        med = float(np.exp(urng.uniform(np.log(2e4), np.log(3e6))))
+        lens = []
+        left = L
+        while left > 0:
+            l = int(np.exp(urng.normal(np.log(med), 0.8)))
+            l = max(1000, min(l, left))
+            if left - l < 1000:
+                l = left
+            lens.append(l)
+            left -= l
+        rec_lens.append(np.array(lens, np.uint32))
+    return Recipe(n, lineage, params, rec_lens, species)
+
+
+def bases_numpy(recipe: Recipe, g: int) -> np.ndarray:
+    """ASCII bases of genome g, records back to back (what a FASTA reader would hand over)."""
+    L = recipe.total_len(g)
+    pos = np.arange(L, dtype=np.uint64)
+    sp, st, iso = (int(x) for x in recipe.lineage[g])
+    acc, sppm, ippm, _ = (int(x) for x in recipe.params[g])
+    codes = synth_codes(sp, st, iso, acc, sppm, ippm, pos)
+    return np.frombuffer(b"ACGT", np.uint8)[codes]
+
+
+def write_fasta(recipe: Recipe, g: int, path: str, width: int = 80) -> None:
+    bases = bases_numpy(recipe, g)
+    off = 0
+    with open(path, "wb") as f:
+        for r, l in enumerate(recipe.rec_lens[g]):
+            f.write((">g%d_rec%d synthetic species %d\n" % (g, r, recipe.species[g])).encode())
+            seq = bases[off:off + int(l)]
+            off += int(l)
+            for i in range(0, len(seq), width):
+                f.write(seq[i:i + width].tobytes())
+                f.write(b"\n")

@@ -1,0 +1,258 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+Integer products must be bit-equal; ANI/AF doubles must be bit-equal as well (the spec uses only
++ - * / in a fixed order).  Run on the GPU box with `pytest -m gpu`."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_table
+
+pytestmark = pytest.mark.gpu
+
+GENOMES = sorted(os.listdir(os.path.join(GOLDEN, "genomes")))
+
+
+def _read_records(path):
+    """FASTA -> (kept record lengths, concatenated kept bases) the way the product's reader does"""
+    op = gzip.open if path.endswith(".gz") else open
+    recs, cur = [], None
+    with op(path, "rb") as f:
+        for line in f:
+            if line.startswith(b">"):
+                cur = []
+                recs.append(cur)
+            elif cur is not None:
+                cur.append(line.strip().replace(b" ", b"").replace(b"\t", b""))
+    seqs = [b"".join(r) for r in recs]
+    kept = [s for s in seqs if len(s) >= 500]
+    return np.array([len(s) for s in kept], np.uint32), np.frombuffer(b"".join(kept), np.uint8)
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "no GPU visible"
+    from skder_amd import engine
+    ctx = engine.Context(0)
+    yield engine, ctx, torch
+    ctx.close()
+
+
+def _sketch(gpu, rec_lens_list, bases_list):
+    engine, ctx, torch = gpu
+    layout = engine.BatchLayout(rec_lens_list)
+    host = layout.pack_host(bases_list)
+    d = torch.from_numpy(host).cuda()
+    s = engine.Sketches(ctx)
+    s.sketch_batch(d.data_ptr(), layout)
+    torch.cuda.synchronize()
+    return s, layout
+
+
+def _compare_sketch(engine, s, oracle, genomes):
+    v = s.view()
+    kmer = engine.download(v["d_seed_kmer"], v["n_seeds"], np.uint32)
+    gpos = engine.download(v["d_seed_gpos"], v["n_seeds"], np.uint32)
+    ctg = engine.download(v["d_seed_ctg"], v["n_seeds"], np.uint32)
+    marks = engine.download(v["d_markers"], v["n_markers"], np.uint64)
+    for g, og in enumerate(genomes):
+        ok, og_pos, oc, of = og.seeds()
+        lo, hi = int(v["seed_off"][g]), int(v["seed_off"][g + 1])
+        assert hi - lo == og.n_seeds, "genome %d: %d seeds on the device, %d in the oracle" % (g, hi - lo, og.n_seeds)
+        assert np.array_equal(gpos[lo:hi], og_pos)
+        assert np.array_equal(kmer[lo:hi] & 0x3FFFFFFF, ok.astype(np.uint32))
+        assert np.array_equal(kmer[lo:hi] >> 31, of.astype(np.uint32))
+        assert np.array_equal(ctg[lo:hi], oc)
+        mlo, mhi = int(v["marker_off"][g]), int(v["marker_off"][g + 1])
+        assert np.array_equal(marks[mlo:mhi], og.markers())
+        assert int(v["genome_len"][g]) == og.total_len
+        assert int(v["genome_nrec"][g]) == og.n_contigs
+
+
+def test_sketch_real_genomes(gpu, oracle):
+    engine, ctx, torch = gpu
+    p = oracle.default_params()
+    paths = [os.path.join(GOLDEN, "genomes", n) for n in GENOMES[:4]]
+    recs = [_read_records(x) for x in paths]
+    s, _ = _sketch(gpu, [r[0] for r in recs], [r[1] for r in recs])
+    _compare_sketch(engine, s, oracle, [oracle.Genome.load(x, p) for x in paths])
+
+
+def test_sketch_edge_cases(gpu, oracle):
+    """ragged tiles, records of exactly 500 bp, lower case, N and IUPAC codes, a tile boundary"""
+    engine, ctx, torch = gpu
+    p = oracle.default_params()
+    rng = np.random.RandomState(7)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    g0 = alpha[rng.randint(0, 4, 500 + 8192 + 8193 + 20000)]
+    lens0 = np.array([500, 8192, 8193, 20000], np.uint32)
+    g1 = alpha[rng.randint(0, 4, 30000)].copy()
+    g1[100:140] = ord("N")
+    g1[5000:5300] = np.frombuffer(b"acgtRYKMSWn", np.uint8)[rng.randint(0, 11, 300)]
+    g1[8185:8200] = ord("n")
+    lens1 = np.array([30000], np.uint32)
+    g2 = np.full(9000, ord("A"), np.uint8)          # homopolymer: every k-mer identical
+    g2[4000:4500] = alpha[rng.randint(0, 4, 500)]
+    lens2 = np.array([9000], np.uint32)
+    s, _ = _sketch(gpu, [lens0, lens1, lens2], [g0, g1, g2])
+    og = [oracle.Genome.from_bases(b, l, p) for b, l in ((g0, lens0), (g1, lens1), (g2, lens2))]
+    _compare_sketch(engine, s, oracle, og)
+
+
+def test_synth_device_matches_numpy(gpu):
+    engine, ctx, torch = gpu
+    from skder_amd import synth
+    rec = synth.make_recipe(6, genome_len=60000, n_species=2, strains_per_species=2)
+    layout = engine.BatchLayout(rec.rec_lens)
+    d = torch.zeros(layout.total_bytes, dtype=torch.uint8, device="cuda")
+    ctx.synth_fill(d.data_ptr(), layout, rec.lineage, rec.params)
+    torch.cuda.synchronize()
+    host = d.cpu().numpy()
+    r = 0
+    for g in range(rec.n):
+        bases = synth.bases_numpy(rec, g)
+        src = 0
+        for l in rec.rec_lens[g]:
+            o = int(layout.rec_off[r])
+            assert np.array_equal(host[o:o + int(l)], bases[src:src + int(l)]), "genome %d record %d" % (g, r)
+            src += int(l)
+            r += 1
+
+
+def _oracle_edges(oracle, genomes, p, screen):
+    out = {}
+    for i in range(len(genomes)):
+        for j in range(i + 1, len(genomes)):
+            ok, _ = oracle.screen(genomes[i], genomes[j], screen, p)
+            if not ok:
+                continue
+            r = oracle.pair(genomes[i], genomes[j], p)
+            if r.n_chains and r.ani > 0:
+                out[(i, j)] = r
+    return out
+
+
+def _check_edges(edges, want):
+    got = {(int(e["ref"]), int(e["query"])): e for e in edges}
+    assert set(got) == set(want), "pair sets differ: missing %s extra %s" % (sorted(set(want) - set(got))[:5],
+                                                                               sorted(set(got) - set(want))[:5])
+    for k, r in want.items():
+        e = got[k]
+        assert int(e["n_anchors"]) == r.n_anchors, (k, "anchors", int(e["n_anchors"]), r.n_anchors)
+        assert int(e["n_chains"]) == r.n_chains, (k, "chains", int(e["n_chains"]), r.n_chains)
+        assert int(e["sum_seeds"]) == r.sum_seeds, (k, "seeds")
+        assert int(e["ani_fx_sum"]) == r.ani_fx_sum, (k, "fx")
+        assert int(e["aligned_bases"]) == r.aligned_bases, (k, "B")
+        # doubles: bit-equal
+        assert float(e["ani"]) == r.ani, (k, float(e["ani"]), r.ani)
+        assert float(e["af_ref"]) == r.af_ref and float(e["af_query"]) == r.af_query, k
+
+
+def test_index_and_triangle_real(gpu, oracle):
+    engine, ctx, torch = gpu
+    p = oracle.default_params()
+    names = GENOMES[:8]
+    paths = [os.path.join(GOLDEN, "genomes", n) for n in names]
+    recs = [_read_records(x) for x in paths]
+    s, _ = _sketch(gpu, [r[0] for r in recs], [r[1] for r in recs])
+    s.index()
+    og = [oracle.Genome.load(x, p) for x in paths]
+    for g, o in enumerate(og):
+        d = s.debug_genome(g, o.n_seeds)
+        assert d["rep_cut"] == o.rep_cut
+        ok, opos, octg, _ = o.seeds()
+        off = o.contig_offsets()
+        chunk_key = octg.astype(np.int64) * (1 << 20) + (opos - off[octg]) // 20000
+        want = np.concatenate([[0], np.cumsum(chunk_key[1:] != chunk_key[:-1])]).astype(np.uint32)
+        assert np.array_equal(d["pchunk"], want)
+        assert d["n_chunks"] == int(want[-1]) + 1
+        # bucket order: same multiset, sorted by (kmer, gpos) inside each bucket
+        order = np.lexsort((d["sgpos"], d["skmer"] & 0x3FFFFFFF))
+        assert np.array_equal(np.sort(d["sgpos"]), np.sort(opos))
+        assert np.array_equal((d["skmer"][order] & 0x3FFFFFFF).astype(np.uint64), np.sort(ok))
+    edges = s.triangle_rows(0, 1, 89.5)
+    _check_edges(edges, _oracle_edges(oracle, og, p, 89.5))
+
+
+def test_triangle_synthetic_with_screen(gpu, oracle):
+    """two species: cross-species pairs must be screened out, within-species pairs must match"""
+    engine, ctx, torch = gpu
+    from skder_amd import synth
+    p = oracle.default_params()
+    rec = synth.make_recipe(12, genome_len=300000, n_species=2, strains_per_species=3)
+    layout = engine.BatchLayout(rec.rec_lens)
+    d = torch.zeros(layout.total_bytes, dtype=torch.uint8, device="cuda")
+    ctx.synth_fill(d.data_ptr(), layout, rec.lineage, rec.params)
+    s = engine.Sketches(ctx)
+    s.sketch_batch(d.data_ptr(), layout)
+    og = [oracle.Genome.from_bases(synth.bases_numpy(rec, g), rec.rec_lens[g], p) for g in range(rec.n)]
+    _compare_sketch(engine, s, oracle, og)
+    edges = s.triangle_rows(0, 1, 80.0)
+    want = _oracle_edges(oracle, og, p, 80.0)
+    assert all(rec.species[i] == rec.species[j] for i, j in want)
+    _check_edges(edges, want)
+    # row sharding (multi-GPU path): union over 3 strided row sets equals the full triangle
+    parts = [s.triangle_rows(r, 3, 80.0) for r in range(3)]
+    _check_edges(np.concatenate(parts), want)
+
+
+def test_dropin_tables_match_oracle_and_golden(gpu, oracle, tmp_path):
+    """file in, TSV out through the reference-shaped functions; text-identical with the oracle's
+    drivers, and within the oracle's measured tolerance of the reference's golden table G1"""
+    import skder_amd
+    p = oracle.default_params()
+    mapping = dict(line.rstrip("\n").split("\t") for line in open(os.path.join(GOLDEN, "plain_to_gz.tsv")))
+    gdir = tmp_path / "genomes"
+    gdir.mkdir()
+    for plain, gz in mapping.items():
+        with gzip.open(os.path.join(GOLDEN, "genomes", gz), "rb") as f, open(gdir / plain, "wb") as o:
+            o.write(f.read())
+    listing = tmp_path / "listing.txt"
+    listing.write_text("".join(str(gdir / n) + "\n" for n in sorted(mapping, reverse=True)))
+    out = tmp_path / "tri.tsv"
+    skder_amd.runSkaniTriangle(str(listing), str(out), "-s 89.0", 50.0, "greedy", False, None, threads=4)
+    ref = tmp_path / "tri_oracle.tsv"
+    oracle.triangle(str(listing), 50.0, 89.0, 4, str(ref), p)
+    assert out.read_text() == ref.read_text()
+    hdr, rows = load_table(str(out))
+    ghdr, grows = load_table(os.path.join(GOLDEN, "G1_triangle_minaf50_s89.tsv"))
+    assert hdr == ghdr
+    key = lambda r: (os.path.basename(r[0]), os.path.basename(r[1]))
+    assert [key(r) for r in rows] == [key(r) for r in grows]          # same rows, same order
+    for r, g in zip(rows, grows):
+        assert r[5:] == g[5:]
+        assert abs(float(r[2]) - float(g[2])) <= 0.65
+        assert abs(float(r[3]) - float(g[3])) <= 1.5 and abs(float(r[4]) - float(g[4])) <= 1.5
+    # rejected skani flags fail loudly
+    with pytest.raises(RuntimeError):
+        skder_amd.runSkaniTriangle(str(listing), str(tmp_path / "x.tsv"), "--no-learned-ani", 50.0, "greedy", False, None)
+    assert not (tmp_path / "x.tsv").exists()
+    # dist (G4 layout) and search
+    reps = tmp_path / "reps.txt"
+    nonreps = tmp_path / "nonreps.txt"
+    names = sorted(mapping)
+    reps.write_text("".join(str(gdir / n) + "\n" for n in names[:4]))
+    nonreps.write_text("".join(str(gdir / n) + "\n" for n in names[4:]))
+    from skder_amd import _lib
+    import ctypes as C
+    err = C.create_string_buffer(2048)
+    dout = tmp_path / "dist.tsv"
+    assert _lib.lib().skder_amd_dist(str(reps).encode(), str(nonreps).encode(), 15.0, 80.0, 0, str(dout).encode(), err, 2048) == 0, err.value
+    dref = tmp_path / "dist_oracle.tsv"
+    oracle.dist(str(reps), str(nonreps), 15.0, 80.0, 4, str(dref), p)
+    assert dout.read_text() == dref.read_text()
+    db = _lib.lib().skder_amd_sketch(str(listing).encode(), 0, err, 2048)
+    assert db, err.value
+    try:
+        q = str(gdir / names[2])
+        sout = tmp_path / "search.tsv"
+        assert _lib.lib().skder_amd_search(db, q.encode(), 15.0, 80.0, str(sout).encode(), err, 2048) == 0, err.value
+        sref = tmp_path / "search_oracle.tsv"
+        oracle.search(str(listing), q, 15.0, 80.0, 4, str(sref), p)
+        assert sout.read_text() == sref.read_text()
+        h, rows = load_table(str(sout))
+        assert any(r[0] == q and r[1] == q and r[2] == "100.00" for r in rows)   # the self hit
+    finally:
+        _lib.lib().skder_amd_db_free(db)
