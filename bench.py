@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""bench.py -- genome-pairs ANI/sec on the 5,000 x 3 Mb synthetic set (BASELINE.json metric).
+
+One "step" = one pass of the hot path over the whole batch: FracMinHash sketching of every genome
+(bases already resident in HBM), index, marker screen, anchors + chaining + ANI/AF of every screened
+pair, edge records back on the host.  value = N(N-1)/2 / step time.  With --gpus G > 1 (launched by
+torch.distributed.run) each rank sketches N/G genomes, the sketches are all-gathered over RCCL and
+the triangle rows are dealt cyclically: total work is fixed, so scaling is "strong".
+
+The JSON line also carries `roofline` (dominant kernel: algorithmic bytes / HIP-event time vs the
+8 TB/s HBM peak) and `cpu_baseline` (the CPU oracle timed on a bounded sample on this host)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(recipe, n_sample=10):
+    """oracle (CPU restatement, 1 thread) on a bounded sample of the same workload: per-genome
+    sketch time and per-chained-pair time, extrapolated to the full pair matrix."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py
+    from skder_amd import synth
+    p = oracle_py.default_params()
+    gs = list(range(n_sample))          # one species: every pair is chained
+    t0 = time.perf_counter()
+    bases = [synth.bases_numpy(recipe, g) for g in gs]
+    t1 = time.perf_counter()
+    og = [oracle_py.Genome.from_bases(b, recipe.rec_lens[g], p) for g, b in zip(gs, bases)]
+    t2 = time.perf_counter()
+    npair = 0
+    for i in range(n_sample):
+        for j in range(i + 1, n_sample):
+            if oracle_py.screen(og[i], og[j], 80.0, p)[0]:
+                oracle_py.pair(og[i], og[j], p)
+            npair += 1
+    t3 = time.perf_counter()
+    return (t2 - t1) / n_sample, (t3 - t2) / max(npair, 1), npair
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genomes", type=int, default=5000)
+    ap.add_argument("--genome-len", type=int, default=3_000_000)
+    ap.add_argument("--screen", type=float, default=80.0)
+    ap.add_argument("--batch-genomes", type=int, default=500)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from skder_amd import engine, multigpu, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    ctx = engine.Context(local_rank)
+
+    N = args.genomes
+    recipe = synth.make_recipe(N, genome_len=args.genome_len)
+    mine = multigpu.partition(N, world)[rank]
+    # inputs: generated on the device, resident in HBM before the timed region
+    batches = []
+    for b0 in range(mine.start, mine.stop, args.batch_genomes):
+        gs = range(b0, min(b0 + args.batch_genomes, mine.stop))
+        layout = engine.BatchLayout([recipe.rec_lens[g] for g in gs])
+        d = torch.empty(layout.total_bytes, dtype=torch.uint8, device="cuda")
+        ctx.synth_fill(d.data_ptr(), layout, recipe.lineage[gs.start:gs.stop], recipe.params[gs.start:gs.stop])
+        batches.append((layout, d))
+    total_bases = sum(l.total_bases for l, _ in batches)
+    torch.cuda.synchronize()
+
+    def step():
+        tm = np.zeros(8)
+        sk = engine.Sketches(ctx)
+        for layout, d in batches:
+            sk.sketch_batch(d.data_ptr(), layout)
+            t = ctx.timing()
+            tm[0] += t[0]; tm[1] += t[1]
+        if world > 1:
+            raw = multigpu.exchange_raw(multigpu.raw_from_sketches(sk))
+            sk.close()
+            sk = multigpu.sketches_from_raw(ctx, raw)
+        sk.index()
+        tm[1] += ctx.timing()[1] - (0 if world > 1 else 0)
+        edges = sk.triangle_rows(rank, world, args.screen)
+        t = ctx.timing()
+        tm[2:] = t[2:]
+        if world > 1:
+            edges = multigpu.gather_edges(edges)
+        sk.close()
+        return edges, tm
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    tms = []
+    for _ in range(args.steps):
+        edges, tm = step()
+        tms.append(tm)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    pairs = N * (N - 1) // 2
+    tm = np.mean(tms, axis=0)
+
+    if rank == 0:
+        # dominant kernel and its roofline (algorithmic bytes, DESIGN.md "Kernels")
+        n_chained, n_anchors = tm[6], tm[7]
+        sketch_bytes = total_bases * (1.0 + 8.0 / 125 + 8.0 / 1000)        # this rank's sketch kernel launches
+        seeds_per_genome = args.genome_len / 125.0
+        anchor_bytes = n_chained * (8.0 * seeds_per_genome) + 12.0 * n_anchors   # chunked seeds read + anchors written
+        chain_bytes = 20.0 * n_anchors                                           # anchors read, f/bp written
+        cand = {"sketch_tiles_kernel": (tm[0], sketch_bytes), "anchors_kernel": (tm[3], anchor_bytes),
+                "chain_kernel": (tm[4], chain_bytes)}
+        dom = max(cand, key=lambda k: cand[k][0])
+        dms, dbytes = cand[dom]
+        achieved = dbytes / (dms * 1e-3) / 1e9 if dms > 0 else 0.0
+        out = {
+            "metric": "genome-pairs ANI/sec on 5k x 3Mb synthetic", "value": pairs / (ms_per_step * 1e-3),
+            "unit": "genome-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u64 hash / i32 chaining / f64 ANI", "data": "synthetic",
+            "config": {"workload": "%d synthetic genomes x %.1f Mb (50 species x 10 strains x 10 isolates), triangle, screen %.0f"
+                       % (N, args.genome_len / 1e6, args.screen), "genomes": N, "pairs": pairs,
+                       "chained_pairs": int(n_chained * (world if world > 1 else 1)), "edges": int(len(edges)),
+                       "parallelism": "rows%d" % world},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms": {k: float(v[0]) for k, v in cand.items()},
+                         "other_ms": {"sketch_post": float(tm[1]), "screen": float(tm[2]), "finalize": float(tm[5])}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            t_sk, t_pair, npair = cpu_baseline(recipe)
+            n_chain_total = n_chained
+            est = N * t_sk + n_chain_total * t_pair
+            out["cpu_baseline"] = {"value": pairs / est, "unit": "genome-pairs/s", "cores": 1, "kind": "port",
+                                   "sample": "oracle (CPU restatement) on 10 genomes of one species: %.3f s/genome sketch, "
+                                             "%.4f s/chained pair (%d pairs); extrapolated to %d genomes + %d chained pairs"
+                                             % (t_sk, t_pair, npair, N, int(n_chain_total))}
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -205,3 +205,17 @@ def download(ptr: int, n: int, dtype) -> np.ndarray:
     if rc != 0:
         raise RuntimeError("hipMemcpy failed: %d" % rc)
     return t.cpu().numpy().view(dtype).copy()
+
+
+def download_tensor(ptr: int, n: int, torch_dtype):
+    """copy n elements from a raw device pointer into a new torch tensor on the current device"""
+    import torch
+    t = torch.empty(max(n, 0), dtype=torch_dtype, device="cuda")
+    if n:
+        torch.cuda.synchronize()
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        rc = hip.hipMemcpy(t.data_ptr(), ptr, n * t.element_size(), 3)
+        if rc != 0:
+            raise RuntimeError("hipMemcpy failed: %d" % rc)
+    return t

@@ -1,0 +1,95 @@
+"""Row-block sharding of the pair matrix over the GPUs of one node.
+
+One process per GPU.  Each rank sketches a contiguous block of genomes, the raw sketches
+(position-ordered seeds: 12 B/seed, sorted markers: 8 B/marker, record tables) are all-gathered
+with torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests),
+every rank builds the lookup index for ALL genomes (cheap next to sketching) and then computes the
+upper-triangle rows i = rank, rank + world, ... (cyclic, because row i has N-1-i entries).  Edge
+records are gathered on rank 0.  The only collective on the data path is the sketch all-gather."""
+from typing import Dict, List
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def partition(n: int, world: int) -> List[range]:
+    """contiguous, balanced blocks of genome indices"""
+    cuts = [(n * r) // world for r in range(world + 1)]
+    return [range(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def _allgather_var(t: torch.Tensor, counts: List[int], group=None) -> torch.Tensor:
+    """all-gather of a 1-D tensor whose length differs per rank: padded to the maximum, then trimmed"""
+    world = len(counts)
+    mx = max(max(counts), 1)
+    pad = torch.zeros(mx, dtype=t.dtype, device=t.device)
+    pad[: t.numel()] = t
+    out = [torch.empty(mx, dtype=t.dtype, device=t.device) for _ in range(world)]
+    dist.all_gather(out, pad, group=group)
+    return torch.cat([out[r][: counts[r]] for r in range(world)])
+
+
+def exchange_raw(raw: Dict, group=None) -> Dict:
+    """raw: dict with torch tensors seed_kmer/seed_gpos/seed_ctg (int32 views of u32) and markers
+    (int64 view of u64) of THIS rank's genomes, and numpy metadata seed_off, marker_off, genome_len,
+    genome_nrec, rec_goff.  Returns the same dict for the concatenation of all ranks' genomes."""
+    world = dist.get_world_size(group)
+    meta = dict(n_genomes=int(raw["n_genomes"]), n_seeds=int(raw["seed_kmer"].numel()),
+                n_markers=int(raw["markers"].numel()),
+                seed_off=np.asarray(raw["seed_off"], np.uint64), marker_off=np.asarray(raw["marker_off"], np.uint64),
+                genome_len=np.asarray(raw["genome_len"], np.uint64), genome_nrec=np.asarray(raw["genome_nrec"], np.uint32),
+                rec_goff=np.asarray(raw["rec_goff"], np.uint32))
+    metas = [None] * world
+    dist.all_gather_object(metas, meta, group=group)
+    out = dict(n_genomes=sum(m["n_genomes"] for m in metas))
+    for key, cnt in (("seed_kmer", "n_seeds"), ("seed_gpos", "n_seeds"), ("seed_ctg", "n_seeds"), ("markers", "n_markers")):
+        out[key] = _allgather_var(raw[key], [m[cnt] for m in metas], group)
+    so, mo = [np.zeros(1, np.uint64)], [np.zeros(1, np.uint64)]
+    sbase = mbase = np.uint64(0)
+    for m in metas:
+        so.append(m["seed_off"][1:] - m["seed_off"][0] + sbase)
+        mo.append(m["marker_off"][1:] - m["marker_off"][0] + mbase)
+        sbase = sbase + np.uint64(m["n_seeds"])
+        mbase = mbase + np.uint64(m["n_markers"])
+    out["seed_off"] = np.concatenate(so)
+    out["marker_off"] = np.concatenate(mo)
+    out["genome_len"] = np.concatenate([m["genome_len"] for m in metas])
+    out["genome_nrec"] = np.concatenate([m["genome_nrec"] for m in metas])
+    out["rec_goff"] = np.concatenate([m["rec_goff"] for m in metas])
+    return out
+
+
+def gather_edges(edges: np.ndarray, group=None) -> np.ndarray:
+    """edge records of all ranks on rank 0 (others get an empty array)"""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    bufs = [None] * world if rank == 0 else None
+    dist.gather_object(edges, bufs, dst=0, group=group)
+    if rank != 0:
+        return edges[:0]
+    return np.concatenate(bufs) if bufs else edges
+
+
+def raw_from_sketches(sk) -> Dict:
+    """wrap a Sketches object's raw arrays as torch tensors on the current device (one D2D copy)"""
+    from .engine import download_tensor
+    v = sk.view()
+    return dict(n_genomes=v["n_genomes"],
+                seed_kmer=download_tensor(v["d_seed_kmer"], v["n_seeds"], torch.int32),
+                seed_gpos=download_tensor(v["d_seed_gpos"], v["n_seeds"], torch.int32),
+                seed_ctg=download_tensor(v["d_seed_ctg"], v["n_seeds"], torch.int32),
+                markers=download_tensor(v["d_markers"], v["n_markers"], torch.int64),
+                seed_off=v["seed_off"], marker_off=v["marker_off"], genome_len=v["genome_len"],
+                genome_nrec=v["genome_nrec"], rec_goff=v["rec_goff"])
+
+
+def sketches_from_raw(ctx, raw: Dict):
+    """a new Sketches object holding the genomes described by `raw` (tensors on ctx's device)"""
+    from .engine import Sketches
+    s = Sketches(ctx)
+    torch.cuda.synchronize()
+    s.append_raw(raw["n_genomes"], raw["seed_kmer"].data_ptr(), raw["seed_gpos"].data_ptr(), raw["seed_ctg"].data_ptr(),
+                 raw["markers"].data_ptr(), raw["seed_off"], raw["marker_off"], raw["genome_len"], raw["genome_nrec"],
+                 raw["rec_goff"])
+    return s
