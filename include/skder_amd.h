@@ -136,9 +136,12 @@ int skder_amd_rectangle(skder_sketches_t *refs, skder_sketches_t *queries, doubl
                         const skder_edge_t **edges, uint64_t *n_edges);
 
 /* timing of the last triangle_rows/rectangle/sketch_batch call, milliseconds by HIP events on the
- * context's stream: [0] sketch kernel, [1] sketch post-processing, [2] screen, [3] anchors,
- * [4] chaining, [5] finalize; counts: [6] pairs screened in, [7] anchors */
+ * context's stream: [0] sketch kernel, [1] sketch post-processing + index, [2] screen,
+ * [3] chaining fast path, [4] chaining slow path, [5] finalize; counts: [6] pairs screened in, [7] anchors */
 int skder_amd_last_timing(skder_ctx_t *ctx, double *out8);
+/* counters of the last triangle_rows/rectangle call: [0] chunks processed, [1] chunks that needed the
+ * unabridged (slow) chaining path */
+int skder_amd_last_counters(skder_ctx_t *ctx, uint64_t *out4);
 
 /* synthetic genomes generated ON the device (SURVEY 8d recipe; bench.py / tests):
  * fills d_bases for one batch from (seed, species, strain, isolate) lineage ids. See synth.h. */

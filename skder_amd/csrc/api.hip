@@ -52,6 +52,7 @@ extern "C" void skder_amd_ctx_destroy(skder_ctx_t *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->chain_work && ctx->chain_work_free) ctx->chain_work_free(ctx->chain_work);
     for (auto &e : ctx->ev) (void)hipEventDestroy(e);
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -64,6 +65,12 @@ extern "C" int skder_amd_last_timing(skder_ctx_t *ctx, double *out8)
 {
     if (!ctx || !out8) return 1;
     for (int i = 0; i < 8; i++) out8[i] = ctx->timing[i];
+    return 0;
+}
+extern "C" int skder_amd_last_counters(skder_ctx_t *ctx, uint64_t *out4)
+{
+    if (!ctx || !out4) return 1;
+    for (int i = 0; i < 4; i++) out4[i] = ctx->counters[i];
     return 0;
 }
 

@@ -4,11 +4,12 @@
 // bit-identical by construction, the few double operations are + - * / in the oracle's order
 // (this file is compiled with -ffp-contract=off).
 //
-//   anchors_kernel   one workgroup per pair.  The chunked genome's seeds are read in position order
-//                    (coalesced), every seed probes the other genome's k-mer bucket index; matches
-//                    are written in order through a workgroup scan: 12 B per anchor.
-//   chain_kernel     one LANE per 20 kb chunk: banded DP (band 50, exact early exit on the running
-//                    maximum), best-first chain extraction with back-tracking; emits chain records.
+//   chain_fast_kernel  one LANE per (pair, 20 kb chunk): seeds streamed, hash-table probes, banded DP
+//                      against a 4-anchor register ring; exact for "simple" chunks, which it proves
+//                      as it goes; everything else is handed to the slow path.
+//   slow_*_kernel      unabridged algorithm for the declined chunks: ordered anchors via the bucket
+//                      index (one wave per chunk), full band-50 DP and best-first chain extraction
+//                      with back-tracking (one lane per chunk).
 //   finalize_kernel  one workgroup per pair: chains into LDS, better-chain overlap filter as a
 //                    parallel fix-point, fixed-point containment ANI, aligned fraction.
 #include "device_utils.h"
@@ -20,16 +21,17 @@ struct SetView {
     const uint32_t *pkmer, *pgpos, *pchunk;   // position order
     const uint32_t *skmer, *sgpos, *sctg;     // bucket order
     const uint32_t *boff;
+    const uint32_t *chunk_start;
+    const uint4 *table;
 };
 
 struct PairDesc {
     uint32_t q, r;          // chunked genome, other genome (indices inside their sets)
-    uint32_t a_base, a_cap; // anchor region of this pair in the batch buffers
-    uint32_t chunk_base;    // first entry of this pair in chunk_aoff (n_chunks + 1 entries)
+    uint32_t chunk_base;    // first work item (chunk) of this pair in the batch
     uint32_t n_chunks;
-    uint32_t c_base, c_cap; // chain-record region
+    uint32_t c_base, c_cap; // chain-record region of the slow path
     uint32_t flags;         // bit0: chunked genome is the pair's Query; bit1: q in set B; bit2: r in set B
-    uint32_t pad[3];
+    uint32_t pad;
 };
 
 struct ChainRec {
@@ -46,27 +48,284 @@ struct PairOut {
 
 #define USED_BIT 0x80000000u
 #define FIN_LDS_CHAINS 2048
+#define FAST_SLOTS 3
+#define RING 4
+#define CHUNK_SLOW 0xFFFFFFFFu
+#define SUCC_BIT 0x80000000u
 
-__global__ __launch_bounds__(256) void anchors_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs,
-                                                      uint32_t *__restrict__ a_qi, uint32_t *__restrict__ a_r,
-                                                      uint32_t *__restrict__ a_rctg, uint32_t *__restrict__ chunk_aoff,
-                                                      uint32_t *__restrict__ pair_na, uint32_t *__restrict__ flags)
+__device__ __forceinline__ uint32_t find_pair(const PairDesc *__restrict__ pairs, uint32_t npairs, uint32_t t)
 {
-    __shared__ uint32_t wsum[4];
-    const PairDesc pd = pairs[blockIdx.x];
+    uint32_t lo = 0, hi = npairs;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (pairs[mid].chunk_base <= t) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// ---------------------------------------------------------------------------------------------
+// FAST PATH: one lane per (pair, 20 kb chunk), no intermediate arrays.
+// The lane streams the chunk's seeds, probes the other genome's hash table (one 16-byte slot read
+// per probe) and runs the banded chaining DP against a 4-anchor register ring.  The result is
+// exact whenever the chunk is "simple": every DP look-back ends inside the ring (early exit on the
+// running maximum or the 2500-base band), predecessor links form disjoint paths with strictly
+// increasing scores, at most 4 hits per seed and at most FAST_SLOTS chains.  Otherwise the chunk is
+// handed to the slow path below, which runs the unabridged algorithm.
+struct RingE {
+    uint32_t qpos, rr, rctg;
+    int32_t f;
+    uint32_t cnt;        // anchors on the path ending here | SUCC_BIT when another anchor chained to it
+    uint32_t first_qi, rmin, rmax, qi;
+    uint32_t path;       // ordinal of the path's first anchor: identifies the path
+};
+
+__global__ __launch_bounds__(256) void chain_fast_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs, uint32_t npairs,
+                                                         uint32_t total_chunks, ChainRec *__restrict__ fast_chains,
+                                                         uint32_t *__restrict__ chunk_state, uint32_t *__restrict__ slow_list,
+                                                         uint32_t *__restrict__ slow_count, uint32_t *__restrict__ pair_na)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= total_chunks) return;
+    const uint32_t pi = find_pair(pairs, npairs, t);
+    const PairDesc pd = pairs[pi];
+    const uint32_t c = t - pd.chunk_base;
+    const SetView &QS = (pd.flags & 2u) ? B : A;
+    const SetView &RS = (pd.flags & 4u) ? B : A;
+    const GenomeMeta *Qm = QS.meta + pd.q, *Rm = RS.meta + pd.r;
+    const uint64_t qoff = Qm->seed_off;
+    const uint32_t *qk = QS.pkmer + qoff, *qg = QS.pgpos + qoff;
+    const uint32_t s0 = QS.chunk_start[Qm->chunk_off + c], s1 = QS.chunk_start[Qm->chunk_off + c + 1];
+    const uint4 *tab = RS.table + Rm->table_off;
+    const uint32_t tbits = Rm->table_bits, tmask = (1u << tbits) - 1u, rrep = Rm->rep_cut;
+    bool cplx = Qm->rep_cut != 0xFFFFFFFFu;   // own-multiplicity filter active: leave it to the slow path
+    uint32_t cause = cplx ? 6u : 0u;
+
+    RingE r0, r1, r2, r3;
+    r0.cnt = r1.cnt = r2.cnt = r3.cnt = 0;
+    r0.f = r1.f = r2.f = r3.f = 0;
+    r0.qpos = r1.qpos = r2.qpos = r3.qpos = 0; r0.rr = r1.rr = r2.rr = r3.rr = 0; r0.rctg = r1.rctg = r2.rctg = r3.rctg = 0;
+    r0.first_qi = r1.first_qi = r2.first_qi = r3.first_qi = 0; r0.rmin = r1.rmin = r2.rmin = r3.rmin = 0;
+    r0.rmax = r1.rmax = r2.rmax = r3.rmax = 0; r0.qi = r1.qi = r2.qi = r3.qi = 0;
+    r0.path = r1.path = r2.path = r3.path = 0;
+    uint32_t ia = 0, nfin = 0;
+    int32_t runmax = -0x40000000;
+    // summaries of the anchors that already left the ring, by path: the two most recent paths
+    // (key = record | strand<<31, best score = score of the last evicted anchor because scores rise
+    // along a path, query position of that anchor) plus one conservative scalar for older paths
+    const int32_t NEG = -0x40000000;
+    uint32_t s0_path = 0xFFFFFFFFu, s0_key = 0, s0_q = 0, s1_path = 0xFFFFFFFFu, s1_key = 0, s1_q = 0, lost_q = 0;
+    int32_t s0_f = NEG, s1_f = NEG, lost_f = NEG;
+    // diagonal range (rpos - qpos, or rpos + qpos on the reverse strand) of each summary: an anchor
+    // more than max_gap away from the whole range cannot chain to any anchor of the summary
+    int32_t s0_dlo = 0, s0_dhi = 0, s1_dlo = 0, s1_dhi = 0, lost_dlo = 0, lost_dhi = 0;
+    ChainRec *slots = fast_chains + (uint64_t)t * FAST_SLOTS;
+
+#define EMIT_PATH(E)                                                                         \
+    do {                                                                                     \
+        if (!((E).cnt & SUCC_BIT) && (E).cnt >= ANI_MIN_ANCHORS) {                           \
+            if (nfin >= FAST_SLOTS) { cplx = true; cause = 1; }                                             \
+            else {                                                                           \
+                ChainRec cr;                                                                 \
+                cr.score = (E).f; cr.n = (E).cnt; cr.n_seeds = (E).qi - (E).first_qi + 1;    \
+                cr.q0 = qg[(E).first_qi]; cr.q1 = (E).qpos; cr.r0 = (E).rmin; cr.r1 = (E).rmax; cr.rctg = (E).rctg; \
+                slots[nfin++] = cr;                                                          \
+            }                                                                                \
+        }                                                                                    \
+    } while (0)
+
+    // software pipeline: the first table slot of seed s+1 is requested while seed s is processed
+    uint32_t km_n = 0;
+    int32_t qp_n = 0;
+    uint4 sl_n = make_uint4(TABLE_EMPTY, 0, 0, 0);
+    uint32_t h_n = 0;
+    if (s0 < s1 && !cplx) {
+        km_n = qk[s0]; qp_n = (int32_t)qg[s0];
+        h_n = kmer_bucket(km_n & SK_SEED_MASK, tbits);
+        sl_n = tab[h_n];
+    }
+    for (uint32_t s = s0; s < s1 && !cplx; s++) {
+        const uint32_t km = km_n, kmer = km & SK_SEED_MASK;
+        const int32_t qp = qp_n;
+        uint32_t h = h_n;
+        uint4 sl = sl_n;
+        if (s + 1 < s1) {
+            km_n = qk[s + 1]; qp_n = (int32_t)qg[s + 1];
+            h_n = kmer_bucket(km_n & SK_SEED_MASK, tbits);
+            sl_n = tab[h_n];
+        }
+        uint32_t m = 0, g0 = 0xFFFFFFFFu, g1 = 0xFFFFFFFFu, g2 = 0xFFFFFFFFu, g3 = 0xFFFFFFFFu, c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        for (;;) {
+            if (sl.x == TABLE_EMPTY) break;
+            if ((sl.x & SK_SEED_MASK) == kmer) {
+                // payload: gpos | rev<<31 ; record ; w = multiplicity of the k-mer in this genome
+                const uint32_t rv = ((km >> 31) != (sl.x >> 31)) ? USED_BIT : 0u;
+                if (m == 0) { g0 = sl.y | rv; c0 = sl.z; }
+                else if (m == 1) { g1 = sl.y | rv; c1 = sl.z; }
+                else if (m == 2) { g2 = sl.y | rv; c2 = sl.z; }
+                else if (m == 3) { g3 = sl.y | rv; c3 = sl.z; }
+                m++;
+                if (m >= sl.w) break;   // all occurrences seen
+            }
+            h = (h + 1) & tmask;
+            sl = tab[h];
+        }
+        if (m == 0 || m > rrep) continue;
+        if (m > 4) { cplx = true; cause = 2; break; }
+        if (m > 1) {   // ascending gpos (ignoring the strand bit): 5-comparator network on 4 slots
+#define CSWAP(ga, ca, gb, cb) if (((gb) & 0x7FFFFFFFu) < ((ga) & 0x7FFFFFFFu) && (gb) != 0xFFFFFFFFu) { uint32_t tg = ga; ga = gb; gb = tg; uint32_t tc = ca; ca = cb; cb = tc; }
+            // unused slots hold 0xFFFFFFFF and must stay behind the used ones
+            CSWAP(g0, c0, g1, c1) CSWAP(g2, c2, g3, c3) CSWAP(g0, c0, g2, c2) CSWAP(g1, c1, g3, c3) CSWAP(g1, c1, g2, c2)
+#undef CSWAP
+        }
+        for (uint32_t u = 0; u < m && !cplx; u++) {
+            const uint32_t rr = g0, rc = c0;
+            g0 = g1; c0 = c1; g1 = g2; c1 = c2; g2 = g3; c2 = c3;
+            const int32_t rp = (int32_t)(rr & 0x7FFFFFFFu);
+            const uint32_t rev = rr >> 31;
+            int32_t best = ANI_ANCHOR_SCORE;
+            int bj = -1;
+            bool exact = false;
+            uint32_t pcnt = 0, pfirst = 0, prmin = 0, prmax = 0, ppath = 0;
+            int32_t pf = 0;
+#define TRY(K, E)                                                                                   \
+            if (!exact) {                                                                           \
+                if ((K) >= ia) exact = true;                                                        \
+                else if (best >= runmax + ANI_ANCHOR_SCORE) exact = true;                           \
+                else {                                                                              \
+                    const int32_t dq = qp - (int32_t)(E).qpos;                                      \
+                    if (dq > ANI_BP_BAND) exact = true;                                             \
+                    else if ((E).rctg == rc && ((E).rr >> 31) == rev) {                             \
+                        const int32_t rpj = (int32_t)((E).rr & 0x7FFFFFFFu);                        \
+                        const int32_t dr = rev ? rpj - rp : rp - rpj;                               \
+                        if (dq > 0 && dr > 0 && dq <= ANI_MAX_LIN && dr <= ANI_MAX_LIN) {           \
+                            const int32_t gap = dq > dr ? dq - dr : dr - dq;                        \
+                            if (gap <= ANI_MAX_GAP) {                                               \
+                                const int32_t sc = (E).f + ANI_ANCHOR_SCORE - gap;                  \
+                                if (sc > best) { best = sc; bj = (K); pcnt = (E).cnt; pfirst = (E).first_qi; \
+                                                 prmin = (E).rmin; prmax = (E).rmax; pf = (E).f; ppath = (E).path; } \
+                            }                                                                       \
+                        }                                                                           \
+                    }                                                                               \
+                }                                                                                   \
+            }
+            TRY(0, r0) TRY(1, r1) TRY(2, r2) TRY(3, r3)
+#undef TRY
+            if (!exact && ia > RING) {
+                // ring exhausted: the full algorithm would go on to the anchors that already left the
+                // ring.  They cannot change (best, bj) when they are outside the 2500-base band, on
+                // another record/strand, or cannot reach `best` (score + 20 at zero gap cost).
+                const uint32_t key = rc | (rev << 31);
+                const int32_t dg = rev ? rp + qp : rp - qp;
+                bool ok = true;
+                if (s0_path != 0xFFFFFFFFu && qp - (int32_t)s0_q <= ANI_BP_BAND && s0_key == key && dg >= s0_dlo - ANI_MAX_GAP &&
+                    dg <= s0_dhi + ANI_MAX_GAP && !(best >= s0_f + ANI_ANCHOR_SCORE)) ok = false;
+                if (s1_path != 0xFFFFFFFFu && qp - (int32_t)s1_q <= ANI_BP_BAND && s1_key == key && dg >= s1_dlo - ANI_MAX_GAP &&
+                    dg <= s1_dhi + ANI_MAX_GAP && !(best >= s1_f + ANI_ANCHOR_SCORE)) ok = false;
+                if (lost_f != NEG && qp - (int32_t)lost_q <= ANI_BP_BAND && dg >= lost_dlo - ANI_MAX_GAP && dg <= lost_dhi + ANI_MAX_GAP &&
+                    !(best >= lost_f + ANI_ANCHOR_SCORE)) ok = false;
+                if (!ok) { cplx = true; cause = 3; break; }
+            }
+            RingE e;
+            e.qpos = (uint32_t)qp; e.rr = rr; e.rctg = rc; e.f = best; e.qi = s;
+            if (bj >= 0) {
+                if ((pcnt & SUCC_BIT) || !(best > pf)) { cplx = true; cause = (pcnt & SUCC_BIT) ? 4 : 5; break; }   // branch, or score not increasing
+                if (bj == 0) r0.cnt |= SUCC_BIT; else if (bj == 1) r1.cnt |= SUCC_BIT;
+                else if (bj == 2) r2.cnt |= SUCC_BIT; else r3.cnt |= SUCC_BIT;
+                e.cnt = (pcnt & 0x7FFFFFFFu) + 1u;
+                e.first_qi = pfirst;
+                e.path = ppath;
+                e.rmin = (uint32_t)rp < prmin ? (uint32_t)rp : prmin;
+                e.rmax = (uint32_t)rp > prmax ? (uint32_t)rp : prmax;
+            } else {
+                e.cnt = 1; e.first_qi = s; e.rmin = e.rmax = (uint32_t)rp; e.path = ia;
+            }
+            if (ia >= RING) {
+                EMIT_PATH(r3);   // the anchor leaving the ring can no longer be extended
+                const uint32_t k3 = r3.rctg | ((r3.rr >> 31) << 31);
+                const int32_t d3 = (r3.rr >> 31) ? (int32_t)(r3.rr & 0x7FFFFFFFu) + (int32_t)r3.qpos
+                                                 : (int32_t)(r3.rr & 0x7FFFFFFFu) - (int32_t)r3.qpos;
+                if (r3.path == s0_path) {
+                    s0_f = r3.f; s0_q = r3.qpos;
+                    s0_dlo = d3 < s0_dlo ? d3 : s0_dlo; s0_dhi = d3 > s0_dhi ? d3 : s0_dhi;
+                } else {
+                    const bool was_s1 = r3.path == s1_path;
+                    const int32_t nlo = was_s1 ? (d3 < s1_dlo ? d3 : s1_dlo) : d3, nhi = was_s1 ? (d3 > s1_dhi ? d3 : s1_dhi) : d3;
+                    if (!was_s1 && s1_path != 0xFFFFFFFFu) {   // the older summary falls out: fold it into the scalar
+                        if (lost_f == NEG) { lost_dlo = s1_dlo; lost_dhi = s1_dhi; }
+                        else { lost_dlo = s1_dlo < lost_dlo ? s1_dlo : lost_dlo; lost_dhi = s1_dhi > lost_dhi ? s1_dhi : lost_dhi; }
+                        lost_f = s1_f > lost_f ? s1_f : lost_f; lost_q = s1_q > lost_q ? s1_q : lost_q;
+                    }
+                    s1_path = s0_path; s1_key = s0_key; s1_f = s0_f; s1_q = s0_q; s1_dlo = s0_dlo; s1_dhi = s0_dhi;
+                    s0_path = r3.path; s0_key = k3; s0_f = r3.f; s0_q = r3.qpos; s0_dlo = nlo; s0_dhi = nhi;
+                }
+            }
+            r3 = r2; r2 = r1; r1 = r0; r0 = e;
+            ia++;
+            runmax = best > runmax ? best : runmax;
+        }
+    }
+    if (!cplx) {
+        if (ia > 3) EMIT_PATH(r3);
+        if (ia > 2 && !cplx) EMIT_PATH(r2);
+        if (ia > 1 && !cplx) EMIT_PATH(r1);
+        if (ia > 0 && !cplx) EMIT_PATH(r0);
+    }
+#undef EMIT_PATH
+    if (cplx) {
+        chunk_state[t] = CHUNK_SLOW;
+        slow_list[atomicAdd(slow_count, 1u)] = t;
+        atomicAdd(slow_count + 1 + cause, 1u);
+    } else {
+        chunk_state[t] = nfin;
+        if (ia) atomicAdd(&pair_na[pi], ia);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SLOW PATH (unabridged algorithm) for the chunks the fast path declined
+
+__global__ __launch_bounds__(256) void slow_caps_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs, uint32_t npairs,
+                                                        const uint32_t *__restrict__ slow_list, uint32_t nslow,
+                                                        uint32_t *__restrict__ cap)
+{
+    const uint32_t w = blockIdx.x * 256u + threadIdx.x;
+    if (w > nslow) return;
+    if (w == nslow) { cap[w] = 0; return; }
+    const uint32_t t = slow_list[w];
+    const PairDesc pd = pairs[find_pair(pairs, npairs, t)];
+    const SetView &QS = (pd.flags & 2u) ? B : A;
+    const GenomeMeta *Qm = QS.meta + pd.q;
+    const uint32_t c = t - pd.chunk_base;
+    const uint32_t s0 = QS.chunk_start[Qm->chunk_off + c], s1 = QS.chunk_start[Qm->chunk_off + c + 1];
+    cap[w] = 4u * (s1 - s0) + 64u;
+}
+
+// one wavefront per slow chunk: ordered anchors through the bucket index (hits in ascending gpos)
+__global__ __launch_bounds__(256) void slow_anchors_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs, uint32_t npairs,
+                                                           const uint32_t *__restrict__ slow_list, uint32_t nslow,
+                                                           const uint32_t *__restrict__ abase, uint32_t *__restrict__ a_qi,
+                                                           uint32_t *__restrict__ a_r, uint32_t *__restrict__ a_rctg,
+                                                           uint32_t *__restrict__ slow_n, uint32_t *__restrict__ flags)
+{
+    const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (w >= nslow) return;
+    const uint32_t t = slow_list[w];
+    const PairDesc pd = pairs[find_pair(pairs, npairs, t)];
     const SetView &QS = (pd.flags & 2u) ? B : A;
     const SetView &RS = (pd.flags & 4u) ? B : A;
     const GenomeMeta Q = QS.meta[pd.q], R = RS.meta[pd.r];
-    const uint32_t *qk = QS.pkmer + Q.seed_off, *qc = QS.pchunk + Q.seed_off;
+    const uint32_t c = t - pd.chunk_base;
+    const uint32_t s0 = QS.chunk_start[Q.chunk_off + c], s1 = QS.chunk_start[Q.chunk_off + c + 1];
+    const uint32_t *qk = QS.pkmer + Q.seed_off;
     const uint32_t *rk = RS.skmer + R.seed_off, *rg = RS.sgpos + R.seed_off, *rc = RS.sctg + R.seed_off;
     const uint32_t *rb = RS.boff + R.bucket_off;
     const uint32_t *qsk = QS.skmer + Q.seed_off, *qb = QS.boff + Q.bucket_off;
-    const uint32_t tid = threadIdx.x, nq = Q.n_seeds;
+    const uint32_t base_out = abase[w], cap = abase[w + 1] - abase[w];
     uint32_t running = 0;
-    for (uint32_t base = 0; base < nq; base += 256) {
-        const uint32_t s = base + tid;
+    for (uint32_t sb = s0; sb < s1; sb += 64) {
+        const uint32_t s = sb + lane;
         uint32_t cnt = 0, first = 0, km = 0;
-        if (s < nq) {
+        if (s < s1) {
             km = qk[s];
             const uint32_t kmer = km & SK_SEED_MASK;
             const uint32_t b = kmer_bucket(kmer, R.bucket_bits);
@@ -85,21 +344,15 @@ __global__ __launch_bounds__(256) void anchors_kernel(SetView A, SetView B, cons
             }
         }
         uint32_t total;
-        const uint32_t ex = block_excl_scan_256(cnt, wsum, total);
-        const uint32_t at = running + ex;
-        if (s < nq) {
-            const uint32_t ck = qc[s];
-            if (s == 0 || qc[s - 1] != ck) chunk_aoff[pd.chunk_base + ck] = pd.a_base + (at < pd.a_cap ? at : pd.a_cap);
-        }
+        const uint32_t at = running + wave_excl_scan(cnt, total);
         if (cnt) {
-            if (at + cnt <= pd.a_cap) {
-                for (uint32_t t = 0; t < cnt; t++) {
-                    const uint32_t idx = pd.a_base + at + t;
-                    const uint32_t rkm = rk[first + t];
-                    const uint32_t rev = (km >> 31) != (rkm >> 31);
+            if (at + cnt <= cap) {
+                for (uint32_t u = 0; u < cnt; u++) {
+                    const uint32_t idx = base_out + at + u;
+                    const uint32_t rkm = rk[first + u];
                     a_qi[idx] = s;
-                    a_r[idx] = rg[first + t] | (rev ? USED_BIT : 0u);
-                    a_rctg[idx] = rc[first + t];
+                    a_r[idx] = rg[first + u] | (((km >> 31) != (rkm >> 31)) ? USED_BIT : 0u);
+                    a_rctg[idx] = rc[first + u];
                 }
             } else {
                 atomicOr(&flags[0], 4u);
@@ -107,31 +360,26 @@ __global__ __launch_bounds__(256) void anchors_kernel(SetView A, SetView B, cons
         }
         running += total;
     }
-    if (tid == 0) {
-        chunk_aoff[pd.chunk_base + pd.n_chunks] = pd.a_base + (running < pd.a_cap ? running : pd.a_cap);
-        pair_na[blockIdx.x] = running;
-    }
+    if (lane == 0) slow_n[w] = running < cap ? running : cap;
 }
 
-__global__ __launch_bounds__(256) void chain_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs, uint32_t npairs,
-                                                    uint32_t total_entries, const uint32_t *__restrict__ a_qi,
-                                                    const uint32_t *__restrict__ a_r, const uint32_t *__restrict__ a_rctg,
-                                                    const uint32_t *__restrict__ chunk_aoff, int32_t *__restrict__ F,
-                                                    uint32_t *__restrict__ BP, ChainRec *__restrict__ chains,
-                                                    uint32_t *__restrict__ pair_nch, uint32_t *__restrict__ flags)
+__global__ __launch_bounds__(256) void slow_chain_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs, uint32_t npairs,
+                                                         const uint32_t *__restrict__ slow_list, uint32_t nslow,
+                                                         const uint32_t *__restrict__ abase, const uint32_t *__restrict__ slow_n,
+                                                         const uint32_t *__restrict__ a_qi, const uint32_t *__restrict__ a_r,
+                                                         const uint32_t *__restrict__ a_rctg, int32_t *__restrict__ F,
+                                                         uint32_t *__restrict__ BP, ChainRec *__restrict__ chains,
+                                                         uint32_t *__restrict__ pair_nch, uint32_t *__restrict__ pair_na,
+                                                         uint32_t *__restrict__ flags)
 {
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if (t >= total_entries) return;
-    uint32_t lo = 0, hi = npairs;
-    while (hi - lo > 1) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (pairs[mid].chunk_base <= t) lo = mid; else hi = mid;
-    }
+    const uint32_t w = blockIdx.x * 256u + threadIdx.x;
+    if (w >= nslow) return;
+    const uint32_t t = slow_list[w];
+    const uint32_t lo = find_pair(pairs, npairs, t);
     const PairDesc pd = pairs[lo];
-    if (t - pd.chunk_base >= pd.n_chunks) return;   // the end sentinel
-    const uint32_t a0 = chunk_aoff[t], a1 = chunk_aoff[t + 1];
-    if (a1 <= a0) return;
-    const uint32_t n = a1 - a0;
+    const uint32_t a0 = abase[w], n = slow_n[w];
+    if (!n) return;
+    atomicAdd(&pair_na[lo], n);
     const SetView &QS = (pd.flags & 2u) ? B : A;
     const uint32_t *qg = QS.pgpos + QS.meta[pd.q].seed_off;
     const uint32_t *qi = a_qi + a0, *ar = a_r + a0, *ac = a_rctg + a0;
@@ -263,6 +511,7 @@ __device__ __forceinline__ bool better(const int32_t *sc, const uint32_t *q0, co
 }
 
 __global__ __launch_bounds__(256) void finalize_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs,
+                                                       const ChainRec *__restrict__ fast_chains, const uint32_t *__restrict__ chunk_state,
                                                        const ChainRec *__restrict__ chains, const uint32_t *__restrict__ pair_nch,
                                                        const uint32_t *__restrict__ pair_na, PairOut *__restrict__ out,
                                                        uint32_t *__restrict__ flags)
@@ -272,22 +521,38 @@ __global__ __launch_bounds__(256) void finalize_kernel(SetView A, SetView B, con
     __shared__ uint32_t na[FIN_LDS_CHAINS], nsd[FIN_LDS_CHAINS];
     __shared__ uint8_t state[FIN_LDS_CHAINS];   // 0 unknown, 1 kept, 2 dropped
     __shared__ unsigned long long s_fx, s_seeds, s_anch, s_span;
-    __shared__ uint32_t s_kept, s_unknown;
+    __shared__ uint32_t s_kept, s_unknown, s_n;
 
     const PairDesc pd = pairs[blockIdx.x];
     const uint32_t tid = threadIdx.x;
-    uint32_t n = pair_nch[blockIdx.x];
-    if (n > pd.c_cap) n = pd.c_cap;
+    if (tid == 0) { s_fx = 0; s_seeds = 0; s_anch = 0; s_span = 0; s_kept = 0; s_unknown = 0; s_n = 0; }
+    __syncthreads();
+    // gather: chains of the fast path (per-chunk slots) and of the slow path (per-pair list)
+    uint32_t nslow = pair_nch[blockIdx.x];
+    if (nslow > pd.c_cap) nslow = pd.c_cap;
+    const uint32_t nfast_items = pd.n_chunks * FAST_SLOTS;
+    for (uint32_t i = tid; i < nfast_items + nslow; i += 256) {
+        ChainRec c;
+        if (i < nfast_items) {
+            const uint32_t ck = i / FAST_SLOTS, k = i - ck * FAST_SLOTS;
+            const uint32_t st = chunk_state[pd.chunk_base + ck];
+            if (st == CHUNK_SLOW || k >= st) continue;
+            c = fast_chains[(uint64_t)(pd.chunk_base + ck) * FAST_SLOTS + k];
+        } else {
+            c = chains[pd.c_base + (i - nfast_items)];
+        }
+        const uint32_t d = atomicAdd(&s_n, 1u);
+        if (d < FIN_LDS_CHAINS) {
+            sc[d] = c.score; q0[d] = c.q0; q1[d] = c.q1; r0[d] = c.r0; r1[d] = c.r1; rc[d] = c.rctg;
+            na[d] = c.n; nsd[d] = c.n_seeds;
+            state[d] = 0;
+        }
+    }
+    __syncthreads();
+    uint32_t n = s_n;
     if (n > FIN_LDS_CHAINS) {
         if (tid == 0) atomicOr(&flags[0], 16u);
         n = FIN_LDS_CHAINS;
-    }
-    if (tid == 0) { s_fx = 0; s_seeds = 0; s_anch = 0; s_span = 0; s_kept = 0; s_unknown = 0; }
-    for (uint32_t i = tid; i < n; i += 256) {
-        const ChainRec c = chains[pd.c_base + i];
-        sc[i] = c.score; q0[i] = c.q0; q1[i] = c.q1; r0[i] = c.r0; r1[i] = c.r1; rc[i] = c.rctg;
-        na[i] = c.n; nsd[i] = c.n_seeds;
-        state[i] = 0;
     }
     __syncthreads();
     // a chain is dropped when ONE better kept chain on the same record covers more than half of
@@ -367,6 +632,7 @@ static SetView view_of(skder_sketches *s)
     v.meta = s->d_meta.p;
     v.pkmer = s->seed_kmer.p; v.pgpos = s->seed_gpos.p; v.pchunk = s->pchunk.p;
     v.skmer = s->skmer.p; v.sgpos = s->sgpos.p; v.sctg = s->sctg.p; v.boff = s->boff.p;
+    v.chunk_start = s->chunk_start.p; v.table = s->table.p;
     return v;
 }
 
@@ -379,6 +645,24 @@ static bool chunk_the_query(const GenomeMeta &ref, const GenomeMeta &query)
     return sq <= sr;
 }
 
+// work buffers of chain_pairs, kept across calls (grow-only) so that steady-state calls allocate nothing
+struct ChainWork {
+    DevBuf<PairDesc> d_pairs;
+    DevBuf<uint32_t> chunk_state, slow_list, counters, pair_na, pair_nch, cap, abase, slow_n, a_qi, a_r, a_rctg, BP;
+    DevBuf<int32_t> F;
+    DevBuf<ChainRec> fast_chains, chains;
+    DevBuf<PairOut> d_out;
+    ScanWorkspace ws;
+};
+static ChainWork *chain_work(skder_ctx *ctx)
+{
+    if (!ctx->chain_work) {
+        ctx->chain_work = new ChainWork();
+        ctx->chain_work_free = [](void *p) { delete static_cast<ChainWork *>(p); };
+    }
+    return static_cast<ChainWork *>(ctx->chain_work);
+}
+
 // pairs: (ref genome in set A, query genome in set B); for the triangle A == B.
 void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint32_t> &pref, const std::vector<uint32_t> &pquery,
                  std::vector<skder_edge_t> &edges)
@@ -386,22 +670,18 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
     skder_ctx *ctx = SA->ctx;
     hipStream_t st = ctx->stream;
     const size_t np = pref.size();
-    size_t budget = 256u << 20;   // anchors per batch (x 20 B)
-    if (const char *e = getenv("SKDER_AMD_ANCHOR_BUDGET")) budget = strtoull(e, nullptr, 10);
-    DevBuf<PairDesc> d_pairs;
-    DevBuf<uint32_t> a_qi, a_r, a_rctg, BP, chunk_aoff, pair_na, pair_nch;
-    DevBuf<int32_t> F;
-    DevBuf<ChainRec> chains;
-    DevBuf<PairOut> d_out;
+    size_t budget = 6u << 20;   // chunks (work items) per batch
+    if (const char *e = getenv("SKDER_AMD_CHUNK_BUDGET")) budget = strtoull(e, nullptr, 10);
+    ChainWork &W = *chain_work(ctx);
     std::vector<PairDesc> hp;
     std::vector<PairOut> ho;
     const SetView VA = view_of(SA), VB = view_of(SB);
-    double t_anchor = 0, t_chain = 0, t_fin = 0;
-    uint64_t tot_anchors = 0;
+    double t_fast = 0, t_slow = 0, t_fin = 0;
+    uint64_t tot_anchors = 0, tot_slow = 0, tot_chunks = 0;
     size_t p0 = 0;
     while (p0 < np) {
         hp.clear();
-        uint64_t acap = 0, nentries = 0, ccap = 0;
+        uint64_t nchunks = 0, ccap = 0;
         size_t p = p0;
         for (; p < np; p++) {
             const GenomeMeta &mr = SA->h_meta[pref[p]], &mq = SB->h_meta[pquery[p]];
@@ -412,49 +692,72 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
             d.q = cq ? pquery[p] : pref[p];
             d.r = cq ? pref[p] : pquery[p];
             d.flags = (cq ? 1u : 0u) | (cq ? 2u : 0u) | (cq ? 0u : 4u);   // Q in B iff cq; R in B iff !cq
-            d.a_cap = 2u * Q.n_seeds + 1024u;
             d.n_chunks = Q.n_chunks;
             d.c_cap = 4u * Q.n_chunks + 64u;
-            if (!hp.empty() && acap + d.a_cap > budget) break;
-            if (acap + d.a_cap > 0xFFFF0000ull || nentries + d.n_chunks + 1 > 0xFFFF0000ull) break;
-            d.a_base = (uint32_t)acap; d.chunk_base = (uint32_t)nentries; d.c_base = (uint32_t)ccap;
-            acap += d.a_cap; nentries += d.n_chunks + 1; ccap += d.c_cap;
+            if (!hp.empty() && nchunks + d.n_chunks > budget) break;
+            if (nchunks + d.n_chunks > 0x7FFF0000ull || ccap + d.c_cap > 0xFFFF0000ull) break;
+            d.chunk_base = (uint32_t)nchunks; d.c_base = (uint32_t)ccap;
+            nchunks += d.n_chunks; ccap += d.c_cap;
             hp.push_back(d);
         }
         const uint32_t nb = (uint32_t)hp.size();
-        d_pairs.resize(nb, st);
-        a_qi.resize(acap + 1, st); a_r.resize(acap + 1, st); a_rctg.resize(acap + 1, st);
-        F.resize(acap + 1, st); BP.resize(acap + 1, st);
-        chunk_aoff.resize(nentries + 1, st);
-        pair_na.resize(nb, st); pair_nch.resize(nb, st);
-        chains.resize(ccap + 1, st);
-        d_out.resize(nb, st);
-        HIPCHECK(hipMemcpyAsync(d_pairs.p, hp.data(), nb * sizeof(PairDesc), hipMemcpyHostToDevice, st));
-        HIPCHECK(hipMemsetAsync(pair_nch.p, 0, nb * 4, st));
+        W.d_pairs.resize(nb, st);
+        W.chunk_state.resize(nchunks + 1, st); W.slow_list.resize(nchunks + 1, st);
+        W.fast_chains.resize(nchunks * FAST_SLOTS + 1, st);
+        W.counters.resize(16, st);
+        W.pair_na.resize(nb, st); W.pair_nch.resize(nb, st);
+        W.chains.resize(ccap + 1, st);
+        W.d_out.resize(nb, st);
+        HIPCHECK(hipMemcpyAsync(W.d_pairs.p, hp.data(), nb * sizeof(PairDesc), hipMemcpyHostToDevice, st));
+        HIPCHECK(hipMemsetAsync(W.pair_nch.p, 0, nb * 4, st));
+        HIPCHECK(hipMemsetAsync(W.pair_na.p, 0, nb * 4, st));
+        HIPCHECK(hipMemsetAsync(W.counters.p, 0, 64, st));
         HIPCHECK(hipMemsetAsync(ctx->d_flags, 0, 64, st));
         HIPCHECK(hipEventRecord(ctx->ev[5], st));
-        hipLaunchKernelGGL(anchors_kernel, dim3(nb), dim3(256), 0, st, VA, VB, d_pairs.p, a_qi.p, a_r.p, a_rctg.p,
-                           chunk_aoff.p, pair_na.p, ctx->d_flags);
+        if (nchunks)
+            hipLaunchKernelGGL(chain_fast_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, st, VA, VB, W.d_pairs.p, nb,
+                               (uint32_t)nchunks, W.fast_chains.p, W.chunk_state.p, W.slow_list.p, W.counters.p, W.pair_na.p);
         HIPCHECK(hipEventRecord(ctx->ev[6], st));
-        hipLaunchKernelGGL(chain_kernel, dim3((unsigned)((nentries + 255) / 256)), dim3(256), 0, st, VA, VB, d_pairs.p, nb,
-                           (uint32_t)nentries, a_qi.p, a_r.p, a_rctg.p, chunk_aoff.p, F.p, BP.p, chains.p, pair_nch.p,
-                           ctx->d_flags);
+        uint32_t hcnt[16] = {0};
+        HIPCHECK(hipMemcpyAsync(hcnt, W.counters.p, 64, hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipStreamSynchronize(st));
+        const uint32_t nslow = hcnt[0];
+        if (getenv("SKDER_AMD_DEBUG"))
+            fprintf(stderr, "[skder_amd] batch: %u pairs %llu chunks, slow %u (none %u, slots %u, hits %u, ring %u, branch %u, score %u, qrep %u)\n",
+                    nb, (unsigned long long)nchunks, nslow, hcnt[1], hcnt[2], hcnt[3], hcnt[4], hcnt[5], hcnt[6], hcnt[7]);
+        if (nslow) {
+            W.cap.resize(nslow + 1, st); W.abase.resize(nslow + 1, st); W.slow_n.resize(nslow + 1, st);
+            hipLaunchKernelGGL(slow_caps_kernel, dim3((nslow + 256) / 256), dim3(256), 0, st, VA, VB, W.d_pairs.p, nb, W.slow_list.p,
+                               nslow, W.cap.p);
+            exclusive_scan_u32(W.cap.p, W.abase.p, nslow + 1, W.ws, st);
+            uint32_t atotal = 0;
+            HIPCHECK(hipMemcpyAsync(&atotal, W.abase.p + nslow, 4, hipMemcpyDeviceToHost, st));
+            HIPCHECK(hipStreamSynchronize(st));
+            W.a_qi.resize(atotal + 1, st); W.a_r.resize(atotal + 1, st); W.a_rctg.resize(atotal + 1, st);
+            W.F.resize(atotal + 1, st); W.BP.resize(atotal + 1, st);
+            hipLaunchKernelGGL(slow_anchors_kernel, dim3((nslow + 3) / 4), dim3(256), 0, st, VA, VB, W.d_pairs.p, nb, W.slow_list.p, nslow,
+                               W.abase.p, W.a_qi.p, W.a_r.p, W.a_rctg.p, W.slow_n.p, ctx->d_flags);
+            hipLaunchKernelGGL(slow_chain_kernel, dim3((nslow + 255) / 256), dim3(256), 0, st, VA, VB, W.d_pairs.p, nb, W.slow_list.p, nslow,
+                               W.abase.p, W.slow_n.p, W.a_qi.p, W.a_r.p, W.a_rctg.p, W.F.p, W.BP.p, W.chains.p, W.pair_nch.p,
+                               W.pair_na.p, ctx->d_flags);
+        }
         HIPCHECK(hipEventRecord(ctx->ev[7], st));
-        hipLaunchKernelGGL(finalize_kernel, dim3(nb), dim3(256), 0, st, VA, VB, d_pairs.p, chains.p, pair_nch.p, pair_na.p,
-                           d_out.p, ctx->d_flags);
+        hipLaunchKernelGGL(finalize_kernel, dim3(nb), dim3(256), 0, st, VA, VB, W.d_pairs.p, W.fast_chains.p, W.chunk_state.p,
+                           W.chains.p, W.pair_nch.p, W.pair_na.p, W.d_out.p, ctx->d_flags);
         HIPCHECK(hipEventRecord(ctx->ev[8], st));
         ho.resize(nb);
         uint32_t h_flags = 0;
-        HIPCHECK(hipMemcpyAsync(ho.data(), d_out.p, nb * sizeof(PairOut), hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipMemcpyAsync(ho.data(), W.d_out.p, nb * sizeof(PairOut), hipMemcpyDeviceToHost, st));
         HIPCHECK(hipMemcpyAsync(&h_flags, ctx->d_flags, 4, hipMemcpyDeviceToHost, st));
         HIPCHECK(hipStreamSynchronize(st));
-        if (h_flags & 4u) throw SkError("anchor buffer overflow (a pair has more than 2*seeds+1024 anchors)");
-        if (h_flags & 8u) throw SkError("chain buffer overflow (a pair has more than 4*chunks+64 chains)");
+        if (h_flags & 4u) throw SkError("anchor buffer overflow in the slow path (a chunk has more than 4*seeds+64 anchors)");
+        if (h_flags & 8u) throw SkError("chain buffer overflow (a pair has more than 4*chunks+64 slow-path chains)");
         if (h_flags & 16u) throw SkError("pair with more than 2048 chains is not supported");
         float ms;
-        HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[6])); t_anchor += ms;
-        HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7])); t_chain += ms;
+        HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[6])); t_fast += ms;
+        HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7])); t_slow += ms;
         HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[7], ctx->ev[8])); t_fin += ms;
+        tot_slow += nslow; tot_chunks += nchunks;
         for (uint32_t i = 0; i < nb; i++) {
             const PairOut &o = ho[i];
             tot_anchors += o.n_anchors;
@@ -472,8 +775,9 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         }
         p0 = p;
     }
-    ctx->timing[3] = t_anchor; ctx->timing[4] = t_chain; ctx->timing[5] = t_fin;
+    ctx->timing[3] = t_fast; ctx->timing[4] = t_slow; ctx->timing[5] = t_fin;
     ctx->timing[6] = (double)np; ctx->timing[7] = (double)tot_anchors;
+    ctx->counters[0] = tot_chunks; ctx->counters[1] = tot_slow;
 }
 
 void triangle_rows_impl(skder_sketches *s, uint32_t row_begin, uint32_t row_stride, double screen_pct)

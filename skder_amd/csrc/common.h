@@ -48,6 +48,12 @@ struct TileDesc {
     uint32_t pad;
 };
 
+// caching device allocator: blocks freed by DevBuf are kept (per device) and handed out again, so a
+// steady-state call sequence performs no hipMalloc/hipFree (both synchronise the device).
+void *pool_alloc(size_t bytes);
+void pool_free(void *p);
+void pool_trim();   // return every cached block to the driver
+
 // device buffer with geometric growth
 template <typename T>
 struct DevBuf {
@@ -58,18 +64,18 @@ struct DevBuf {
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) pool_free(p);
         p = nullptr; n = cap = 0;
     }
     // make room for `want` elements; keeps the first `keep` elements
     void reserve(size_t want, size_t keep, hipStream_t st) {
         if (want <= cap) return;
-        size_t nc = cap ? cap : 1024;
-        while (nc < want) nc = nc + nc / 2 + 1024;
-        T *q = nullptr;
-        HIPCHECK(hipMalloc(&q, nc * sizeof(T)));
+        size_t nc = cap ? cap + cap / 2 : want;
+        if (nc < want) nc = want;
+        nc = (nc + 1023) & ~(size_t)1023;
+        T *q = static_cast<T *>(pool_alloc(nc * sizeof(T)));
         if (keep) HIPCHECK(hipMemcpyAsync(q, p, keep * sizeof(T), hipMemcpyDeviceToDevice, st));
-        if (p) { HIPCHECK(hipStreamSynchronize(st)); (void)hipFree(p); }
+        if (p) { if (keep) HIPCHECK(hipStreamSynchronize(st)); pool_free(p); }
         p = q; cap = nc;
     }
     void resize(size_t want, hipStream_t st) { reserve(want, n, st); n = want; }
@@ -83,4 +89,7 @@ struct skder_ctx {
     double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<skder_edge_t> edges;
     uint32_t *d_flags = nullptr;   // [0] overflow / error flags from kernels
+    uint64_t counters[4] = {0, 0, 0, 0};   // [0] chunks processed, [1] chunks sent to the slow path
+    void *chain_work = nullptr;            // grow-only work buffers of chain_pairs (chain.hip)
+    void (*chain_work_free)(void *) = nullptr;
 };

@@ -12,7 +12,7 @@ __global__ __launch_bounds__(256) void index_genome_kernel(
     GenomeMeta *__restrict__ meta, const uint32_t *__restrict__ rec_goff, const uint32_t *__restrict__ seed_kmer,
     const uint32_t *__restrict__ seed_gpos, const uint32_t *__restrict__ seed_ctg, uint32_t *__restrict__ skmer,
     uint32_t *__restrict__ sgpos, uint32_t *__restrict__ sctg, uint32_t *__restrict__ boff_all,
-    uint32_t *__restrict__ pchunk)
+    uint32_t *__restrict__ pchunk, uint32_t *__restrict__ chunk_start_all, uint4 *__restrict__ table_all)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t *cnt = reinterpret_cast<uint32_t *>(smem_raw);   // 2^bits counters, later cursor, later histogram
@@ -27,6 +27,8 @@ __global__ __launch_bounds__(256) void index_genome_kernel(
     uint32_t *boff = boff_all + m.bucket_off;
     const uint32_t *rg = rec_goff + m.rec_goff_off;
 
+    uint4 *tab = table_all + m.table_off;
+    const uint32_t tbits = m.table_bits, tmask = (1u << tbits) - 1u;
     for (uint32_t b = tid; b < nb; b += 256) cnt[b] = 0;
     if (tid == 0) s_distinct = 0;
     __syncthreads();
@@ -76,6 +78,17 @@ __global__ __launch_bounds__(256) void index_genome_kernel(
             uint32_t mult = j - i;
             atomicAdd(&cnt[mult < IDX_REP_HIST - 1 ? mult : IDX_REP_HIST - 1], 1u);
             my_distinct++;
+            // open-addressing table (linear probing, multiplicative hash): one 16-byte slot per seed
+            // occurrence, {kmer|fwd<<31, gpos, record, multiplicity}; cleared to TABLE_EMPTY by the host
+            for (uint32_t e = i; e < j; e++) {
+                uint32_t h = kmer_bucket(kk, tbits);
+                for (;;) {
+                    uint32_t old = atomicCAS(&tab[h].x, TABLE_EMPTY, ok[e]);
+                    if (old == TABLE_EMPTY) break;
+                    h = (h + 1) & tmask;
+                }
+                tab[h].y = og[e]; tab[h].z = oc[e]; tab[h].w = mult;
+            }
             i = j;
         }
     }
@@ -109,10 +122,13 @@ __global__ __launch_bounds__(256) void index_genome_kernel(
         }
         uint32_t total;
         uint32_t ex = block_excl_scan_256(flag, wsum, total);
-        if (s < n) pchunk[m.seed_off + s] = crun + ex + flag - 1u;
+        if (s < n) {
+            pchunk[m.seed_off + s] = crun + ex + flag - 1u;
+            if (flag) chunk_start_all[m.chunk_off + crun + ex] = s;
+        }
         crun += total;
     }
-    if (tid == 0) meta[g].n_chunks = crun;
+    if (tid == 0) { meta[g].n_chunks = crun; chunk_start_all[m.chunk_off + crun] = n; }
 }
 
 void index_impl(skder_sketches *s)
@@ -122,7 +138,7 @@ void index_impl(skder_sketches *s)
     hipStream_t st = ctx->stream;
     const uint32_t G = s->n_genomes;
     s->h_meta.resize(G);
-    uint64_t boff_total = 0, rg = 0;
+    uint64_t boff_total = 0, rg = 0, table_total = 0, chunk_total = 0;
     for (uint32_t g = 0; g < G; g++) {
         GenomeMeta &m = s->h_meta[g];
         m.seed_off = s->h_seed_off[g];
@@ -140,6 +156,14 @@ void index_impl(skder_sketches *s)
         boff_total += (1u << bits) + 1;
         m.n_chunks = 0;
         m.rep_cut = 0xFFFFFFFFu;
+        uint32_t tb = 6;
+        while ((1ull << tb) < 3ull * m.n_seeds) tb++;
+        if (tb > 31) throw SkError("genome with too many seeds");
+        m.table_bits = tb; m.pad0 = 0;
+        m.table_off = table_total;
+        table_total += 1ull << tb;
+        m.chunk_off = chunk_total;
+        chunk_total += m.total_len / ANI_CHUNK_LEN + m.n_rec + 2;   // upper bound on chunks + sentinel
     }
     const uint64_t ns = s->h_seed_off[G];
     s->d_meta.resize(G, st);
@@ -147,13 +171,16 @@ void index_impl(skder_sketches *s)
     s->skmer.resize(ns + 1, st); s->sgpos.resize(ns + 1, st); s->sctg.resize(ns + 1, st);
     s->pchunk.resize(ns + 1, st);
     s->boff.resize(boff_total + 1, st);
+    s->chunk_start.resize(chunk_total + 1, st);
+    s->table.resize(table_total + 1, st);
+    HIPCHECK(hipMemsetAsync(s->table.p, 0xFF, (table_total + 1) * sizeof(uint4), st));
     if (G) {
         HIPCHECK(hipMemcpyAsync(s->d_meta.p, s->h_meta.data(), G * sizeof(GenomeMeta), hipMemcpyHostToDevice, st));
         HIPCHECK(hipMemcpyAsync(s->d_rec_goff.p, s->h_rec_goff.data(), s->h_rec_goff.size() * 4, hipMemcpyHostToDevice, st));
         HIPCHECK(hipEventRecord(ctx->ev[3], st));
         hipLaunchKernelGGL(index_genome_kernel, dim3(G), dim3(256), (1u << IDX_MAX_BUCKET_BITS) * 4, st, s->d_meta.p,
                            s->d_rec_goff.p, s->seed_kmer.p, s->seed_gpos.p, s->seed_ctg.p, s->skmer.p, s->sgpos.p,
-                           s->sctg.p, s->boff.p, s->pchunk.p);
+                           s->sctg.p, s->boff.p, s->pchunk.p, s->chunk_start.p, s->table.p);
         HIPCHECK(hipEventRecord(ctx->ev[4], st));
         HIPCHECK(hipMemcpyAsync(s->h_meta.data(), s->d_meta.p, G * sizeof(GenomeMeta), hipMemcpyDeviceToHost, st));
         HIPCHECK(hipStreamSynchronize(st));

@@ -93,6 +93,11 @@ class Context:
         _lib.lib().skder_amd_last_timing(self.h, out)
         return np.array(out[:])
 
+    def counters(self) -> np.ndarray:
+        out = (C.c_uint64 * 4)()
+        _lib.lib().skder_amd_last_counters(self.h, out)
+        return np.array(out[:], np.uint64)
+
     def synth_fill(self, d_bases_ptr: int, layout: BatchLayout, lineage: np.ndarray, params: np.ndarray):
         lineage = np.ascontiguousarray(lineage, np.uint64)
         params = np.ascontiguousarray(params, np.uint32)
