@@ -133,26 +133,38 @@ __global__ __launch_bounds__(256) void chain_fast_kernel(SetView A, SetView B, c
         }                                                                                    \
     } while (0)
 
-    // software pipeline: the first table slot of seed s+1 is requested while seed s is processed
-    uint32_t km_n = 0;
-    int32_t qp_n = 0;
-    uint4 sl_n = make_uint4(TABLE_EMPTY, 0, 0, 0);
-    uint32_t h_n = 0;
-    if (s0 < s1 && !cplx) {
-        km_n = qk[s0]; qp_n = (int32_t)qg[s0];
-        h_n = kmer_bucket(km_n & SK_SEED_MASK, tbits);
-        sl_n = tab[h_n];
+    // software pipeline over blocks of 4 seeds: the four table slots of a block are requested
+    // together (independent loads), and the seeds of the NEXT block are fetched while the current
+    // block is processed, so a lane waits for one memory round trip per 4 seeds instead of two per seed
+    uint32_t kmA[4], hA[4], kmB[4];
+    int32_t qpA[4], qpB[4];
+    uint4 slA[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        kmB[k] = 0; qpB[k] = 0;
+        if (s0 + k < s1 && !cplx) { kmB[k] = qk[s0 + k]; qpB[k] = (int32_t)qg[s0 + k]; }
     }
-    for (uint32_t s = s0; s < s1 && !cplx; s++) {
-        const uint32_t km = km_n, kmer = km & SK_SEED_MASK;
-        const int32_t qp = qp_n;
-        uint32_t h = h_n;
-        uint4 sl = sl_n;
-        if (s + 1 < s1) {
-            km_n = qk[s + 1]; qp_n = (int32_t)qg[s + 1];
-            h_n = kmer_bucket(km_n & SK_SEED_MASK, tbits);
-            sl_n = tab[h_n];
+    for (uint32_t sb = s0; sb < s1 && !cplx; sb += 4) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            kmA[k] = kmB[k]; qpA[k] = qpB[k];
+            hA[k] = kmer_bucket(kmA[k] & SK_SEED_MASK, tbits);
+            slA[k] = (sb + k < s1) ? tab[hA[k]] : make_uint4(TABLE_EMPTY, 0, 0, 0);
         }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (sb + 4 + k < s1) { kmB[k] = qk[sb + 4 + k]; qpB[k] = (int32_t)qg[sb + 4 + k]; }
+        const uint32_t nk = s1 - sb < 4u ? s1 - sb : 4u;
+      for (uint32_t kk = 0; kk < nk && !cplx; kk++) {
+        const uint32_t s = sb + kk;
+        const uint32_t km = kmA[0], kmer = km & SK_SEED_MASK;
+        const int32_t qp = qpA[0];
+        uint32_t h = hA[0];
+        uint4 sl = slA[0];
+        kmA[0] = kmA[1]; kmA[1] = kmA[2]; kmA[2] = kmA[3];
+        qpA[0] = qpA[1]; qpA[1] = qpA[2]; qpA[2] = qpA[3];
+        hA[0] = hA[1]; hA[1] = hA[2]; hA[2] = hA[3];
+        slA[0] = slA[1]; slA[1] = slA[2]; slA[2] = slA[3];
         uint32_t m = 0, g0 = 0xFFFFFFFFu, g1 = 0xFFFFFFFFu, g2 = 0xFFFFFFFFu, g3 = 0xFFFFFFFFu, c0 = 0, c1 = 0, c2 = 0, c3 = 0;
         for (;;) {
             if (sl.x == TABLE_EMPTY) break;
@@ -263,6 +275,7 @@ __global__ __launch_bounds__(256) void chain_fast_kernel(SetView A, SetView B, c
             ia++;
             runmax = best > runmax ? best : runmax;
         }
+    }
     }
     if (!cplx) {
         if (ia > 3) EMIT_PATH(r3);
