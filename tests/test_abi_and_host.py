@@ -1,0 +1,103 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/skder_amd.h declares, host-only logic works, and every compute entry point fails LOUDLY on a
+machine without a gfx950 device (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "skder_amd.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(skder_amd_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from skder_amd import _lib
+    L = _lib.lib()
+    decl = _declared_symbols()
+    assert len(decl) >= 20
+    for name in decl:
+        assert hasattr(L, name), "include/skder_amd.h declares %s but libskder_amd.so does not export it" % name
+        assert name in _lib.SYMBOLS, "%s has no ctypes prototype in skder_amd/_lib.py" % name
+
+
+def test_struct_layouts_match_header():
+    from skder_amd import _lib, engine
+    assert C.sizeof(_lib.Edge) == 64 and engine.EDGE_DTYPE.itemsize == 64
+    assert C.sizeof(_lib.Batch) == 32
+    assert C.sizeof(_lib.RawView) == 8 + 3 * 8 + 9 * 8
+
+
+def test_parse_skani_params():
+    """bin/skder:132,199-201: the -p string; '-s X' accepted, every other skani flag rejected loudly"""
+    from skder_amd.skder import parse_skani_params
+    assert parse_skani_params("-s 89.5") == 89.5
+    assert parse_skani_params("") == 80.0
+    assert parse_skani_params("  -s   70 ") == 70.0
+    for bad in ("--no-learned-ani", "-c 30", "-s", "-s abc", "--robust", "-m 200", "-s 90 --median", "--fast"):
+        with pytest.raises(RuntimeError):
+            parse_skani_params(bad)
+
+
+def _no_gpu():
+    try:
+        import torch
+        return not torch.cuda.is_available()
+    except Exception:
+        return True
+
+
+@pytest.mark.skipif(not _no_gpu(), reason="checks the behaviour WITHOUT a GPU")
+def test_compute_entry_points_fail_loudly_without_gpu(tmp_path):
+    """the product path must not fall back to anything when the device is missing; like util.runCmd
+    (util.py:636-652) the caller gets a RuntimeError and no output file"""
+    import skder_amd
+    from skder_amd import engine
+    listing = tmp_path / "l.txt"
+    listing.write_text("/nonexistent/a.fna\n")
+    out = tmp_path / "out.tsv"
+    with pytest.raises(RuntimeError, match="skani triangle"):
+        skder_amd.runSkaniTriangle(str(listing), str(out), "-s 89.5", 50.0, "greedy", False, None, threads=1)
+    assert not out.exists()
+    with pytest.raises(RuntimeError, match="no HIP device|CPU fallback"):
+        engine.Context(0)
+    n50 = tmp_path / "n50.txt"
+    n50.write_text("/nonexistent/a.fna\t1000\n")
+    with pytest.raises(RuntimeError):
+        skder_amd.lowMemGreedyDerep(str(listing), str(tmp_path) + "/", str(n50), str(tmp_path / "res.txt"), str(tmp_path) + "/",
+                                    99.0, 90.0, None, threads=1)
+
+
+def test_batch_layout_alignment():
+    from skder_amd import engine
+    lay = engine.BatchLayout([np.array([500, 8192, 777], np.uint32), np.array([100000], np.uint32)])
+    assert (lay.rec_off % 32 == 0).all() and lay.rec_off[0] == 32
+    assert list(lay.genome_rec_begin) == [0, 3, 4]
+    assert lay.total_bytes >= int(lay.rec_off[-1]) + 100000 + engine.SKDER_TILE + 32
+    with pytest.raises(ValueError):
+        engine.BatchLayout([np.array([499], np.uint32)])
+    host = lay.pack_host([np.full(500 + 8192 + 777, ord("C"), np.uint8), np.full(100000, ord("G"), np.uint8)])
+    assert host[32] == ord("C") and host[int(lay.rec_off[3])] == ord("G") and host[31] == ord("A")
+
+
+def test_synthetic_recipe_is_deterministic_and_structured():
+    from skder_amd import synth
+    a, b = synth.make_recipe(40, genome_len=50000, n_species=2), synth.make_recipe(40, genome_len=50000, n_species=2)
+    assert np.array_equal(a.lineage, b.lineage) and np.array_equal(a.params, b.params)
+    assert all(np.array_equal(x, y) for x, y in zip(a.rec_lens, b.rec_lens))
+    assert all((r >= 1000).all() for r in a.rec_lens)
+    g0, g1, g20 = (synth.bases_numpy(a, g) for g in (0, 1, 20))
+    assert set(np.unique(g0)) <= set(b"ACGT")
+    n = min(len(g0), len(g1))
+    ident_strain = (g0[:n] == g1[:n]).mean()          # same species, different strain
+    ident_isolate = (g0[:n] == synth.bases_numpy(a, 10)[:n]).mean()   # same strain
+    m = min(len(g0), len(g20))
+    ident_species = (g0[:m] == g20[:m]).mean()        # different species: ~0.25
+    assert ident_isolate > ident_strain > 0.6 and ident_species < 0.3
+    assert ident_isolate > 0.99

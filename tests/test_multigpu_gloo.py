@@ -1,0 +1,91 @@
+"""N > 1 path on CPU: two processes, backend gloo.  Exercises the genome partition, the padded
+variable-length all-gather of raw sketches and the edge gather of skder_amd/multigpu.py -- everything
+of the multi-GPU path except the kernels themselves."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _fake_raw(rank):
+    rng = np.random.RandomState(100 + rank)
+    ng = 3 + rank
+    ns = rng.randint(5, 40, ng)
+    nm = rng.randint(1, 9, ng)
+    nrec = rng.randint(1, 4, ng).astype(np.uint32)
+    return dict(
+        n_genomes=ng,
+        seed_kmer=torch.from_numpy(rng.randint(0, 2 ** 30, ns.sum()).astype(np.int32)),
+        seed_gpos=torch.from_numpy(rng.randint(0, 2 ** 20, ns.sum()).astype(np.int32)),
+        seed_ctg=torch.from_numpy(rng.randint(0, 3, ns.sum()).astype(np.int32)),
+        markers=torch.from_numpy(rng.randint(0, 2 ** 40, nm.sum()).astype(np.int64)),
+        seed_off=np.concatenate([[0], np.cumsum(ns)]).astype(np.uint64) + np.uint64(7 * rank),   # offsets need not start at 0
+        marker_off=np.concatenate([[0], np.cumsum(nm)]).astype(np.uint64),
+        genome_len=rng.randint(1000, 9000, ng).astype(np.uint64),
+        genome_nrec=nrec,
+        rec_goff=np.concatenate([np.arange(k + 1, dtype=np.uint32) * 500 for k in nrec]))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from skder_amd import engine, multigpu
+    raw = _fake_raw(rank)
+    merged = multigpu.exchange_raw(raw)
+    edges = np.zeros(2 + rank, engine.EDGE_DTYPE)
+    edges["ref"] = rank
+    edges["query"] = np.arange(len(edges)) + 10 * rank
+    allv = multigpu.gather_edges(edges)
+    q.put((rank, {k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in merged.items()}, allv))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_partition_is_balanced_and_complete():
+    sys.path.insert(0, ROOT)
+    from skder_amd import multigpu
+    for n, w in ((5000, 8), (7, 2), (3, 4), (0, 2)):
+        parts = multigpu.partition(n, w)
+        assert [i for p in parts for i in p] == list(range(n))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def test_exchange_and_gather_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, merged, allv = q.get(timeout=120)
+        res[r] = (merged, allv)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    raws = [_fake_raw(r) for r in range(world)]
+    for r in range(world):
+        m = res[r][0]
+        assert m["n_genomes"] == sum(x["n_genomes"] for x in raws)
+        for k in ("seed_kmer", "seed_gpos", "seed_ctg", "markers"):
+            assert np.array_equal(m[k], np.concatenate([x[k].numpy() for x in raws])), k
+        # offsets are rebased to the concatenated arrays
+        ns0 = int(raws[0]["seed_off"][-1] - raws[0]["seed_off"][0])
+        want_so = np.concatenate([raws[0]["seed_off"] - raws[0]["seed_off"][0],
+                                  raws[1]["seed_off"][1:] - raws[1]["seed_off"][0] + np.uint64(ns0)])
+        assert np.array_equal(m["seed_off"], want_so)
+        assert m["marker_off"][-1] == sum(len(x["markers"]) for x in raws)
+        assert np.array_equal(m["genome_len"], np.concatenate([x["genome_len"] for x in raws]))
+        assert np.array_equal(m["rec_goff"], np.concatenate([x["rec_goff"] for x in raws]))
+    assert len(res[0][1]) == 2 + 3 and len(res[1][1]) == 0          # edges land on rank 0 only
+    assert sorted(res[0][1]["ref"].tolist()) == [0, 0, 1, 1, 1]

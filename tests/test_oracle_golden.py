@@ -1,0 +1,164 @@
+"""CPU tests: the oracle (oracle/ani_oracle.c) against the reference's golden skani tables.
+
+The engine behind the goldens (skani, version unpinned, source absent) cannot be run here, so these
+tests pin what CAN be pinned: exact header / row set / row order / names, and ANI/AF within the
+residual measured when the restatement was fitted (DESIGN.md "Oracle": AF rms 0.43 max 1.41,
+ANI rms 0.16 max 0.61 on G5).  The bounds below are those measurements plus a small margin."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_table
+
+GENOMES = sorted(os.listdir(os.path.join(GOLDEN, "genomes")))
+
+
+def _key(r):
+    return (os.path.basename(r[0]), os.path.basename(r[1]))
+
+
+def _residuals(rows, grows):
+    got = {_key(r): r for r in rows}
+    da, df = [], []
+    for g in grows:
+        r = got[_key(g)]
+        da.append(float(r[2]) - float(g[2]))
+        df += [float(r[3]) - float(g[3]), float(r[4]) - float(g[4])]
+    return np.array(da), np.array(df)
+
+
+@pytest.fixture(scope="module")
+def g5_table(oracle, tmp_path_factory):
+    td = tmp_path_factory.mktemp("g5")
+    listing = td / "listing.txt"
+    listing.write_text("".join(os.path.join(GOLDEN, "genomes", n) + "\n" for n in reversed(GENOMES)))
+    out = td / "tri.tsv"
+    oracle.triangle(str(listing), 10.0, 89.5, 8, str(out), oracle.default_params())
+    return load_table(str(out))
+
+
+def test_g5_rows_order_names(g5_table):
+    hdr, rows = g5_table
+    ghdr, grows = load_table(os.path.join(GOLDEN, "G5_triangle_minaf10_s89.5.tsv"))
+    assert hdr == ghdr
+    assert len(rows) == len(grows) == 561
+    assert [_key(r) for r in rows] == [_key(g) for g in grows]     # skani's hash-map row order
+    assert all(r[5:] == g[5:] for r, g in zip(rows, grows))        # first record >= 500 bp names (V3)
+
+
+def test_g5_ani_af_residual(g5_table):
+    _, rows = g5_table
+    _, grows = load_table(os.path.join(GOLDEN, "G5_triangle_minaf10_s89.5.tsv"))
+    da, df = _residuals(rows, grows)
+    assert np.sqrt((da ** 2).mean()) <= 0.18 and np.abs(da).max() <= 0.65
+    assert np.sqrt((df ** 2).mean()) <= 0.47 and np.abs(df).max() <= 1.50
+    assert abs(df.mean()) <= 0.10 and abs(da.mean()) <= 0.03       # unbiased
+
+
+def _plain_dir(tmp_path):
+    mapping = dict(line.rstrip("\n").split("\t") for line in open(os.path.join(GOLDEN, "plain_to_gz.tsv")))
+    d = tmp_path / "plain"
+    d.mkdir()
+    for plain, gz in mapping.items():
+        with gzip.open(os.path.join(GOLDEN, "genomes", gz), "rb") as f, open(d / plain, "wb") as o:
+            o.write(f.read())
+    return d, sorted(mapping)
+
+
+def test_g1_plain_fasta_min_af_filter(oracle, tmp_path):
+    """G1: the 7 plain-FASTA genomes, --min-af 50 -s 89.0 (skder_results/Command_Issued.txt)"""
+    d, names = _plain_dir(tmp_path)
+    listing = tmp_path / "l.txt"
+    listing.write_text("".join(str(d / n) + "\n" for n in names))
+    out = tmp_path / "o.tsv"
+    oracle.triangle(str(listing), 50.0, 89.0, 4, str(out), oracle.default_params())
+    hdr, rows = load_table(str(out))
+    ghdr, grows = load_table(os.path.join(GOLDEN, "G1_triangle_minaf50_s89.tsv"))
+    assert hdr == ghdr and [_key(r) for r in rows] == [_key(g) for g in grows]
+    assert all(r[5:] == g[5:] for r, g in zip(rows, grows))
+    da, df = _residuals(rows, grows)
+    assert np.abs(da).max() <= 0.65 and np.abs(df).max() <= 1.5
+    # the near-identical pair (draft vs complete genome of one strain): AF capped at 100
+    near = [r for r in rows if "001700755" in r[0] and "900186975" in r[1]][0]
+    assert abs(float(near[3]) - 100.0) <= 0.1 and abs(float(near[2]) - 99.99) <= 0.02
+
+
+def test_min_af_is_max_of_both_fractions(oracle, tmp_path):
+    """SURVEY V4 (G2 is G3 minus the rows whose larger AF is below 90): same rule here"""
+    d, names = _plain_dir(tmp_path)
+    listing = tmp_path / "l.txt"
+    listing.write_text("".join(str(d / n) + "\n" for n in names))
+    lo, hi = tmp_path / "lo.tsv", tmp_path / "hi.tsv"
+    p = oracle.default_params()
+    oracle.triangle(str(listing), 0.0, 89.0, 4, str(lo), p)
+    oracle.triangle(str(listing), 90.0, 89.0, 4, str(hi), p)
+    _, all_rows = load_table(str(lo))
+    _, kept = load_table(str(hi))
+    assert len(all_rows) == 21
+    # the filter acts on unrounded values: a printed 90.00 may be 89.996 -> only check clear cases
+    assert {_key(r) for r in all_rows if max(float(r[3]), float(r[4])) >= 90.01} <= {_key(r) for r in kept}
+    assert all(max(float(r[3]), float(r[4])) >= 89.99 for r in kept)
+    assert [r for r in all_rows if _key(r) in {_key(k) for k in kept}] == kept   # order preserved
+
+
+def test_g4_dist_layout(oracle, tmp_path):
+    """G4: `skani dist --rl reps --ql nonreps`: grouped by query in --ql order, refs by ANI descending;
+    values equal the triangle's with the AF columns swapped when the roles swap"""
+    d, _ = _plain_dir(tmp_path)
+    reps = [l.strip() for l in open(os.path.join(GOLDEN, "G4_dist_reps.txt"))]
+    nonreps = [l.strip() for l in open(os.path.join(GOLDEN, "G4_dist_nonreps.txt"))]
+    rl, ql = tmp_path / "r.txt", tmp_path / "q.txt"
+    rl.write_text("".join(str(d / os.path.basename(x)) + "\n" for x in reps))
+    ql.write_text("".join(str(d / os.path.basename(x)) + "\n" for x in nonreps))
+    out = tmp_path / "dist.tsv"
+    oracle.dist(str(rl), str(ql), 15.0, 80.0, 4, str(out), oracle.default_params())
+    hdr, rows = load_table(str(out))
+    ghdr, grows = load_table(os.path.join(GOLDEN, "G4_dist.tsv"))
+    assert hdr == ghdr and len(rows) == len(grows) == 12
+    assert [os.path.basename(r[1]) for r in rows] == [os.path.basename(g[1]) for g in grows]   # query grouping
+    assert {_key(r) for r in rows} == {_key(g) for g in grows}
+    for q in {os.path.basename(r[1]) for r in rows}:
+        anis = [float(r[2]) for r in rows if os.path.basename(r[1]) == q]
+        assert anis == sorted(anis, reverse=True)
+    da, df = _residuals(rows, grows)
+    assert np.abs(da).max() <= 0.65 and np.abs(df).max() <= 1.5
+
+
+def test_older_skani_goldens_are_within_version_drift(oracle, tmp_path):
+    """G3 (older skani): differs from G1 by up to 0.15 ANI / 0.10 AF; same loose bound"""
+    d, names = _plain_dir(tmp_path)
+    listing = tmp_path / "l.txt"
+    listing.write_text("".join(str(d / n) + "\n" for n in names))
+    out = tmp_path / "o.tsv"
+    oracle.triangle(str(listing), 0.0, 89.0, 4, str(out), oracle.default_params())
+    _, rows = load_table(str(out))
+    _, grows = load_table(os.path.join(GOLDEN, "G3_triangle_old.tsv"))
+    da, df = _residuals(rows, grows)
+    assert np.abs(da).max() <= 0.80 and np.abs(df).max() <= 1.6
+
+
+def test_n50_matches_reference_tables(oracle):
+    """util.py:686-724 rule, pinned by Concatenated_N50.txt of both reference runs"""
+    p = oracle.default_params()
+    want = {}
+    for line in open(os.path.join(GOLDEN, "downstream", "skder_gtdb_results__Concatenated_N50.txt")):
+        path, n50 = line.rstrip("\n").split("\t")
+        want[os.path.basename(path)] = int(n50)
+    assert len(want) == 34
+    for n in GENOMES:
+        g = oracle.Genome.load(os.path.join(GOLDEN, "genomes", n), p)
+        assert g.n50 == want[n], n
+
+
+def test_fixed_point_root_and_hash_known_answers(oracle):
+    L = oracle.lib()
+    for num, den in ((1, 3), (3, 160), (100, 160), (159, 160), (5, 2000), (99, 100)):
+        exact = (num / den) ** (1.0 / 15.0) * 2.0 ** 32
+        assert abs(L.oracle_root_fx(num, den, 15) - exact) <= 0.51
+    assert L.oracle_root_fx(7, 7, 15) == 0xFFFFFFFF and L.oracle_root_fx(0, 9, 15) == 0
+    # invertible 64-bit mix: distinct inputs give distinct outputs; known value for 0 and 1
+    vals = {L.oracle_mm_hash64(i) for i in range(4096)}
+    assert len(vals) == 4096
+    assert L.oracle_mm_hash64(0) == 0x77CFA1EEF01BCA90
