@@ -12,6 +12,8 @@
 //                      with back-tracking (one lane per chunk).
 //   finalize_kernel  one workgroup per pair: chains into LDS, better-chain overlap filter as a
 //                    parallel fix-point, fixed-point containment ANI, aligned fraction.
+#include <algorithm>
+
 #include "device_utils.h"
 #include "engine.h"
 #include "screen.h"
@@ -22,7 +24,8 @@ struct SetView {
     const uint32_t *skmer, *sgpos, *sctg;     // bucket order
     const uint32_t *boff;
     const uint32_t *chunk_start;
-    const uint4 *table;
+    const uint2 *table;
+    const uint32_t *rec_goff;
 };
 
 struct PairDesc {
@@ -82,9 +85,17 @@ struct RingE {
 __global__ __launch_bounds__(256) void chain_fast_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs, uint32_t npairs,
                                                          uint32_t total_chunks, ChainRec *__restrict__ fast_chains,
                                                          uint32_t *__restrict__ chunk_state, uint32_t *__restrict__ slow_list,
-                                                         uint32_t *__restrict__ slow_count, uint32_t *__restrict__ pair_na)
+                                                         uint32_t *__restrict__ slow_count, uint32_t *__restrict__ pair_na,
+                                                         int xcd_remap)
 {
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    // XCD-aware work mapping: workgroups are dealt round-robin to the 8 XCDs, so give every XCD one
+    // contiguous eighth of the (R-sorted) work list: its private L2 then sees few hash tables at a time
+    uint32_t wg = blockIdx.x;
+    if (xcd_remap) {
+        const uint32_t nwg = gridDim.x, xcd = wg & 7u, idx = wg >> 3, q8 = nwg >> 3, r8 = nwg & 7u;
+        wg = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + idx;
+    }
+    const uint32_t t = wg * 256u + threadIdx.x;
     if (t >= total_chunks) return;
     const uint32_t pi = find_pair(pairs, npairs, t);
     const PairDesc pd = pairs[pi];
@@ -95,7 +106,10 @@ __global__ __launch_bounds__(256) void chain_fast_kernel(SetView A, SetView B, c
     const uint64_t qoff = Qm->seed_off;
     const uint32_t *qk = QS.pkmer + qoff, *qg = QS.pgpos + qoff;
     const uint32_t s0 = QS.chunk_start[Qm->chunk_off + c], s1 = QS.chunk_start[Qm->chunk_off + c + 1];
-    const uint4 *tab = RS.table + Rm->table_off;
+    const uint2 *tab = RS.table + Rm->table_off;
+    const uint32_t *rgo = RS.rec_goff + Rm->rec_goff_off;
+    const uint32_t rnrec = Rm->n_rec;
+    uint32_t cur_rec = 0, cur_lo = rgo[0], cur_hi = rgo[1];   // record interval of the last hit (hits cluster)
     const uint32_t tbits = Rm->table_bits, tmask = (1u << tbits) - 1u, rrep = Rm->rep_cut;
     bool cplx = Qm->rep_cut != 0xFFFFFFFFu;   // own-multiplicity filter active: leave it to the slow path
     uint32_t cause = cplx ? 6u : 0u;
@@ -138,7 +152,7 @@ __global__ __launch_bounds__(256) void chain_fast_kernel(SetView A, SetView B, c
     // block is processed, so a lane waits for one memory round trip per 4 seeds instead of two per seed
     uint32_t kmA[4], hA[4], kmB[4];
     int32_t qpA[4], qpB[4];
-    uint4 slA[4];
+    uint2 slA[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         kmB[k] = 0; qpB[k] = 0;
@@ -149,7 +163,7 @@ __global__ __launch_bounds__(256) void chain_fast_kernel(SetView A, SetView B, c
         for (int k = 0; k < 4; k++) {
             kmA[k] = kmB[k]; qpA[k] = qpB[k];
             hA[k] = kmer_bucket(kmA[k] & SK_SEED_MASK, tbits);
-            slA[k] = (sb + k < s1) ? tab[hA[k]] : make_uint4(TABLE_EMPTY, 0, 0, 0);
+            slA[k] = (sb + k < s1) ? tab[hA[k]] : make_uint2(TABLE_EMPTY, 0);
         }
 #pragma unroll
         for (int k = 0; k < 4; k++)
@@ -160,23 +174,23 @@ __global__ __launch_bounds__(256) void chain_fast_kernel(SetView A, SetView B, c
         const uint32_t km = kmA[0], kmer = km & SK_SEED_MASK;
         const int32_t qp = qpA[0];
         uint32_t h = hA[0];
-        uint4 sl = slA[0];
+        uint2 sl = slA[0];
         kmA[0] = kmA[1]; kmA[1] = kmA[2]; kmA[2] = kmA[3];
         qpA[0] = qpA[1]; qpA[1] = qpA[2]; qpA[2] = qpA[3];
         hA[0] = hA[1]; hA[1] = hA[2]; hA[2] = hA[3];
         slA[0] = slA[1]; slA[1] = slA[2]; slA[2] = slA[3];
-        uint32_t m = 0, g0 = 0xFFFFFFFFu, g1 = 0xFFFFFFFFu, g2 = 0xFFFFFFFFu, g3 = 0xFFFFFFFFu, c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        uint32_t m = 0, g0 = 0xFFFFFFFFu, g1 = 0xFFFFFFFFu, g2 = 0xFFFFFFFFu, g3 = 0xFFFFFFFFu;
         for (;;) {
             if (sl.x == TABLE_EMPTY) break;
             if ((sl.x & SK_SEED_MASK) == kmer) {
-                // payload: gpos | rev<<31 ; record ; w = multiplicity of the k-mer in this genome
-                const uint32_t rv = ((km >> 31) != (sl.x >> 31)) ? USED_BIT : 0u;
-                if (m == 0) { g0 = sl.y | rv; c0 = sl.z; }
-                else if (m == 1) { g1 = sl.y | rv; c1 = sl.z; }
-                else if (m == 2) { g2 = sl.y | rv; c2 = sl.z; }
-                else if (m == 3) { g3 = sl.y | rv; c3 = sl.z; }
+                // payload: gpos | rev<<31
+                const uint32_t rv = ((km >> 31) != ((sl.x >> 30) & 1u)) ? USED_BIT : 0u;
+                if (m == 0) g0 = sl.y | rv;
+                else if (m == 1) g1 = sl.y | rv;
+                else if (m == 2) g2 = sl.y | rv;
+                else if (m == 3) g3 = sl.y | rv;
                 m++;
-                if (m >= sl.w) break;   // all occurrences seen
+                if (!(sl.x & TABLE_MULTI)) break;   // the only occurrence
             }
             h = (h + 1) & tmask;
             sl = tab[h];
@@ -184,15 +198,24 @@ __global__ __launch_bounds__(256) void chain_fast_kernel(SetView A, SetView B, c
         if (m == 0 || m > rrep) continue;
         if (m > 4) { cplx = true; cause = 2; break; }
         if (m > 1) {   // ascending gpos (ignoring the strand bit): 5-comparator network on 4 slots
-#define CSWAP(ga, ca, gb, cb) if (((gb) & 0x7FFFFFFFu) < ((ga) & 0x7FFFFFFFu) && (gb) != 0xFFFFFFFFu) { uint32_t tg = ga; ga = gb; gb = tg; uint32_t tc = ca; ca = cb; cb = tc; }
+#define CSWAP(ga, gb) if (((gb) & 0x7FFFFFFFu) < ((ga) & 0x7FFFFFFFu) && (gb) != 0xFFFFFFFFu) { uint32_t tg = ga; ga = gb; gb = tg; }
             // unused slots hold 0xFFFFFFFF and must stay behind the used ones
-            CSWAP(g0, c0, g1, c1) CSWAP(g2, c2, g3, c3) CSWAP(g0, c0, g2, c2) CSWAP(g1, c1, g3, c3) CSWAP(g1, c1, g2, c2)
+            CSWAP(g0, g1) CSWAP(g2, g3) CSWAP(g0, g2) CSWAP(g1, g3) CSWAP(g1, g2)
 #undef CSWAP
         }
         for (uint32_t u = 0; u < m && !cplx; u++) {
-            const uint32_t rr = g0, rc = c0;
-            g0 = g1; c0 = c1; g1 = g2; c1 = c2; g2 = g3; c2 = c3;
+            const uint32_t rr = g0;
+            g0 = g1; g1 = g2; g2 = g3;
             const int32_t rp = (int32_t)(rr & 0x7FFFFFFFu);
+            if ((uint32_t)rp < cur_lo || (uint32_t)rp >= cur_hi) {   // record of this hit: binary search
+                uint32_t lo = 0, hi = rnrec;
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (rgo[mid] <= (uint32_t)rp) lo = mid; else hi = mid;
+                }
+                cur_rec = lo; cur_lo = rgo[lo]; cur_hi = rgo[lo + 1];
+            }
+            const uint32_t rc = cur_rec;
             const uint32_t rev = rr >> 31;
             int32_t best = ANI_ANCHOR_SCORE;
             int bj = -1;
@@ -493,6 +516,15 @@ __device__ __forceinline__ uint32_t root_fx(uint32_t num, uint32_t den)
     return (uint32_t)s;
 }
 
+// root_fx for every (num, den) below ROOT_LUT: filled once per context by the same device function, so
+// a table hit is bit-identical with the direct computation
+#define ROOT_LUT 256
+__global__ __launch_bounds__(256) void root_lut_kernel(uint32_t *__restrict__ lut)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < ROOT_LUT * ROOT_LUT) lut[i] = root_fx(i / ROOT_LUT, i % ROOT_LUT);
+}
+
 __device__ __forceinline__ double calibrate_ani(double ani_raw)
 {
     const double cx[ANI_CAL_N] = ANI_CAL_X;
@@ -527,12 +559,14 @@ __global__ __launch_bounds__(256) void finalize_kernel(SetView A, SetView B, con
                                                        const ChainRec *__restrict__ fast_chains, const uint32_t *__restrict__ chunk_state,
                                                        const ChainRec *__restrict__ chains, const uint32_t *__restrict__ pair_nch,
                                                        const uint32_t *__restrict__ pair_na, PairOut *__restrict__ out,
-                                                       uint32_t *__restrict__ flags)
+                                                       uint32_t *__restrict__ flags, const uint32_t *__restrict__ root_lut, uint32_t lds_cap)
 {
-    __shared__ int32_t sc[FIN_LDS_CHAINS];
-    __shared__ uint32_t q0[FIN_LDS_CHAINS], q1[FIN_LDS_CHAINS], r0[FIN_LDS_CHAINS], r1[FIN_LDS_CHAINS], rc[FIN_LDS_CHAINS];
-    __shared__ uint32_t na[FIN_LDS_CHAINS], nsd[FIN_LDS_CHAINS];
-    __shared__ uint8_t state[FIN_LDS_CHAINS];   // 0 unknown, 1 kept, 2 dropped
+    // dynamic LDS: 8 word arrays + 1 byte array of `lds_cap` chains (sized per batch by the host)
+    extern __shared__ __attribute__((aligned(16))) unsigned char fin_smem[];
+    int32_t *sc = reinterpret_cast<int32_t *>(fin_smem);
+    uint32_t *q0 = reinterpret_cast<uint32_t *>(fin_smem) + lds_cap, *q1 = q0 + lds_cap, *r0 = q1 + lds_cap, *r1 = r0 + lds_cap;
+    uint32_t *rc = r1 + lds_cap, *na = rc + lds_cap, *nsd = na + lds_cap;
+    uint8_t *state = reinterpret_cast<uint8_t *>(nsd + lds_cap);   // 0 unknown, 1 kept, 2 dropped
     __shared__ unsigned long long s_fx, s_seeds, s_anch, s_span;
     __shared__ uint32_t s_kept, s_unknown, s_n;
 
@@ -555,7 +589,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(SetView A, SetView B, con
             c = chains[pd.c_base + (i - nfast_items)];
         }
         const uint32_t d = atomicAdd(&s_n, 1u);
-        if (d < FIN_LDS_CHAINS) {
+        if (d < lds_cap) {
             sc[d] = c.score; q0[d] = c.q0; q1[d] = c.q1; r0[d] = c.r0; r1[d] = c.r1; rc[d] = c.rctg;
             na[d] = c.n; nsd[d] = c.n_seeds;
             state[d] = 0;
@@ -563,9 +597,9 @@ __global__ __launch_bounds__(256) void finalize_kernel(SetView A, SetView B, con
     }
     __syncthreads();
     uint32_t n = s_n;
-    if (n > FIN_LDS_CHAINS) {
+    if (n > lds_cap) {
         if (tid == 0) atomicOr(&flags[0], 16u);
-        n = FIN_LDS_CHAINS;
+        n = lds_cap;
     }
     __syncthreads();
     // a chain is dropped when ONE better kept chain on the same record covers more than half of
@@ -604,7 +638,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(SetView A, SetView B, con
     uint32_t kept = 0;
     for (uint32_t i = tid; i < n; i += 256) {
         if (state[i] != 1) continue;
-        fx += (unsigned long long)nsd[i] * (unsigned long long)root_fx(na[i], nsd[i]);
+        const uint32_t rf = (na[i] < ROOT_LUT && nsd[i] < ROOT_LUT) ? root_lut[na[i] * ROOT_LUT + nsd[i]] : root_fx(na[i], nsd[i]);
+        fx += (unsigned long long)nsd[i] * (unsigned long long)rf;
         sd += nsd[i];
         an += na[i];
         sp += q1[i] - q0[i];
@@ -645,7 +680,7 @@ static SetView view_of(skder_sketches *s)
     v.meta = s->d_meta.p;
     v.pkmer = s->seed_kmer.p; v.pgpos = s->seed_gpos.p; v.pchunk = s->pchunk.p;
     v.skmer = s->skmer.p; v.sgpos = s->sgpos.p; v.sctg = s->sctg.p; v.boff = s->boff.p;
-    v.chunk_start = s->chunk_start.p; v.table = s->table.p;
+    v.chunk_start = s->chunk_start.p; v.table = s->table.p; v.rec_goff = s->d_rec_goff.p;
     return v;
 }
 
@@ -665,6 +700,7 @@ struct ChainWork {
     DevBuf<int32_t> F;
     DevBuf<ChainRec> fast_chains, chains;
     DevBuf<PairOut> d_out;
+    DevBuf<uint32_t> root_lut;
     ScanWorkspace ws;
 };
 static ChainWork *chain_work(skder_ctx *ctx)
@@ -686,25 +722,43 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
     size_t budget = 6u << 20;   // chunks (work items) per batch
     if (const char *e = getenv("SKDER_AMD_CHUNK_BUDGET")) budget = strtoull(e, nullptr, 10);
     ChainWork &W = *chain_work(ctx);
+    if (!W.root_lut.p) {
+        W.root_lut.resize(ROOT_LUT * ROOT_LUT, st);
+        hipLaunchKernelGGL(root_lut_kernel, dim3(ROOT_LUT * ROOT_LUT / 256), dim3(256), 0, st, W.root_lut.p);
+    }
     std::vector<PairDesc> hp;
     std::vector<PairOut> ho;
     const SetView VA = view_of(SA), VB = view_of(SB);
     double t_fast = 0, t_slow = 0, t_fin = 0;
     uint64_t tot_anchors = 0, tot_slow = 0, tot_chunks = 0;
+    // orientation of every pair, then order the work by the probed genome (R): consecutive
+    // workgroups probe the same hash table, which keeps it in the XCD's L2
+    struct PairJob { uint32_t q, r, flags, orig; };
+    std::vector<PairJob> jobs(np);
+    for (size_t p = 0; p < np; p++) {
+        const GenomeMeta &mr = SA->h_meta[pref[p]], &mq = SB->h_meta[pquery[p]];
+        const bool cq = chunk_the_query(mr, mq);
+        jobs[p].q = cq ? pquery[p] : pref[p];
+        jobs[p].r = cq ? pref[p] : pquery[p];
+        jobs[p].flags = (cq ? 1u : 0u) | (cq ? 2u : 0u) | (cq ? 0u : 4u);   // Q in B iff cq; R in B iff !cq
+        jobs[p].orig = (uint32_t)p;
+    }
+    std::sort(jobs.begin(), jobs.end(), [](const PairJob &a, const PairJob &b) {
+        if ((a.flags & 4u) != (b.flags & 4u)) return (a.flags & 4u) < (b.flags & 4u);
+        if (a.r != b.r) return a.r < b.r;
+        return a.q < b.q;
+    });
     size_t p0 = 0;
     while (p0 < np) {
         hp.clear();
         uint64_t nchunks = 0, ccap = 0;
         size_t p = p0;
         for (; p < np; p++) {
-            const GenomeMeta &mr = SA->h_meta[pref[p]], &mq = SB->h_meta[pquery[p]];
-            const bool cq = chunk_the_query(mr, mq);
-            const GenomeMeta &Q = cq ? mq : mr;
+            const PairJob &jb = jobs[p];
+            const GenomeMeta &Q = (jb.flags & 2u) ? SB->h_meta[jb.q] : SA->h_meta[jb.q];
             PairDesc d;
             memset(&d, 0, sizeof d);
-            d.q = cq ? pquery[p] : pref[p];
-            d.r = cq ? pref[p] : pquery[p];
-            d.flags = (cq ? 1u : 0u) | (cq ? 2u : 0u) | (cq ? 0u : 4u);   // Q in B iff cq; R in B iff !cq
+            d.q = jb.q; d.r = jb.r; d.flags = jb.flags;
             d.n_chunks = Q.n_chunks;
             d.c_cap = 4u * Q.n_chunks + 64u;
             if (!hp.empty() && nchunks + d.n_chunks > budget) break;
@@ -729,7 +783,8 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         HIPCHECK(hipEventRecord(ctx->ev[5], st));
         if (nchunks)
             hipLaunchKernelGGL(chain_fast_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, st, VA, VB, W.d_pairs.p, nb,
-                               (uint32_t)nchunks, W.fast_chains.p, W.chunk_state.p, W.slow_list.p, W.counters.p, W.pair_na.p);
+                               (uint32_t)nchunks, W.fast_chains.p, W.chunk_state.p, W.slow_list.p, W.counters.p, W.pair_na.p,
+                               getenv("SKDER_AMD_NO_XCD") ? 0 : 1);
         HIPCHECK(hipEventRecord(ctx->ev[6], st));
         uint32_t hcnt[16] = {0};
         HIPCHECK(hipMemcpyAsync(hcnt, W.counters.p, 64, hipMemcpyDeviceToHost, st));
@@ -755,8 +810,14 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
                                W.pair_na.p, ctx->d_flags);
         }
         HIPCHECK(hipEventRecord(ctx->ev[7], st));
-        hipLaunchKernelGGL(finalize_kernel, dim3(nb), dim3(256), 0, st, VA, VB, W.d_pairs.p, W.fast_chains.p, W.chunk_state.p,
-                           W.chains.p, W.pair_nch.p, W.pair_na.p, W.d_out.p, ctx->d_flags);
+        // LDS capacity of the finalize step: the most chains any pair of the batch can plausibly have
+        // (3 per chunk on the fast path + slack), rounded up, at most 4096 (132 KB)
+        uint32_t max_chunks = 0;
+        for (const PairDesc &d : hp) max_chunks = d.n_chunks > max_chunks ? d.n_chunks : max_chunks;
+        uint32_t lds_cap = 512;
+        while (lds_cap < FAST_SLOTS * max_chunks / 2 + 128 && lds_cap < 4096) lds_cap <<= 1;
+        hipLaunchKernelGGL(finalize_kernel, dim3(nb), dim3(256), lds_cap * 33u, st, VA, VB, W.d_pairs.p, W.fast_chains.p, W.chunk_state.p,
+                           W.chains.p, W.pair_nch.p, W.pair_na.p, W.d_out.p, ctx->d_flags, W.root_lut.p, lds_cap);
         HIPCHECK(hipEventRecord(ctx->ev[8], st));
         ho.resize(nb);
         uint32_t h_flags = 0;
@@ -765,7 +826,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         HIPCHECK(hipStreamSynchronize(st));
         if (h_flags & 4u) throw SkError("anchor buffer overflow in the slow path (a chunk has more than 4*seeds+64 anchors)");
         if (h_flags & 8u) throw SkError("chain buffer overflow (a pair has more than 4*chunks+64 slow-path chains)");
-        if (h_flags & 16u) throw SkError("pair with more than 2048 chains is not supported");
+        if (h_flags & 16u) throw SkError("pair with more chains than the finalize step holds in LDS (1.5 per chunk + 128, at most 4096)");
         float ms;
         HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[6])); t_fast += ms;
         HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7])); t_slow += ms;
@@ -777,7 +838,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
             if (!o.n_chains || !(o.ani > 0.0)) continue;
             const bool cq = hp[i].flags & 1u;
             skder_edge_t e;
-            e.ref = pref[p0 + i]; e.query = pquery[p0 + i];
+            e.ref = pref[jobs[p0 + i].orig]; e.query = pquery[jobs[p0 + i].orig];
             e.ani = o.ani;
             e.af_query = cq ? o.af_q : o.af_r;
             e.af_ref = cq ? o.af_r : o.af_q;

@@ -18,7 +18,7 @@ struct GenomeMeta {
     uint32_t n_markers;
     uint32_t n_rec;
     uint32_t bucket_bits;
-    uint32_t table_bits;    // hash table has 2^table_bits slots (>= 3 * n_seeds)
+    uint32_t table_bits;    // hash table has 2^table_bits slots (>= 2 * n_seeds)
     uint32_t pad0;
     uint32_t n_chunks;      // filled by the index kernel
     uint32_t rep_cut;       // filled by the index kernel
@@ -41,7 +41,7 @@ struct skder_sketches {
     DevBuf<uint32_t> boff;                 // bucket offset tables
     DevBuf<uint32_t> pchunk;               // chunk id of every seed (position order)
     DevBuf<uint32_t> chunk_start;          // first seed of every chunk (+ end sentinel), per genome
-    DevBuf<uint4> table;                   // open-addressing k-mer tables: {kmer|fwd<<31, gpos, ctg, 0}
+    DevBuf<uint2> table;                   // open-addressing k-mer tables: {kmer | fwd<<30 | multi<<31, gpos}
 };
 
 void sketch_batch_impl(skder_sketches *s, const uint8_t *d_bases, const skder_batch_t *b);
@@ -52,6 +52,8 @@ void synth_fill_impl(skder_ctx *ctx, uint8_t *d_bases, const skder_batch_t *b, c
                      const uint32_t *params);
 
 #define TABLE_EMPTY 0xFFFFFFFFu
+#define TABLE_FWD 0x40000000u
+#define TABLE_MULTI 0x80000000u
 __host__ __device__ inline uint32_t kmer_bucket(uint32_t kmer, uint32_t bits)
 {
     return (kmer * 0x9E3779B1u) >> (32u - bits);

@@ -12,7 +12,7 @@ __global__ __launch_bounds__(256) void index_genome_kernel(
     GenomeMeta *__restrict__ meta, const uint32_t *__restrict__ rec_goff, const uint32_t *__restrict__ seed_kmer,
     const uint32_t *__restrict__ seed_gpos, const uint32_t *__restrict__ seed_ctg, uint32_t *__restrict__ skmer,
     uint32_t *__restrict__ sgpos, uint32_t *__restrict__ sctg, uint32_t *__restrict__ boff_all,
-    uint32_t *__restrict__ pchunk, uint32_t *__restrict__ chunk_start_all, uint4 *__restrict__ table_all)
+    uint32_t *__restrict__ pchunk, uint32_t *__restrict__ chunk_start_all, uint2 *__restrict__ table_all)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t *cnt = reinterpret_cast<uint32_t *>(smem_raw);   // 2^bits counters, later cursor, later histogram
@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void index_genome_kernel(
     uint32_t *boff = boff_all + m.bucket_off;
     const uint32_t *rg = rec_goff + m.rec_goff_off;
 
-    uint4 *tab = table_all + m.table_off;
+    uint2 *tab = table_all + m.table_off;
     const uint32_t tbits = m.table_bits, tmask = (1u << tbits) - 1u;
     for (uint32_t b = tid; b < nb; b += 256) cnt[b] = 0;
     if (tid == 0) s_distinct = 0;
@@ -78,16 +78,19 @@ __global__ __launch_bounds__(256) void index_genome_kernel(
             uint32_t mult = j - i;
             atomicAdd(&cnt[mult < IDX_REP_HIST - 1 ? mult : IDX_REP_HIST - 1], 1u);
             my_distinct++;
-            // open-addressing table (linear probing, multiplicative hash): one 16-byte slot per seed
-            // occurrence, {kmer|fwd<<31, gpos, record, multiplicity}; cleared to TABLE_EMPTY by the host
+            // open-addressing table (linear probing, multiplicative hash): one 8-byte slot per seed
+            // occurrence, {kmer | fwd<<30 | multi<<31, gpos}; cleared to TABLE_EMPTY by the host.
+            // multi = the k-mer occurs more than once in this genome (a probe must then run to the
+            // next empty slot to see every occurrence)
             for (uint32_t e = i; e < j; e++) {
+                const uint32_t x = kk | ((ok[e] >> 31) ? TABLE_FWD : 0u) | (mult > 1 ? TABLE_MULTI : 0u);
                 uint32_t h = kmer_bucket(kk, tbits);
                 for (;;) {
-                    uint32_t old = atomicCAS(&tab[h].x, TABLE_EMPTY, ok[e]);
+                    uint32_t old = atomicCAS(&tab[h].x, TABLE_EMPTY, x);
                     if (old == TABLE_EMPTY) break;
                     h = (h + 1) & tmask;
                 }
-                tab[h].y = og[e]; tab[h].z = oc[e]; tab[h].w = mult;
+                tab[h].y = og[e];
             }
             i = j;
         }
@@ -157,7 +160,8 @@ void index_impl(skder_sketches *s)
         m.n_chunks = 0;
         m.rep_cut = 0xFFFFFFFFu;
         uint32_t tb = 6;
-        while ((1ull << tb) < 3ull * m.n_seeds) tb++;
+        static const uint64_t tfac = getenv("SKDER_AMD_TABLE_FACTOR") ? strtoull(getenv("SKDER_AMD_TABLE_FACTOR"), nullptr, 10) : 4;
+        while ((1ull << tb) < tfac * m.n_seeds) tb++;
         if (tb > 31) throw SkError("genome with too many seeds");
         m.table_bits = tb; m.pad0 = 0;
         m.table_off = table_total;
@@ -173,7 +177,7 @@ void index_impl(skder_sketches *s)
     s->boff.resize(boff_total + 1, st);
     s->chunk_start.resize(chunk_total + 1, st);
     s->table.resize(table_total + 1, st);
-    HIPCHECK(hipMemsetAsync(s->table.p, 0xFF, (table_total + 1) * sizeof(uint4), st));
+    HIPCHECK(hipMemsetAsync(s->table.p, 0xFF, (table_total + 1) * sizeof(uint2), st));
     if (G) {
         HIPCHECK(hipMemcpyAsync(s->d_meta.p, s->h_meta.data(), G * sizeof(GenomeMeta), hipMemcpyHostToDevice, st));
         HIPCHECK(hipMemcpyAsync(s->d_rec_goff.p, s->h_rec_goff.data(), s->h_rec_goff.size() * 4, hipMemcpyHostToDevice, st));
