@@ -65,11 +65,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # SKDER_AMD_DIST_BACKEND=gloo lets several ranks share one GPU (functional check of the N>1 path on
+    # a 1-GPU box: the exchange then goes through host memory); the default is RCCL, one GPU per rank
+    backend = os.environ.get("SKDER_AMD_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev = local_rank % max(ndev, 1)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    ctx = engine.Context(local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
+    torch.cuda.set_device(dev)
+    ctx = engine.Context(dev)
 
     N = args.genomes
     recipe = synth.make_recipe(N, genome_len=args.genome_len)
@@ -93,7 +101,7 @@ def main():
             t = ctx.timing()
             tm[0] += t[0]; tm[1] += t[1]
         if world > 1:
-            raw = multigpu.exchange_raw(multigpu.raw_from_sketches(sk))
+            raw = multigpu.exchange_raw(multigpu.raw_from_sketches(sk), staging="cpu" if backend != "nccl" else None)
             sk.close()
             sk = multigpu.sketches_from_raw(ctx, raw)
         sk.index()
@@ -123,12 +131,17 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
     pairs = N * (N - 1) // 2
     tm = np.mean(tms, axis=0)
+    n_chained_all = float(tm[6])
+    if world > 1:
+        t = torch.tensor([tm[6]], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        n_chained_all = float(t.item())
 
     if rank == 0:
         # dominant kernel and its roofline (algorithmic bytes, DESIGN.md "Kernels")
@@ -149,7 +162,7 @@ def main():
             "dtype": "u64 hash / i32 chaining / f64 ANI", "data": "synthetic",
             "config": {"workload": "%d synthetic genomes x %.1f Mb (50 species x 10 strains x 10 isolates), triangle, screen %.0f"
                        % (N, args.genome_len / 1e6, args.screen), "genomes": N, "pairs": pairs,
-                       "chained_pairs": int(n_chained * (world if world > 1 else 1)), "edges": int(len(edges)),
+                       "chained_pairs": int(n_chained_all), "edges": int(len(edges)),
                        "chunks": int(step.counters[0]), "slow_path_chunks": int(step.counters[1]),
                        "parallelism": "rows%d" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

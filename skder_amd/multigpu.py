@@ -30,10 +30,11 @@ def _allgather_var(t: torch.Tensor, counts: List[int], group=None) -> torch.Tens
     return torch.cat([out[r][: counts[r]] for r in range(world)])
 
 
-def exchange_raw(raw: Dict, group=None) -> Dict:
+def exchange_raw(raw: Dict, group=None, staging: str = None) -> Dict:
     """raw: dict with torch tensors seed_kmer/seed_gpos/seed_ctg (int32 views of u32) and markers
     (int64 view of u64) of THIS rank's genomes, and numpy metadata seed_off, marker_off, genome_len,
-    genome_nrec, rec_goff.  Returns the same dict for the concatenation of all ranks' genomes."""
+    genome_nrec, rec_goff.  Returns the same dict for the concatenation of all ranks' genomes.
+    staging="cpu": move device tensors through host memory (gloo backend)."""
     world = dist.get_world_size(group)
     meta = dict(n_genomes=int(raw["n_genomes"]), n_seeds=int(raw["seed_kmer"].numel()),
                 n_markers=int(raw["markers"].numel()),
@@ -44,7 +45,11 @@ def exchange_raw(raw: Dict, group=None) -> Dict:
     dist.all_gather_object(metas, meta, group=group)
     out = dict(n_genomes=sum(m["n_genomes"] for m in metas))
     for key, cnt in (("seed_kmer", "n_seeds"), ("seed_gpos", "n_seeds"), ("seed_ctg", "n_seeds"), ("markers", "n_markers")):
-        out[key] = _allgather_var(raw[key], [m[cnt] for m in metas], group)
+        src = raw[key]
+        if staging == "cpu" and src.is_cuda:      # gloo functional runs: exchange through host memory
+            out[key] = _allgather_var(src.cpu(), [m[cnt] for m in metas], group).to(src.device)
+        else:
+            out[key] = _allgather_var(src, [m[cnt] for m in metas], group)
     so, mo = [np.zeros(1, np.uint64)], [np.zeros(1, np.uint64)]
     sbase = mbase = np.uint64(0)
     for m in metas:

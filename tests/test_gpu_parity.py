@@ -256,3 +256,25 @@ def test_dropin_tables_match_oracle_and_golden(gpu, oracle, tmp_path):
         assert any(r[0] == q and r[1] == q and r[2] == "100.00" for r in rows)   # the self hit
     finally:
         _lib.lib().skder_amd_db_free(db)
+
+
+def test_two_ranks_share_the_triangle(gpu):
+    """N > 1 path end to end on the real kernels: two ranks (gloo, both on this GPU) sketch half of the
+    genomes each, exchange raw sketches, deal the rows cyclically; rank 0 must see the same edge count
+    as a single-rank run"""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, SKDER_AMD_DIST_BACKEND="gloo")
+    common = ["--genomes", "40", "--genome-len", "200000", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, env=env, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(29600 + os.getpid() % 300), os.path.join(ROOT, "bench.py"), "--gpus", "2"]
+                         + common, capture_output=True, text=True, env=env, timeout=900)
+    assert two.returncode == 0, two.stderr[-2000:]
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    assert j2["n_gpus"] == 2 and j1["config"]["edges"] == j2["config"]["edges"] > 0
+    assert j1["config"]["chained_pairs"] == j2["config"]["chained_pairs"]
