@@ -79,7 +79,8 @@ struct RingE {
     int32_t f;
     uint32_t cnt;        // anchors on the path ending here | SUCC_BIT when another anchor chained to it
     uint32_t first_qi, rmin, rmax, qi;
-    uint32_t path;       // ordinal of the path's first anchor: identifies the path
+    uint32_t path;       // ordinal of the first anchor of the current diagonal segment of the path
+    int32_t pmax;        // highest score among the EARLIER anchors of the path
 };
 
 __global__ __launch_bounds__(256) void chain_fast_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs, uint32_t npairs,
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256) void chain_fast_kernel(SetView A, SetView B, c
     // XCD-aware work mapping: workgroups are dealt round-robin to the 8 XCDs, so give every XCD one
     // contiguous eighth of the (R-sorted) work list: its private L2 then sees few hash tables at a time
     uint32_t wg = blockIdx.x;
-    if (xcd_remap) {
+    if (xcd_remap & 1) {
         const uint32_t nwg = gridDim.x, xcd = wg & 7u, idx = wg >> 3, q8 = nwg >> 3, r8 = nwg & 7u;
         wg = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + idx;
     }
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256) void chain_fast_kernel(SetView A, SetView B, c
     r0.qpos = r1.qpos = r2.qpos = r3.qpos = 0; r0.rr = r1.rr = r2.rr = r3.rr = 0; r0.rctg = r1.rctg = r2.rctg = r3.rctg = 0;
     r0.first_qi = r1.first_qi = r2.first_qi = r3.first_qi = 0; r0.rmin = r1.rmin = r2.rmin = r3.rmin = 0;
     r0.rmax = r1.rmax = r2.rmax = r3.rmax = 0; r0.qi = r1.qi = r2.qi = r3.qi = 0;
-    r0.path = r1.path = r2.path = r3.path = 0;
+    r0.path = r1.path = r2.path = r3.path = 0; r0.pmax = r1.pmax = r2.pmax = r3.pmax = 0;
     uint32_t ia = 0, nfin = 0;
     int32_t runmax = -0x40000000;
     // summaries of the anchors that already left the ring, by path: the two most recent paths
@@ -137,7 +138,8 @@ __global__ __launch_bounds__(256) void chain_fast_kernel(SetView A, SetView B, c
 #define EMIT_PATH(E)                                                                         \
     do {                                                                                     \
         if (!((E).cnt & SUCC_BIT) && (E).cnt >= ANI_MIN_ANCHORS) {                           \
-            if (nfin >= FAST_SLOTS) { cplx = true; cause = 1; }                                             \
+            if (!((E).f > (E).pmax)) { cplx = true; cause = 5; } /* best end is not the last anchor */ \
+            else if (nfin >= FAST_SLOTS) { cplx = true; cause = 1; }                                 \
             else {                                                                           \
                 ChainRec cr;                                                                 \
                 cr.score = (E).f; cr.n = (E).cnt; cr.n_seeds = (E).qi - (E).first_qi + 1;    \
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(256) void chain_fast_kernel(SetView A, SetView B, c
             int bj = -1;
             bool exact = false;
             uint32_t pcnt = 0, pfirst = 0, prmin = 0, prmax = 0, ppath = 0;
-            int32_t pf = 0;
+            int32_t pf = 0, ppmax = 0, pgap = 0;
 #define TRY(K, E)                                                                                   \
             if (!exact) {                                                                           \
                 if ((K) >= ia) exact = true;                                                        \
@@ -236,8 +238,8 @@ __global__ __launch_bounds__(256) void chain_fast_kernel(SetView A, SetView B, c
                             const int32_t gap = dq > dr ? dq - dr : dr - dq;                        \
                             if (gap <= ANI_MAX_GAP) {                                               \
                                 const int32_t sc = (E).f + ANI_ANCHOR_SCORE - gap;                  \
-                                if (sc > best) { best = sc; bj = (K); pcnt = (E).cnt; pfirst = (E).first_qi; \
-                                                 prmin = (E).rmin; prmax = (E).rmax; pf = (E).f; ppath = (E).path; } \
+                                if (sc > best) { best = sc; bj = (K); pcnt = (E).cnt; pfirst = (E).first_qi; pgap = gap; \
+                                                 prmin = (E).rmin; prmax = (E).rmax; pf = (E).f; ppath = (E).path; ppmax = (E).pmax; } \
                             }                                                                       \
                         }                                                                           \
                     }                                                                               \
@@ -252,27 +254,33 @@ __global__ __launch_bounds__(256) void chain_fast_kernel(SetView A, SetView B, c
                 const uint32_t key = rc | (rev << 31);
                 const int32_t dg = rev ? rp + qp : rp - qp;
                 bool ok = true;
-                if (s0_path != 0xFFFFFFFFu && qp - (int32_t)s0_q <= ANI_BP_BAND && s0_key == key && dg >= s0_dlo - ANI_MAX_GAP &&
-                    dg <= s0_dhi + ANI_MAX_GAP && !(best >= s0_f + ANI_ANCHOR_SCORE)) ok = false;
-                if (s1_path != 0xFFFFFFFFu && qp - (int32_t)s1_q <= ANI_BP_BAND && s1_key == key && dg >= s1_dlo - ANI_MAX_GAP &&
-                    dg <= s1_dhi + ANI_MAX_GAP && !(best >= s1_f + ANI_ANCHOR_SCORE)) ok = false;
-                if (lost_f != NEG && qp - (int32_t)lost_q <= ANI_BP_BAND && dg >= lost_dlo - ANI_MAX_GAP && dg <= lost_dhi + ANI_MAX_GAP &&
-                    !(best >= lost_f + ANI_ANCHOR_SCORE)) ok = false;
+                // an anchor of a summary is at least `off` away from this anchor's diagonal, so it can
+                // offer at most (summary score + 20 - off); beyond max_gap it cannot chain at all
+#define SUMMARY_BLOCKS(SF, SQ, DLO, DHI, KEYOK)                                                                  \
+                if ((KEYOK) && qp - (int32_t)(SQ) <= ANI_BP_BAND) {                                              \
+                    const int32_t off = dg < (DLO) ? (DLO) - dg : (dg > (DHI) ? dg - (DHI) : 0);                  \
+                    if (off <= ANI_MAX_GAP && !(best >= (SF) + ANI_ANCHOR_SCORE - off)) ok = false;               \
+                }
+                SUMMARY_BLOCKS(s0_f, s0_q, s0_dlo, s0_dhi, s0_path != 0xFFFFFFFFu && s0_key == key)
+                SUMMARY_BLOCKS(s1_f, s1_q, s1_dlo, s1_dhi, s1_path != 0xFFFFFFFFu && s1_key == key)
+                SUMMARY_BLOCKS(lost_f, lost_q, lost_dlo, lost_dhi, lost_f != NEG)
+#undef SUMMARY_BLOCKS
                 if (!ok) { cplx = true; cause = 3; break; }
             }
             RingE e;
             e.qpos = (uint32_t)qp; e.rr = rr; e.rctg = rc; e.f = best; e.qi = s;
             if (bj >= 0) {
-                if ((pcnt & SUCC_BIT) || !(best > pf)) { cplx = true; cause = (pcnt & SUCC_BIT) ? 4 : 5; break; }   // branch, or score not increasing
+                if (pcnt & SUCC_BIT) { cplx = true; cause = 4; break; }   // two anchors chain to the same predecessor
                 if (bj == 0) r0.cnt |= SUCC_BIT; else if (bj == 1) r1.cnt |= SUCC_BIT;
                 else if (bj == 2) r2.cnt |= SUCC_BIT; else r3.cnt |= SUCC_BIT;
                 e.cnt = (pcnt & 0x7FFFFFFFu) + 1u;
                 e.first_qi = pfirst;
-                e.path = ppath;
+                e.path = pgap >= ANI_ANCHOR_SCORE ? ia : ppath;   // a score-lowering indel starts a new diagonal segment
+                e.pmax = pf > ppmax ? pf : ppmax;
                 e.rmin = (uint32_t)rp < prmin ? (uint32_t)rp : prmin;
                 e.rmax = (uint32_t)rp > prmax ? (uint32_t)rp : prmax;
             } else {
-                e.cnt = 1; e.first_qi = s; e.rmin = e.rmax = (uint32_t)rp; e.path = ia;
+                e.cnt = 1; e.first_qi = s; e.rmin = e.rmax = (uint32_t)rp; e.path = ia; e.pmax = -0x40000000;
             }
             if (ia >= RING) {
                 EMIT_PATH(r3);   // the anchor leaving the ring can no longer be extended
@@ -280,18 +288,19 @@ __global__ __launch_bounds__(256) void chain_fast_kernel(SetView A, SetView B, c
                 const int32_t d3 = (r3.rr >> 31) ? (int32_t)(r3.rr & 0x7FFFFFFFu) + (int32_t)r3.qpos
                                                  : (int32_t)(r3.rr & 0x7FFFFFFFu) - (int32_t)r3.qpos;
                 if (r3.path == s0_path) {
-                    s0_f = r3.f; s0_q = r3.qpos;
+                    s0_f = r3.f > s0_f ? r3.f : s0_f; s0_q = r3.qpos;
                     s0_dlo = d3 < s0_dlo ? d3 : s0_dlo; s0_dhi = d3 > s0_dhi ? d3 : s0_dhi;
                 } else {
                     const bool was_s1 = r3.path == s1_path;
                     const int32_t nlo = was_s1 ? (d3 < s1_dlo ? d3 : s1_dlo) : d3, nhi = was_s1 ? (d3 > s1_dhi ? d3 : s1_dhi) : d3;
+                    const int32_t nf = was_s1 ? (r3.f > s1_f ? r3.f : s1_f) : r3.f;
                     if (!was_s1 && s1_path != 0xFFFFFFFFu) {   // the older summary falls out: fold it into the scalar
                         if (lost_f == NEG) { lost_dlo = s1_dlo; lost_dhi = s1_dhi; }
                         else { lost_dlo = s1_dlo < lost_dlo ? s1_dlo : lost_dlo; lost_dhi = s1_dhi > lost_dhi ? s1_dhi : lost_dhi; }
                         lost_f = s1_f > lost_f ? s1_f : lost_f; lost_q = s1_q > lost_q ? s1_q : lost_q;
                     }
                     s1_path = s0_path; s1_key = s0_key; s1_f = s0_f; s1_q = s0_q; s1_dlo = s0_dlo; s1_dhi = s0_dhi;
-                    s0_path = r3.path; s0_key = k3; s0_f = r3.f; s0_q = r3.qpos; s0_dlo = nlo; s0_dhi = nhi;
+                    s0_path = r3.path; s0_key = k3; s0_f = nf; s0_q = r3.qpos; s0_dlo = nlo; s0_dhi = nhi;
                 }
             }
             r3 = r2; r2 = r1; r1 = r0; r0 = e;
