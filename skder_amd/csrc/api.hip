@@ -71,6 +71,7 @@ extern "C" int skder_amd_last_counters(skder_ctx_t *ctx, uint64_t *out4)
 {
     if (!ctx || !out4) return 1;
     for (int i = 0; i < 4; i++) out4[i] = ctx->counters[i];
+    out4[2] = (uint64_t)(ctx->timing_join * 1000.0);   // join kernel time, microseconds
     return 0;
 }
 
@@ -126,6 +127,7 @@ extern "C" int skder_amd_sketches_append_raw(skder_sketches_t *s, const skder_ra
     hipStream_t st = s->ctx->stream;
     const uint64_t sb = s->seed_kmer.n, mb = s->markers.n;
     s->seed_kmer.resize(sb + raw->n_seeds, st);
+    s->seed_gpos.reserve(sb + raw->n_seeds + 32, s->seed_gpos.n, st);
     s->seed_gpos.resize(sb + raw->n_seeds, st);
     s->seed_ctg.resize(sb + raw->n_seeds, st);
     s->markers.resize(mb + raw->n_markers, st);

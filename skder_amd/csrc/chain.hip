@@ -21,10 +21,9 @@
 struct SetView {
     const GenomeMeta *meta;
     const uint32_t *pkmer, *pgpos, *pchunk;   // position order
-    const uint32_t *skmer, *sgpos, *sctg;     // bucket order
+    const uint32_t *skmer, *sgpos, *sctg, *sidx;   // bucket order
     const uint32_t *boff;
     const uint32_t *chunk_start;
-    const uint2 *table;
     const uint32_t *rec_goff;
 };
 
@@ -34,8 +33,15 @@ struct PairDesc {
     uint32_t n_chunks;
     uint32_t c_base, c_cap; // chain-record region of the slow path
     uint32_t flags;         // bit0: chunked genome is the pair's Query; bit1: q in set B; bit2: r in set B
-    uint32_t pad;
+    uint32_t hit_base;      // first entry of this pair in the hit array (one u32 per seed of the chunked genome)
+    uint32_t multi_base, multi_cap;   // region of 4-hit records for seeds with several hits
+    uint32_t pad[2];
 };
+
+// hit[s] for seed s of the chunked genome: gpos on the other genome | rev<<31, or one of
+#define HIT_NONE 0xFFFFFFFFu      // no occurrence on the other genome
+#define HIT_MULTI 0x7F000000u     // | slot: 2..4 occurrences, listed (ascending gpos) in multi[slot]
+#define HIT_MANY 0x7FFFFFFFu      // more than 4 occurrences (or no room): the chunk takes the slow path
 
 struct ChainRec {
     int32_t score;
@@ -67,6 +73,99 @@ __device__ __forceinline__ uint32_t find_pair(const PairDesc *__restrict__ pairs
 }
 
 // ---------------------------------------------------------------------------------------------
+// JOIN: one workgroup per pair.  Both genomes keep their seeds in 2^b multiplicative-hash buckets
+// sorted by (k-mer, gpos); bucket b of one genome can only match bucket b of the other (nested when the
+// bucket counts differ), so one thread per bucket streams both bucket-ordered arrays once (coalesced,
+// 8 B per seed and side) and writes, for every matching seed of the chunked genome, its hit into
+// the position-indexed hit array.  No hashing-table probes, no random reads.
+#define JOIN_TILE 256      // buckets per tile (one per thread)
+#define JOIN_CAP 1536      // seeds per side staged in LDS per tile (mean ~780 for 3 seeds per bucket)
+
+// match the seeds of bucket range [qlo,qhi) of the chunked genome against [rlo,rhi) of the other genome
+// (arrays may live in LDS or in global memory) and record the hits
+__device__ __forceinline__ void join_bucket(const uint32_t *qk, const uint32_t *qx, uint32_t qlo, uint32_t qhi, const uint32_t *rk,
+                                            const uint32_t *rg, uint32_t rlo, uint32_t rhi, uint32_t bits, uint32_t qbits, uint32_t fb,
+                                            uint32_t rrep, uint32_t *hit, uint4 *multi, uint32_t *nmulti, const PairDesc &pd)
+{
+    for (uint32_t e = qlo; e < qhi; e++) {
+        const uint32_t kq = qk[e], kmer = kq & SK_SEED_MASK;
+        if (bits != qbits && kmer_bucket(kmer, bits) != fb) continue;   // another thread owns this seed
+        uint32_t cnt = 0, first = 0;
+        for (uint32_t e2 = rlo; e2 < rhi; e2++) {
+            const uint32_t k2 = rk[e2] & SK_SEED_MASK;
+            if (k2 == kmer) { if (!cnt) first = e2; cnt++; }
+            else if (k2 > kmer) break;
+        }
+        if (!cnt || cnt > rrep) continue;
+        const uint32_t qi = qx[e];
+        if (cnt == 1) {
+            hit[qi] = rg[first] | (((kq >> 31) != (rk[first] >> 31)) ? USED_BIT : 0u);
+        } else if (cnt <= 4) {
+            const uint32_t slot = atomicAdd(nmulti, 1u);
+            if (slot < pd.multi_cap) {
+                uint32_t v[4] = {HIT_NONE, HIT_NONE, HIT_NONE, HIT_NONE};
+                for (uint32_t u = 0; u < cnt; u++)
+                    v[u] = rg[first + u] | (((kq >> 31) != (rk[first + u] >> 31)) ? USED_BIT : 0u);
+                multi[pd.multi_base + slot] = make_uint4(v[0], v[1], v[2], v[3]);
+                hit[qi] = HIT_MULTI | slot;
+            } else {
+                hit[qi] = HIT_MANY;
+            }
+        } else {
+            hit[qi] = HIT_MANY;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void join_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs,
+                                                   uint32_t *__restrict__ hits, uint4 *__restrict__ multi,
+                                                   uint32_t *__restrict__ pair_nmulti)
+{
+    __shared__ uint32_t s_qb[JOIN_TILE + 1], s_rb[JOIN_TILE + 1];
+    __shared__ uint32_t s_qk[JOIN_CAP], s_qx[JOIN_CAP], s_rk[JOIN_CAP], s_rg[JOIN_CAP];
+    const PairDesc pd = pairs[blockIdx.x];
+    const SetView &QS = (pd.flags & 2u) ? B : A;
+    const SetView &RS = (pd.flags & 4u) ? B : A;
+    const GenomeMeta *Qm = QS.meta + pd.q, *Rm = RS.meta + pd.r;
+    const uint32_t qbits = Qm->bucket_bits, rbits = Rm->bucket_bits, bits = qbits > rbits ? qbits : rbits;
+    const uint32_t *qk = QS.skmer + Qm->seed_off, *qx = QS.sidx + Qm->seed_off, *qb = QS.boff + Qm->bucket_off;
+    const uint32_t *rk = RS.skmer + Rm->seed_off, *rg = RS.sgpos + Rm->seed_off, *rb = RS.boff + Rm->bucket_off;
+    const uint32_t rrep = Rm->rep_cut, tid = threadIdx.x;
+    uint32_t *hit = hits + pd.hit_base;
+    uint32_t *nmulti = pair_nmulti + blockIdx.x;
+    if (qbits == rbits && (1u << bits) >= JOIN_TILE) {
+        // equal bucket counts: tiles of 256 buckets, both sides staged in LDS with coalesced loads
+        for (uint32_t b0 = 0; b0 < (1u << bits); b0 += JOIN_TILE) {
+            __syncthreads();
+            s_qb[tid] = qb[b0 + tid]; s_rb[tid] = rb[b0 + tid];
+            if (tid == 0) { s_qb[JOIN_TILE] = qb[b0 + JOIN_TILE]; s_rb[JOIN_TILE] = rb[b0 + JOIN_TILE]; }
+            __syncthreads();
+            const uint32_t q0 = s_qb[0], nq = s_qb[JOIN_TILE] - q0, r0 = s_rb[0], nr = s_rb[JOIN_TILE] - r0;
+            const bool staged = nq <= JOIN_CAP && nr <= JOIN_CAP;
+            if (staged) {
+                for (uint32_t i = tid; i < nq; i += 256) { s_qk[i] = qk[q0 + i]; s_qx[i] = qx[q0 + i]; }
+                for (uint32_t i = tid; i < nr; i += 256) { s_rk[i] = rk[r0 + i]; s_rg[i] = rg[r0 + i]; }
+            }
+            __syncthreads();
+            const uint32_t qlo = s_qb[tid], qhi = s_qb[tid + 1], rlo = s_rb[tid], rhi = s_rb[tid + 1];
+            if (qlo == qhi || rlo == rhi) continue;
+            if (staged)
+                join_bucket(s_qk, s_qx, qlo - q0, qhi - q0, s_rk, s_rg, rlo - r0, rhi - r0, bits, qbits, b0 + tid, rrep, hit, multi, nmulti, pd);
+            else
+                join_bucket(qk, qx, qlo, qhi, rk, rg, rlo, rhi, bits, qbits, b0 + tid, rrep, hit, multi, nmulti, pd);
+        }
+        return;
+    }
+    // different bucket counts: the finer index space, nested coarse buckets, straight from global memory
+    for (uint32_t fb = tid; fb < (1u << bits); fb += 256) {
+        const uint32_t qbk = fb >> (bits - qbits), rbk = fb >> (bits - rbits);
+        const uint32_t qlo = qb[qbk], qhi = qb[qbk + 1], rlo = rb[rbk], rhi = rb[rbk + 1];
+        if (qlo == qhi || rlo == rhi) continue;
+        join_bucket(qk, qx, qlo, qhi, rk, rg, rlo, rhi, bits, qbits, fb, rrep, hit, multi, nmulti, pd);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // FAST PATH: one lane per (pair, 20 kb chunk), no intermediate arrays.
 // The lane streams the chunk's seeds, probes the other genome's hash table (one 16-byte slot read
 // per probe) and runs the banded chaining DP against a 4-anchor register ring.  The result is
@@ -83,8 +182,9 @@ struct RingE {
     int32_t pmax;        // highest score among the EARLIER anchors of the path
 };
 
-__global__ __launch_bounds__(256) void chain_fast_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs, uint32_t npairs,
-                                                         uint32_t total_chunks, ChainRec *__restrict__ fast_chains,
+__global__ __launch_bounds__(256, 4) void chain_fast_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs, uint32_t npairs,
+                                                         uint32_t total_chunks, const uint32_t *__restrict__ hits,
+                                                         const uint4 *__restrict__ multi, ChainRec *__restrict__ fast_chains,
                                                          uint32_t *__restrict__ chunk_state, uint32_t *__restrict__ slow_list,
                                                          uint32_t *__restrict__ slow_count, uint32_t *__restrict__ pair_na,
                                                          int xcd_remap)
@@ -105,13 +205,11 @@ __global__ __launch_bounds__(256) void chain_fast_kernel(SetView A, SetView B, c
     const SetView &RS = (pd.flags & 4u) ? B : A;
     const GenomeMeta *Qm = QS.meta + pd.q, *Rm = RS.meta + pd.r;
     const uint64_t qoff = Qm->seed_off;
-    const uint32_t *qk = QS.pkmer + qoff, *qg = QS.pgpos + qoff;
+    const uint32_t *qg = QS.pgpos + qoff;
     const uint32_t s0 = QS.chunk_start[Qm->chunk_off + c], s1 = QS.chunk_start[Qm->chunk_off + c + 1];
-    const uint2 *tab = RS.table + Rm->table_off;
     const uint32_t *rgo = RS.rec_goff + Rm->rec_goff_off;
     const uint32_t rnrec = Rm->n_rec;
     uint32_t cur_rec = 0, cur_lo = rgo[0], cur_hi = rgo[1];   // record interval of the last hit (hits cluster)
-    const uint32_t tbits = Rm->table_bits, tmask = (1u << tbits) - 1u, rrep = Rm->rep_cut;
     bool cplx = Qm->rep_cut != 0xFFFFFFFFu;   // own-multiplicity filter active: leave it to the slow path
     uint32_t cause = cplx ? 6u : 0u;
 
@@ -149,62 +247,43 @@ __global__ __launch_bounds__(256) void chain_fast_kernel(SetView A, SetView B, c
         }                                                                                    \
     } while (0)
 
-    // software pipeline over blocks of 4 seeds: the four table slots of a block are requested
-    // together (independent loads), and the seeds of the NEXT block are fetched while the current
-    // block is processed, so a lane waits for one memory round trip per 4 seeds instead of two per seed
-    uint32_t kmA[4], hA[4], kmB[4];
-    int32_t qpA[4], qpB[4];
-    uint2 slA[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        kmB[k] = 0; qpB[k] = 0;
-        if (s0 + k < s1 && !cplx) { kmB[k] = qk[s0 + k]; qpB[k] = (int32_t)qg[s0 + k]; }
-    }
-    for (uint32_t sb = s0; sb < s1 && !cplx; sb += 4) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            kmA[k] = kmB[k]; qpA[k] = qpB[k];
-            hA[k] = kmer_bucket(kmA[k] & SK_SEED_MASK, tbits);
-            slA[k] = (sb + k < s1) ? tab[hA[k]] : make_uint2(TABLE_EMPTY, 0);
+    // Each lane streams two arrays (hit words, seed positions) from its own place in memory.  To fetch
+    // every 64-byte line exactly once the lane pulls a whole line (16 entries, 4 x 16-B loads) into a
+    // private LDS strip when its stream crosses a line boundary and then reads single entries from LDS.
+    __shared__ uint32_t lb_hit[16][256], lb_qp[16][256];
+    const uint32_t tidx = threadIdx.x;
+    const uint64_t hbase = pd.hit_base;          // absolute entry index of seed 0 in the hit array
+    const uint32_t *qg_abs = QS.pgpos;           // absolute base of the position array
+    {
+      for (uint32_t s = s0; s < s1 && !cplx; s++) {
+        const uint64_t ah = hbase + s, aq = qoff + s;
+        if (s == s0 || (ah & 15u) == 0) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(hits + (ah & ~(uint64_t)15));
+            const uint4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+            lb_hit[0][tidx] = v0.x; lb_hit[1][tidx] = v0.y; lb_hit[2][tidx] = v0.z; lb_hit[3][tidx] = v0.w;
+            lb_hit[4][tidx] = v1.x; lb_hit[5][tidx] = v1.y; lb_hit[6][tidx] = v1.z; lb_hit[7][tidx] = v1.w;
+            lb_hit[8][tidx] = v2.x; lb_hit[9][tidx] = v2.y; lb_hit[10][tidx] = v2.z; lb_hit[11][tidx] = v2.w;
+            lb_hit[12][tidx] = v3.x; lb_hit[13][tidx] = v3.y; lb_hit[14][tidx] = v3.z; lb_hit[15][tidx] = v3.w;
         }
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            if (sb + 4 + k < s1) { kmB[k] = qk[sb + 4 + k]; qpB[k] = (int32_t)qg[sb + 4 + k]; }
-        const uint32_t nk = s1 - sb < 4u ? s1 - sb : 4u;
-      for (uint32_t kk = 0; kk < nk && !cplx; kk++) {
-        const uint32_t s = sb + kk;
-        const uint32_t km = kmA[0], kmer = km & SK_SEED_MASK;
-        const int32_t qp = qpA[0];
-        uint32_t h = hA[0];
-        uint2 sl = slA[0];
-        kmA[0] = kmA[1]; kmA[1] = kmA[2]; kmA[2] = kmA[3];
-        qpA[0] = qpA[1]; qpA[1] = qpA[2]; qpA[2] = qpA[3];
-        hA[0] = hA[1]; hA[1] = hA[2]; hA[2] = hA[3];
-        slA[0] = slA[1]; slA[1] = slA[2]; slA[2] = slA[3];
-        uint32_t m = 0, g0 = 0xFFFFFFFFu, g1 = 0xFFFFFFFFu, g2 = 0xFFFFFFFFu, g3 = 0xFFFFFFFFu;
-        for (;;) {
-            if (sl.x == TABLE_EMPTY) break;
-            if ((sl.x & SK_SEED_MASK) == kmer) {
-                // payload: gpos | rev<<31
-                const uint32_t rv = ((km >> 31) != ((sl.x >> 30) & 1u)) ? USED_BIT : 0u;
-                if (m == 0) g0 = sl.y | rv;
-                else if (m == 1) g1 = sl.y | rv;
-                else if (m == 2) g2 = sl.y | rv;
-                else if (m == 3) g3 = sl.y | rv;
-                m++;
-                if (!(sl.x & TABLE_MULTI)) break;   // the only occurrence
-            }
-            h = (h + 1) & tmask;
-            sl = tab[h];
+        if (s == s0 || (aq & 15u) == 0) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(qg_abs + (aq & ~(uint64_t)15));
+            const uint4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+            lb_qp[0][tidx] = v0.x; lb_qp[1][tidx] = v0.y; lb_qp[2][tidx] = v0.z; lb_qp[3][tidx] = v0.w;
+            lb_qp[4][tidx] = v1.x; lb_qp[5][tidx] = v1.y; lb_qp[6][tidx] = v1.z; lb_qp[7][tidx] = v1.w;
+            lb_qp[8][tidx] = v2.x; lb_qp[9][tidx] = v2.y; lb_qp[10][tidx] = v2.z; lb_qp[11][tidx] = v2.w;
+            lb_qp[12][tidx] = v3.x; lb_qp[13][tidx] = v3.y; lb_qp[14][tidx] = v3.z; lb_qp[15][tidx] = v3.w;
         }
-        if (m == 0 || m > rrep) continue;
-        if (m > 4) { cplx = true; cause = 2; break; }
-        if (m > 1) {   // ascending gpos (ignoring the strand bit): 5-comparator network on 4 slots
-#define CSWAP(ga, gb) if (((gb) & 0x7FFFFFFFu) < ((ga) & 0x7FFFFFFFu) && (gb) != 0xFFFFFFFFu) { uint32_t tg = ga; ga = gb; gb = tg; }
-            // unused slots hold 0xFFFFFFFF and must stay behind the used ones
-            CSWAP(g0, g1) CSWAP(g2, g3) CSWAP(g0, g2) CSWAP(g1, g3) CSWAP(g1, g2)
-#undef CSWAP
+        const uint32_t hw = lb_hit[ah & 15u][tidx];
+        const int32_t qp = (int32_t)lb_qp[aq & 15u][tidx];
+        if (hw == HIT_NONE) continue;
+        if (hw == HIT_MANY) { cplx = true; cause = 2; break; }
+        uint32_t m = 1, g0 = hw, g1 = HIT_NONE, g2 = HIT_NONE, g3 = HIT_NONE;
+        if ((hw & 0xFF000000u) == HIT_MULTI) {   // 2..4 occurrences, ascending gpos
+            const uint4 mv = multi[pd.multi_base + (hw & 0x00FFFFFFu)];
+            g0 = mv.x; g1 = mv.y; g2 = mv.z; g3 = mv.w;
+            m = 2u + (g2 != HIT_NONE) + (g3 != HIT_NONE);
         }
+
         for (uint32_t u = 0; u < m && !cplx; u++) {
             const uint32_t rr = g0;
             g0 = g1; g1 = g2; g2 = g3;
@@ -688,8 +767,8 @@ static SetView view_of(skder_sketches *s)
     SetView v;
     v.meta = s->d_meta.p;
     v.pkmer = s->seed_kmer.p; v.pgpos = s->seed_gpos.p; v.pchunk = s->pchunk.p;
-    v.skmer = s->skmer.p; v.sgpos = s->sgpos.p; v.sctg = s->sctg.p; v.boff = s->boff.p;
-    v.chunk_start = s->chunk_start.p; v.table = s->table.p; v.rec_goff = s->d_rec_goff.p;
+    v.skmer = s->skmer.p; v.sgpos = s->sgpos.p; v.sctg = s->sctg.p; v.sidx = s->sidx.p; v.boff = s->boff.p;
+    v.chunk_start = s->chunk_start.p; v.rec_goff = s->d_rec_goff.p;
     return v;
 }
 
@@ -706,6 +785,8 @@ static bool chunk_the_query(const GenomeMeta &ref, const GenomeMeta &query)
 struct ChainWork {
     DevBuf<PairDesc> d_pairs;
     DevBuf<uint32_t> chunk_state, slow_list, counters, pair_na, pair_nch, cap, abase, slow_n, a_qi, a_r, a_rctg, BP;
+    DevBuf<uint32_t> hits, pair_nmulti;
+    DevBuf<uint4> multi;
     DevBuf<int32_t> F;
     DevBuf<ChainRec> fast_chains, chains;
     DevBuf<PairOut> d_out;
@@ -738,7 +819,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
     std::vector<PairDesc> hp;
     std::vector<PairOut> ho;
     const SetView VA = view_of(SA), VB = view_of(SB);
-    double t_fast = 0, t_slow = 0, t_fin = 0;
+    double t_fast = 0, t_slow = 0, t_fin = 0, t_join = 0;
     uint64_t tot_anchors = 0, tot_slow = 0, tot_chunks = 0;
     // orientation of every pair, then order the work by the probed genome (R): consecutive
     // workgroups probe the same hash table, which keeps it in the XCD's L2
@@ -760,7 +841,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
     size_t p0 = 0;
     while (p0 < np) {
         hp.clear();
-        uint64_t nchunks = 0, ccap = 0;
+        uint64_t nchunks = 0, ccap = 0, nhits = 0, nmulti = 0;
         size_t p = p0;
         for (; p < np; p++) {
             const PairJob &jb = jobs[p];
@@ -770,10 +851,13 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
             d.q = jb.q; d.r = jb.r; d.flags = jb.flags;
             d.n_chunks = Q.n_chunks;
             d.c_cap = 4u * Q.n_chunks + 64u;
+            d.multi_cap = 256u + Q.n_seeds / 8u;
+            if (d.multi_cap > 0x00FFFFF0u) d.multi_cap = 0x00FFFFF0u;
             if (!hp.empty() && nchunks + d.n_chunks > budget) break;
-            if (nchunks + d.n_chunks > 0x7FFF0000ull || ccap + d.c_cap > 0xFFFF0000ull) break;
-            d.chunk_base = (uint32_t)nchunks; d.c_base = (uint32_t)ccap;
-            nchunks += d.n_chunks; ccap += d.c_cap;
+            if (nchunks + d.n_chunks > 0x7FFF0000ull || ccap + d.c_cap > 0xFFFF0000ull || nhits + Q.n_seeds > 0xFFFF0000ull ||
+                nmulti + d.multi_cap > 0xFFFF0000ull) break;
+            d.chunk_base = (uint32_t)nchunks; d.c_base = (uint32_t)ccap; d.hit_base = (uint32_t)nhits; d.multi_base = (uint32_t)nmulti;
+            nchunks += d.n_chunks; ccap += d.c_cap; nhits += (Q.n_seeds + 15u) & ~15u; nmulti += d.multi_cap;
             hp.push_back(d);
         }
         const uint32_t nb = (uint32_t)hp.size();
@@ -781,18 +865,23 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         W.chunk_state.resize(nchunks + 1, st); W.slow_list.resize(nchunks + 1, st);
         W.fast_chains.resize(nchunks * FAST_SLOTS + 1, st);
         W.counters.resize(16, st);
-        W.pair_na.resize(nb, st); W.pair_nch.resize(nb, st);
+        W.pair_na.resize(nb, st); W.pair_nch.resize(nb, st); W.pair_nmulti.resize(nb, st);
+        W.hits.resize(nhits + 32, st); W.multi.resize(nmulti + 1, st);
         W.chains.resize(ccap + 1, st);
         W.d_out.resize(nb, st);
         HIPCHECK(hipMemcpyAsync(W.d_pairs.p, hp.data(), nb * sizeof(PairDesc), hipMemcpyHostToDevice, st));
         HIPCHECK(hipMemsetAsync(W.pair_nch.p, 0, nb * 4, st));
         HIPCHECK(hipMemsetAsync(W.pair_na.p, 0, nb * 4, st));
+        HIPCHECK(hipMemsetAsync(W.pair_nmulti.p, 0, nb * 4, st));
+        HIPCHECK(hipMemsetAsync(W.hits.p, 0xFF, (nhits + 32) * 4, st));
         HIPCHECK(hipMemsetAsync(W.counters.p, 0, 64, st));
         HIPCHECK(hipMemsetAsync(ctx->d_flags, 0, 64, st));
+        HIPCHECK(hipEventRecord(ctx->ev[11], st));
+        hipLaunchKernelGGL(join_kernel, dim3(nb), dim3(256), 0, st, VA, VB, W.d_pairs.p, W.hits.p, W.multi.p, W.pair_nmulti.p);
         HIPCHECK(hipEventRecord(ctx->ev[5], st));
         if (nchunks)
             hipLaunchKernelGGL(chain_fast_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, st, VA, VB, W.d_pairs.p, nb,
-                               (uint32_t)nchunks, W.fast_chains.p, W.chunk_state.p, W.slow_list.p, W.counters.p, W.pair_na.p,
+                               (uint32_t)nchunks, W.hits.p, W.multi.p, W.fast_chains.p, W.chunk_state.p, W.slow_list.p, W.counters.p, W.pair_na.p,
                                getenv("SKDER_AMD_NO_XCD") ? 0 : 1);
         HIPCHECK(hipEventRecord(ctx->ev[6], st));
         uint32_t hcnt[16] = {0};
@@ -838,6 +927,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         if (h_flags & 16u) throw SkError("pair with more chains than the finalize step holds in LDS (1.5 per chunk + 128, at most 4096)");
         float ms;
         HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[6])); t_fast += ms;
+        HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[11], ctx->ev[5])); t_join += ms;
         HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7])); t_slow += ms;
         HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[7], ctx->ev[8])); t_fin += ms;
         tot_slow += nslow; tot_chunks += nchunks;
@@ -861,6 +951,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
     ctx->timing[3] = t_fast; ctx->timing[4] = t_slow; ctx->timing[5] = t_fin;
     ctx->timing[6] = (double)np; ctx->timing[7] = (double)tot_anchors;
     ctx->counters[0] = tot_chunks; ctx->counters[1] = tot_slow;
+    ctx->timing_join = t_join;
 }
 
 void triangle_rows_impl(skder_sketches *s, uint32_t row_begin, uint32_t row_stride, double screen_pct)

@@ -87,6 +87,7 @@ struct skder_ctx {
     std::string last_error;
     hipEvent_t ev[16];
     double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double timing_join = 0;
     std::vector<skder_edge_t> edges;
     uint32_t *d_flags = nullptr;   // [0] overflow / error flags from kernels
     uint64_t counters[4] = {0, 0, 0, 0};   // [0] chunks processed, [1] chunks sent to the slow path

@@ -12,14 +12,11 @@ struct GenomeMeta {
     uint64_t marker_off;
     uint64_t total_len;     // sum of kept record lengths
     uint64_t rec_goff_off;  // offset into d_rec_goff (n_rec+1 entries)
-    uint64_t table_off;     // offset (in slots) of the genome's k-mer hash table
     uint64_t chunk_off;     // offset of its chunk_start table (n_chunks+1 entries)
     uint32_t n_seeds;
     uint32_t n_markers;
     uint32_t n_rec;
     uint32_t bucket_bits;
-    uint32_t table_bits;    // hash table has 2^table_bits slots (>= 2 * n_seeds)
-    uint32_t pad0;
     uint32_t n_chunks;      // filled by the index kernel
     uint32_t rep_cut;       // filled by the index kernel
 };
@@ -37,11 +34,10 @@ struct skder_sketches {
     DevBuf<GenomeMeta> d_meta;
     std::vector<GenomeMeta> h_meta;
     DevBuf<uint32_t> d_rec_goff;
-    DevBuf<uint32_t> skmer, sgpos, sctg;   // by-(kmer,gpos) order inside each genome's hash bucket
+    DevBuf<uint32_t> skmer, sgpos, sctg, sidx;   // by-(kmer,gpos) order inside each hash bucket; sidx = position-order index
     DevBuf<uint32_t> boff;                 // bucket offset tables
     DevBuf<uint32_t> pchunk;               // chunk id of every seed (position order)
     DevBuf<uint32_t> chunk_start;          // first seed of every chunk (+ end sentinel), per genome
-    DevBuf<uint2> table;                   // open-addressing k-mer tables: {kmer | fwd<<30 | multi<<31, gpos}
 };
 
 void sketch_batch_impl(skder_sketches *s, const uint8_t *d_bases, const skder_batch_t *b);
@@ -51,9 +47,6 @@ void rectangle_impl(skder_sketches *refs, skder_sketches *queries, double screen
 void synth_fill_impl(skder_ctx *ctx, uint8_t *d_bases, const skder_batch_t *b, const uint64_t *lineage,
                      const uint32_t *params);
 
-#define TABLE_EMPTY 0xFFFFFFFFu
-#define TABLE_FWD 0x40000000u
-#define TABLE_MULTI 0x80000000u
 __host__ __device__ inline uint32_t kmer_bucket(uint32_t kmer, uint32_t bits)
 {
     return (kmer * 0x9E3779B1u) >> (32u - bits);

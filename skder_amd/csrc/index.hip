@@ -3,7 +3,8 @@
 //     sorted by (k-mer, gpos) -- the "radix sort + dedup" stage of the sketch (one radix pass on a
 //     hashed digit + in-bucket insertion sort; buckets hold ~4 seeds);
 //   * repetitive k-mer cut-off (ani_oracle.c genome_finish);
-//   * chunk id of every seed: (record, (gpos - record_off) / 20000) numbered in position order.
+//   * chunk id of every seed: (record, (gpos - record_off) / 20000) numbered in position order;
+//   * sidx: for every bucket-ordered seed its index in position order (used by the pair join).
 // One 256-thread workgroup per genome; all counters live in LDS.
 #include "device_utils.h"
 #include "engine.h"
@@ -12,7 +13,7 @@ __global__ __launch_bounds__(256) void index_genome_kernel(
     GenomeMeta *__restrict__ meta, const uint32_t *__restrict__ rec_goff, const uint32_t *__restrict__ seed_kmer,
     const uint32_t *__restrict__ seed_gpos, const uint32_t *__restrict__ seed_ctg, uint32_t *__restrict__ skmer,
     uint32_t *__restrict__ sgpos, uint32_t *__restrict__ sctg, uint32_t *__restrict__ boff_all,
-    uint32_t *__restrict__ pchunk, uint32_t *__restrict__ chunk_start_all, uint2 *__restrict__ table_all)
+    uint32_t *__restrict__ pchunk, uint32_t *__restrict__ chunk_start_all, uint32_t *__restrict__ sidx)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t *cnt = reinterpret_cast<uint32_t *>(smem_raw);   // 2^bits counters, later cursor, later histogram
@@ -27,8 +28,7 @@ __global__ __launch_bounds__(256) void index_genome_kernel(
     uint32_t *boff = boff_all + m.bucket_off;
     const uint32_t *rg = rec_goff + m.rec_goff_off;
 
-    uint2 *tab = table_all + m.table_off;
-    const uint32_t tbits = m.table_bits, tmask = (1u << tbits) - 1u;
+    uint32_t *oi = sidx + m.seed_off;
     for (uint32_t b = tid; b < nb; b += 256) cnt[b] = 0;
     if (tid == 0) s_distinct = 0;
     __syncthreads();
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void index_genome_kernel(
         uint32_t km = pk[s];
         uint32_t b = kmer_bucket(km & SK_SEED_MASK, bits);
         uint32_t pos = boff[b] + atomicAdd(&cnt[b], 1u);
-        ok[pos] = km; og[pos] = pg[s]; oc[pos] = pc[s];
+        ok[pos] = km; og[pos] = pg[s]; oc[pos] = pc[s]; oi[pos] = s;
     }
     __syncthreads();   // global writes of this workgroup are visible to it after the barrier
     // histogram of multiplicities reuses the counter array
@@ -61,16 +61,16 @@ __global__ __launch_bounds__(256) void index_genome_kernel(
         const uint32_t lo = boff[b], hi = (b + 1 == nb) ? n : boff[b + 1];
         // insertion sort by (kmer, gpos); gpos is unique inside a genome, so the order is total
         for (uint32_t i = lo + 1; i < hi; i++) {
-            uint32_t km = ok[i], gp = og[i], ct = oc[i];
+            uint32_t km = ok[i], gp = og[i], ct = oc[i], ix = oi[i];
             uint32_t kk = km & SK_SEED_MASK;
             uint32_t j = i;
             while (j > lo) {
                 uint32_t pk2 = ok[j - 1] & SK_SEED_MASK;
                 if (pk2 < kk || (pk2 == kk && og[j - 1] < gp)) break;
-                ok[j] = ok[j - 1]; og[j] = og[j - 1]; oc[j] = oc[j - 1];
+                ok[j] = ok[j - 1]; og[j] = og[j - 1]; oc[j] = oc[j - 1]; oi[j] = oi[j - 1];
                 j--;
             }
-            ok[j] = km; og[j] = gp; oc[j] = ct;
+            ok[j] = km; og[j] = gp; oc[j] = ct; oi[j] = ix;
         }
         for (uint32_t i = lo; i < hi;) {
             uint32_t kk = ok[i] & SK_SEED_MASK, j = i + 1;
@@ -78,20 +78,6 @@ __global__ __launch_bounds__(256) void index_genome_kernel(
             uint32_t mult = j - i;
             atomicAdd(&cnt[mult < IDX_REP_HIST - 1 ? mult : IDX_REP_HIST - 1], 1u);
             my_distinct++;
-            // open-addressing table (linear probing, multiplicative hash): one 8-byte slot per seed
-            // occurrence, {kmer | fwd<<30 | multi<<31, gpos}; cleared to TABLE_EMPTY by the host.
-            // multi = the k-mer occurs more than once in this genome (a probe must then run to the
-            // next empty slot to see every occurrence)
-            for (uint32_t e = i; e < j; e++) {
-                const uint32_t x = kk | ((ok[e] >> 31) ? TABLE_FWD : 0u) | (mult > 1 ? TABLE_MULTI : 0u);
-                uint32_t h = kmer_bucket(kk, tbits);
-                for (;;) {
-                    uint32_t old = atomicCAS(&tab[h].x, TABLE_EMPTY, x);
-                    if (old == TABLE_EMPTY) break;
-                    h = (h + 1) & tmask;
-                }
-                tab[h].y = og[e];
-            }
             i = j;
         }
     }
@@ -141,7 +127,7 @@ void index_impl(skder_sketches *s)
     hipStream_t st = ctx->stream;
     const uint32_t G = s->n_genomes;
     s->h_meta.resize(G);
-    uint64_t boff_total = 0, rg = 0, table_total = 0, chunk_total = 0;
+    uint64_t boff_total = 0, rg = 0, chunk_total = 0;
     for (uint32_t g = 0; g < G; g++) {
         GenomeMeta &m = s->h_meta[g];
         m.seed_off = s->h_seed_off[g];
@@ -159,13 +145,6 @@ void index_impl(skder_sketches *s)
         boff_total += (1u << bits) + 1;
         m.n_chunks = 0;
         m.rep_cut = 0xFFFFFFFFu;
-        uint32_t tb = 6;
-        static const uint64_t tfac = getenv("SKDER_AMD_TABLE_FACTOR") ? strtoull(getenv("SKDER_AMD_TABLE_FACTOR"), nullptr, 10) : 4;
-        while ((1ull << tb) < tfac * m.n_seeds) tb++;
-        if (tb > 31) throw SkError("genome with too many seeds");
-        m.table_bits = tb; m.pad0 = 0;
-        m.table_off = table_total;
-        table_total += 1ull << tb;
         m.chunk_off = chunk_total;
         chunk_total += m.total_len / ANI_CHUNK_LEN + m.n_rec + 2;   // upper bound on chunks + sentinel
     }
@@ -176,15 +155,14 @@ void index_impl(skder_sketches *s)
     s->pchunk.resize(ns + 1, st);
     s->boff.resize(boff_total + 1, st);
     s->chunk_start.resize(chunk_total + 1, st);
-    s->table.resize(table_total + 1, st);
-    HIPCHECK(hipMemsetAsync(s->table.p, 0xFF, (table_total + 1) * sizeof(uint2), st));
+    s->sidx.resize(ns + 1, st);
     if (G) {
         HIPCHECK(hipMemcpyAsync(s->d_meta.p, s->h_meta.data(), G * sizeof(GenomeMeta), hipMemcpyHostToDevice, st));
         HIPCHECK(hipMemcpyAsync(s->d_rec_goff.p, s->h_rec_goff.data(), s->h_rec_goff.size() * 4, hipMemcpyHostToDevice, st));
         HIPCHECK(hipEventRecord(ctx->ev[3], st));
         hipLaunchKernelGGL(index_genome_kernel, dim3(G), dim3(256), (1u << IDX_MAX_BUCKET_BITS) * 4, st, s->d_meta.p,
                            s->d_rec_goff.p, s->seed_kmer.p, s->seed_gpos.p, s->seed_ctg.p, s->skmer.p, s->sgpos.p,
-                           s->sctg.p, s->boff.p, s->pchunk.p, s->chunk_start.p, s->table.p);
+                           s->sctg.p, s->boff.p, s->pchunk.p, s->chunk_start.p, s->sidx.p);
         HIPCHECK(hipEventRecord(ctx->ev[4], st));
         HIPCHECK(hipMemcpyAsync(s->h_meta.data(), s->d_meta.p, G * sizeof(GenomeMeta), hipMemcpyDeviceToHost, st));
         HIPCHECK(hipStreamSynchronize(st));

@@ -300,7 +300,7 @@ static void build_tiles(const skder_batch_t *b, std::vector<TileDesc> &tiles, st
         for (uint32_t r = r0; r < r1; r++) {
             uint32_t len = b->rec_len[r];
             if (b->rec_off[r] % 32) throw SkError("record offsets must be multiples of 32");
-            if ((uint64_t)gpos + len >= 0x7FFFFFFFull) throw SkError("genome longer than 2^31 bases");
+            if ((uint64_t)gpos + len >= 0x7F000000ull) throw SkError("genome longer than 2.1e9 bases");
             rec_goff.push_back(gpos);
             for (uint32_t p = 0; p < len; p += SKDER_TILE) {
                 TileDesc t;
@@ -369,6 +369,7 @@ void sketch_batch_impl(skder_sketches *s, const uint8_t *d_bases, const skder_ba
     // seeds
     const uint64_t seed_base = s->seed_kmer.n;
     s->seed_kmer.resize(seed_base + add_seeds, st);
+    s->seed_gpos.reserve(seed_base + add_seeds + 32, s->seed_gpos.n, st);   // chain_fast_kernel reads whole 64-B lines
     s->seed_gpos.resize(seed_base + add_seeds, st);
     s->seed_ctg.resize(seed_base + add_seeds, st);
     if (nt)
