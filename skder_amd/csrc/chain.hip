@@ -166,20 +166,29 @@ __global__ __launch_bounds__(256) void join_kernel(SetView A, SetView B, const P
 }
 
 // ---------------------------------------------------------------------------------------------
-// FAST PATH: one lane per (pair, 20 kb chunk), no intermediate arrays.
-// The lane streams the chunk's seeds, probes the other genome's hash table (one 16-byte slot read
-// per probe) and runs the banded chaining DP against a 4-anchor register ring.  The result is
-// exact whenever the chunk is "simple": every DP look-back ends inside the ring (early exit on the
-// running maximum or the 2500-base band), predecessor links form disjoint paths with strictly
-// increasing scores, at most 4 hits per seed and at most FAST_SLOTS chains.  Otherwise the chunk is
-// handed to the slow path below, which runs the unabridged algorithm.
-struct RingE {
-    uint32_t qpos, rr, rctg;
-    int32_t f;
-    uint32_t cnt;        // anchors on the path ending here | SUCC_BIT when another anchor chained to it
-    uint32_t first_qi, rmin, rmax, qi;
-    uint32_t path;       // ordinal of the first anchor of the current diagonal segment of the path
-    int32_t pmax;        // highest score among the EARLIER anchors of the path
+// FAST PATH: one lane per (pair, 20 kb chunk).
+//
+// The lane streams the chunk's hit words (from the join) and seed positions and runs the banded
+// chaining DP of ani_oracle.c on a compressed state: a register ring of the 4 most recently touched
+// RUNS.  A run is a maximal stretch of anchors chained with zero gap cost (same record, strand and
+// diagonal); its scores rise by 20 per anchor, so among the anchors of a run only the last one can be
+// the best predecessor of a later anchor (it is nearer and scores higher) -- unless the later anchor
+// lies inside the run's own extent, which is detected and declined.  Extending a run is an in-place
+// update of a few registers; anything else walks the ring exactly like the oracle's look-back loop
+// (nearest first, strict '>', early exits on the running maximum / 2500-base band / 50-anchor band).
+// Runs that fall out of the ring are kept as summaries (best score, last position, diagonal range);
+// a look-back that would have to continue into them is accepted only if no summarised anchor can
+// reach the current best.  The lane proves as it goes that its result is the oracle's; a chunk where
+// the proof fails (branching chains, best end not last, too many hits or chains) goes to the slow path.
+struct Run {
+    uint32_t q_last, rr_last, rctg;   // last anchor: query pos, ref pos | rev<<31, ref record
+    int32_t f;                        // score of the last anchor
+    uint32_t cnt;                     // anchors on the PATH ending at the last anchor | SUCC_BIT
+    uint32_t first_qi, rmin, rmax;    // path aggregates: first seed index, ref extent
+    uint32_t qi_last, idx_last;       // seed index / anchor ordinal of the last anchor
+    int32_t pmax;                     // highest score among the earlier anchors of the path
+    uint32_t r_first;                 // ref pos of the run's first anchor
+    uint32_t seg;                     // summary key: changes along a path only at score-lowering indels
 };
 
 __global__ __launch_bounds__(256, 4) void chain_fast_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs, uint32_t npairs,
@@ -190,13 +199,15 @@ __global__ __launch_bounds__(256, 4) void chain_fast_kernel(SetView A, SetView B
                                                          int xcd_remap)
 {
     // XCD-aware work mapping: workgroups are dealt round-robin to the 8 XCDs, so give every XCD one
-    // contiguous eighth of the (R-sorted) work list: its private L2 then sees few hash tables at a time
+    // contiguous eighth of the (R-sorted) work list
     uint32_t wg = blockIdx.x;
     if (xcd_remap & 1) {
         const uint32_t nwg = gridDim.x, xcd = wg & 7u, idx = wg >> 3, q8 = nwg >> 3, r8 = nwg & 7u;
         wg = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + idx;
     }
     const uint32_t t = wg * 256u + threadIdx.x;
+    // lane-private LDS strips: one 64-byte line of each stream (see the refill below)
+    __shared__ uint32_t lb_hit[16][256], lb_qp[16][256];
     if (t >= total_chunks) return;
     const uint32_t pi = find_pair(pairs, npairs, t);
     const PairDesc pd = pairs[pi];
@@ -213,69 +224,130 @@ __global__ __launch_bounds__(256, 4) void chain_fast_kernel(SetView A, SetView B
     bool cplx = Qm->rep_cut != 0xFFFFFFFFu;   // own-multiplicity filter active: leave it to the slow path
     uint32_t cause = cplx ? 6u : 0u;
 
-    RingE r0, r1, r2, r3;
-    r0.cnt = r1.cnt = r2.cnt = r3.cnt = 0;
-    r0.f = r1.f = r2.f = r3.f = 0;
-    r0.qpos = r1.qpos = r2.qpos = r3.qpos = 0; r0.rr = r1.rr = r2.rr = r3.rr = 0; r0.rctg = r1.rctg = r2.rctg = r3.rctg = 0;
-    r0.first_qi = r1.first_qi = r2.first_qi = r3.first_qi = 0; r0.rmin = r1.rmin = r2.rmin = r3.rmin = 0;
-    r0.rmax = r1.rmax = r2.rmax = r3.rmax = 0; r0.qi = r1.qi = r2.qi = r3.qi = 0;
-    r0.path = r1.path = r2.path = r3.path = 0; r0.pmax = r1.pmax = r2.pmax = r3.pmax = 0;
-    uint32_t ia = 0, nfin = 0;
-    int32_t runmax = -0x40000000;
-    // summaries of the anchors that already left the ring, by path: the two most recent paths
-    // (key = record | strand<<31, best score = score of the last evicted anchor because scores rise
-    // along a path, query position of that anchor) plus one conservative scalar for older paths
     const int32_t NEG = -0x40000000;
-    uint32_t s0_path = 0xFFFFFFFFu, s0_key = 0, s0_q = 0, s1_path = 0xFFFFFFFFu, s1_key = 0, s1_q = 0, lost_q = 0;
-    int32_t s0_f = NEG, s1_f = NEG, lost_f = NEG;
-    // diagonal range (rpos - qpos, or rpos + qpos on the reverse strand) of each summary: an anchor
-    // more than max_gap away from the whole range cannot chain to any anchor of the summary
-    int32_t s0_dlo = 0, s0_dhi = 0, s1_dlo = 0, s1_dhi = 0, lost_dlo = 0, lost_dhi = 0;
+    Run r0, r1, r2, r3;
+    r0.cnt = r1.cnt = r2.cnt = r3.cnt = 0;          // cnt == 0: empty ring position
+    r0.f = r1.f = r2.f = r3.f = NEG;
+    r0.q_last = r1.q_last = r2.q_last = r3.q_last = 0; r0.rr_last = r1.rr_last = r2.rr_last = r3.rr_last = 0;
+    r0.rctg = r1.rctg = r2.rctg = r3.rctg = 0; r0.first_qi = r1.first_qi = r2.first_qi = r3.first_qi = 0;
+    r0.rmin = r1.rmin = r2.rmin = r3.rmin = 0; r0.rmax = r1.rmax = r2.rmax = r3.rmax = 0;
+    r0.qi_last = r1.qi_last = r2.qi_last = r3.qi_last = 0; r0.idx_last = r1.idx_last = r2.idx_last = r3.idx_last = 0;
+    r0.pmax = r1.pmax = r2.pmax = r3.pmax = NEG; r0.r_first = r1.r_first = r2.r_first = r3.r_first = 0;
+    r0.seg = r1.seg = r2.seg = r3.seg = 0;
+    uint32_t ia = 0, nfin = 0, nevict = 0;
+    int32_t runmax = NEG;
+    // summaries of runs that left the ring: the most recent segment, plus one conservative scalar
+    uint32_t s0_seg = 0xFFFFFFFFu, s0_key = 0, s0_q = 0, lost_q = 0;
+    int32_t s0_f = NEG, lost_f = NEG, s0_dlo = 0, s0_dhi = 0, lost_dlo = 0, lost_dhi = 0;
     ChainRec *slots = fast_chains + (uint64_t)t * FAST_SLOTS;
 
 #define EMIT_PATH(E)                                                                         \
     do {                                                                                     \
-        if (!((E).cnt & SUCC_BIT) && (E).cnt >= ANI_MIN_ANCHORS) {                           \
+        if ((E).cnt && !((E).cnt & SUCC_BIT) && (E).cnt >= ANI_MIN_ANCHORS) {                \
             if (!((E).f > (E).pmax)) { cplx = true; cause = 5; } /* best end is not the last anchor */ \
-            else if (nfin >= FAST_SLOTS) { cplx = true; cause = 1; }                                 \
+            else if (nfin >= FAST_SLOTS) { cplx = true; cause = 1; }                         \
             else {                                                                           \
                 ChainRec cr;                                                                 \
-                cr.score = (E).f; cr.n = (E).cnt; cr.n_seeds = (E).qi - (E).first_qi + 1;    \
-                cr.q0 = qg[(E).first_qi]; cr.q1 = (E).qpos; cr.r0 = (E).rmin; cr.r1 = (E).rmax; cr.rctg = (E).rctg; \
+                cr.score = (E).f; cr.n = (E).cnt; cr.n_seeds = (E).qi_last - (E).first_qi + 1; \
+                cr.q0 = qg[(E).first_qi]; cr.q1 = (E).q_last; cr.r0 = (E).rmin; cr.r1 = (E).rmax; cr.rctg = (E).rctg; \
                 slots[nfin++] = cr;                                                          \
             }                                                                                \
         }                                                                                    \
     } while (0)
 
-    // Each lane streams two arrays (hit words, seed positions) from its own place in memory.  To fetch
-    // every 64-byte line exactly once the lane pulls a whole line (16 entries, 4 x 16-B loads) into a
-    // private LDS strip when its stream crosses a line boundary and then reads single entries from LDS.
-    __shared__ uint32_t lb_hit[16][256], lb_qp[16][256];
+    // a run leaves the ring: it can no longer be extended; fold it into the summaries
+#define EVICT(E)                                                                             \
+    do {                                                                                     \
+        if ((E).cnt) {                                                                       \
+            EMIT_PATH(E);                                                                    \
+            nevict++;                                                                        \
+            const uint32_t k3 = (E).rctg | (((E).rr_last >> 31) << 31);                      \
+            const int32_t d3 = ((E).rr_last >> 31) ? (int32_t)((E).rr_last & 0x7FFFFFFFu) + (int32_t)(E).q_last \
+                                                   : (int32_t)((E).rr_last & 0x7FFFFFFFu) - (int32_t)(E).q_last; \
+            if ((E).seg == s0_seg) {                                                         \
+                s0_f = (E).f > s0_f ? (E).f : s0_f; s0_q = (E).q_last > s0_q ? (E).q_last : s0_q; \
+                s0_dlo = d3 < s0_dlo ? d3 : s0_dlo; s0_dhi = d3 > s0_dhi ? d3 : s0_dhi;      \
+            } else {                                                                         \
+                if (s0_seg != 0xFFFFFFFFu) {                                                 \
+                    if (lost_f == NEG) { lost_dlo = s0_dlo; lost_dhi = s0_dhi; }             \
+                    else { lost_dlo = s0_dlo < lost_dlo ? s0_dlo : lost_dlo; lost_dhi = s0_dhi > lost_dhi ? s0_dhi : lost_dhi; } \
+                    lost_f = s0_f > lost_f ? s0_f : lost_f; lost_q = s0_q > lost_q ? s0_q : lost_q; \
+                }                                                                            \
+                s0_seg = (E).seg; s0_key = k3; s0_f = (E).f; s0_q = (E).q_last; s0_dlo = d3; s0_dhi = d3; \
+            }                                                                                \
+        }                                                                                    \
+    } while (0)
+
     const uint32_t tidx = threadIdx.x;
     const uint64_t hbase = pd.hit_base;          // absolute entry index of seed 0 in the hit array
     const uint32_t *qg_abs = QS.pgpos;           // absolute base of the position array
-    {
-      for (uint32_t s = s0; s < s1 && !cplx; s++) {
-        const uint64_t ah = hbase + s, aq = qoff + s;
-        if (s == s0 || (ah & 15u) == 0) {
-            const uint4 *src = reinterpret_cast<const uint4 *>(hits + (ah & ~(uint64_t)15));
-            const uint4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
-            lb_hit[0][tidx] = v0.x; lb_hit[1][tidx] = v0.y; lb_hit[2][tidx] = v0.z; lb_hit[3][tidx] = v0.w;
-            lb_hit[4][tidx] = v1.x; lb_hit[5][tidx] = v1.y; lb_hit[6][tidx] = v1.z; lb_hit[7][tidx] = v1.w;
-            lb_hit[8][tidx] = v2.x; lb_hit[9][tidx] = v2.y; lb_hit[10][tidx] = v2.z; lb_hit[11][tidx] = v2.w;
-            lb_hit[12][tidx] = v3.x; lb_hit[13][tidx] = v3.y; lb_hit[14][tidx] = v3.z; lb_hit[15][tidx] = v3.w;
+    // Control structure against wave divergence: in the INNER loop every lane advances through its
+    // own seeds for as long as they are misses or plain extensions of its current run (a handful of
+    // instructions); a lane that meets anything else parks.  When all 64 lanes have parked or finished,
+    // the general step below runs once for the parked lanes, and the inner loop resumes.  The general
+    // code is therefore executed a few times per chunk instead of once per seed.
+    uint32_t s = s0, rf_h = s0, rf_q = s0;   // rf_*: first seed NOT covered by the lane's LDS strip
+    bool dom = false;   // "r0 dominates": no other run or summary can out-score an extension of r0
+    for (;;) {
+        bool park = false;
+        uint32_t hw = HIT_NONE;
+        int32_t qp = 0;
+        // refill round: every lane whose LDS strip is used up pulls the next 64-byte line (16 entries,
+        // 4 x 16-B loads) of that stream.  All lanes that need one refill together, so the wave pays
+        // one memory round trip per round, not one per seed
+        if (!cplx && s < s1) {
+            if (s >= rf_h) {
+                const uint64_t ah = hbase + s;
+                const uint4 *src = reinterpret_cast<const uint4 *>(hits + (ah & ~(uint64_t)15));
+                const uint4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+                lb_hit[0][tidx] = v0.x; lb_hit[1][tidx] = v0.y; lb_hit[2][tidx] = v0.z; lb_hit[3][tidx] = v0.w;
+                lb_hit[4][tidx] = v1.x; lb_hit[5][tidx] = v1.y; lb_hit[6][tidx] = v1.z; lb_hit[7][tidx] = v1.w;
+                lb_hit[8][tidx] = v2.x; lb_hit[9][tidx] = v2.y; lb_hit[10][tidx] = v2.z; lb_hit[11][tidx] = v2.w;
+                lb_hit[12][tidx] = v3.x; lb_hit[13][tidx] = v3.y; lb_hit[14][tidx] = v3.z; lb_hit[15][tidx] = v3.w;
+                rf_h = s + 16u - (uint32_t)(ah & 15u);
+            }
+            if (s >= rf_q) {
+                const uint64_t aq = qoff + s;
+                const uint4 *src = reinterpret_cast<const uint4 *>(qg_abs + (aq & ~(uint64_t)15));
+                const uint4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+                lb_qp[0][tidx] = v0.x; lb_qp[1][tidx] = v0.y; lb_qp[2][tidx] = v0.z; lb_qp[3][tidx] = v0.w;
+                lb_qp[4][tidx] = v1.x; lb_qp[5][tidx] = v1.y; lb_qp[6][tidx] = v1.z; lb_qp[7][tidx] = v1.w;
+                lb_qp[8][tidx] = v2.x; lb_qp[9][tidx] = v2.y; lb_qp[10][tidx] = v2.z; lb_qp[11][tidx] = v2.w;
+                lb_qp[12][tidx] = v3.x; lb_qp[13][tidx] = v3.y; lb_qp[14][tidx] = v3.z; lb_qp[15][tidx] = v3.w;
+                rf_q = s + 16u - (uint32_t)(aq & 15u);
+            }
         }
-        if (s == s0 || (aq & 15u) == 0) {
-            const uint4 *src = reinterpret_cast<const uint4 *>(qg_abs + (aq & ~(uint64_t)15));
-            const uint4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
-            lb_qp[0][tidx] = v0.x; lb_qp[1][tidx] = v0.y; lb_qp[2][tidx] = v0.z; lb_qp[3][tidx] = v0.w;
-            lb_qp[4][tidx] = v1.x; lb_qp[5][tidx] = v1.y; lb_qp[6][tidx] = v1.z; lb_qp[7][tidx] = v1.w;
-            lb_qp[8][tidx] = v2.x; lb_qp[9][tidx] = v2.y; lb_qp[10][tidx] = v2.z; lb_qp[11][tidx] = v2.w;
-            lb_qp[12][tidx] = v3.x; lb_qp[13][tidx] = v3.y; lb_qp[14][tidx] = v3.z; lb_qp[15][tidx] = v3.w;
+        while (!cplx && s < s1) {
+            if (s >= rf_h || s >= rf_q) break;    // strip used up: leave for the next refill round
+            const uint64_t ah = hbase + s, aq = qoff + s;
+            hw = lb_hit[ah & 15u][tidx];
+            if (hw == HIT_NONE) { s++; continue; }
+            qp = (int32_t)lb_qp[aq & 15u][tidx];
+            // plain extension of the current run: single hit, same record and strand, zero gap cost,
+            // inside the 2500-base band, and r0 dominates every other possible predecessor.  r0's last
+            // anchor is anchor ia-1, the nearest candidate, and scores r0.f + 20 >= everything else.
+            const uint32_t rpu = hw & 0x7FFFFFFFu;
+            if (dom && (hw & 0xFF000000u) != HIT_MULTI && rpu >= cur_lo && rpu < cur_hi && (hw >> 31) == (r0.rr_last >> 31)) {
+                const int32_t dq = qp - (int32_t)r0.q_last;
+                const int32_t rpj = (int32_t)(r0.rr_last & 0x7FFFFFFFu);
+                const int32_t dr = (hw >> 31) ? rpj - (int32_t)rpu : (int32_t)rpu - rpj;
+                if (dq > 0 && dq == dr && dq <= ANI_BP_BAND) {
+                    r0.pmax = r0.f > r0.pmax ? r0.f : r0.pmax;
+                    r0.f += ANI_ANCHOR_SCORE;
+                    runmax = r0.f > runmax ? r0.f : runmax;
+                    r0.q_last = (uint32_t)qp; r0.rr_last = hw; r0.cnt += 1u;
+                    r0.rmin = rpu < r0.rmin ? rpu : r0.rmin;
+                    r0.rmax = rpu > r0.rmax ? rpu : r0.rmax;
+                    r0.qi_last = s; r0.idx_last = ia;
+                    ia++; s++;
+                    continue;
+                }
+            }
+            park = true;
+            break;
         }
-        const uint32_t hw = lb_hit[ah & 15u][tidx];
-        const int32_t qp = (int32_t)lb_qp[aq & 15u][tidx];
-        if (hw == HIT_NONE) continue;
+        if (!park) { if (cplx || s >= s1) break; continue; }   // finished / declined, or just a refill
+        // ---- general step for seed s (all of its hits)
         if (hw == HIT_MANY) { cplx = true; cause = 2; break; }
         uint32_t m = 1, g0 = hw, g1 = HIT_NONE, g2 = HIT_NONE, g3 = HIT_NONE;
         if ((hw & 0xFF000000u) == HIT_MULTI) {   // 2..4 occurrences, ascending gpos
@@ -283,7 +355,7 @@ __global__ __launch_bounds__(256, 4) void chain_fast_kernel(SetView A, SetView B
             g0 = mv.x; g1 = mv.y; g2 = mv.z; g3 = mv.w;
             m = 2u + (g2 != HIT_NONE) + (g3 != HIT_NONE);
         }
-
+        dom = false;
         for (uint32_t u = 0; u < m && !cplx; u++) {
             const uint32_t rr = g0;
             g0 = g1; g1 = g2; g2 = g3;
@@ -298,27 +370,34 @@ __global__ __launch_bounds__(256, 4) void chain_fast_kernel(SetView A, SetView B
             }
             const uint32_t rc = cur_rec;
             const uint32_t rev = rr >> 31;
-            int32_t best = ANI_ANCHOR_SCORE;
+            const uint32_t key = rc | (rev << 31);
+            const int32_t dg = rev ? rp + qp : rp - qp;
+
+            // ---- general case: the oracle's look-back over the last anchors of the ring's runs
+            int32_t best = ANI_ANCHOR_SCORE, pgap = 0;
             int bj = -1;
             bool exact = false;
-            uint32_t pcnt = 0, pfirst = 0, prmin = 0, prmax = 0, ppath = 0;
-            int32_t pf = 0, ppmax = 0, pgap = 0;
 #define TRY(K, E)                                                                                   \
-            if (!exact) {                                                                           \
-                if ((K) >= ia) exact = true;                                                        \
+            if (!exact && !cplx) {                                                                  \
+                if (!(E).cnt) exact = true;                       /* no older anchors at all */     \
                 else if (best >= runmax + ANI_ANCHOR_SCORE) exact = true;                           \
+                else if (ia - (E).idx_last > ANI_BAND) exact = true;                                \
                 else {                                                                              \
-                    const int32_t dq = qp - (int32_t)(E).qpos;                                      \
+                    const int32_t dq = qp - (int32_t)(E).q_last;                                    \
                     if (dq > ANI_BP_BAND) exact = true;                                             \
-                    else if ((E).rctg == rc && ((E).rr >> 31) == rev) {                             \
-                        const int32_t rpj = (int32_t)((E).rr & 0x7FFFFFFFu);                        \
+                    else if ((E).rctg == rc && ((E).rr_last >> 31) == rev) {                        \
+                        const int32_t rpj = (int32_t)((E).rr_last & 0x7FFFFFFFu);                   \
                         const int32_t dr = rev ? rpj - rp : rp - rpj;                               \
-                        if (dq > 0 && dr > 0 && dq <= ANI_MAX_LIN && dr <= ANI_MAX_LIN) {           \
-                            const int32_t gap = dq > dr ? dq - dr : dr - dq;                        \
-                            if (gap <= ANI_MAX_GAP) {                                               \
-                                const int32_t sc = (E).f + ANI_ANCHOR_SCORE - gap;                  \
-                                if (sc > best) { best = sc; bj = (K); pcnt = (E).cnt; pfirst = (E).first_qi; pgap = gap; \
-                                                 prmin = (E).rmin; prmax = (E).rmax; pf = (E).f; ppath = (E).path; ppmax = (E).pmax; } \
+                        const int32_t ed = rev ? rpj + (int32_t)(E).q_last : rpj - (int32_t)(E).q_last; /* run diagonal */ \
+                        const int32_t off = dg > ed ? dg - ed : ed - dg;                            \
+                        if (off <= ANI_MAX_GAP) {                                                   \
+                            /* an INTERIOR anchor of the run could be a valid predecessor where the last one is not */ \
+                            const int32_t rf = (int32_t)(E).r_first;                                \
+                            const bool inside = rev ? (rp < rf && dr <= 0) : (rp > rf && dr <= 0);  \
+                            if (dq <= 0 || inside) { cplx = true; cause = 7; }                      \
+                            else if (dr > 0 && dq <= ANI_MAX_LIN && dr <= ANI_MAX_LIN) {            \
+                                const int32_t sc = (E).f + ANI_ANCHOR_SCORE - off;                  \
+                                if (sc > best) { best = sc; bj = (K); pgap = off; }                 \
                             }                                                                       \
                         }                                                                           \
                     }                                                                               \
@@ -326,75 +405,87 @@ __global__ __launch_bounds__(256, 4) void chain_fast_kernel(SetView A, SetView B
             }
             TRY(0, r0) TRY(1, r1) TRY(2, r2) TRY(3, r3)
 #undef TRY
-            if (!exact && ia > RING) {
-                // ring exhausted: the full algorithm would go on to the anchors that already left the
-                // ring.  They cannot change (best, bj) when they are outside the 2500-base band, on
-                // another record/strand, or cannot reach `best` (score + 20 at zero gap cost).
-                const uint32_t key = rc | (rev << 31);
-                const int32_t dg = rev ? rp + qp : rp - qp;
+            if (cplx) break;
+            if (!exact && nevict) {
+                // the look-back would continue into evicted runs: accept only if none of them can matter
                 bool ok = true;
-                // an anchor of a summary is at least `off` away from this anchor's diagonal, so it can
-                // offer at most (summary score + 20 - off); beyond max_gap it cannot chain at all
 #define SUMMARY_BLOCKS(SF, SQ, DLO, DHI, KEYOK)                                                                  \
                 if ((KEYOK) && qp - (int32_t)(SQ) <= ANI_BP_BAND) {                                              \
                     const int32_t off = dg < (DLO) ? (DLO) - dg : (dg > (DHI) ? dg - (DHI) : 0);                  \
                     if (off <= ANI_MAX_GAP && !(best >= (SF) + ANI_ANCHOR_SCORE - off)) ok = false;               \
                 }
-                SUMMARY_BLOCKS(s0_f, s0_q, s0_dlo, s0_dhi, s0_path != 0xFFFFFFFFu && s0_key == key)
-                SUMMARY_BLOCKS(s1_f, s1_q, s1_dlo, s1_dhi, s1_path != 0xFFFFFFFFu && s1_key == key)
+                SUMMARY_BLOCKS(s0_f, s0_q, s0_dlo, s0_dhi, s0_seg != 0xFFFFFFFFu && s0_key == key)
                 SUMMARY_BLOCKS(lost_f, lost_q, lost_dlo, lost_dhi, lost_f != NEG)
 #undef SUMMARY_BLOCKS
                 if (!ok) { cplx = true; cause = 3; break; }
             }
-            RingE e;
-            e.qpos = (uint32_t)qp; e.rr = rr; e.rctg = rc; e.f = best; e.qi = s;
             if (bj >= 0) {
-                if (pcnt & SUCC_BIT) { cplx = true; cause = 4; break; }   // two anchors chain to the same predecessor
-                if (bj == 0) r0.cnt |= SUCC_BIT; else if (bj == 1) r1.cnt |= SUCC_BIT;
-                else if (bj == 2) r2.cnt |= SUCC_BIT; else r3.cnt |= SUCC_BIT;
-                e.cnt = (pcnt & 0x7FFFFFFFu) + 1u;
-                e.first_qi = pfirst;
-                e.path = pgap >= ANI_ANCHOR_SCORE ? ia : ppath;   // a score-lowering indel starts a new diagonal segment
-                e.pmax = pf > ppmax ? pf : ppmax;
-                e.rmin = (uint32_t)rp < prmin ? (uint32_t)rp : prmin;
-                e.rmax = (uint32_t)rp > prmax ? (uint32_t)rp : prmax;
-            } else {
-                e.cnt = 1; e.first_qi = s; e.rmin = e.rmax = (uint32_t)rp; e.path = ia; e.pmax = -0x40000000;
-            }
-            if (ia >= RING) {
-                EMIT_PATH(r3);   // the anchor leaving the ring can no longer be extended
-                const uint32_t k3 = r3.rctg | ((r3.rr >> 31) << 31);
-                const int32_t d3 = (r3.rr >> 31) ? (int32_t)(r3.rr & 0x7FFFFFFFu) + (int32_t)r3.qpos
-                                                 : (int32_t)(r3.rr & 0x7FFFFFFFu) - (int32_t)r3.qpos;
-                if (r3.path == s0_path) {
-                    s0_f = r3.f > s0_f ? r3.f : s0_f; s0_q = r3.qpos;
-                    s0_dlo = d3 < s0_dlo ? d3 : s0_dlo; s0_dhi = d3 > s0_dhi ? d3 : s0_dhi;
+                // bring the predecessor run to the front (ring order = recency of the last anchor)
+                if (bj == 1) { const Run tr = r1; r1 = r0; r0 = tr; }
+                else if (bj == 2) { const Run tr = r2; r2 = r1; r1 = r0; r0 = tr; }
+                else if (bj == 3) { const Run tr = r3; r3 = r2; r2 = r1; r1 = r0; r0 = tr; }
+                if (r0.cnt & SUCC_BIT) { cplx = true; cause = 4; break; }   // two anchors chain to one predecessor
+                if (pgap == 0) {
+                    // same diagonal: the run simply grows
+                    r0.pmax = r0.f > r0.pmax ? r0.f : r0.pmax;
+                    r0.f = best;
+                    r0.q_last = (uint32_t)qp; r0.rr_last = rr; r0.cnt += 1u;
+                    r0.rmin = (uint32_t)rp < r0.rmin ? (uint32_t)rp : r0.rmin;
+                    r0.rmax = (uint32_t)rp > r0.rmax ? (uint32_t)rp : r0.rmax;
+                    r0.qi_last = s; r0.idx_last = ia;
                 } else {
-                    const bool was_s1 = r3.path == s1_path;
-                    const int32_t nlo = was_s1 ? (d3 < s1_dlo ? d3 : s1_dlo) : d3, nhi = was_s1 ? (d3 > s1_dhi ? d3 : s1_dhi) : d3;
-                    const int32_t nf = was_s1 ? (r3.f > s1_f ? r3.f : s1_f) : r3.f;
-                    if (!was_s1 && s1_path != 0xFFFFFFFFu) {   // the older summary falls out: fold it into the scalar
-                        if (lost_f == NEG) { lost_dlo = s1_dlo; lost_dhi = s1_dhi; }
-                        else { lost_dlo = s1_dlo < lost_dlo ? s1_dlo : lost_dlo; lost_dhi = s1_dhi > lost_dhi ? s1_dhi : lost_dhi; }
-                        lost_f = s1_f > lost_f ? s1_f : lost_f; lost_q = s1_q > lost_q ? s1_q : lost_q;
-                    }
-                    s1_path = s0_path; s1_key = s0_key; s1_f = s0_f; s1_q = s0_q; s1_dlo = s0_dlo; s1_dhi = s0_dhi;
-                    s0_path = r3.path; s0_key = k3; s0_f = nf; s0_q = r3.qpos; s0_dlo = nlo; s0_dhi = nhi;
+                    // an indel: new run on the same path; the old run's last anchor now has a successor
+                    Run e;
+                    e.q_last = (uint32_t)qp; e.rr_last = rr; e.rctg = rc; e.f = best;
+                    e.cnt = (r0.cnt & 0x7FFFFFFFu) + 1u; e.first_qi = r0.first_qi;
+                    e.rmin = (uint32_t)rp < r0.rmin ? (uint32_t)rp : r0.rmin;
+                    e.rmax = (uint32_t)rp > r0.rmax ? (uint32_t)rp : r0.rmax;
+                    e.qi_last = s; e.idx_last = ia; e.pmax = r0.f > r0.pmax ? r0.f : r0.pmax;
+                    e.r_first = (uint32_t)rp; e.seg = pgap >= ANI_ANCHOR_SCORE ? ia : r0.seg;
+                    r0.cnt |= SUCC_BIT;
+                    EVICT(r3);
+                    r3 = r2; r2 = r1; r1 = r0; r0 = e;
                 }
+            } else {
+                Run e;
+                e.q_last = (uint32_t)qp; e.rr_last = rr; e.rctg = rc; e.f = best;
+                e.cnt = 1; e.first_qi = s; e.rmin = e.rmax = (uint32_t)rp;
+                e.qi_last = s; e.idx_last = ia; e.pmax = NEG; e.r_first = (uint32_t)rp; e.seg = ia;
+                EVICT(r3);
+                r3 = r2; r2 = r1; r1 = r0; r0 = e;
             }
-            r3 = r2; r2 = r1; r1 = r0; r0 = e;
             ia++;
             runmax = best > runmax ? best : runmax;
         }
+        if (cplx) break;
+        s++;
+        // does r0 now dominate?  every other run / summary must be unable to offer more than r0.f + 20
+        // to an anchor that extends r0: other record or strand, more than max_gap off r0's diagonal,
+        // out of the 2500-base band for good, or simply not scoring higher than r0
+        if (r0.cnt && !(r0.cnt & SUCC_BIT)) {
+            const uint32_t k0 = r0.rctg | ((r0.rr_last >> 31) << 31);
+            const int32_t q0l = (int32_t)r0.q_last;
+            const int32_t d0 = (r0.rr_last >> 31) ? (int32_t)(r0.rr_last & 0x7FFFFFFFu) + q0l : (int32_t)(r0.rr_last & 0x7FFFFFFFu) - q0l;
+#define CANNOT_BEAT(E)                                                                              \
+            (!(E).cnt || ((E).rctg | (((E).rr_last >> 31) << 31)) != k0 || (E).f <= r0.f || q0l - (int32_t)(E).q_last > ANI_BP_BAND || \
+             abs((((E).rr_last >> 31) ? (int32_t)((E).rr_last & 0x7FFFFFFFu) + (int32_t)(E).q_last                                       \
+                                      : (int32_t)((E).rr_last & 0x7FFFFFFFu) - (int32_t)(E).q_last) - d0) > ANI_MAX_GAP)
+            dom = CANNOT_BEAT(r1) && CANNOT_BEAT(r2) && CANNOT_BEAT(r3);
+#undef CANNOT_BEAT
+            if (dom && s0_seg != 0xFFFFFFFFu)
+                dom = s0_key != k0 || s0_f <= r0.f || q0l - (int32_t)s0_q > ANI_BP_BAND || d0 < s0_dlo - ANI_MAX_GAP || d0 > s0_dhi + ANI_MAX_GAP;
+            if (dom && lost_f != NEG)
+                dom = lost_f <= r0.f || q0l - (int32_t)lost_q > ANI_BP_BAND || d0 < lost_dlo - ANI_MAX_GAP || d0 > lost_dhi + ANI_MAX_GAP;
+            // the plain-extension test compares the next hit with r0's record interval
+            if (dom) { const uint32_t rl = r0.rr_last & 0x7FFFFFFFu; if (rl < cur_lo || rl >= cur_hi) dom = false; }
+        }
     }
-    }
-    if (!cplx) {
-        if (ia > 3) EMIT_PATH(r3);
-        if (ia > 2 && !cplx) EMIT_PATH(r2);
-        if (ia > 1 && !cplx) EMIT_PATH(r1);
-        if (ia > 0 && !cplx) EMIT_PATH(r0);
-    }
+    if (!cplx) EMIT_PATH(r3);
+    if (!cplx) EMIT_PATH(r2);
+    if (!cplx) EMIT_PATH(r1);
+    if (!cplx) EMIT_PATH(r0);
 #undef EMIT_PATH
+#undef EVICT
     if (cplx) {
         chunk_state[t] = CHUNK_SLOW;
         slow_list[atomicAdd(slow_count, 1u)] = t;
@@ -889,8 +980,8 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         HIPCHECK(hipStreamSynchronize(st));
         const uint32_t nslow = hcnt[0];
         if (getenv("SKDER_AMD_DEBUG"))
-            fprintf(stderr, "[skder_amd] batch: %u pairs %llu chunks, slow %u (none %u, slots %u, hits %u, ring %u, branch %u, score %u, qrep %u)\n",
-                    nb, (unsigned long long)nchunks, nslow, hcnt[1], hcnt[2], hcnt[3], hcnt[4], hcnt[5], hcnt[6], hcnt[7]);
+            fprintf(stderr, "[skder_amd] batch: %u pairs %llu chunks, slow %u (none %u, slots %u, hits %u, ring %u, branch %u, score %u, qrep %u, inside %u)\n",
+                    nb, (unsigned long long)nchunks, nslow, hcnt[1], hcnt[2], hcnt[3], hcnt[4], hcnt[5], hcnt[6], hcnt[7], hcnt[8]);
         if (nslow) {
             W.cap.resize(nslow + 1, st); W.abase.resize(nslow + 1, st); W.slow_n.resize(nslow + 1, st);
             hipLaunchKernelGGL(slow_caps_kernel, dim3((nslow + 256) / 256), dim3(256), 0, st, VA, VB, W.d_pairs.p, nb, W.slow_list.p,
