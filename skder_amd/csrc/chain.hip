@@ -123,7 +123,14 @@ __global__ __launch_bounds__(256) void join_kernel(SetView A, SetView B, const P
 {
     __shared__ uint32_t s_qb[JOIN_TILE + 1], s_rb[JOIN_TILE + 1];
     __shared__ uint32_t s_qk[JOIN_CAP], s_qx[JOIN_CAP], s_rk[JOIN_CAP], s_rg[JOIN_CAP];
-    const PairDesc pd = pairs[blockIdx.x];
+    // XCD-aware mapping (workgroups are dealt round-robin to the 8 XCDs): each XCD gets a contiguous
+    // eighth of the R-sorted pair list, so the other genome's arrays stay in its private L2
+    uint32_t pidx = blockIdx.x;
+    {
+        const uint32_t nwg = gridDim.x, xcd = pidx & 7u, idx = pidx >> 3, q8 = nwg >> 3, r8 = nwg & 7u;
+        pidx = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + idx;
+    }
+    const PairDesc pd = pairs[pidx];
     const SetView &QS = (pd.flags & 2u) ? B : A;
     const SetView &RS = (pd.flags & 4u) ? B : A;
     const GenomeMeta *Qm = QS.meta + pd.q, *Rm = RS.meta + pd.r;
@@ -132,7 +139,7 @@ __global__ __launch_bounds__(256) void join_kernel(SetView A, SetView B, const P
     const uint32_t *rk = RS.skmer + Rm->seed_off, *rg = RS.sgpos + Rm->seed_off, *rb = RS.boff + Rm->bucket_off;
     const uint32_t rrep = Rm->rep_cut, tid = threadIdx.x;
     uint32_t *hit = hits + pd.hit_base;
-    uint32_t *nmulti = pair_nmulti + blockIdx.x;
+    uint32_t *nmulti = pair_nmulti + pidx;
     if (qbits == rbits && (1u << bits) >= JOIN_TILE) {
         // equal bucket counts: tiles of 256 buckets, both sides staged in LDS with coalesced loads
         for (uint32_t b0 = 0; b0 < (1u << bits); b0 += JOIN_TILE) {
