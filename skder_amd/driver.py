@@ -1,0 +1,135 @@
+"""End-to-end dereplication flow of bin/skder on top of the MI355X engine:
+listing -> N50 table -> edge table (GPU) -> representative selection -> result files.
+
+Only the flow around the hot path is reproduced (no downloads, MGE filtering, plots); file names and
+formats follow the reference so that outputs can be diffed against its result directories.
+
+    python -m skder_amd.driver -g GENOME_DIR_OR_FILES... -o OUT/ [-d greedy|dynamic|low_mem_greedy]
+                               [-i 99.5] [-f 50.0] [-a 10.0] [-n] [-p "-s 89.5"]
+"""
+import argparse
+import gzip
+import os
+import sys
+from collections import OrderedDict
+
+from . import selection
+from .skder import lowMemGreedyDerep, runSkaniDist, runSkaniTriangle
+
+ACCEPTED_SUFFICES = ("fasta", "fas", "fna", "fa")      # util.py:21
+
+
+def n50_of_fasta(path: str) -> int:
+    """util.py:686-724: all records, half = int(sum/2), lengths descending, first cumulative >= half"""
+    op = gzip.open if path.endswith(".gz") else open
+    lens, cur = [], None
+    with op(path, "rt") as f:
+        for line in f:
+            if line.startswith(">"):
+                if cur is not None:
+                    lens.append(cur)
+                cur = 0
+            elif cur is not None:
+                cur += len(line.strip())
+    if cur is not None:
+        lens.append(cur)
+    lens.sort(reverse=True)
+    half, cum = int(sum(lens) / 2), 0
+    for l in lens:
+        cum += l
+        if cum >= half:
+            return l
+    return 0
+
+
+def list_genomes(inputs):
+    out = []
+    for x in inputs:
+        if os.path.isdir(x):
+            for fn in os.listdir(x):             # os.listdir order, as util.processInputGenomes
+                base = fn[:-3] if fn.endswith(".gz") else fn
+                if base.split(".")[-1] in ACCEPTED_SUFFICES:
+                    out.append(os.path.abspath(os.path.join(x, fn)))
+        else:
+            out.append(os.path.abspath(x))
+    return out
+
+
+def run(genomes, outdir, mode="greedy", ani=99.5, af=50.0, max_af_dist=10.0, clusters=False, params="-s X"):
+    outdir = os.path.abspath(outdir) + "/"
+    os.makedirs(outdir, exist_ok=True)
+    if params == "-s X":                          # bin/skder:199-201
+        params = "-s %s" % max(ani - 10.0, 0.0)
+    if clusters and mode == "dynamic":            # bin/skder:216-219
+        af_tri = max(af - 20.0, 0.0)
+    else:
+        af_tri = af
+    listing = outdir + "All_Genomes_Listing.txt"
+    with open(listing, "w") as f:
+        f.write("".join(g + "\n" for g in genomes))
+    n50 = OrderedDict((g, n50_of_fasta(g)) for g in genomes)
+    n50_file = outdir + "Concatenated_N50.txt"
+    with open(n50_file, "w") as f:
+        f.write("".join("%s\t%d\n" % kv for kv in n50.items()))
+    result_file = outdir + "skDER_Results.txt"
+    edge_file = outdir + "Skani_Triangle_Edge_Output.txt"
+    if mode == "low_mem_greedy":
+        ws = outdir + "skder_lm_workspace/"
+        os.makedirs(ws, exist_ok=True)
+        lowMemGreedyDerep(listing, ws, n50_file, result_file, outdir, ani, af, None)
+        if clusters:
+            cdir = outdir + "Clustering_Workspace/"
+            os.makedirs(cdir, exist_ok=True)
+            edge_file = outdir + "Skani_Dist_Output.txt"
+            runSkaniDist(cdir, result_file, listing, edge_file, params, af, mode, False, None)
+        reps = [l.strip() for l in open(result_file)]
+    else:
+        runSkaniTriangle(listing, edge_file, params, af_tri, mode, False, None)
+        edges = selection.edges_from_table(edge_file)
+        if mode == "greedy":
+            info = selection.genome_information(edges, n50, ani, af)
+            with open(outdir + "Genome_Information_for_Greedy_Clustering.txt", "w") as f:
+                f.write("".join(l + "\n" for l in info))
+            srt = selection.sort_like_coreutils(info)
+            with open(outdir + "Genome_Information_for_Greedy_Clustering.sorted.txt", "w") as f:
+                f.write("".join(l + "\n" for l in srt))
+            reps = selection.greedy(srt)
+        elif mode == "dynamic":
+            reps = selection.dynamic(edges, n50, ani, af, max_af_dist)
+        else:
+            raise ValueError("unknown dereplication mode " + mode)
+        with open(result_file, "w") as f:
+            f.write("".join(r + "\n" for r in reps))
+    if clusters:
+        edges = selection.edges_from_table(edge_file)
+        with open(outdir + "skDER_Clustering.txt", "w") as f:
+            f.write("".join(l + "\n" for l in selection.determine_clusters(reps, edges, af, ani)))
+    rep_dir = outdir + "Dereplicated_Representative_Genomes/"
+    os.makedirs(rep_dir, exist_ok=True)
+    for r in reps:
+        dst = rep_dir + os.path.basename(r)
+        if not os.path.lexists(dst):
+            os.symlink(r, dst)
+    with open(outdir + "COMPLETED.txt", "w") as f:
+        f.write("skDER completed successfully!\n")
+    return reps
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawTextHelpFormatter)
+    ap.add_argument("-g", "--genomes", nargs="+", required=True)
+    ap.add_argument("-o", "--output-directory", required=True)
+    ap.add_argument("-d", "--dereplication-mode", default="greedy")
+    ap.add_argument("-i", "--percent-identity-cutoff", type=float, default=99.5)
+    ap.add_argument("-f", "--aligned-fraction-cutoff", type=float, default=50.0)
+    ap.add_argument("-a", "--max-af-distance-cutoff", type=float, default=10.0)
+    ap.add_argument("-p", "--skani-triangle-parameters", default="-s X")
+    ap.add_argument("-n", "--determine-clusters", action="store_true")
+    a = ap.parse_args(argv)
+    reps = run(list_genomes(a.genomes), a.output_directory, a.dereplication_mode, a.percent_identity_cutoff,
+               a.aligned_fraction_cutoff, a.max_af_distance_cutoff, a.determine_clusters, a.skani_triangle_parameters)
+    print("%d representative genomes -> %s" % (len(reps), os.path.join(a.output_directory, "skDER_Results.txt")))
+
+
+if __name__ == "__main__":
+    main()

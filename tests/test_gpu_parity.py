@@ -278,3 +278,24 @@ def test_two_ranks_share_the_triangle(gpu):
     j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
     assert j2["n_gpus"] == 2 and j1["config"]["edges"] == j2["config"]["edges"] > 0
     assert j1["config"]["chained_pairs"] == j2["config"]["chained_pairs"]
+
+
+def test_driver_end_to_end_listings(gpu, tmp_path):
+    """bin/skder's flow on the 34 reference genomes through the GPU engine: the representative listing
+    equals the reference's golden listing at the cut-offs skDER is run with (greedy, -i 99.5 / 99.0),
+    and the three selection modes run to completion (low_mem_greedy drives sketch + search on the device)"""
+    from skder_amd import driver
+    gdir = os.path.join(GOLDEN, "genomes")
+    n50_gold = [l.split("\t")[0] for l in open(os.path.join(GOLDEN, "downstream", "skder_gtdb_results__Concatenated_N50.txt"))]
+    genomes = [os.path.join(gdir, n) for n in n50_gold]           # the reference run's listing order
+    for ani in (99.5, 99.0):
+        reps = driver.run(genomes, str(tmp_path / ("greedy%s" % ani)), "greedy", ani, 50.0, clusters=True)
+        want = [l.strip() for l in open(os.path.join(GOLDEN, "downstream", "tc", "skDER_Results_ANI%s_AF50.0.txt" % ani))]
+        assert [os.path.basename(r) for r in reps] == want
+        assert os.path.isfile(tmp_path / ("greedy%s" % ani) / "skDER_Clustering.txt")
+    reps_g = driver.run(genomes, str(tmp_path / "g"), "greedy", 99.5, 50.0)
+    reps_d = driver.run(genomes, str(tmp_path / "d"), "dynamic", 99.5, 50.0)
+    reps_l = driver.run(genomes, str(tmp_path / "l"), "low_mem_greedy", 99.5, 50.0, clusters=True)
+    assert 0 < len(reps_d) <= len(reps_g)                          # dynamic is the more concise mode (README)
+    assert 0 < len(reps_l) <= len(genomes) and os.path.isfile(tmp_path / "l" / "Skani_Dist_Output.txt")
+    assert set(reps_l) <= set(genomes)
