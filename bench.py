@@ -159,6 +159,15 @@ def main():
         dom = max(cand, key=lambda k: cand[k][0])
         dms, dbytes = cand[dom]
         achieved = dbytes / (dms * 1e-3) / 1e9 if dms > 0 else 0.0
+        # measured HBM traffic of the dominant kernel per step (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+        # separate passes, profiles/round1_pmc_traffic.json; only valid for the default workload on 1 GPU)
+        traffic = None
+        try:
+            if N == 5000 and world == 1:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")))[dom]
+                traffic = (pm["FETCH_SIZE"]["sum_counter_kb"] + pm["WRITE_SIZE"]["sum_counter_kb"]) * 1024.0
+        except Exception:
+            traffic = None
         out = {
             "metric": "genome-pairs ANI/sec on 5k x 3Mb synthetic", "value": pairs / (ms_per_step * 1e-3),
             "unit": "genome-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -170,7 +179,7 @@ def main():
                        "chunks": int(step.counters[0]), "slow_path_chunks": int(step.counters[1]),
                        "parallelism": "rows%d" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": dbytes,
                          "kernel_ms": {k: float(v[0]) for k, v in cand.items()},
                          "other_ms": {"sketch_post": float(tm[1]), "screen": float(tm[2]), "chain_slow_path": float(tm[4]),
                                       "finalize": float(tm[5])}},

@@ -123,13 +123,7 @@ __global__ __launch_bounds__(256) void join_kernel(SetView A, SetView B, const P
 {
     __shared__ uint32_t s_qb[JOIN_TILE + 1], s_rb[JOIN_TILE + 1];
     __shared__ uint32_t s_qk[JOIN_CAP], s_qx[JOIN_CAP], s_rk[JOIN_CAP], s_rg[JOIN_CAP];
-    // XCD-aware mapping (workgroups are dealt round-robin to the 8 XCDs): each XCD gets a contiguous
-    // eighth of the R-sorted pair list, so the other genome's arrays stay in its private L2
-    uint32_t pidx = blockIdx.x;
-    {
-        const uint32_t nwg = gridDim.x, xcd = pidx & 7u, idx = pidx >> 3, q8 = nwg >> 3, r8 = nwg & 7u;
-        pidx = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + idx;
-    }
+    const uint32_t pidx = blockIdx.x;
     const PairDesc pd = pairs[pidx];
     const SetView &QS = (pd.flags & 2u) ? B : A;
     const SetView &RS = (pd.flags & 4u) ? B : A;
