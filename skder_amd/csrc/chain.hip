@@ -13,6 +13,7 @@
 //   finalize_kernel  one workgroup per pair: chains into LDS, better-chain overlap filter as a
 //                    parallel fix-point, fixed-point containment ANI, aligned fraction.
 #include <algorithm>
+#include <chrono>
 
 #include "device_utils.h"
 #include "engine.h"
@@ -915,6 +916,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
     uint64_t tot_anchors = 0, tot_slow = 0, tot_chunks = 0;
     // orientation of every pair, then order the work by the probed genome (R): consecutive
     // workgroups probe the same hash table, which keeps it in the XCD's L2
+    const auto t_host0 = std::chrono::steady_clock::now();
     struct PairJob { uint32_t q, r, flags, orig; };
     std::vector<PairJob> jobs(np);
     for (size_t p = 0; p < np; p++) {
@@ -925,11 +927,20 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         jobs[p].flags = (cq ? 1u : 0u) | (cq ? 2u : 0u) | (cq ? 0u : 4u);   // Q in B iff cq; R in B iff !cq
         jobs[p].orig = (uint32_t)p;
     }
-    std::sort(jobs.begin(), jobs.end(), [](const PairJob &a, const PairJob &b) {
-        if ((a.flags & 4u) != (b.flags & 4u)) return (a.flags & 4u) < (b.flags & 4u);
-        if (a.r != b.r) return a.r < b.r;
-        return a.q < b.q;
-    });
+    {   // stable counting sort by (set of R, R): O(n), the order inside a group stays the screen's
+        const size_t na = SA->n_genomes, nbk = na + SB->n_genomes + 1;
+        std::vector<uint32_t> start(nbk + 1, 0);
+        auto keyof = [&](const PairJob &j) { return (size_t)((j.flags & 4u) ? na + j.r : j.r); };
+        for (const PairJob &j : jobs) start[keyof(j) + 1]++;
+        for (size_t k = 0; k < nbk; k++) start[k + 1] += start[k];
+        std::vector<PairJob> sorted(np);
+        for (const PairJob &j : jobs) sorted[start[keyof(j)]++] = j;
+        jobs.swap(sorted);
+    }
+    const auto t_host1 = std::chrono::steady_clock::now();
+    if (getenv("SKDER_AMD_DEBUG"))
+        fprintf(stderr, "[skder_amd] host: orient+sort of %zu pairs %.2f ms\n", np,
+                std::chrono::duration<double, std::milli>(t_host1 - t_host0).count());
     size_t p0 = 0;
     while (p0 < np) {
         hp.clear();

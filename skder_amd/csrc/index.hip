@@ -160,7 +160,9 @@ void index_impl(skder_sketches *s)
         HIPCHECK(hipMemcpyAsync(s->d_meta.p, s->h_meta.data(), G * sizeof(GenomeMeta), hipMemcpyHostToDevice, st));
         HIPCHECK(hipMemcpyAsync(s->d_rec_goff.p, s->h_rec_goff.data(), s->h_rec_goff.size() * 4, hipMemcpyHostToDevice, st));
         HIPCHECK(hipEventRecord(ctx->ev[3], st));
-        hipLaunchKernelGGL(index_genome_kernel, dim3(G), dim3(256), (1u << IDX_MAX_BUCKET_BITS) * 4, st, s->d_meta.p,
+        uint32_t max_bits = 12;   // the multiplicity histogram needs 4096 counters
+        for (uint32_t g = 0; g < G; g++) max_bits = s->h_meta[g].bucket_bits > max_bits ? s->h_meta[g].bucket_bits : max_bits;
+        hipLaunchKernelGGL(index_genome_kernel, dim3(G), dim3(256), (1u << max_bits) * 4, st, s->d_meta.p,
                            s->d_rec_goff.p, s->seed_kmer.p, s->seed_gpos.p, s->seed_ctg.p, s->skmer.p, s->sgpos.p,
                            s->sctg.p, s->boff.p, s->pchunk.p, s->chunk_start.p, s->sidx.p);
         HIPCHECK(hipEventRecord(ctx->ev[4], st));
