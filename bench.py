@@ -148,13 +148,14 @@ def main():
         n_chained, n_anchors = tm[6], tm[7]
         sketch_bytes = total_bases * (1.0 + 8.0 / 125 + 8.0 / 1000)        # this rank's sketch kernel launches
         seeds_per_genome = args.genome_len / 125.0
-        # join_kernel: per chained pair both bucket-ordered seed arrays are streamed once (8 B per seed
-        # and side) and one 4-byte hit word per seed of the chunked genome is written;
+        # join_probe_kernel: per chained pair the chunked genome's position-ordered k-mers are read once
+        # (4 B per seed), one hit word per seed is written (4 B) and the matched position is gathered for
+        # about 70 % of the seeds (4 B); the probed genome's index is staged in LDS once per <= 16 pairs;
         # chain_fast_kernel: per chained pair the hit word and the position of every seed are read (8 B)
-        join_bytes = n_chained * (20.0 * seeds_per_genome)
+        join_bytes = n_chained * (11.0 * seeds_per_genome)
         chain_bytes = n_chained * (8.0 * seeds_per_genome)
         join_ms = float(step.counters[2]) / 1000.0
-        cand = {"sketch_tiles_kernel": (tm[0], sketch_bytes), "join_kernel": (join_ms, join_bytes),
+        cand = {"sketch_tiles_kernel": (tm[0], sketch_bytes), "join_probe_kernel": (join_ms, join_bytes),
                 "chain_fast_kernel": (tm[3], chain_bytes)}
         dom = max(cand, key=lambda k: cand[k][0])
         dms, dbytes = cand[dom]

@@ -22,7 +22,7 @@
 struct SetView {
     const GenomeMeta *meta;
     const uint32_t *pkmer, *pgpos, *pchunk;   // position order
-    const uint32_t *skmer, *sgpos, *sctg, *sidx;   // bucket order
+    const uint32_t *skmer, *sgpos, *sctg;     // bucket order
     const uint32_t *boff;
     const uint32_t *chunk_start;
     const uint32_t *rec_goff;
@@ -74,96 +74,104 @@ __device__ __forceinline__ uint32_t find_pair(const PairDesc *__restrict__ pairs
 }
 
 // ---------------------------------------------------------------------------------------------
-// JOIN: one workgroup per pair.  Both genomes keep their seeds in 2^b multiplicative-hash buckets
-// sorted by (k-mer, gpos); bucket b of one genome can only match bucket b of the other (nested when the
-// bucket counts differ), so one thread per bucket streams both bucket-ordered arrays once (coalesced,
-// 8 B per seed and side) and writes, for every matching seed of the chunked genome, its hit into
-// the position-indexed hit array.  No hashing-table probes, no random reads.
-#define JOIN_TILE 256      // buckets per tile (one per thread)
-#define JOIN_CAP 1536      // seeds per side staged in LDS per tile (mean ~780 for 3 seeds per bucket)
+// JOIN: hit words for every (pair, seed of the chunked genome), R-stationary.
+// Pairs are sorted by the probed genome R.  One 1024-thread workgroup takes a group of pairs that
+// share R, loads R's bucket offsets and bucket-ordered k-mers into LDS once (132 KB for a 3 Mb genome),
+// and then streams the position-ordered k-mers of every chunked genome of the group past it: one
+// coalesced 4-byte read per seed, a probe of the LDS-resident bucket (about 5 LDS reads), a gather of
+// the matched position from R's sgpos array (L2-resident), and one coalesced 4-byte hit word written
+// per seed -- in position order, so nothing is scattered into HBM and no memset is needed.
+// Genomes whose index does not fit in LDS are probed in several passes over bucket ranges.
+struct JoinGroup { uint32_t pair_begin, pair_end; };
+#define JOIN_THREADS 1024
+#define JOIN_BCAP 8200       // bucket offsets held in LDS per pass
+#define JOIN_KCAP 30720      // k-mers held in LDS per pass
+#define JOIN_SMEM_BYTES ((JOIN_BCAP + JOIN_KCAP + 8) * 4)
 
-// match the seeds of bucket range [qlo,qhi) of the chunked genome against [rlo,rhi) of the other genome
-// (arrays may live in LDS or in global memory) and record the hits
-__device__ __forceinline__ void join_bucket(const uint32_t *qk, const uint32_t *qx, uint32_t qlo, uint32_t qhi, const uint32_t *rk,
-                                            const uint32_t *rg, uint32_t rlo, uint32_t rhi, uint32_t bits, uint32_t qbits, uint32_t fb,
-                                            uint32_t rrep, uint32_t *hit, uint4 *multi, uint32_t *nmulti, const PairDesc &pd)
+__global__ __launch_bounds__(JOIN_THREADS) void join_probe_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs,
+                                                                  const JoinGroup *__restrict__ groups,
+                                                                  uint32_t *__restrict__ hits, uint4 *__restrict__ multi,
+                                                                  uint32_t *__restrict__ pair_nmulti)
 {
-    for (uint32_t e = qlo; e < qhi; e++) {
-        const uint32_t kq = qk[e], kmer = kq & SK_SEED_MASK;
-        if (bits != qbits && kmer_bucket(kmer, bits) != fb) continue;   // another thread owns this seed
-        uint32_t cnt = 0, first = 0;
-        for (uint32_t e2 = rlo; e2 < rhi; e2++) {
-            const uint32_t k2 = rk[e2] & SK_SEED_MASK;
-            if (k2 == kmer) { if (!cnt) first = e2; cnt++; }
-            else if (k2 > kmer) break;
-        }
-        if (!cnt || cnt > rrep) continue;
-        const uint32_t qi = qx[e];
-        if (cnt == 1) {
-            hit[qi] = rg[first] | (((kq >> 31) != (rk[first] >> 31)) ? USED_BIT : 0u);
-        } else if (cnt <= 4) {
-            const uint32_t slot = atomicAdd(nmulti, 1u);
-            if (slot < pd.multi_cap) {
-                uint32_t v[4] = {HIT_NONE, HIT_NONE, HIT_NONE, HIT_NONE};
-                for (uint32_t u = 0; u < cnt; u++)
-                    v[u] = rg[first + u] | (((kq >> 31) != (rk[first + u] >> 31)) ? USED_BIT : 0u);
-                multi[pd.multi_base + slot] = make_uint4(v[0], v[1], v[2], v[3]);
-                hit[qi] = HIT_MULTI | slot;
-            } else {
-                hit[qi] = HIT_MANY;
-            }
-        } else {
-            hit[qi] = HIT_MANY;
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void join_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs,
-                                                   uint32_t *__restrict__ hits, uint4 *__restrict__ multi,
-                                                   uint32_t *__restrict__ pair_nmulti)
-{
-    __shared__ uint32_t s_qb[JOIN_TILE + 1], s_rb[JOIN_TILE + 1];
-    __shared__ uint32_t s_qk[JOIN_CAP], s_qx[JOIN_CAP], s_rk[JOIN_CAP], s_rg[JOIN_CAP];
-    const uint32_t pidx = blockIdx.x;
-    const PairDesc pd = pairs[pidx];
-    const SetView &QS = (pd.flags & 2u) ? B : A;
-    const SetView &RS = (pd.flags & 4u) ? B : A;
-    const GenomeMeta *Qm = QS.meta + pd.q, *Rm = RS.meta + pd.r;
-    const uint32_t qbits = Qm->bucket_bits, rbits = Rm->bucket_bits, bits = qbits > rbits ? qbits : rbits;
-    const uint32_t *qk = QS.skmer + Qm->seed_off, *qx = QS.sidx + Qm->seed_off, *qb = QS.boff + Qm->bucket_off;
+    extern __shared__ __attribute__((aligned(16))) unsigned char join_smem[];
+    uint32_t *s_boff = reinterpret_cast<uint32_t *>(join_smem);   // JOIN_BCAP, relative to the pass's first seed
+    uint32_t *s_rk = s_boff + JOIN_BCAP;                           // JOIN_KCAP
+    uint32_t *s_ctl = s_rk + JOIN_KCAP;                            // [0] = end bucket of the pass
+    const uint32_t tid = threadIdx.x;
+    const JoinGroup g = groups[blockIdx.x];
+    const PairDesc pd0 = pairs[g.pair_begin];
+    const SetView &RS = (pd0.flags & 4u) ? B : A;
+    const GenomeMeta *Rm = RS.meta + pd0.r;
+    const uint32_t bits = Rm->bucket_bits, nbk = 1u << bits, rrep = Rm->rep_cut;
     const uint32_t *rk = RS.skmer + Rm->seed_off, *rg = RS.sgpos + Rm->seed_off, *rb = RS.boff + Rm->bucket_off;
-    const uint32_t rrep = Rm->rep_cut, tid = threadIdx.x;
-    uint32_t *hit = hits + pd.hit_base;
-    uint32_t *nmulti = pair_nmulti + pidx;
-    if (qbits == rbits && (1u << bits) >= JOIN_TILE) {
-        // equal bucket counts: tiles of 256 buckets, both sides staged in LDS with coalesced loads
-        for (uint32_t b0 = 0; b0 < (1u << bits); b0 += JOIN_TILE) {
-            __syncthreads();
-            s_qb[tid] = qb[b0 + tid]; s_rb[tid] = rb[b0 + tid];
-            if (tid == 0) { s_qb[JOIN_TILE] = qb[b0 + JOIN_TILE]; s_rb[JOIN_TILE] = rb[b0 + JOIN_TILE]; }
-            __syncthreads();
-            const uint32_t q0 = s_qb[0], nq = s_qb[JOIN_TILE] - q0, r0 = s_rb[0], nr = s_rb[JOIN_TILE] - r0;
-            const bool staged = nq <= JOIN_CAP && nr <= JOIN_CAP;
-            if (staged) {
-                for (uint32_t i = tid; i < nq; i += 256) { s_qk[i] = qk[q0 + i]; s_qx[i] = qx[q0 + i]; }
-                for (uint32_t i = tid; i < nr; i += 256) { s_rk[i] = rk[r0 + i]; s_rg[i] = rg[r0 + i]; }
+
+    for (uint32_t bb0 = 0; bb0 < nbk;) {
+        __syncthreads();
+        if (tid == 0) {
+            // the largest bucket range [bb0, bb1) whose offsets and k-mers fit
+            uint32_t hi = bb0 + (JOIN_BCAP - 1) < nbk ? bb0 + (JOIN_BCAP - 1) : nbk, lo = bb0 + 1;
+            const uint32_t base = rb[bb0];
+            if (rb[hi] - base > JOIN_KCAP) {
+                while (lo < hi) {   // largest bb1 in [bb0+1, hi] with rb[bb1] - base <= KCAP
+                    const uint32_t mid = (lo + hi + 1) >> 1;
+                    if (rb[mid] - base <= JOIN_KCAP) lo = mid; else hi = mid - 1;
+                }
+                hi = lo;
             }
-            __syncthreads();
-            const uint32_t qlo = s_qb[tid], qhi = s_qb[tid + 1], rlo = s_rb[tid], rhi = s_rb[tid + 1];
-            if (qlo == qhi || rlo == rhi) continue;
-            if (staged)
-                join_bucket(s_qk, s_qx, qlo - q0, qhi - q0, s_rk, s_rg, rlo - r0, rhi - r0, bits, qbits, b0 + tid, rrep, hit, multi, nmulti, pd);
-            else
-                join_bucket(qk, qx, qlo, qhi, rk, rg, rlo, rhi, bits, qbits, b0 + tid, rrep, hit, multi, nmulti, pd);
+            s_ctl[0] = hi;
         }
-        return;
-    }
-    // different bucket counts: the finer index space, nested coarse buckets, straight from global memory
-    for (uint32_t fb = tid; fb < (1u << bits); fb += 256) {
-        const uint32_t qbk = fb >> (bits - qbits), rbk = fb >> (bits - rbits);
-        const uint32_t qlo = qb[qbk], qhi = qb[qbk + 1], rlo = rb[rbk], rhi = rb[rbk + 1];
-        if (qlo == qhi || rlo == rhi) continue;
-        join_bucket(qk, qx, qlo, qhi, rk, rg, rlo, rhi, bits, qbits, fb, rrep, hit, multi, nmulti, pd);
+        __syncthreads();
+        const uint32_t bb1 = s_ctl[0];
+        const uint32_t base = rb[bb0], nk = rb[bb1] - base;
+        const bool fits = nk <= JOIN_KCAP;   // false only for one bucket with more than KCAP seeds
+        for (uint32_t i = tid; i <= bb1 - bb0; i += JOIN_THREADS) s_boff[i] = rb[bb0 + i] - base;
+        if (fits)
+            for (uint32_t i = tid; i < nk; i += JOIN_THREADS) s_rk[i] = rk[base + i];
+        __syncthreads();
+        for (uint32_t p = g.pair_begin; p < g.pair_end; p++) {
+            const PairDesc pd = pairs[p];
+            const SetView &QS = (pd.flags & 2u) ? B : A;
+            const GenomeMeta *Qm = QS.meta + pd.q;
+            const uint32_t *pk = QS.pkmer + Qm->seed_off;
+            const uint32_t nq = Qm->n_seeds;
+            uint32_t *hit = hits + pd.hit_base;
+            for (uint32_t s = tid; s < nq; s += JOIN_THREADS) {
+                const uint32_t kq = pk[s], kmer = kq & SK_SEED_MASK;
+                const uint32_t b = kmer_bucket(kmer, bits);
+                if (b < bb0 || b >= bb1) continue;          // this seed's bucket belongs to another pass
+                const uint32_t lo = s_boff[b - bb0], hi = s_boff[b - bb0 + 1];
+                uint32_t cnt = 0, first = 0;
+                for (uint32_t e = lo; e < hi; e++) {
+                    const uint32_t k2 = (fits ? s_rk[e] : rk[base + e]) & SK_SEED_MASK;
+                    if (k2 == kmer) { if (!cnt) first = e; cnt++; }
+                    else if (k2 > kmer) break;
+                }
+                uint32_t hv = HIT_NONE;
+                if (cnt && cnt <= rrep) {
+                    if (cnt == 1) {
+                        const uint32_t rkm = fits ? s_rk[first] : rk[base + first];
+                        hv = rg[base + first] | (((kq >> 31) != (rkm >> 31)) ? USED_BIT : 0u);
+                    } else if (cnt <= 4) {
+                        const uint32_t slot = atomicAdd(&pair_nmulti[p], 1u);
+                        if (slot < pd.multi_cap) {
+                            uint32_t v[4] = {HIT_NONE, HIT_NONE, HIT_NONE, HIT_NONE};
+                            for (uint32_t u = 0; u < cnt; u++) {
+                                const uint32_t rkm = fits ? s_rk[first + u] : rk[base + first + u];
+                                v[u] = rg[base + first + u] | (((kq >> 31) != (rkm >> 31)) ? USED_BIT : 0u);
+                            }
+                            multi[pd.multi_base + slot] = make_uint4(v[0], v[1], v[2], v[3]);
+                            hv = HIT_MULTI | slot;
+                        } else {
+                            hv = HIT_MANY;
+                        }
+                    } else {
+                        hv = HIT_MANY;
+                    }
+                }
+                hit[s] = hv;
+            }
+        }
+        bb0 = bb1;
     }
 }
 
@@ -860,7 +868,7 @@ static SetView view_of(skder_sketches *s)
     SetView v;
     v.meta = s->d_meta.p;
     v.pkmer = s->seed_kmer.p; v.pgpos = s->seed_gpos.p; v.pchunk = s->pchunk.p;
-    v.skmer = s->skmer.p; v.sgpos = s->sgpos.p; v.sctg = s->sctg.p; v.sidx = s->sidx.p; v.boff = s->boff.p;
+    v.skmer = s->skmer.p; v.sgpos = s->sgpos.p; v.sctg = s->sctg.p; v.boff = s->boff.p;
     v.chunk_start = s->chunk_start.p; v.rec_goff = s->d_rec_goff.p;
     return v;
 }
@@ -878,7 +886,8 @@ static bool chunk_the_query(const GenomeMeta &ref, const GenomeMeta &query)
 struct ChainWork {
     DevBuf<PairDesc> d_pairs;
     DevBuf<uint32_t> chunk_state, slow_list, counters, pair_na, pair_nch, cap, abase, slow_n, a_qi, a_r, a_rctg, BP;
-    DevBuf<uint32_t> hits, pair_nmulti;
+    DevBuf<uint32_t> hits, pair_nmulti, groups;
+    std::vector<JoinGroup> h_groups;
     DevBuf<uint4> multi;
     DevBuf<int32_t> F;
     DevBuf<ChainRec> fast_chains, chains;
@@ -976,11 +985,32 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         HIPCHECK(hipMemsetAsync(W.pair_nch.p, 0, nb * 4, st));
         HIPCHECK(hipMemsetAsync(W.pair_na.p, 0, nb * 4, st));
         HIPCHECK(hipMemsetAsync(W.pair_nmulti.p, 0, nb * 4, st));
-        HIPCHECK(hipMemsetAsync(W.hits.p, 0xFF, (nhits + 32) * 4, st));
         HIPCHECK(hipMemsetAsync(W.counters.p, 0, 64, st));
         HIPCHECK(hipMemsetAsync(ctx->d_flags, 0, 64, st));
         HIPCHECK(hipEventRecord(ctx->ev[11], st));
-        hipLaunchKernelGGL(join_kernel, dim3(nb), dim3(256), 0, st, VA, VB, W.d_pairs.p, W.hits.p, W.multi.p, W.pair_nmulti.p);
+        {
+            // groups of consecutive pairs that probe the same genome, at most 16 pairs each (load balance)
+            std::vector<JoinGroup> &hg = W.h_groups;
+            hg.clear();
+            for (uint32_t i = 0; i < nb;) {
+                uint32_t j = i;
+                while (j < nb && j - i < 16 && hp[j].r == hp[i].r && (hp[j].flags & 4u) == (hp[i].flags & 4u)) j++;
+                JoinGroup g;
+                g.pair_begin = i; g.pair_end = j;
+                hg.push_back(g);
+                i = j;
+            }
+            W.groups.resize(hg.size() * 2, st);
+            HIPCHECK(hipMemcpyAsync(W.groups.p, hg.data(), hg.size() * sizeof(JoinGroup), hipMemcpyHostToDevice, st));
+            static bool join_attr_set = false;
+            if (!join_attr_set) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(join_probe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          JOIN_SMEM_BYTES);
+                join_attr_set = true;
+            }
+            hipLaunchKernelGGL(join_probe_kernel, dim3((unsigned)hg.size()), dim3(JOIN_THREADS), JOIN_SMEM_BYTES, st, VA, VB, W.d_pairs.p,
+                               reinterpret_cast<const JoinGroup *>(W.groups.p), W.hits.p, W.multi.p, W.pair_nmulti.p);
+        }
         HIPCHECK(hipEventRecord(ctx->ev[5], st));
         if (nchunks)
             hipLaunchKernelGGL(chain_fast_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, st, VA, VB, W.d_pairs.p, nb,

@@ -34,7 +34,7 @@ struct skder_sketches {
     DevBuf<GenomeMeta> d_meta;
     std::vector<GenomeMeta> h_meta;
     DevBuf<uint32_t> d_rec_goff;
-    DevBuf<uint32_t> skmer, sgpos, sctg, sidx;   // by-(kmer,gpos) order inside each hash bucket; sidx = position-order index
+    DevBuf<uint32_t> skmer, sgpos, sctg;   // by-(kmer,gpos) order inside each hash bucket
     DevBuf<uint32_t> boff;                 // bucket offset tables
     DevBuf<uint32_t> pchunk;               // chunk id of every seed (position order)
     DevBuf<uint32_t> chunk_start;          // first seed of every chunk (+ end sentinel), per genome

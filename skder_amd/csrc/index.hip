@@ -3,8 +3,7 @@
 //     sorted by (k-mer, gpos) -- the "radix sort + dedup" stage of the sketch (one radix pass on a
 //     hashed digit + in-bucket insertion sort; buckets hold ~4 seeds);
 //   * repetitive k-mer cut-off (ani_oracle.c genome_finish);
-//   * chunk id of every seed: (record, (gpos - record_off) / 20000) numbered in position order;
-//   * sidx: for every bucket-ordered seed its index in position order (used by the pair join).
+//   * chunk id of every seed: (record, (gpos - record_off) / 20000) numbered in position order.
 // One 256-thread workgroup per genome; all counters live in LDS.
 #include "device_utils.h"
 #include "engine.h"
@@ -13,7 +12,7 @@ __global__ __launch_bounds__(256) void index_genome_kernel(
     GenomeMeta *__restrict__ meta, const uint32_t *__restrict__ rec_goff, const uint32_t *__restrict__ seed_kmer,
     const uint32_t *__restrict__ seed_gpos, const uint32_t *__restrict__ seed_ctg, uint32_t *__restrict__ skmer,
     uint32_t *__restrict__ sgpos, uint32_t *__restrict__ sctg, uint32_t *__restrict__ boff_all,
-    uint32_t *__restrict__ pchunk, uint32_t *__restrict__ chunk_start_all, uint32_t *__restrict__ sidx)
+    uint32_t *__restrict__ pchunk, uint32_t *__restrict__ chunk_start_all)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t *cnt = reinterpret_cast<uint32_t *>(smem_raw);   // 2^bits counters, later cursor, later histogram
@@ -28,7 +27,6 @@ __global__ __launch_bounds__(256) void index_genome_kernel(
     uint32_t *boff = boff_all + m.bucket_off;
     const uint32_t *rg = rec_goff + m.rec_goff_off;
 
-    uint32_t *oi = sidx + m.seed_off;
     for (uint32_t b = tid; b < nb; b += 256) cnt[b] = 0;
     if (tid == 0) s_distinct = 0;
     __syncthreads();
@@ -50,7 +48,7 @@ __global__ __launch_bounds__(256) void index_genome_kernel(
         uint32_t km = pk[s];
         uint32_t b = kmer_bucket(km & SK_SEED_MASK, bits);
         uint32_t pos = boff[b] + atomicAdd(&cnt[b], 1u);
-        ok[pos] = km; og[pos] = pg[s]; oc[pos] = pc[s]; oi[pos] = s;
+        ok[pos] = km; og[pos] = pg[s]; oc[pos] = pc[s];
     }
     __syncthreads();   // global writes of this workgroup are visible to it after the barrier
     // histogram of multiplicities reuses the counter array
@@ -61,16 +59,16 @@ __global__ __launch_bounds__(256) void index_genome_kernel(
         const uint32_t lo = boff[b], hi = (b + 1 == nb) ? n : boff[b + 1];
         // insertion sort by (kmer, gpos); gpos is unique inside a genome, so the order is total
         for (uint32_t i = lo + 1; i < hi; i++) {
-            uint32_t km = ok[i], gp = og[i], ct = oc[i], ix = oi[i];
+            uint32_t km = ok[i], gp = og[i], ct = oc[i];
             uint32_t kk = km & SK_SEED_MASK;
             uint32_t j = i;
             while (j > lo) {
                 uint32_t pk2 = ok[j - 1] & SK_SEED_MASK;
                 if (pk2 < kk || (pk2 == kk && og[j - 1] < gp)) break;
-                ok[j] = ok[j - 1]; og[j] = og[j - 1]; oc[j] = oc[j - 1]; oi[j] = oi[j - 1];
+                ok[j] = ok[j - 1]; og[j] = og[j - 1]; oc[j] = oc[j - 1];
                 j--;
             }
-            ok[j] = km; og[j] = gp; oc[j] = ct; oi[j] = ix;
+            ok[j] = km; og[j] = gp; oc[j] = ct;
         }
         for (uint32_t i = lo; i < hi;) {
             uint32_t kk = ok[i] & SK_SEED_MASK, j = i + 1;
@@ -155,7 +153,6 @@ void index_impl(skder_sketches *s)
     s->pchunk.resize(ns + 1, st);
     s->boff.resize(boff_total + 1, st);
     s->chunk_start.resize(chunk_total + 1, st);
-    s->sidx.resize(ns + 1, st);
     if (G) {
         HIPCHECK(hipMemcpyAsync(s->d_meta.p, s->h_meta.data(), G * sizeof(GenomeMeta), hipMemcpyHostToDevice, st));
         HIPCHECK(hipMemcpyAsync(s->d_rec_goff.p, s->h_rec_goff.data(), s->h_rec_goff.size() * 4, hipMemcpyHostToDevice, st));
@@ -164,7 +161,7 @@ void index_impl(skder_sketches *s)
         for (uint32_t g = 0; g < G; g++) max_bits = s->h_meta[g].bucket_bits > max_bits ? s->h_meta[g].bucket_bits : max_bits;
         hipLaunchKernelGGL(index_genome_kernel, dim3(G), dim3(256), (1u << max_bits) * 4, st, s->d_meta.p,
                            s->d_rec_goff.p, s->seed_kmer.p, s->seed_gpos.p, s->seed_ctg.p, s->skmer.p, s->sgpos.p,
-                           s->sctg.p, s->boff.p, s->pchunk.p, s->chunk_start.p, s->sidx.p);
+                           s->sctg.p, s->boff.p, s->pchunk.p, s->chunk_start.p);
         HIPCHECK(hipEventRecord(ctx->ev[4], st));
         HIPCHECK(hipMemcpyAsync(s->h_meta.data(), s->d_meta.p, G * sizeof(GenomeMeta), hipMemcpyDeviceToHost, st));
         HIPCHECK(hipStreamSynchronize(st));
