@@ -135,40 +135,58 @@ __global__ __launch_bounds__(JOIN_THREADS) void join_probe_kernel(SetView A, Set
             const uint32_t *pk = QS.pkmer + Qm->seed_off;
             const uint32_t nq = Qm->n_seeds;
             uint32_t *hit = hits + pd.hit_base;
-            for (uint32_t s = tid; s < nq; s += JOIN_THREADS) {
-                const uint32_t kq = pk[s], kmer = kq & SK_SEED_MASK;
-                const uint32_t b = kmer_bucket(kmer, bits);
-                if (b < bb0 || b >= bb1) continue;          // this seed's bucket belongs to another pass
-                const uint32_t lo = s_boff[b - bb0], hi = s_boff[b - bb0 + 1];
-                uint32_t cnt = 0, first = 0;
-                for (uint32_t e = lo; e < hi; e++) {
-                    const uint32_t k2 = (fits ? s_rk[e] : rk[base + e]) & SK_SEED_MASK;
-                    if (k2 == kmer) { if (!cnt) first = e; cnt++; }
-                    else if (k2 > kmer) break;
+            // four independent seeds per thread and iteration: their loads and probes overlap
+            for (uint32_t s0 = tid; s0 < nq; s0 += 4 * JOIN_THREADS) {
+                uint32_t kqv[4], lov[4], hiv[4];
+                bool mine[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t s = s0 + u * JOIN_THREADS;
+                    kqv[u] = s < nq ? pk[s] : 0u;
                 }
-                uint32_t hv = HIT_NONE;
-                if (cnt && cnt <= rrep) {
-                    if (cnt == 1) {
-                        const uint32_t rkm = fits ? s_rk[first] : rk[base + first];
-                        hv = rg[base + first] | (((kq >> 31) != (rkm >> 31)) ? USED_BIT : 0u);
-                    } else if (cnt <= 4) {
-                        const uint32_t slot = atomicAdd(&pair_nmulti[p], 1u);
-                        if (slot < pd.multi_cap) {
-                            uint32_t v[4] = {HIT_NONE, HIT_NONE, HIT_NONE, HIT_NONE};
-                            for (uint32_t u = 0; u < cnt; u++) {
-                                const uint32_t rkm = fits ? s_rk[first + u] : rk[base + first + u];
-                                v[u] = rg[base + first + u] | (((kq >> 31) != (rkm >> 31)) ? USED_BIT : 0u);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t s = s0 + u * JOIN_THREADS;
+                    const uint32_t b = kmer_bucket(kqv[u] & SK_SEED_MASK, bits);
+                    mine[u] = s < nq && b >= bb0 && b < bb1;      // else: this seed's bucket belongs to another pass
+                    lov[u] = mine[u] ? s_boff[b - bb0] : 0u;
+                    hiv[u] = mine[u] ? s_boff[b - bb0 + 1] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (!mine[u]) continue;
+                    const uint32_t s = s0 + u * JOIN_THREADS;
+                    const uint32_t kq = kqv[u], kmer = kq & SK_SEED_MASK, lo = lov[u], hi = hiv[u];
+                    uint32_t cnt = 0, first = 0;
+                    for (uint32_t e = lo; e < hi; e++) {
+                        const uint32_t k2 = (fits ? s_rk[e] : rk[base + e]) & SK_SEED_MASK;
+                        if (k2 == kmer) { if (!cnt) first = e; cnt++; }
+                        else if (k2 > kmer) break;
+                    }
+                    uint32_t hv = HIT_NONE;
+                    if (cnt && cnt <= rrep) {
+                        if (cnt == 1) {
+                            const uint32_t rkm = fits ? s_rk[first] : rk[base + first];
+                            hv = rg[base + first] | (((kq >> 31) != (rkm >> 31)) ? USED_BIT : 0u);
+                        } else if (cnt <= 4) {
+                            const uint32_t slot = atomicAdd(&pair_nmulti[p], 1u);
+                            if (slot < pd.multi_cap) {
+                                uint32_t v[4] = {HIT_NONE, HIT_NONE, HIT_NONE, HIT_NONE};
+                                for (uint32_t w = 0; w < cnt; w++) {
+                                    const uint32_t rkm = fits ? s_rk[first + w] : rk[base + first + w];
+                                    v[w] = rg[base + first + w] | (((kq >> 31) != (rkm >> 31)) ? USED_BIT : 0u);
+                                }
+                                multi[pd.multi_base + slot] = make_uint4(v[0], v[1], v[2], v[3]);
+                                hv = HIT_MULTI | slot;
+                            } else {
+                                hv = HIT_MANY;
                             }
-                            multi[pd.multi_base + slot] = make_uint4(v[0], v[1], v[2], v[3]);
-                            hv = HIT_MULTI | slot;
                         } else {
                             hv = HIT_MANY;
                         }
-                    } else {
-                        hv = HIT_MANY;
                     }
+                    hit[s] = hv;
                 }
-                hit[s] = hv;
             }
         }
         bb0 = bb1;
