@@ -84,9 +84,9 @@ __device__ __forceinline__ uint32_t find_pair(const PairDesc *__restrict__ pairs
 // Genomes whose index does not fit in LDS are probed in several passes over bucket ranges.
 struct JoinGroup { uint32_t pair_begin, pair_end; };
 #define JOIN_THREADS 1024
-#define JOIN_BCAP 8200       // bucket offsets held in LDS per pass
+#define JOIN_BCAP 16400      // bucket offsets (16-bit, relative to the pass) held in LDS per pass
 #define JOIN_KCAP 30720      // k-mers held in LDS per pass
-#define JOIN_SMEM_BYTES ((JOIN_BCAP + JOIN_KCAP + 8) * 4)
+#define JOIN_SMEM_BYTES (JOIN_BCAP * 2 + (JOIN_KCAP + 8) * 4)
 
 __global__ __launch_bounds__(JOIN_THREADS) void join_probe_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs,
                                                                   const JoinGroup *__restrict__ groups,
@@ -94,9 +94,9 @@ __global__ __launch_bounds__(JOIN_THREADS) void join_probe_kernel(SetView A, Set
                                                                   uint32_t *__restrict__ pair_nmulti)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char join_smem[];
-    uint32_t *s_boff = reinterpret_cast<uint32_t *>(join_smem);   // JOIN_BCAP, relative to the pass's first seed
-    uint32_t *s_rk = s_boff + JOIN_BCAP;                           // JOIN_KCAP
+    uint32_t *s_rk = reinterpret_cast<uint32_t *>(join_smem);      // JOIN_KCAP
     uint32_t *s_ctl = s_rk + JOIN_KCAP;                            // [0] = end bucket of the pass
+    uint16_t *s_boff = reinterpret_cast<uint16_t *>(s_ctl + 8);    // JOIN_BCAP, relative to the pass's first seed (< 65536)
     const uint32_t tid = threadIdx.x;
     const JoinGroup g = groups[blockIdx.x];
     const PairDesc pd0 = pairs[g.pair_begin];
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(JOIN_THREADS) void join_probe_kernel(SetView A, Set
         const uint32_t bb1 = s_ctl[0];
         const uint32_t base = rb[bb0], nk = rb[bb1] - base;
         const bool fits = nk <= JOIN_KCAP;   // false only for one bucket with more than KCAP seeds
-        for (uint32_t i = tid; i <= bb1 - bb0; i += JOIN_THREADS) s_boff[i] = rb[bb0 + i] - base;
+        for (uint32_t i = tid; i <= bb1 - bb0; i += JOIN_THREADS) s_boff[i] = (uint16_t)(rb[bb0 + i] - base);
         if (fits)
             for (uint32_t i = tid; i < nk; i += JOIN_THREADS) s_rk[i] = rk[base + i];
         __syncthreads();

@@ -2,7 +2,7 @@
 #pragma once
 #include "common.h"
 
-#define IDX_MAX_BUCKET_BITS 14
+#define IDX_MAX_BUCKET_BITS 15
 #define IDX_REP_HIST ANI_REP_HIST
 
 // per-genome record on the device (index stage)

@@ -137,7 +137,7 @@ void index_impl(skder_sketches *s)
         m.rec_goff_off = rg;
         rg += m.n_rec + 1;
         uint32_t bits = 4;
-        while (bits < IDX_MAX_BUCKET_BITS && (1u << bits) * 4u < m.n_seeds) bits++;
+        while (bits < IDX_MAX_BUCKET_BITS && (1u << bits) * 2u < m.n_seeds) bits++;   // 1-2 seeds per bucket
         m.bucket_bits = bits;
         m.bucket_off = boff_total;
         boff_total += (1u << bits) + 1;
