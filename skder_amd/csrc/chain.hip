@@ -704,6 +704,179 @@ __global__ __launch_bounds__(256) void slow_chain_kernel(SetView A, SetView B, c
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// SLOW PATH, main form: one WAVEFRONT per declined chunk, everything in LDS.
+// The wave builds the chunk's ordered anchor list through the bucket index (64 seeds at a time, hits
+// in ascending gpos), runs the unabridged DP with the 64 lanes spread over the 50 look-back
+// candidates of one anchor (packed max-reduce: score first, nearest predecessor on ties), then extracts
+// chains best end first with back-tracking by lane 0.  Chunks with more than SLOWW_MAXA anchors are
+// passed on to the global-memory kernels above.
+#define SLOWW_MAXA 1024
+#define SLOWW_WAVES 2        // wavefronts (chunks) per workgroup
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t y = __shfl_xor(v, o, 64);
+        v = y > v ? y : v;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(64 * SLOWW_WAVES) void slow_wave_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs, uint32_t npairs,
+                                                                    const uint32_t *__restrict__ slow_list, uint32_t nslow,
+                                                                    ChainRec *__restrict__ chains, uint32_t *__restrict__ pair_nch,
+                                                                    uint32_t *__restrict__ pair_na, uint32_t *__restrict__ over_list,
+                                                                    uint32_t *__restrict__ over_count, uint32_t *__restrict__ flags)
+{
+    __shared__ uint32_t s_qi[SLOWW_WAVES][SLOWW_MAXA], s_qp[SLOWW_WAVES][SLOWW_MAXA], s_rr[SLOWW_WAVES][SLOWW_MAXA];
+    __shared__ uint32_t s_rc[SLOWW_WAVES][SLOWW_MAXA], s_bp[SLOWW_WAVES][SLOWW_MAXA];
+    __shared__ int32_t s_f[SLOWW_WAVES][SLOWW_MAXA];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t w = blockIdx.x * SLOWW_WAVES + wv;
+    if (w >= nslow) return;
+    uint32_t *qi = s_qi[wv], *qp = s_qp[wv], *ar = s_rr[wv], *ac = s_rc[wv], *bp = s_bp[wv];
+    int32_t *f = s_f[wv];
+    const uint32_t t = slow_list[w];
+    const uint32_t pi = find_pair(pairs, npairs, t);
+    const PairDesc pd = pairs[pi];
+    const SetView &QS = (pd.flags & 2u) ? B : A;
+    const SetView &RS = (pd.flags & 4u) ? B : A;
+    const GenomeMeta Q = QS.meta[pd.q], R = RS.meta[pd.r];
+    const uint32_t c = t - pd.chunk_base;
+    const uint32_t s0 = QS.chunk_start[Q.chunk_off + c], s1 = QS.chunk_start[Q.chunk_off + c + 1];
+    const uint32_t *qk = QS.pkmer + Q.seed_off, *qg = QS.pgpos + Q.seed_off;
+    const uint32_t *rk = RS.skmer + R.seed_off, *rg = RS.sgpos + R.seed_off, *rcg = RS.sctg + R.seed_off;
+    const uint32_t *rb = RS.boff + R.bucket_off;
+    const uint32_t *qsk = QS.skmer + Q.seed_off, *qb = QS.boff + Q.bucket_off;
+
+    // 1. ordered anchors
+    uint32_t n = 0;
+    bool over = false;
+    for (uint32_t sb = s0; sb < s1; sb += 64) {
+        const uint32_t s = sb + lane;
+        uint32_t cnt = 0, first = 0, km = 0;
+        if (s < s1) {
+            km = qk[s];
+            const uint32_t kmer = km & SK_SEED_MASK;
+            const uint32_t b = kmer_bucket(kmer, R.bucket_bits);
+            const uint32_t lo = rb[b], hi = rb[b + 1];
+            for (uint32_t e = lo; e < hi; e++) {
+                const uint32_t k2 = rk[e] & SK_SEED_MASK;
+                if (k2 == kmer) { if (!cnt) first = e; cnt++; }
+                else if (k2 > kmer) break;
+            }
+            if (cnt > R.rep_cut) cnt = 0;
+            if (cnt && Q.rep_cut != 0xFFFFFFFFu) {   // multiplicity inside the chunked genome itself
+                const uint32_t b2 = kmer_bucket(kmer, Q.bucket_bits);
+                uint32_t m2 = 0;
+                for (uint32_t e = qb[b2]; e < qb[b2 + 1]; e++) m2 += ((qsk[e] & SK_SEED_MASK) == kmer);
+                if (m2 > Q.rep_cut) cnt = 0;
+            }
+        }
+        uint32_t total;
+        const uint32_t at = n + wave_excl_scan(cnt, total);
+        if (n + total > SLOWW_MAXA) { over = true; break; }     // wave-uniform
+        for (uint32_t u = 0; u < cnt; u++) {
+            const uint32_t idx = at + u, rkm = rk[first + u];
+            qi[idx] = s; qp[idx] = qg[s];
+            ar[idx] = rg[first + u] | (((km >> 31) != (rkm >> 31)) ? USED_BIT : 0u);
+            ac[idx] = rcg[first + u];
+        }
+        n += total;
+    }
+    if (over) {   // too many anchors for LDS: hand the chunk to the global-memory kernels
+        if (lane == 0) over_list[atomicAdd(over_count, 1u)] = t;
+        return;
+    }
+    if (!n) return;
+    if (lane == 0) atomicAdd(&pair_na[pi], n);
+    __builtin_amdgcn_wave_barrier();
+
+    // 2. banded chaining: lane l examines predecessor i-1-l of anchor i
+    for (uint32_t i = 0; i < n; i++) {
+        const int32_t qpi = (int32_t)qp[i];
+        const uint32_t rr = ar[i], rc = ac[i];
+        const int32_t rp = (int32_t)(rr & 0x7FFFFFFFu);
+        const uint32_t rev = rr >> 31;
+        uint32_t key = 0;     // (score << 6) | (63 - lane): the maximum is the best score, nearest on ties
+        if (lane < i && lane < ANI_BAND) {
+            const uint32_t j = i - 1 - lane;
+            const int32_t dq = qpi - (int32_t)qp[j];
+            const uint32_t rj = ar[j];
+            if (dq <= ANI_BP_BAND && ac[j] == rc && (rj >> 31) == rev) {
+                const int32_t rpj = (int32_t)(rj & 0x7FFFFFFFu);
+                const int32_t dr = rev ? rpj - rp : rp - rpj;
+                if (dq > 0 && dr > 0 && dq <= ANI_MAX_LIN && dr <= ANI_MAX_LIN) {
+                    const int32_t gap = dq > dr ? dq - dr : dr - dq;
+                    if (gap <= ANI_MAX_GAP) {
+                        const int32_t sc = f[j] + ANI_ANCHOR_SCORE - gap;
+                        if (sc > ANI_ANCHOR_SCORE) key = ((uint32_t)sc << 6) | (63u - lane);
+                    }
+                }
+            }
+        }
+        key = wave_max_u32(key);
+        if (lane == 0) {
+            if (key) { f[i] = (int32_t)(key >> 6); bp[i] = i - (63u - (key & 63u)); }   // bp = predecessor index + 1
+            else { f[i] = ANI_ANCHOR_SCORE; bp[i] = 0; }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // 3. chains: best end first (ties: lowest index); back-track until the start or a used anchor
+    for (;;) {
+        uint32_t key = 0;     // (score << 10) | (1023 - index)
+        for (uint32_t i = lane; i < n; i += 64) {
+            const int32_t v = f[i];
+            if (v > ANI_ANCHOR_SCORE) {
+                const uint32_t k2 = ((uint32_t)v << 10) | (1023u - i);
+                key = k2 > key ? k2 : key;
+            }
+        }
+        key = wave_max_u32(key);
+        if (!key) break;
+        const uint32_t besti = 1023u - (key & 1023u);
+        const int32_t bestv = (int32_t)(key >> 10);
+        if (lane == 0) {
+            uint32_t cnt = 0, rmin = 0xFFFFFFFFu, rmax = 0;
+            int32_t cur = (int32_t)besti, first = (int32_t)besti;
+            while (cur >= 0) {
+                const uint32_t b = bp[cur];
+                if (b & USED_BIT) break;
+                cnt++;
+                first = cur;
+                const uint32_t rp = ar[cur] & 0x7FFFFFFFu;
+                rmin = rp < rmin ? rp : rmin;
+                rmax = rp > rmax ? rp : rmax;
+                cur = (int32_t)(b & 0x7FFFFFFFu) - 1;
+            }
+            if (cnt < ANI_MIN_ANCHORS) {
+                f[besti] = (int32_t)0x80000000;
+            } else {
+                cur = (int32_t)besti;
+                while (cur >= 0) {
+                    const uint32_t b = bp[cur];
+                    if (b & USED_BIT) break;
+                    bp[cur] = b | USED_BIT;
+                    f[cur] = (int32_t)0x80000000;
+                    cur = (int32_t)(b & 0x7FFFFFFFu) - 1;
+                }
+                const uint32_t slot = atomicAdd(&pair_nch[pi], 1u);
+                if (slot < pd.c_cap) {
+                    ChainRec cr;
+                    cr.score = bestv; cr.n = cnt; cr.n_seeds = qi[besti] - qi[first] + 1;
+                    cr.q0 = qp[first]; cr.q1 = qp[besti]; cr.r0 = rmin; cr.r1 = rmax; cr.rctg = ac[besti];
+                    chains[pd.c_base + slot] = cr;
+                } else {
+                    atomicOr(&flags[0], 8u);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // round(2^32 * (num/den)^(1/15)): Newton on doubles, + - * / only (oracle_root_fx)
 __device__ __forceinline__ uint32_t root_fx(uint32_t num, uint32_t den)
 {
@@ -904,7 +1077,7 @@ static bool chunk_the_query(const GenomeMeta &ref, const GenomeMeta &query)
 struct ChainWork {
     DevBuf<PairDesc> d_pairs;
     DevBuf<uint32_t> chunk_state, slow_list, counters, pair_na, pair_nch, cap, abase, slow_n, a_qi, a_r, a_rctg, BP;
-    DevBuf<uint32_t> hits, pair_nmulti, groups;
+    DevBuf<uint32_t> hits, pair_nmulti, groups, over_list;
     std::vector<JoinGroup> h_groups;
     DevBuf<uint4> multi;
     DevBuf<int32_t> F;
@@ -940,7 +1113,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
     std::vector<PairOut> ho;
     const SetView VA = view_of(SA), VB = view_of(SB);
     double t_fast = 0, t_slow = 0, t_fin = 0, t_join = 0;
-    uint64_t tot_anchors = 0, tot_slow = 0, tot_chunks = 0;
+    uint64_t tot_anchors = 0, tot_slow = 0, tot_chunks = 0, tot_over = 0;
     // orientation of every pair, then order the work by the probed genome (R): consecutive
     // workgroups probe the same hash table, which keeps it in the XCD's L2
     const auto t_host0 = std::chrono::steady_clock::now();
@@ -1043,20 +1216,31 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
             fprintf(stderr, "[skder_amd] batch: %u pairs %llu chunks, slow %u (none %u, slots %u, hits %u, ring %u, branch %u, score %u, qrep %u, inside %u)\n",
                     nb, (unsigned long long)nchunks, nslow, hcnt[1], hcnt[2], hcnt[3], hcnt[4], hcnt[5], hcnt[6], hcnt[7], hcnt[8]);
         if (nslow) {
-            W.cap.resize(nslow + 1, st); W.abase.resize(nslow + 1, st); W.slow_n.resize(nslow + 1, st);
-            hipLaunchKernelGGL(slow_caps_kernel, dim3((nslow + 256) / 256), dim3(256), 0, st, VA, VB, W.d_pairs.p, nb, W.slow_list.p,
-                               nslow, W.cap.p);
-            exclusive_scan_u32(W.cap.p, W.abase.p, nslow + 1, W.ws, st);
-            uint32_t atotal = 0;
-            HIPCHECK(hipMemcpyAsync(&atotal, W.abase.p + nslow, 4, hipMemcpyDeviceToHost, st));
+            // declined chunks: one wavefront each, in LDS; the rare chunk with more than 1024 anchors is
+            // handed on to the global-memory kernels
+            W.over_list.resize(nslow + 1, st);
+            hipLaunchKernelGGL(slow_wave_kernel, dim3((nslow + SLOWW_WAVES - 1) / SLOWW_WAVES), dim3(64 * SLOWW_WAVES), 0, st, VA, VB, W.d_pairs.p,
+                               nb, W.slow_list.p, nslow, W.chains.p, W.pair_nch.p, W.pair_na.p, W.over_list.p, W.counters.p + 15, ctx->d_flags);
+            uint32_t nover = 0;
+            HIPCHECK(hipMemcpyAsync(&nover, W.counters.p + 15, 4, hipMemcpyDeviceToHost, st));
             HIPCHECK(hipStreamSynchronize(st));
-            W.a_qi.resize(atotal + 1, st); W.a_r.resize(atotal + 1, st); W.a_rctg.resize(atotal + 1, st);
-            W.F.resize(atotal + 1, st); W.BP.resize(atotal + 1, st);
-            hipLaunchKernelGGL(slow_anchors_kernel, dim3((nslow + 3) / 4), dim3(256), 0, st, VA, VB, W.d_pairs.p, nb, W.slow_list.p, nslow,
-                               W.abase.p, W.a_qi.p, W.a_r.p, W.a_rctg.p, W.slow_n.p, ctx->d_flags);
-            hipLaunchKernelGGL(slow_chain_kernel, dim3((nslow + 255) / 256), dim3(256), 0, st, VA, VB, W.d_pairs.p, nb, W.slow_list.p, nslow,
-                               W.abase.p, W.slow_n.p, W.a_qi.p, W.a_r.p, W.a_rctg.p, W.F.p, W.BP.p, W.chains.p, W.pair_nch.p,
-                               W.pair_na.p, ctx->d_flags);
+            if (nover) {
+                W.cap.resize(nover + 1, st); W.abase.resize(nover + 1, st); W.slow_n.resize(nover + 1, st);
+                hipLaunchKernelGGL(slow_caps_kernel, dim3((nover + 256) / 256), dim3(256), 0, st, VA, VB, W.d_pairs.p, nb, W.over_list.p,
+                                   nover, W.cap.p);
+                exclusive_scan_u32(W.cap.p, W.abase.p, nover + 1, W.ws, st);
+                uint32_t atotal = 0;
+                HIPCHECK(hipMemcpyAsync(&atotal, W.abase.p + nover, 4, hipMemcpyDeviceToHost, st));
+                HIPCHECK(hipStreamSynchronize(st));
+                W.a_qi.resize(atotal + 1, st); W.a_r.resize(atotal + 1, st); W.a_rctg.resize(atotal + 1, st);
+                W.F.resize(atotal + 1, st); W.BP.resize(atotal + 1, st);
+                hipLaunchKernelGGL(slow_anchors_kernel, dim3((nover + 3) / 4), dim3(256), 0, st, VA, VB, W.d_pairs.p, nb, W.over_list.p, nover,
+                                   W.abase.p, W.a_qi.p, W.a_r.p, W.a_rctg.p, W.slow_n.p, ctx->d_flags);
+                hipLaunchKernelGGL(slow_chain_kernel, dim3((nover + 255) / 256), dim3(256), 0, st, VA, VB, W.d_pairs.p, nb, W.over_list.p, nover,
+                                   W.abase.p, W.slow_n.p, W.a_qi.p, W.a_r.p, W.a_rctg.p, W.F.p, W.BP.p, W.chains.p, W.pair_nch.p,
+                                   W.pair_na.p, ctx->d_flags);
+            }
+            tot_over += nover;
         }
         HIPCHECK(hipEventRecord(ctx->ev[7], st));
         // LDS capacity of the finalize step: the most chains any pair of the batch can plausibly have
@@ -1101,7 +1285,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
     }
     ctx->timing[3] = t_fast; ctx->timing[4] = t_slow; ctx->timing[5] = t_fin;
     ctx->timing[6] = (double)np; ctx->timing[7] = (double)tot_anchors;
-    ctx->counters[0] = tot_chunks; ctx->counters[1] = tot_slow;
+    ctx->counters[0] = tot_chunks; ctx->counters[1] = tot_slow; ctx->counters[3] = tot_over;
     ctx->timing_join = t_join;
 }
 
