@@ -93,20 +93,28 @@ def main():
     total_bases = sum(l.total_bases for l, _ in batches)
     torch.cuda.synchronize()
 
+    wall = {"sketch": 0.0, "exchange": 0.0, "index": 0.0, "triangle": 0.0}
+
     def step():
         tm = np.zeros(8)
+        t0 = time.perf_counter()
         sk = engine.Sketches(ctx)
         for layout, d in batches:
             sk.sketch_batch(d.data_ptr(), layout)
             t = ctx.timing()
             tm[0] += t[0]; tm[1] += t[1]
+        t1 = time.perf_counter()
         if world > 1:
             raw = multigpu.exchange_raw(multigpu.raw_from_sketches(sk), staging="cpu" if backend != "nccl" else None)
             sk.close()
             sk = multigpu.sketches_from_raw(ctx, raw)
+        t2 = time.perf_counter()
         sk.index()
         tm[1] += ctx.timing()[1] - (0 if world > 1 else 0)
+        t3 = time.perf_counter()
         edges = sk.triangle_rows(rank, world, args.screen)
+        t4 = time.perf_counter()
+        wall["sketch"] += t1 - t0; wall["exchange"] += t2 - t1; wall["index"] += t3 - t2; wall["triangle"] += t4 - t3
         t = ctx.timing()
         tm[2:] = t[2:]
         step.counters = ctx.counters()
@@ -182,6 +190,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": dbytes,
                          "kernel_ms": {k: float(v[0]) for k, v in cand.items()},
+                         "host_wall_ms": {k: 1e3 * v / (args.steps + args.warmup) for k, v in wall.items()},
                          "other_ms": {"sketch_post": float(tm[1]), "screen": float(tm[2]), "chain_slow_path": float(tm[4]),
                                       "finalize": float(tm[5])}},
         }

@@ -289,12 +289,43 @@ __global__ __launch_bounds__(256) void marker_compact_kernel(const uint64_t *__r
 // ---------------------------------------------------------------------------------------------
 // host side
 
-static void build_tiles(const skder_batch_t *b, std::vector<TileDesc> &tiles, std::vector<uint32_t> &genome_tile_begin,
-                        std::vector<uint32_t> &rec_goff /* per genome nrec+1 */, std::vector<uint64_t> &genome_len)
+// per-record table (host-built, small) from which the tile descriptors are expanded on the device
+struct RecDesc {
+    uint64_t base_off;    // offset of the record in d_bases
+    uint32_t len, genome, ctg, gpos0;
+    uint32_t tile_base;   // index of the record's first tile
+    uint32_t pad;
+};
+
+__global__ __launch_bounds__(256) void make_tiles_kernel(const RecDesc *__restrict__ recs, uint32_t nrec, uint32_t ntiles,
+                                                         TileDesc *__restrict__ tiles)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= ntiles) return;
+    uint32_t lo = 0, hi = nrec;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (recs[mid].tile_base <= t) lo = mid; else hi = mid;
+    }
+    const RecDesc r = recs[lo];
+    const uint32_t p = (t - r.tile_base) * SKDER_TILE;
+    TileDesc d;
+    d.base_off = r.base_off + p;
+    d.genome = r.genome; d.ctg = r.ctg; d.pos0 = p;
+    d.npos = r.len - p < SKDER_TILE ? r.len - p : SKDER_TILE;
+    d.gpos0 = r.gpos0 + p;
+    d.pad = 0;
+    tiles[t] = d;
+}
+
+static uint32_t build_records(const skder_batch_t *b, std::vector<RecDesc> &recs, std::vector<uint32_t> &genome_tile_begin,
+                              std::vector<uint32_t> &rec_goff /* per genome nrec+1 */, std::vector<uint64_t> &genome_len)
 {
     genome_tile_begin.assign(b->n_genomes + 1, 0);
+    recs.reserve(b->n_records);
+    uint64_t nt = 0;
     for (uint32_t g = 0; g < b->n_genomes; g++) {
-        genome_tile_begin[g] = (uint32_t)tiles.size();
+        genome_tile_begin[g] = (uint32_t)nt;
         uint32_t gpos = 0;
         uint32_t r0 = b->genome_rec_begin[g], r1 = b->genome_rec_begin[g + 1];
         for (uint32_t r = r0; r < r1; r++) {
@@ -302,23 +333,19 @@ static void build_tiles(const skder_batch_t *b, std::vector<TileDesc> &tiles, st
             if (b->rec_off[r] % 32) throw SkError("record offsets must be multiples of 32");
             if ((uint64_t)gpos + len >= 0x7F000000ull) throw SkError("genome longer than 2.1e9 bases");
             rec_goff.push_back(gpos);
-            for (uint32_t p = 0; p < len; p += SKDER_TILE) {
-                TileDesc t;
-                t.base_off = b->rec_off[r] + p;
-                t.genome = g;
-                t.ctg = r - r0;
-                t.pos0 = p;
-                t.npos = len - p < SKDER_TILE ? len - p : SKDER_TILE;
-                t.gpos0 = gpos + p;
-                t.pad = 0;
-                tiles.push_back(t);
-            }
+            RecDesc d;
+            d.base_off = b->rec_off[r]; d.len = len; d.genome = g; d.ctg = r - r0; d.gpos0 = gpos;
+            d.tile_base = (uint32_t)nt; d.pad = 0;
+            recs.push_back(d);
+            nt += (len + SKDER_TILE - 1) / SKDER_TILE;
+            if (nt >= 0xFFFF0000ull) throw SkError("too many tiles in one batch");
             gpos += len;
         }
         rec_goff.push_back(gpos);
         genome_len.push_back(gpos);
     }
-    genome_tile_begin[b->n_genomes] = (uint32_t)tiles.size();
+    genome_tile_begin[b->n_genomes] = (uint32_t)nt;
+    return (uint32_t)nt;
 }
 
 void sketch_batch_impl(skder_sketches *s, const uint8_t *d_bases, const skder_batch_t *b)
@@ -327,17 +354,20 @@ void sketch_batch_impl(skder_sketches *s, const uint8_t *d_bases, const skder_ba
     hipStream_t st = ctx->stream;
     if (s->indexed) throw SkError("sketch set already indexed; cannot append");
     if (b->n_genomes == 0) return;
-    std::vector<TileDesc> tiles;
+    std::vector<RecDesc> recs;
     std::vector<uint32_t> gtb, rec_goff;
     std::vector<uint64_t> glen;
-    build_tiles(b, tiles, gtb, rec_goff, glen);
-    const uint32_t nt = (uint32_t)tiles.size();
+    const uint32_t nt = build_records(b, recs, gtb, rec_goff, glen);
 
     DevBuf<TileDesc> d_tiles;
+    DevBuf<RecDesc> d_recs;
     DevBuf<uint32_t> slot_kmer, slot_gpos, tile_ns, tile_nm, tile_soff, tile_moff;
     DevBuf<uint64_t> slot_mark;
     d_tiles.resize(nt, st);
-    HIPCHECK(hipMemcpyAsync(d_tiles.p, tiles.data(), nt * sizeof(TileDesc), hipMemcpyHostToDevice, st));
+    d_recs.resize(recs.size(), st);
+    HIPCHECK(hipMemcpyAsync(d_recs.p, recs.data(), recs.size() * sizeof(RecDesc), hipMemcpyHostToDevice, st));
+    if (nt)
+        hipLaunchKernelGGL(make_tiles_kernel, dim3((nt + 255) / 256), dim3(256), 0, st, d_recs.p, (uint32_t)recs.size(), nt, d_tiles.p);
     slot_kmer.resize((size_t)nt * SK_SLOT_SEEDS, st);
     slot_gpos.resize((size_t)nt * SK_SLOT_SEEDS, st);
     slot_mark.resize((size_t)nt * SK_SLOT_MARKS, st);
