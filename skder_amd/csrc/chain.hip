@@ -58,6 +58,7 @@ struct PairOut {
 
 #define USED_BIT 0x80000000u
 #define FIN_LDS_CHAINS 2048
+#define FIN_BINS 1024
 #define FAST_SLOTS 3
 #define RING 4
 #define CHUNK_SLOW 0xFFFFFFFFu
@@ -947,6 +948,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(SetView A, SetView B, con
     uint32_t *q0 = reinterpret_cast<uint32_t *>(fin_smem) + lds_cap, *q1 = q0 + lds_cap, *r0 = q1 + lds_cap, *r1 = r0 + lds_cap;
     uint32_t *rc = r1 + lds_cap, *na = rc + lds_cap, *nsd = na + lds_cap;
     uint8_t *state = reinterpret_cast<uint8_t *>(nsd + lds_cap);   // 0 unknown, 1 kept, 2 dropped
+    uint16_t *order = reinterpret_cast<uint16_t *>(state + lds_cap);  // chain indices grouped by bin
     __shared__ unsigned long long s_fx, s_seeds, s_anch, s_span;
     __shared__ uint32_t s_kept, s_unknown, s_n;
 
@@ -982,6 +984,47 @@ __global__ __launch_bounds__(256) void finalize_kernel(SetView A, SetView B, con
         n = lds_cap;
     }
     __syncthreads();
+    // Spatial binning on the other genome so that a chain is compared only with chains that can
+    // overlap it: bins of width 2^shift >= the longest chain, chains filed under the bin of r0; a chain
+    // in bin b can only overlap chains of bins b-1, b, b+1.  (Exact for any input: a very long chain
+    // just makes the bins wide.)
+    __shared__ uint32_t s_maxlen, s_maxr;
+    __shared__ uint32_t bin_start[FIN_BINS + 2], bin_fill[FIN_BINS + 1];
+    __shared__ uint32_t wsum[4];
+    if (tid == 0) { s_maxlen = 0; s_maxr = 0; }
+    for (uint32_t b = tid; b <= FIN_BINS; b += 256) bin_fill[b] = 0;
+    __syncthreads();
+    {
+        uint32_t ml = 0, mr = 0;
+        for (uint32_t i = tid; i < n; i += 256) { ml = max(ml, r1[i] - r0[i]); mr = max(mr, r1[i]); }
+        if (ml) atomicMax(&s_maxlen, ml);
+        if (mr) atomicMax(&s_maxr, mr);
+    }
+    __syncthreads();
+    uint32_t shift = 1;
+    while ((1u << shift) <= s_maxlen) shift++;
+    while ((s_maxr >> shift) >= FIN_BINS) shift++;
+    for (uint32_t i = tid; i < n; i += 256) atomicAdd(&bin_fill[r0[i] >> shift], 1u);
+    __syncthreads();
+    {
+        uint32_t running = 0;
+        for (uint32_t base = 0; base < FIN_BINS; base += 256) {
+            const uint32_t v = bin_fill[base + tid];
+            uint32_t total;
+            const uint32_t ex = block_excl_scan_256(v, wsum, total);
+            bin_start[base + tid] = running + ex;
+            running += total;
+        }
+        if (tid == 0) { bin_start[FIN_BINS] = n; bin_start[FIN_BINS + 1] = n; }
+    }
+    __syncthreads();
+    for (uint32_t b = tid; b <= FIN_BINS; b += 256) bin_fill[b] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += 256) {
+        const uint32_t b = r0[i] >> shift;
+        order[bin_start[b] + atomicAdd(&bin_fill[b], 1u)] = (uint16_t)i;
+    }
+    __syncthreads();
     // a chain is dropped when ONE better kept chain on the same record covers more than half of
     // its span on the other genome.  Chains without any better overlapping chain are kept at once;
     // the rest resolve in rounds, each chain waiting for its better overlapping chains.
@@ -991,7 +1034,10 @@ __global__ __launch_bounds__(256) void finalize_kernel(SetView A, SetView B, con
             if (state[i]) continue;
             const uint32_t li = r1[i] - r0[i];
             bool dropped = false, pending = false;
-            for (uint32_t j = 0; j < n; j++) {
+            const uint32_t b = r0[i] >> shift;
+            const uint32_t k0 = bin_start[b ? b - 1 : 0], k1 = bin_start[b + 2 <= FIN_BINS ? b + 2 : FIN_BINS];
+            for (uint32_t k = k0; k < k1; k++) {
+                const uint32_t j = order[k];
                 if (rc[j] != rc[i] || j == i) continue;
                 const uint32_t lo = r0[i] > r0[j] ? r0[i] : r0[j];
                 const uint32_t hi = r1[i] < r1[j] ? r1[i] : r1[j];
@@ -1025,7 +1071,14 @@ __global__ __launch_bounds__(256) void finalize_kernel(SetView A, SetView B, con
         sp += q1[i] - q0[i];
         kept++;
     }
-    if (kept) {
+    // wave-level reduction first: 4 LDS atomics per sum and workgroup instead of 256
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        fx += __shfl_down(fx, o, 64); sd += __shfl_down(sd, o, 64);
+        an += __shfl_down(an, o, 64); sp += __shfl_down(sp, o, 64);
+        kept += __shfl_down(kept, o, 64);
+    }
+    if ((tid & 63u) == 0 && kept) {
         atomicAdd(&s_fx, fx); atomicAdd(&s_seeds, sd); atomicAdd(&s_anch, an); atomicAdd(&s_span, sp);
         atomicAdd(&s_kept, kept);
     }
@@ -1249,7 +1302,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         for (const PairDesc &d : hp) max_chunks = d.n_chunks > max_chunks ? d.n_chunks : max_chunks;
         uint32_t lds_cap = 512;
         while (lds_cap < FAST_SLOTS * max_chunks / 2 + 128 && lds_cap < 4096) lds_cap <<= 1;
-        hipLaunchKernelGGL(finalize_kernel, dim3(nb), dim3(256), lds_cap * 33u, st, VA, VB, W.d_pairs.p, W.fast_chains.p, W.chunk_state.p,
+        hipLaunchKernelGGL(finalize_kernel, dim3(nb), dim3(256), lds_cap * 35u, st, VA, VB, W.d_pairs.p, W.fast_chains.p, W.chunk_state.p,
                            W.chains.p, W.pair_nch.p, W.pair_na.p, W.d_out.p, ctx->d_flags, W.root_lut.p, lds_cap);
         HIPCHECK(hipEventRecord(ctx->ev[8], st));
         ho.resize(nb);
