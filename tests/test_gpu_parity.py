@@ -299,3 +299,126 @@ def test_driver_end_to_end_listings(gpu, tmp_path):
     assert 0 < len(reps_d) <= len(reps_g)                          # dynamic is the more concise mode (README)
     assert 0 < len(reps_l) <= len(genomes) and os.path.isfile(tmp_path / "l" / "Skani_Dist_Output.txt")
     assert set(reps_l) <= set(genomes)
+
+
+def _custom_recipe(lens_species, per_species, seed=11):
+    """a small recipe with explicit species lengths (mixed genome sizes)"""
+    from skder_amd import synth
+    base = synth.make_recipe(len(lens_species) * per_species, genome_len=100000, n_species=len(lens_species),
+                             strains_per_species=2, seed=seed)
+    rng = np.random.RandomState(seed)
+    rec_lens = []
+    for g in range(base.n):
+        L = int(lens_species[g // per_species])
+        cuts = np.sort(rng.choice(np.arange(2000, L - 2000), size=rng.randint(0, 12), replace=False)) if L > 8000 else np.array([], int)
+        edges = np.concatenate([[0], cuts, [L]])
+        lens = np.diff(edges)
+        lens = lens[lens > 0]
+        # merge records that would fall below 1000 bp into their neighbour
+        out = []
+        for l in lens:
+            if out and (l < 1000 or out[-1] < 1000):
+                out[-1] += l
+            else:
+                out.append(l)
+        rec_lens.append(np.array(out, np.uint32))
+    base.rec_lens = rec_lens
+    return base
+
+
+def test_mixed_genome_sizes_multi_pass_join(gpu, oracle):
+    """1 / 4.5 / 8 Mb genomes in one set: different bucket counts, several LDS passes in the join
+    (an 8 Mb genome has ~64k seeds), > 400 chunks per pair; still bit-equal with the oracle"""
+    engine, ctx, torch = gpu
+    from skder_amd import synth
+    p = oracle.default_params()
+    rec = _custom_recipe([1_000_000, 4_500_000, 8_000_000], 3)
+    layout = engine.BatchLayout(rec.rec_lens)
+    d = torch.zeros(layout.total_bytes, dtype=torch.uint8, device="cuda")
+    ctx.synth_fill(d.data_ptr(), layout, rec.lineage, rec.params)
+    s = engine.Sketches(ctx)
+    s.sketch_batch(d.data_ptr(), layout)
+    og = [oracle.Genome.from_bases(synth.bases_numpy(rec, g), rec.rec_lens[g], p) for g in range(rec.n)]
+    assert max(o.n_seeds for o in og) > 60000
+    _compare_sketch(engine, s, oracle, og)
+    edges = s.triangle_rows(0, 1, 80.0)
+    want = _oracle_edges(oracle, og, p, 80.0)
+    assert len(want) == 9
+    _check_edges(edges, want)
+    # rectangle (dist/search shape): the three big genomes as queries against everything
+    q = engine.Sketches(ctx)
+    big = [g for g in range(rec.n) if rec.total_len(g) > 6_000_000]
+    lq = engine.BatchLayout([rec.rec_lens[g] for g in big])
+    dq = torch.zeros(lq.total_bytes, dtype=torch.uint8, device="cuda")
+    ctx.synth_fill(dq.data_ptr(), lq, rec.lineage[big], rec.params[big])
+    q.sketch_batch(dq.data_ptr(), lq)
+    rect = s.rectangle(q, 80.0)
+    got = {(int(e["ref"]), int(e["query"])): e for e in rect}
+    for r in range(rec.n):
+        for qi, g in enumerate(big):
+            ok, _ = oracle.screen(og[r], og[g], 80.0, p)
+            pr = oracle.pair(og[r], og[g], p) if ok else None
+            if pr is not None and pr.n_chains and pr.ani > 0:
+                e = got[(r, qi)]
+                assert int(e["ani_fx_sum"]) == pr.ani_fx_sum and float(e["ani"]) == pr.ani
+                assert float(e["af_ref"]) == pr.af_ref and float(e["af_query"]) == pr.af_query
+            else:
+                assert (r, qi) not in got
+    # a genome against itself: every seed anchors, ANI prints as 100.00
+    self_hits = [e for e in rect if int(e["ref"]) == big[int(e["query"])]]
+    assert len(self_hits) == len(big) and all(abs(float(e["ani"]) - 1.0) < 1e-6 and float(e["af_ref"]) > 0.99 for e in self_hits)
+
+
+def test_degenerate_inputs(gpu, oracle, tmp_path):
+    """a genome whose records are all shorter than 500 bp (no seeds), a one-genome listing (header-only
+    table), identical genomes, a missing file (error, no output), search with a query outside the database"""
+    import ctypes as C
+    import skder_amd
+    from skder_amd import _lib
+    rng = np.random.RandomState(3)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+
+    def fasta(path, recs):
+        with open(path, "wb") as f:
+            for i, r in enumerate(recs):
+                f.write((">rec%d some description\n" % i).encode() + r.tobytes() + b"\n")
+
+    g = alpha[rng.randint(0, 4, 120000)]
+    mut = g.copy()
+    idx = rng.choice(len(g), 1200, replace=False)
+    mut[idx] = alpha[(np.searchsorted(alpha, mut[idx]) + 1 + rng.randint(0, 3, len(idx))) % 4]
+    fasta(tmp_path / "a.fna", [g[:70000], g[70000:]])
+    fasta(tmp_path / "a_copy.fna", [g[:70000], g[70000:]])
+    fasta(tmp_path / "b.fna", [mut])
+    fasta(tmp_path / "tiny.fna", [g[:300], g[300:799]])                  # nothing >= 500 bp
+    listing = tmp_path / "l.txt"
+    names = ["a.fna", "a_copy.fna", "b.fna", "tiny.fna"]
+    listing.write_text("".join(str(tmp_path / n) + "\n" for n in names))
+    out, ref = tmp_path / "o.tsv", tmp_path / "o_oracle.tsv"
+    skder_amd.runSkaniTriangle(str(listing), str(out), "-s 80", 15.0, "greedy", False, None)
+    oracle.triangle(str(listing), 15.0, 80.0, 2, str(ref), oracle.default_params())
+    assert out.read_text() == ref.read_text()
+    hdr, rows = load_table(str(out))
+    assert len(rows) == 3 and not any("tiny" in r[0] or "tiny" in r[1] for r in rows)
+    ident = [r for r in rows if "a.fna" in r[0] and "a_copy" in r[1]][0]
+    assert ident[2] == "100.00" and float(ident[3]) > 99.5 and ident[3] == ident[4]
+    one = tmp_path / "one.txt"
+    one.write_text(str(tmp_path / "a.fna") + "\n")
+    skder_amd.runSkaniTriangle(str(one), str(tmp_path / "one.tsv"), "", 15.0, "greedy", False, None)
+    assert (tmp_path / "one.tsv").read_text().count("\n") == 1            # header only
+    bad = tmp_path / "bad.txt"
+    bad.write_text(str(tmp_path / "a.fna") + "\n" + str(tmp_path / "missing.fna") + "\n")
+    with pytest.raises(RuntimeError, match="missing.fna"):
+        skder_amd.runSkaniTriangle(str(bad), str(tmp_path / "bad.tsv"), "", 15.0, "greedy", False, None)
+    assert not (tmp_path / "bad.tsv").exists()
+    err = C.create_string_buffer(2048)
+    db = _lib.lib().skder_amd_sketch(str(listing).encode(), 0, err, 2048)
+    assert db, err.value
+    try:
+        fasta(tmp_path / "outside.fna", [mut[:90000]])
+        so, sr = tmp_path / "s.tsv", tmp_path / "s_oracle.tsv"
+        assert _lib.lib().skder_amd_search(db, str(tmp_path / "outside.fna").encode(), 15.0, 80.0, str(so).encode(), err, 2048) == 0, err.value
+        oracle.search(str(listing), str(tmp_path / "outside.fna"), 15.0, 80.0, 2, str(sr), oracle.default_params())
+        assert so.read_text() == sr.read_text() and so.read_text().count("\n") == 4
+    finally:
+        _lib.lib().skder_amd_db_free(db)
