@@ -424,13 +424,19 @@ typedef struct {
 } anchor_t;
 
 /* Which genome is cut into chunks?  The one with the smaller T * (T / n_contigs) (shorter and
- * more fragmented); ties chunk the `query` argument.  Returns 1 to chunk `query`. */
+ * more fragmented); ties: fewer seeds, then fewer markers, then the `query` argument.
+ * Returns 1 to chunk `query`. */
 static int chunk_query(const oracle_genome_t *ref, const oracle_genome_t *query)
 {
     double tq = (double)query->total_len, tr = (double)ref->total_len;
     double sq = tq * (tq / (double)(query->n_contigs ? query->n_contigs : 1));
     double sr = tr * (tr / (double)(ref->n_contigs ? ref->n_contigs : 1));
-    return sq <= sr;
+    if (sq != sr) return sq < sr;
+    /* equal scores: decide by content, not by argument order, so that swapping Ref and Query only
+     * swaps the two AF columns */
+    if (query->n_seeds != ref->n_seeds) return query->n_seeds < ref->n_seeds;
+    if (query->n_markers != ref->n_markers) return query->n_markers < ref->n_markers;
+    return 1;
 }
 
 static uint32_t lower_bound_kmer(const oracle_genome_t *g, uint64_t kmer)

@@ -1117,13 +1117,17 @@ static SetView view_of(skder_sketches *s)
     return v;
 }
 
-// which genome is chunked: smaller T*(T/n_records); ties chunk the query (ani_oracle.c chunk_query)
+// which genome is chunked: smaller T*(T/n_records); ties: fewer seeds, fewer markers, then the query
+// (ani_oracle.c chunk_query)
 static bool chunk_the_query(const GenomeMeta &ref, const GenomeMeta &query)
 {
     double tq = (double)query.total_len, tr = (double)ref.total_len;
     double sq = tq * (tq / (double)(query.n_rec ? query.n_rec : 1));
     double sr = tr * (tr / (double)(ref.n_rec ? ref.n_rec : 1));
-    return sq <= sr;
+    if (sq != sr) return sq < sr;
+    if (query.n_seeds != ref.n_seeds) return query.n_seeds < ref.n_seeds;     // content, not argument order
+    if (query.n_markers != ref.n_markers) return query.n_markers < ref.n_markers;
+    return true;
 }
 
 // work buffers of chain_pairs, kept across calls (grow-only) so that steady-state calls allocate nothing

@@ -74,7 +74,10 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None):
-            _lib.lib().skder_amd_ctx_destroy(self.h)
+            try:
+                _lib.lib().skder_amd_ctx_destroy(self.h)
+            except Exception:      # interpreter shutdown: the module globals may already be gone
+                pass
             self.h = None
 
     def __del__(self):
@@ -123,7 +126,11 @@ class Sketches:
 
     def close(self):
         if getattr(self, "h", None):
-            _lib.lib().skder_amd_sketches_free(self.h)
+            try:
+                if getattr(self.ctx, "h", None):
+                    _lib.lib().skder_amd_sketches_free(self.h)
+            except Exception:
+                pass
             self.h = None
 
     def __del__(self):

@@ -422,3 +422,45 @@ def test_degenerate_inputs(gpu, oracle, tmp_path):
         assert so.read_text() == sr.read_text() and so.read_text().count("\n") == 4
     finally:
         _lib.lib().skder_amd_db_free(db)
+
+
+def test_properties_at_scale(gpu):
+    """size-independent properties on a set too large for the oracle to cross-check pair by pair
+    (400 genomes x 1 Mb, 19,800 chained pairs): determinism, dist == triangle with the AF columns
+    swapped when the roles swap, structure of the pair set, ordering of ANI by lineage"""
+    engine, ctx, torch = gpu
+    from skder_amd import synth
+    rec = synth.make_recipe(400, genome_len=1_000_000, n_species=4, strains_per_species=10)
+    layout = engine.BatchLayout(rec.rec_lens)
+    d = torch.empty(layout.total_bytes, dtype=torch.uint8, device="cuda")
+    ctx.synth_fill(d.data_ptr(), layout, rec.lineage, rec.params)
+    s = engine.Sketches(ctx)
+    s.sketch_batch(d.data_ptr(), layout)
+    e1 = s.triangle_rows(0, 1, 80.0)
+    e2 = s.triangle_rows(0, 1, 80.0)
+    order = lambda e: e[np.lexsort((e["query"], e["ref"]))]
+    assert np.array_equal(order(e1), order(e2))                                  # bit-identical reruns
+    tri = {(int(e["ref"]), int(e["query"])): e for e in e1}
+    per = 100
+    want = {(i, j) for i in range(400) for j in range(i + 1, 400) if i // per == j // per}
+    assert set(tri) == want                                                       # all within-species pairs, nothing else
+    rect = s.rectangle(s, 80.0)                                                   # every ordered pair incl. self
+    assert len(rect) == 2 * len(want) + 400
+    n_checked = 0
+    for e in rect[:: 37]:
+        r, q = int(e["ref"]), int(e["query"])
+        if r == q:
+            continue
+        t = tri[(min(r, q), max(r, q))]
+        assert float(e["ani"]) == float(t["ani"])                                 # ANI is symmetric
+        if r < q:
+            assert float(e["af_ref"]) == float(t["af_ref"]) and float(e["af_query"]) == float(t["af_query"])
+        else:
+            assert float(e["af_ref"]) == float(t["af_query"]) and float(e["af_query"]) == float(t["af_ref"])
+        n_checked += 1
+    assert n_checked > 500
+    # same-strain isolates are closer than different strains of the species (strain = index % 10 inside a species)
+    same = [float(e["ani"]) for (i, j), e in tri.items() if (i % per) % 10 == (j % per) % 10]
+    diff = [float(e["ani"]) for (i, j), e in tri.items() if (i % per) % 10 != (j % per) % 10]
+    assert min(same) > max(diff) and min(same) > 0.98 and 0.85 < np.mean(diff) < 0.99
+    assert all(0.0 < float(e["af_ref"]) <= 1.0 and 0.0 < float(e["af_query"]) <= 1.0 for e in e1)
