@@ -149,6 +149,45 @@ int skder_amd_synth_fill(skder_ctx_t *ctx, uint8_t *d_bases, const skder_batch_t
                          const uint64_t *genome_lineage /* 3 per genome: species,strain,isolate seeds */,
                          const uint32_t *genome_params /* 4 per genome, see synth.h */);
 
+/* ======================================================================================
+ * C. the callers either side of the path: all work on the resident database
+ * ====================================================================================== */
+
+/* 8f-2  N50 fused into ingest.  The pass that parses/uploads a listing's FASTA files also yields
+ * the N50 of every file exactly as util.n50_calc does (/root/reference/src/skDER/util.py:686-724:
+ * all records incl. < 500 bp, half = int(sum/2), first cumulative >= half, lengths descending).
+ * n50_tsv (may be NULL) receives `path<TAB>N50` lines in LISTING order, the format of
+ * Concatenated_N50.txt (util.py:476-501, bin/skder:322-323). */
+int skder_amd_triangle_n50(const char *listing, double min_af_pct, double screen_pct, int device,
+                           const char *out_tsv, const char *n50_tsv, char *err, size_t errlen);
+skder_db_t *skder_amd_sketch_n50(const char *listing, int device, const char *n50_tsv, char *err, size_t errlen);
+/* genomes in the database, their listing lines and N50 values (listing order) */
+uint32_t skder_amd_db_size(skder_db_t *db);
+const char *skder_amd_db_path(skder_db_t *db, uint32_t i);
+uint64_t skder_amd_db_n50(skder_db_t *db, uint32_t i);
+
+/* 8f-1  edge list handed over IN MEMORY.  All-pairs table of the resident database: the rows of
+ * `skani triangle` (Ref = the genome whose path sorts first, skani's row order, --min-af applied),
+ * `ref`/`query` being LISTING indices.  out_tsv may be NULL (no text round trip: the selection step
+ * reads *edges); the array is owned by the database and valid until its next call. */
+int skder_amd_db_triangle(skder_db_t *db, double min_af_pct, double screen_pct, const char *out_tsv,
+                          const skder_edge_t **edges, uint64_t *n_edges, char *err, size_t errlen);
+
+/* 8f-3  speculative batch of `skani search` calls (skder.py:116-133 evaluates one representative
+ * at a time): the rows of n_queries candidates are computed in one pass.  Rows come grouped by
+ * query in the order given, references by ANI descending, `query` = index into query_paths.
+ * out_tsvs may be NULL, or hold one output name per query (NULL entries are skipped). */
+int skder_amd_search_batch(skder_db_t *db, const char *const *query_paths, uint32_t n_queries, double min_af_pct,
+                           double screen_pct, const char *const *out_tsvs, const skder_edge_t **edges,
+                           uint64_t *n_edges, char *err, size_t errlen);
+
+/* 8f-4  sketch store on disk (the counterpart of the directory `skani sketch -o` creates,
+ * skder.py:102-104): one file holding the raw sketches, record tables, names, paths and N50s of a
+ * database, so a run over 10^4..10^5 genomes can resume without re-ingesting FASTA.  The format is
+ * this library's own (little endian, versioned magic); a file that does not match is refused. */
+int skder_amd_db_save(skder_db_t *db, const char *store_path, char *err, size_t errlen);
+skder_db_t *skder_amd_db_load(const char *store_path, int device, char *err, size_t errlen);
+
 #ifdef __cplusplus
 }
 #endif

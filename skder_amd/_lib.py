@@ -56,6 +56,19 @@ SYMBOLS = {
     "skder_amd_last_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "skder_amd_last_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "skder_amd_synth_fill": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p]),
+    "skder_amd_triangle_n50": (C.c_int, [C.c_char_p, C.c_double, C.c_double, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p,
+                                         C.c_size_t]),
+    "skder_amd_sketch_n50": (C.c_void_p, [C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_size_t]),
+    "skder_amd_db_size": (C.c_uint32, [C.c_void_p]),
+    "skder_amd_db_path": (C.c_char_p, [C.c_void_p, C.c_uint32]),
+    "skder_amd_db_n50": (C.c_uint64, [C.c_void_p, C.c_uint32]),
+    "skder_amd_db_triangle": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_char_p, C.POINTER(C.POINTER(Edge)),
+                                        C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]),
+    "skder_amd_search_batch": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.c_uint32, C.c_double, C.c_double,
+                                         C.POINTER(C.c_char_p), C.POINTER(C.POINTER(Edge)), C.POINTER(C.c_uint64),
+                                         C.c_char_p, C.c_size_t]),
+    "skder_amd_db_save": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]),
+    "skder_amd_db_load": (C.c_void_p, [C.c_char_p, C.c_int, C.c_char_p, C.c_size_t]),
     "skder_amd_debug_genome": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                          C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }

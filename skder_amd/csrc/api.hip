@@ -270,9 +270,10 @@ extern "C" int skder_amd_synth_fill(skder_ctx_t *ctx, uint8_t *d_bases, const sk
 
 struct skder_db {
     skder_ctx *ctx = nullptr;
-    skder_sketches *refs = nullptr;
+    skder_sketches *refs = nullptr;          // genomes in LISTING order, indexed
     GenomeNames names;
     std::vector<std::pair<std::string, uint32_t>> by_path;   // sorted (path, index)
+    std::vector<skder_edge_t> rows;          // last table handed out in memory
 };
 
 extern "C" int skder_amd_parse_skani_params(const char *params, double *screen_pct, char *err, size_t errlen)
@@ -303,35 +304,107 @@ extern "C" int skder_amd_parse_skani_params(const char *params, double *screen_p
     return 0;
 }
 
-static void sorted_unique_listing(const char *listing, std::vector<std::string> &paths)
+static void db_finish(skder_db *db)
 {
-    paths = read_listing(listing);
-    std::sort(paths.begin(), paths.end());   // skani indexes genomes by ascending path
+    index_impl(db->refs);
+    db->by_path.clear();
+    for (uint32_t i = 0; i < db->names.path.size(); i++) db->by_path.emplace_back(db->names.path[i], i);
+    std::stable_sort(db->by_path.begin(), db->by_path.end());
+}
+
+static void db_destroy(skder_db *db)
+{
+    if (!db) return;
+    skder_amd_sketches_free(db->refs);
+    skder_amd_ctx_destroy(db->ctx);
+    delete db;
+}
+
+extern "C" skder_db_t *skder_amd_sketch_n50(const char *listing, int device, const char *n50_tsv, char *err, size_t errlen)
+{
+    if (!listing) { set_err(err, errlen, "null argument"); return nullptr; }
+    skder_ctx *ctx = skder_amd_ctx_create(device, err, errlen);
+    if (!ctx) return nullptr;
+    skder_db *db = new skder_db();
+    db->ctx = ctx;
+    try {
+        std::vector<std::string> paths = read_listing(listing);
+        db->refs = skder_amd_sketches_new(ctx);
+        sketch_files(db->refs, paths, db->names);
+        db_finish(db);
+        if (n50_tsv) write_n50_tsv(n50_tsv, db->names);
+        return db;
+    } catch (const std::exception &e) {
+        set_err(err, errlen, e.what());
+        db_destroy(db);
+        return nullptr;
+    }
+}
+
+extern "C" skder_db_t *skder_amd_sketch(const char *listing, int device, char *err, size_t errlen)
+{
+    return skder_amd_sketch_n50(listing, device, nullptr, err, errlen);
+}
+
+extern "C" void skder_amd_db_free(skder_db_t *db) { db_destroy(db); }
+extern "C" uint32_t skder_amd_db_size(skder_db_t *db) { return db ? (uint32_t)db->names.path.size() : 0; }
+extern "C" const char *skder_amd_db_path(skder_db_t *db, uint32_t i)
+{
+    return db && i < db->names.path.size() ? db->names.path[i].c_str() : nullptr;
+}
+extern "C" uint64_t skder_amd_db_n50(skder_db_t *db, uint32_t i) { return db && i < db->names.n50.size() ? db->names.n50[i] : 0; }
+
+// All-pairs table of the database in skani's triangle conventions.  skani numbers genomes by
+// ascending path whereas the database keeps listing order: rows are formed in rank space
+// (Ref = the path that sorts first, AFs swapped along) and mapped back to listing indices.
+static void db_triangle_rows(skder_db *db, double min_af_pct, double screen_pct)
+{
+    const uint32_t n = (uint32_t)db->names.path.size();
+    std::vector<uint32_t> rank(n), perm(n);
+    for (uint32_t r = 0; r < n; r++) { perm[r] = db->by_path[r].second; rank[perm[r]] = r; }
+    triangle_rows_impl(db->refs, 0, 1, screen_pct);
+    std::vector<skder_edge_t> E(db->ctx->edges);
+    for (auto &e : E) {
+        uint32_t a = rank[e.ref], b = rank[e.query];
+        if (a > b) { std::swap(a, b); std::swap(e.af_ref, e.af_query); }
+        e.ref = a; e.query = b;
+    }
+    db->rows = triangle_rows_ordered(E, min_af_pct);
+    for (auto &e : db->rows) { e.ref = perm[e.ref]; e.query = perm[e.query]; }
+}
+
+extern "C" int skder_amd_db_triangle(skder_db_t *db, double min_af_pct, double screen_pct, const char *out_tsv,
+                                     const skder_edge_t **edges, uint64_t *n_edges, char *err, size_t errlen)
+{
+    if (!db) { set_err(err, errlen, "null argument"); return 1; }
+    try {
+        HIPCHECK(hipSetDevice(db->ctx->device));
+        db_triangle_rows(db, min_af_pct, screen_pct);
+        if (out_tsv) write_rows_tsv(out_tsv, db->rows.data(), db->rows.size(), db->names, db->names);
+        if (edges) *edges = db->rows.data();
+        if (n_edges) *n_edges = db->rows.size();
+        return 0;
+    } catch (const std::exception &e) {
+        set_err(err, errlen, e.what());
+        return 2;
+    }
+}
+
+extern "C" int skder_amd_triangle_n50(const char *listing, double min_af_pct, double screen_pct, int device, const char *out_tsv,
+                                      const char *n50_tsv, char *err, size_t errlen)
+{
+    if (!listing || !out_tsv) { set_err(err, errlen, "null argument"); return 1; }
+    skder_db *db = skder_amd_sketch_n50(listing, device, n50_tsv, err, errlen);
+    if (!db) return 1;
+    int rc = skder_amd_db_triangle(db, min_af_pct, screen_pct, out_tsv, nullptr, nullptr, err, errlen);
+    db_destroy(db);
+    return rc;
 }
 
 extern "C" int skder_amd_triangle(const char *listing, double min_af_pct, double screen_pct, int device, const char *out_tsv,
                                   char *err, size_t errlen)
 {
-    skder_ctx *ctx = skder_amd_ctx_create(device, err, errlen);
-    if (!ctx) return 1;
-    skder_sketches *s = nullptr;
-    int rc = 0;
-    try {
-        std::vector<std::string> paths;
-        sorted_unique_listing(listing, paths);
-        s = skder_amd_sketches_new(ctx);
-        GenomeNames names;
-        sketch_files(s, paths, names);
-        index_impl(s);
-        triangle_rows_impl(s, 0, 1, screen_pct);
-        write_triangle_tsv(out_tsv, ctx->edges, names, min_af_pct);
-    } catch (const std::exception &e) {
-        set_err(err, errlen, e.what());
-        rc = 2;
-    }
-    skder_amd_sketches_free(s);
-    skder_amd_ctx_destroy(ctx);
-    return rc;
+    return skder_amd_triangle_n50(listing, min_af_pct, screen_pct, device, out_tsv, nullptr, err, errlen);
 }
 
 extern "C" int skder_amd_dist(const char *ref_listing, const char *query_listing, double min_af_pct, double screen_pct, int device,
@@ -360,33 +433,9 @@ extern "C" int skder_amd_dist(const char *ref_listing, const char *query_listing
     return rc;
 }
 
-extern "C" skder_db_t *skder_amd_sketch(const char *listing, int device, char *err, size_t errlen)
+// append genome g of `src` (raw sketch, D2D copy) to the un-indexed set `dst`
+static void append_genome(skder_sketches *dst, skder_sketches *src, uint32_t g)
 {
-    skder_ctx *ctx = skder_amd_ctx_create(device, err, errlen);
-    if (!ctx) return nullptr;
-    skder_db *db = new skder_db();
-    db->ctx = ctx;
-    try {
-        std::vector<std::string> paths = read_listing(listing);
-        db->refs = skder_amd_sketches_new(ctx);
-        sketch_files(db->refs, paths, db->names);
-        index_impl(db->refs);
-        for (uint32_t i = 0; i < paths.size(); i++) db->by_path.emplace_back(paths[i], i);
-        std::sort(db->by_path.begin(), db->by_path.end());
-        return db;
-    } catch (const std::exception &e) {
-        set_err(err, errlen, e.what());
-        skder_amd_sketches_free(db->refs);
-        skder_amd_ctx_destroy(ctx);
-        delete db;
-        return nullptr;
-    }
-}
-
-// one-genome view of genome g of `src`, sharing nothing: copies its raw sketch into a new set
-static skder_sketches *single_genome_set(skder_sketches *src, uint32_t g)
-{
-    skder_sketches *q = skder_amd_sketches_new(src->ctx);
     skder_raw_view_t v;
     skder_amd_sketches_view(src, &v);
     skder_raw_view_t one = v;
@@ -400,34 +449,49 @@ static skder_sketches *single_genome_set(skder_sketches *src, uint32_t g)
     one.h_seed_off = so; one.h_marker_off = mo;
     one.h_genome_len = v.h_genome_len + g; one.h_genome_nrec = v.h_genome_nrec + g;
     one.h_rec_goff = v.h_rec_goff + rg;
-    if (skder_amd_sketches_append_raw(q, &one) != 0) {
-        std::string m = src->ctx->last_error;
-        skder_amd_sketches_free(q);
-        throw SkError(m);
-    }
-    return q;
+    if (skder_amd_sketches_append_raw(dst, &one) != 0) throw SkError(src->ctx->last_error);
 }
 
-extern "C" int skder_amd_search(skder_db_t *db, const char *query_path, double min_af_pct, double screen_pct, const char *out_tsv,
-                                char *err, size_t errlen)
+extern "C" int skder_amd_search_batch(skder_db_t *db, const char *const *query_paths, uint32_t n_queries, double min_af_pct,
+                                      double screen_pct, const char *const *out_tsvs, const skder_edge_t **edges,
+                                      uint64_t *n_edges, char *err, size_t errlen)
 {
-    if (!db || !query_path || !out_tsv) { set_err(err, errlen, "null argument"); return 1; }
+    if (!db || !query_paths) { set_err(err, errlen, "null argument"); return 1; }
     skder_sketches *q = nullptr;
     int rc = 0;
     try {
         HIPCHECK(hipSetDevice(db->ctx->device));
         GenomeNames qn;
-        auto it = std::lower_bound(db->by_path.begin(), db->by_path.end(), std::make_pair(std::string(query_path), 0u));
-        if (it != db->by_path.end() && it->first == query_path) {
-            q = single_genome_set(db->refs, it->second);
-            qn.path.push_back(db->names.path[it->second]);
-            qn.first_name.push_back(db->names.first_name[it->second]);
-        } else {
-            q = skder_amd_sketches_new(db->ctx);
-            sketch_files(q, {std::string(query_path)}, qn);
+        q = skder_amd_sketches_new(db->ctx);
+        for (uint32_t k = 0; k < n_queries; k++) {
+            if (!query_paths[k]) throw SkError("null query path");
+            const std::string qp(query_paths[k]);
+            auto it = std::lower_bound(db->by_path.begin(), db->by_path.end(), std::make_pair(qp, 0u));
+            if (it != db->by_path.end() && it->first == qp) {     // resident: reuse its sketch
+                append_genome(q, db->refs, it->second);
+                qn.path.push_back(db->names.path[it->second]);
+                qn.first_name.push_back(db->names.first_name[it->second]);
+                qn.n50.push_back(db->names.n50[it->second]);
+            } else {
+                sketch_files(q, {qp}, qn);
+            }
         }
-        rectangle_impl(db->refs, q, screen_pct);
-        write_rect_tsv(out_tsv, db->ctx->edges, db->names, qn, min_af_pct);
+        db->rows.clear();
+        if (n_queries) {
+            rectangle_impl(db->refs, q, screen_pct);
+            db->rows = rect_rows_ordered(db->ctx->edges, min_af_pct);
+        }
+        if (out_tsvs) {
+            size_t lo = 0;
+            for (uint32_t k = 0; k < n_queries; k++) {
+                size_t hi = lo;
+                while (hi < db->rows.size() && db->rows[hi].query == k) hi++;
+                if (out_tsvs[k]) write_rows_tsv(out_tsvs[k], db->rows.data() + lo, hi - lo, db->names, qn);
+                lo = hi;
+            }
+        }
+        if (edges) *edges = db->rows.data();
+        if (n_edges) *n_edges = db->rows.size();
     } catch (const std::exception &e) {
         set_err(err, errlen, e.what());
         rc = 2;
@@ -436,10 +500,41 @@ extern "C" int skder_amd_search(skder_db_t *db, const char *query_path, double m
     return rc;
 }
 
-extern "C" void skder_amd_db_free(skder_db_t *db)
+extern "C" int skder_amd_search(skder_db_t *db, const char *query_path, double min_af_pct, double screen_pct, const char *out_tsv,
+                                char *err, size_t errlen)
 {
-    if (!db) return;
-    skder_amd_sketches_free(db->refs);
-    skder_amd_ctx_destroy(db->ctx);
-    delete db;
+    if (!db || !query_path || !out_tsv) { set_err(err, errlen, "null argument"); return 1; }
+    return skder_amd_search_batch(db, &query_path, 1, min_af_pct, screen_pct, &out_tsv, nullptr, nullptr, err, errlen);
+}
+
+extern "C" int skder_amd_db_save(skder_db_t *db, const char *store_path, char *err, size_t errlen)
+{
+    if (!db || !store_path) { set_err(err, errlen, "null argument"); return 1; }
+    try {
+        HIPCHECK(hipSetDevice(db->ctx->device));
+        store_save(store_path, db->refs, db->names);
+        return 0;
+    } catch (const std::exception &e) {
+        set_err(err, errlen, e.what());
+        return 2;
+    }
+}
+
+extern "C" skder_db_t *skder_amd_db_load(const char *store_path, int device, char *err, size_t errlen)
+{
+    if (!store_path) { set_err(err, errlen, "null argument"); return nullptr; }
+    skder_ctx *ctx = skder_amd_ctx_create(device, err, errlen);
+    if (!ctx) return nullptr;
+    skder_db *db = new skder_db();
+    db->ctx = ctx;
+    try {
+        db->refs = skder_amd_sketches_new(ctx);
+        store_load(store_path, db->refs, db->names);
+        db_finish(db);
+        return db;
+    } catch (const std::exception &e) {
+        set_err(err, errlen, e.what());
+        db_destroy(db);
+        return nullptr;
+    }
 }

@@ -22,10 +22,16 @@ void read_fasta(const std::string &path, HostGenome &g)
     std::string cur_name;
     bool in_header = false, have_rec = false, have_first = false;
     size_t rec_start = 0;   // offset in g.bases where the current record starts
+    // N50 bookkeeping follows util.py:686-724 to the letter: a record's length is the sum of
+    // len(line.strip()) over its lines (inner blanks count, empty records are not recorded, text
+    // in front of the first header forms a record of its own)
+    uint64_t n50_cur = 0, n50_ws = 0;
+    bool n50_line_has = false;
     auto close_rec = [&]() {
+        if (n50_cur) all_len.push_back(n50_cur);
+        n50_cur = 0;
         if (!have_rec) return;
         size_t len = g.bases.size() - rec_start;
-        all_len.push_back(len);
         if (len >= ANI_MIN_CONTIG) {
             if (len > 0x7FFFFFFFull) throw SkError("record longer than 2^31 in " + path);
             g.rec_len.push_back((uint32_t)len);
@@ -46,7 +52,7 @@ void read_fasta(const std::string &path, HostGenome &g)
                 else if (c != '\r') cur_name.push_back(c);
                 continue;
             }
-            if (c == '\n') { at_line_start = true; continue; }
+            if (c == '\n') { at_line_start = true; n50_ws = 0; n50_line_has = false; continue; }
             if (at_line_start && c == '>') {
                 close_rec();
                 have_rec = true;
@@ -56,13 +62,17 @@ void read_fasta(const std::string &path, HostGenome &g)
                 continue;
             }
             at_line_start = false;
-            if (c == '\r' || c == ' ' || c == '\t') continue;
+            if (c == '\r' || c == ' ' || c == '\t' || c == '\v' || c == '\f') {
+                if (n50_line_has) n50_ws++;
+                continue;
+            }
+            n50_cur += n50_ws + 1; n50_ws = 0; n50_line_has = true;
             if (have_rec) g.bases.push_back((uint8_t)c);
         }
     }
     close_rec();
     gzclose(f);
-    if (all_len.empty()) throw SkError("no FASTA records in " + path);
+    if (all_len.empty()) throw SkError("no sequence in " + path);
     // N50 as util.py:686-724
     std::sort(all_len.begin(), all_len.end());
     uint64_t tot = 0;
@@ -171,7 +181,9 @@ void sketch_files(skder_sketches *s, const std::vector<std::string> &paths, Geno
         }
         HIPCHECK(hipStreamSynchronize(st));
         (void)hipFree(d); (void)hipHostFree(h);
-        for (auto &g : gs) { names.path.push_back(g.path); names.first_name.push_back(g.first_name); }
+        for (auto &g : gs) {
+            names.path.push_back(g.path); names.first_name.push_back(g.first_name); names.n50.push_back(g.n50);
+        }
         i0 = i1;
     }
 }
@@ -242,15 +254,14 @@ struct TmpFile {
     ~TmpFile() { if (f) { fclose(f); remove(tmp.c_str()); } }
 };
 
-void write_triangle_tsv(const std::string &out, const std::vector<skder_edge_t> &edges, const GenomeNames &names, double min_af_pct)
+std::vector<skder_edge_t> triangle_rows_ordered(const std::vector<skder_edge_t> &edges, double min_af_pct)
 {
     // rows by Ref index; inside a row by Query index ascending (the insertion order of skani's inner map)
-    std::vector<skder_edge_t> E(edges);
+    std::vector<skder_edge_t> E(edges), rows;
     std::sort(E.begin(), E.end(), [](const skder_edge_t &a, const skder_edge_t &b) {
         return a.ref != b.ref ? a.ref < b.ref : a.query < b.query;
     });
-    TmpFile tf(out);
-    fputs(TSV_HEADER, tf.f);
+    rows.reserve(E.size());
     FxMap outer;
     for (size_t i = 0; i < E.size(); i++)
         if (i == 0 || E[i].ref != E[i - 1].ref) outer.insert(E[i].ref);
@@ -265,15 +276,13 @@ void write_triangle_tsv(const std::string &out, const std::vector<skder_edge_t> 
             if (!inner.full[bb]) continue;
             const uint32_t q = (uint32_t)inner.key[bb];
             auto it = std::lower_bound(lo, hi, q, [](const skder_edge_t &e, uint32_t qq) { return e.query < qq; });
-            if (!passes_min_af(*it, min_af_pct)) continue;
-            print_row(tf.f, names.path[ref], names.path[q], *it, names.first_name[ref], names.first_name[q]);
+            if (passes_min_af(*it, min_af_pct)) rows.push_back(*it);
         }
     }
-    tf.commit();
+    return rows;
 }
 
-void write_rect_tsv(const std::string &out, const std::vector<skder_edge_t> &edges, const GenomeNames &ref_names,
-                    const GenomeNames &query_names, double min_af_pct)
+std::vector<skder_edge_t> rect_rows_ordered(const std::vector<skder_edge_t> &edges, double min_af_pct)
 {
     // grouped by query in listing order; references by ANI descending
     std::vector<skder_edge_t> E;
@@ -284,10 +293,170 @@ void write_rect_tsv(const std::string &out, const std::vector<skder_edge_t> &edg
         if (x != y) return x > y;
         return a.ref < b.ref;
     });
+    return E;
+}
+
+void write_rows_tsv(const std::string &out, const skder_edge_t *rows, size_t n, const GenomeNames &ref_names,
+                    const GenomeNames &query_names)
+{
     TmpFile tf(out);
     fputs(TSV_HEADER, tf.f);
-    for (const auto &e : E)
+    for (size_t i = 0; i < n; i++) {
+        const skder_edge_t &e = rows[i];
         print_row(tf.f, ref_names.path[e.ref], query_names.path[e.query], e, ref_names.first_name[e.ref],
                   query_names.first_name[e.query]);
+    }
     tf.commit();
+}
+
+void write_triangle_tsv(const std::string &out, const std::vector<skder_edge_t> &edges, const GenomeNames &names, double min_af_pct)
+{
+    std::vector<skder_edge_t> rows = triangle_rows_ordered(edges, min_af_pct);
+    write_rows_tsv(out, rows.data(), rows.size(), names, names);
+}
+
+void write_rect_tsv(const std::string &out, const std::vector<skder_edge_t> &edges, const GenomeNames &ref_names,
+                    const GenomeNames &query_names, double min_af_pct)
+{
+    std::vector<skder_edge_t> rows = rect_rows_ordered(edges, min_af_pct);
+    write_rows_tsv(out, rows.data(), rows.size(), ref_names, query_names);
+}
+
+void write_n50_tsv(const std::string &out, const GenomeNames &names)
+{
+    TmpFile tf(out);
+    for (size_t i = 0; i < names.path.size(); i++)
+        fprintf(tf.f, "%s\t%llu\n", names.path[i].c_str(), (unsigned long long)names.n50[i]);
+    tf.commit();
+}
+
+// ---------------------------------------------------------------------------------------------
+// sketch store.  Layout, little endian:
+//   "SKDRAMD1" | u32 version | u32 k, c, marker k, marker c, min contig | u64 n_genomes, n_seeds,
+//   n_markers, n_rec_goff | seed_off[n+1] marker_off[n+1] genome_len[n] n50[n] (u64) |
+//   genome_nrec[n] rec_goff[n_rec_goff] (u32) | per genome: u32 len + path, u32 len + first name |
+//   markers (u64 x n_markers) | seed_kmer, seed_gpos, seed_ctg (u32 x n_seeds) | u64 FNV-1a of all before
+
+static const char STORE_MAGIC[8] = {'S', 'K', 'D', 'R', 'A', 'M', 'D', '1'};
+
+struct StoreIO {
+    FILE *f;
+    uint64_t h = 0xcbf29ce484222325ULL;
+    void mix(const void *p, size_t n)
+    {
+        // FNV-1a over 8-byte words (tail bytes one by one): cheap enough for multi-GB stores
+        const uint8_t *b = (const uint8_t *)p;
+        size_t i = 0;
+        for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, b + i, 8); h = (h ^ w) * 0x100000001b3ULL; }
+        for (; i < n; i++) h = (h ^ b[i]) * 0x100000001b3ULL;
+    }
+    void put(const void *p, size_t n)
+    {
+        if (n && fwrite(p, 1, n, f) != n) throw SkError("sketch store: write error");
+        mix(p, n);
+    }
+    void get(void *p, size_t n)
+    {
+        if (n && fread(p, 1, n, f) != n) throw SkError("sketch store: file is truncated");
+        mix(p, n);
+    }
+    template <class T> void putv(const std::vector<T> &v) { put(v.data(), v.size() * sizeof(T)); }
+    template <class T> void getv(std::vector<T> &v, size_t n) { v.resize(n); get(v.data(), n * sizeof(T)); }
+    void puts_(const std::string &s) { uint32_t l = (uint32_t)s.size(); put(&l, 4); put(s.data(), l); }
+    std::string gets_()
+    {
+        uint32_t l; get(&l, 4);
+        if (l > (1u << 20)) throw SkError("sketch store: corrupt string length");
+        std::string s(l, 0); get(&s[0], l);
+        return s;
+    }
+};
+
+void store_save(const std::string &out, skder_sketches *s, const GenomeNames &names)
+{
+    hipStream_t st = s->ctx->stream;
+    const uint64_t n = s->n_genomes, ns = s->h_seed_off.back(), nm = s->h_marker_off.back(), nr = s->h_rec_goff.size();
+    if (names.path.size() != n || names.n50.size() != n) throw SkError("sketch store: name table does not match the sketches");
+    std::vector<uint32_t> kmer(ns), gpos(ns), ctg(ns);
+    std::vector<uint64_t> markers(nm);
+    if (ns) {
+        HIPCHECK(hipMemcpyAsync(kmer.data(), s->seed_kmer.p, ns * 4, hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipMemcpyAsync(gpos.data(), s->seed_gpos.p, ns * 4, hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipMemcpyAsync(ctg.data(), s->seed_ctg.p, ns * 4, hipMemcpyDeviceToHost, st));
+    }
+    if (nm) HIPCHECK(hipMemcpyAsync(markers.data(), s->markers.p, nm * 8, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    TmpFile tf(out);
+    StoreIO io{tf.f};
+    io.put(STORE_MAGIC, 8);
+    const uint32_t head[6] = {1, ANI_K, ANI_C, ANI_MARKER_K, ANI_MARKER_C, ANI_MIN_CONTIG};
+    io.put(head, sizeof head);
+    const uint64_t cnt[4] = {n, ns, nm, nr};
+    io.put(cnt, sizeof cnt);
+    io.putv(s->h_seed_off); io.putv(s->h_marker_off); io.putv(s->h_genome_len); io.putv(names.n50);
+    io.putv(s->h_genome_nrec); io.putv(s->h_rec_goff);
+    for (uint64_t g = 0; g < n; g++) { io.puts_(names.path[g]); io.puts_(names.first_name[g]); }
+    io.putv(markers); io.putv(kmer); io.putv(gpos); io.putv(ctg);
+    const uint64_t sum = io.h;
+    if (fwrite(&sum, 1, 8, tf.f) != 8) throw SkError("sketch store: write error");
+    tf.commit();
+}
+
+void store_load(const std::string &path, skder_sketches *s, GenomeNames &names)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) throw SkError("cannot open sketch store " + path);
+    struct Closer { FILE *f; ~Closer() { fclose(f); } } closer{f};
+    StoreIO io{f};
+    char magic[8];
+    io.get(magic, 8);
+    if (memcmp(magic, STORE_MAGIC, 8) != 0) throw SkError(path + " is not a libskder_amd sketch store");
+    uint32_t head[6];
+    io.get(head, sizeof head);
+    if (head[0] != 1) throw SkError("sketch store: unsupported version " + std::to_string(head[0]));
+    if (head[1] != ANI_K || head[2] != ANI_C || head[3] != ANI_MARKER_K || head[4] != ANI_MARKER_C || head[5] != ANI_MIN_CONTIG)
+        throw SkError("sketch store was written with different sketching parameters");
+    uint64_t cnt[4];
+    io.get(cnt, sizeof cnt);
+    const uint64_t n = cnt[0], ns = cnt[1], nm = cnt[2], nr = cnt[3];
+    if (fseek(f, 0, SEEK_END) != 0) throw SkError("sketch store: cannot seek");
+    const uint64_t fsize = (uint64_t)ftell(f);
+    const uint64_t fixed = 8 + sizeof head + sizeof cnt + (2 * (n + 1) + 2 * n) * 8 + (n + nr) * 4 + ns * 12 + nm * 8 + 8;
+    if (n > 0xFFFFFFFFull || fsize < fixed || nr < n) throw SkError("sketch store: header does not match the file size");
+    if (fseek(f, 8 + sizeof head + sizeof cnt, SEEK_SET) != 0) throw SkError("sketch store: cannot seek");
+    std::vector<uint64_t> seed_off, marker_off, genome_len;
+    std::vector<uint32_t> nrec, rec_goff;
+    io.getv(seed_off, n + 1); io.getv(marker_off, n + 1); io.getv(genome_len, n); io.getv(names.n50, n);
+    io.getv(nrec, n); io.getv(rec_goff, nr);
+    if (seed_off[0] != 0 || seed_off[n] != ns || marker_off[0] != 0 || marker_off[n] != nm)
+        throw SkError("sketch store: offset tables are inconsistent");
+    uint64_t rsum = 0;
+    for (uint64_t g = 0; g < n; g++) {
+        if (seed_off[g + 1] < seed_off[g] || marker_off[g + 1] < marker_off[g]) throw SkError("sketch store: offset tables are inconsistent");
+        rsum += (uint64_t)nrec[g] + 1;
+    }
+    if (rsum != nr) throw SkError("sketch store: record tables are inconsistent");
+    names.path.resize(n); names.first_name.resize(n);
+    for (uint64_t g = 0; g < n; g++) { names.path[g] = io.gets_(); names.first_name[g] = io.gets_(); }
+    // payload through pinned memory straight into HBM
+    uint8_t *h = nullptr;
+    const uint64_t bytes = ns * 12 + nm * 8;
+    HIPCHECK(hipHostMalloc(&h, bytes ? bytes : 8));
+    struct HostFree { uint8_t *p; ~HostFree() { (void)hipHostFree(p); } } hf{h};
+    io.get(h, bytes);
+    uint64_t sum_file = 0, sum_calc = io.h;
+    if (fread(&sum_file, 1, 8, f) != 8) throw SkError("sketch store: file is truncated");
+    if (sum_file != sum_calc) throw SkError("sketch store: checksum mismatch (file is corrupt)");
+    hipStream_t st = s->ctx->stream;
+    DevBuf<uint8_t> d;
+    d.resize(bytes ? bytes : 8, st);
+    HIPCHECK(hipMemcpyAsync(d.p, h, bytes, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    skder_raw_view_t v;
+    v.n_genomes = (uint32_t)n; v.n_seeds = ns; v.n_markers = nm; v.n_rec_goff = nr;
+    v.d_markers = (const uint64_t *)d.p;
+    v.d_seed_kmer = (const uint32_t *)(d.p + nm * 8); v.d_seed_gpos = v.d_seed_kmer + ns; v.d_seed_ctg = v.d_seed_gpos + ns;
+    v.h_seed_off = seed_off.data(); v.h_marker_off = marker_off.data(); v.h_genome_len = genome_len.data();
+    v.h_genome_nrec = nrec.data(); v.h_rec_goff = rec_goff.data();
+    if (skder_amd_sketches_append_raw(s, &v) != 0) throw SkError(s->ctx->last_error);
 }

@@ -5,7 +5,12 @@ Only the flow around the hot path is reproduced (no downloads, MGE filtering, pl
 formats follow the reference so that outputs can be diffed against its result directories.
 
     python -m skder_amd.driver -g GENOME_DIR_OR_FILES... -o OUT/ [-d greedy|dynamic|low_mem_greedy]
-                               [-i 99.5] [-f 50.0] [-a 10.0] [-n] [-p "-s 89.5"]
+                               [-i 99.5] [-f 50.0] [-a 10.0] [-n] [-p "-s 89.5"] [--store FILE]
+
+The FASTA files are read ONCE: the pass that uploads them also yields Concatenated_N50.txt
+(SURVEY.md 8f-2), the edge rows reach the selection step in memory (8f-1; the text table is still
+written because it is one of skDER's outputs) and, with --store, the sketches are kept on disk so a
+later run over the same listing skips ingest (8f-4).
 """
 import argparse
 import gzip
@@ -14,7 +19,7 @@ import sys
 from collections import OrderedDict
 
 from . import selection
-from .skder import lowMemGreedyDerep, runSkaniDist, runSkaniTriangle
+from .skder import Database, lowMemGreedyDerep, parse_skani_params, runSkaniDist
 
 ACCEPTED_SUFFICES = ("fasta", "fas", "fna", "fa")      # util.py:21
 
@@ -55,7 +60,23 @@ def list_genomes(inputs):
     return out
 
 
-def run(genomes, outdir, mode="greedy", ani=99.5, af=50.0, max_af_dist=10.0, clusters=False, params="-s X"):
+def open_database(listing, genomes, n50_file, store=None):
+    """the resident sketch database of the listing + its N50 table; reuses a sketch store when it
+    describes exactly these paths"""
+    if store and os.path.isfile(store):
+        db = Database.load(store)
+        if db.paths == list(genomes):
+            with open(n50_file, "w") as f:
+                f.write("".join("%s\t%d\n" % kv for kv in zip(db.paths, db.n50)))
+            return db
+        db.close()
+    db = Database.from_listing(listing, n50_file)
+    if store:
+        db.save(store)
+    return db
+
+
+def run(genomes, outdir, mode="greedy", ani=99.5, af=50.0, max_af_dist=10.0, clusters=False, params="-s X", store=None):
     outdir = os.path.abspath(outdir) + "/"
     os.makedirs(outdir, exist_ok=True)
     if params == "-s X":                          # bin/skder:199-201
@@ -67,16 +88,22 @@ def run(genomes, outdir, mode="greedy", ani=99.5, af=50.0, max_af_dist=10.0, clu
     listing = outdir + "All_Genomes_Listing.txt"
     with open(listing, "w") as f:
         f.write("".join(g + "\n" for g in genomes))
-    n50 = OrderedDict((g, n50_of_fasta(g)) for g in genomes)
     n50_file = outdir + "Concatenated_N50.txt"
-    with open(n50_file, "w") as f:
-        f.write("".join("%s\t%d\n" % kv for kv in n50.items()))
+    db = open_database(listing, genomes, n50_file, store)
+    try:
+        return _run(db, genomes, outdir, mode, ani, af, af_tri, max_af_dist, clusters, params, listing, n50_file)
+    finally:
+        db.close()
+
+
+def _run(db, genomes, outdir, mode, ani, af, af_tri, max_af_dist, clusters, params, listing, n50_file):
+    n50 = OrderedDict(zip(db.paths, db.n50))
     result_file = outdir + "skDER_Results.txt"
     edge_file = outdir + "Skani_Triangle_Edge_Output.txt"
     if mode == "low_mem_greedy":
         ws = outdir + "skder_lm_workspace/"
         os.makedirs(ws, exist_ok=True)
-        lowMemGreedyDerep(listing, ws, n50_file, result_file, outdir, ani, af, None)
+        lowMemGreedyDerep(listing, ws, n50_file, result_file, outdir, ani, af, None, database=db)
         if clusters:
             cdir = outdir + "Clustering_Workspace/"
             os.makedirs(cdir, exist_ok=True)
@@ -84,8 +111,8 @@ def run(genomes, outdir, mode="greedy", ani=99.5, af=50.0, max_af_dist=10.0, clu
             runSkaniDist(cdir, result_file, listing, edge_file, params, af, mode, False, None)
         reps = [l.strip() for l in open(result_file)]
     else:
-        runSkaniTriangle(listing, edge_file, params, af_tri, mode, False, None)
-        edges = selection.edges_from_table(edge_file)
+        rows = db.triangle(af_tri, parse_skani_params(params), out_tsv=edge_file)
+        edges = selection.edges_from_engine(rows, db.paths)
         if mode == "greedy":
             info = selection.genome_information(edges, n50, ani, af)
             with open(outdir + "Genome_Information_for_Greedy_Clustering.txt", "w") as f:
@@ -101,7 +128,8 @@ def run(genomes, outdir, mode="greedy", ani=99.5, af=50.0, max_af_dist=10.0, clu
         with open(result_file, "w") as f:
             f.write("".join(r + "\n" for r in reps))
     if clusters:
-        edges = selection.edges_from_table(edge_file)
+        if mode == "low_mem_greedy":
+            edges = selection.edges_from_table(edge_file)
         with open(outdir + "skDER_Clustering.txt", "w") as f:
             f.write("".join(l + "\n" for l in selection.determine_clusters(reps, edges, af, ani)))
     rep_dir = outdir + "Dereplicated_Representative_Genomes/"
@@ -125,9 +153,10 @@ def main(argv=None):
     ap.add_argument("-a", "--max-af-distance-cutoff", type=float, default=10.0)
     ap.add_argument("-p", "--skani-triangle-parameters", default="-s X")
     ap.add_argument("-n", "--determine-clusters", action="store_true")
+    ap.add_argument("--store", default=None, help="sketch store file: loaded if present, written otherwise")
     a = ap.parse_args(argv)
     reps = run(list_genomes(a.genomes), a.output_directory, a.dereplication_mode, a.percent_identity_cutoff,
-               a.aligned_fraction_cutoff, a.max_af_distance_cutoff, a.determine_clusters, a.skani_triangle_parameters)
+               a.aligned_fraction_cutoff, a.max_af_distance_cutoff, a.determine_clusters, a.skani_triangle_parameters, a.store)
     print("%d representative genomes -> %s" % (len(reps), os.path.join(a.output_directory, "skDER_Results.txt")))
 
 

@@ -33,8 +33,9 @@ def _log(logObject, level, msg):
 
 
 def runSkaniTriangle(genome_listing_file, skani_result_file, skani_triangle_parameters,
-                     aligned_fraction_cutoff, selection_mode, test_cutoffs_flag, logObject, threads=1):
-    """Replaces skder.py:10-28: `skani triangle -l LIST --min-af AF -E <params> -t T -o OUT`."""
+                     aligned_fraction_cutoff, selection_mode, test_cutoffs_flag, logObject, threads=1, n50_file=None):
+    """Replaces skder.py:10-28: `skani triangle -l LIST --min-af AF -E <params> -t T -o OUT`.
+    n50_file (optional): also write Concatenated_N50.txt from the same ingest pass."""
     try:
         min_af = float(aligned_fraction_cutoff)
         if test_cutoffs_flag:   # skder.py:19-25
@@ -45,8 +46,9 @@ def runSkaniTriangle(genome_listing_file, skani_result_file, skani_triangle_para
         what = 'skder_amd_triangle(%s, min_af=%s, screen=%s) -> %s' % (genome_listing_file, min_af, screen, skani_result_file)
         _log(logObject, 'info', 'Running %s' % what)
         err = C.create_string_buffer(_lib.ERRLEN)
-        rc = _lib.lib().skder_amd_triangle(genome_listing_file.encode(), min_af, screen, _device(),
-                                           skani_result_file.encode(), err, _lib.ERRLEN)
+        rc = _lib.lib().skder_amd_triangle_n50(genome_listing_file.encode(), min_af, screen, _device(),
+                                               skani_result_file.encode(), n50_file.encode() if n50_file else None,
+                                               err, _lib.ERRLEN)
         if rc != 0 or not os.path.isfile(skani_result_file):
             _log(logObject, 'error', 'Had an issue running: %s: %s' % (what, err.value.decode()))
             raise RuntimeError('Had an issue running: %s: %s' % (what, err.value.decode()))
@@ -85,15 +87,110 @@ def runSkaniDist(cluster_dir, skder_result_file, genome_listing_file, skani_resu
         raise RuntimeError('Error running skani dist command: %s' % e)
 
 
+class Database:
+    """The sketch database resident in HBM (section C of include/skder_amd.h): built from a listing
+    (N50s computed in the same pass, util.py:686-724) or loaded from a sketch store."""
+
+    def __init__(self, handle):
+        self._h = handle
+        L = _lib.lib()
+        n = L.skder_amd_db_size(handle)
+        self.paths = [L.skder_amd_db_path(handle, i).decode() for i in range(n)]
+        self.n50 = [int(L.skder_amd_db_n50(handle, i)) for i in range(n)]
+
+    @classmethod
+    def from_listing(cls, listing_file, n50_file=None, device=None):
+        err = C.create_string_buffer(_lib.ERRLEN)
+        h = _lib.lib().skder_amd_sketch_n50(listing_file.encode(), _device() if device is None else device,
+                                            n50_file.encode() if n50_file else None, err, _lib.ERRLEN)
+        if not h:
+            raise RuntimeError('Had an issue running: skder_amd_sketch: %s' % err.value.decode())
+        return cls(h)
+
+    @classmethod
+    def load(cls, store_file, device=None):
+        err = C.create_string_buffer(_lib.ERRLEN)
+        h = _lib.lib().skder_amd_db_load(store_file.encode(), _device() if device is None else device, err, _lib.ERRLEN)
+        if not h:
+            raise RuntimeError('Had an issue running: skder_amd_db_load: %s' % err.value.decode())
+        return cls(h)
+
+    def save(self, store_file):
+        err = C.create_string_buffer(_lib.ERRLEN)
+        if _lib.lib().skder_amd_db_save(self._h, store_file.encode(), err, _lib.ERRLEN) != 0 or not os.path.isfile(store_file):
+            raise RuntimeError('Had an issue running: skder_amd_db_save: %s' % err.value.decode())
+
+    @staticmethod
+    def _rows(p, n):
+        import numpy as np
+        from .engine import EDGE_DTYPE
+        if n.value == 0:
+            return np.zeros(0, EDGE_DTYPE)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (n.value * EDGE_DTYPE.itemsize,)).view(EDGE_DTYPE).copy()
+
+    def triangle(self, min_af, screen, out_tsv=None):
+        """rows of `skani triangle` over the database, in skani's order, as an edge array"""
+        p, n = C.POINTER(_lib.Edge)(), C.c_uint64()
+        err = C.create_string_buffer(_lib.ERRLEN)
+        rc = _lib.lib().skder_amd_db_triangle(self._h, float(min_af), float(screen), out_tsv.encode() if out_tsv else None,
+                                              C.byref(p), C.byref(n), err, _lib.ERRLEN)
+        if rc != 0 or (out_tsv and not os.path.isfile(out_tsv)):
+            raise RuntimeError('Had an issue running: skder_amd_db_triangle: %s' % err.value.decode())
+        return self._rows(p, n)
+
+    def search_batch(self, queries, min_af=SKANI_DEFAULT_MIN_AF, screen=SKANI_DEFAULT_SCREEN, out_tsvs=None):
+        """rows of `skani search` for several queries at once; `query` = position in `queries`"""
+        k = len(queries)
+        qs = (C.c_char_p * max(k, 1))(*[q.encode() for q in queries])
+        outs = None
+        if out_tsvs is not None:
+            outs = (C.c_char_p * max(k, 1))(*[o.encode() if o else None for o in out_tsvs])
+        p, n = C.POINTER(_lib.Edge)(), C.c_uint64()
+        err = C.create_string_buffer(_lib.ERRLEN)
+        rc = _lib.lib().skder_amd_search_batch(self._h, qs, k, float(min_af), float(screen), outs, C.byref(p), C.byref(n),
+                                               err, _lib.ERRLEN)
+        if rc != 0:
+            raise RuntimeError('Had an issue running: skder_amd_search_batch: %s' % err.value.decode())
+        return self._rows(p, n)
+
+    def close(self):
+        if self._h:
+            try:
+                _lib.lib().skder_amd_db_free(self._h)
+            except Exception:
+                pass
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        self.close()
+
+
+def text_value(x):
+    """the number the reference would parse from skani's table for a fraction x: float('%.2f' % (f32(x)*100))"""
+    import numpy as np
+    return float('%.2f' % float(np.float32(x) * np.float32(100)))
+
+
 def lowMemGreedyDerep(all_genomes_listing_file, skder_lm_workspace, concat_n50_result_file, skder_result_file, outdir,
-                      ani_cutoff, af_cutoff, logObject, mge_proc_to_unproc_mapping=None, threads=1):
+                      ani_cutoff, af_cutoff, logObject, mge_proc_to_unproc_mapping=None, threads=1, search_batch=None,
+                      database=None):
     """Replaces skder.py:95-134: `skani sketch` once, then one `skani search` per representative in
-    N50-descending order.  The sketch database lives in HBM for the whole loop; each search writes
-    the same 7-column TSV the reference parses, and the parsing below is the reference's."""
-    err = C.create_string_buffer(_lib.ERRLEN)
-    db = _lib.lib().skder_amd_sketch(all_genomes_listing_file.encode(), _device(), err, _lib.ERRLEN)
-    if not db:
-        raise RuntimeError('Had an issue running: skder_amd_sketch: %s' % err.value.decode())
+    N50-descending order.  The sketch database lives in HBM for the whole loop.
+
+    search_batch=1 reproduces the reference loop call for call (each search writes the 7-column TSV,
+    which is parsed by the reference's code).  Otherwise (default) the rows of the
+    next few unaccounted candidates are computed speculatively in one pass and applied in order;
+    rows of candidates that an earlier member of the batch accounted for are discarded, so the
+    result equals the sequential loop's."""
+    if search_batch is None:
+        search_batch = int(os.environ.get('SKDER_AMD_SEARCH_BATCH', '0'))
+    db = database if database is not None else Database.from_listing(all_genomes_listing_file)
     try:
         n50_data = []
         with open(concat_n50_result_file) as ocnrf:
@@ -101,28 +198,66 @@ def lowMemGreedyDerep(all_genomes_listing_file, skder_lm_workspace, concat_n50_r
                 line = line.strip()
                 genome, n50 = line.split('\t')
                 n50_data.append([genome, float(n50)])
+        order = sorted(n50_data, key=itemgetter(1), reverse=True)
         skder_result_handle = open(skder_result_file, 'w')
         accounted_genomes = set([])
-        for gn in sorted(n50_data, key=itemgetter(1), reverse=True):
-            if gn[0] in accounted_genomes:
-                continue
-            skani_search_result = skder_lm_workspace + 'current_search_results.tsv'
-            rc = _lib.lib().skder_amd_search(db, gn[0].encode(), SKANI_DEFAULT_MIN_AF, SKANI_DEFAULT_SCREEN,
-                                             skani_search_result.encode(), err, _lib.ERRLEN)
-            if rc != 0 or not os.path.isfile(skani_search_result):
-                raise RuntimeError('Had an issue running: skder_amd_search %s: %s' % (gn[0], err.value.decode()))
-            with open(skani_search_result) as ossr:
-                for i, line in enumerate(ossr):
-                    if i == 0:
-                        continue
-                    line = line.strip('\n')
-                    ref_file, query_file, ani, align_frac_query, align_frac_ref, ref_name, query_name = line.split('\t')
-                    if float(ani) >= ani_cutoff and float(align_frac_ref) >= af_cutoff:
-                        accounted_genomes.add(ref_file)
-            name = gn[0]
+
+        def emit(genome):
+            name = genome
             if mge_proc_to_unproc_mapping is not None:
-                name = mge_proc_to_unproc_mapping[gn[0]]
+                name = mge_proc_to_unproc_mapping[genome]
             skder_result_handle.write(name + '\n')
+
+        if search_batch == 1:
+            err = C.create_string_buffer(_lib.ERRLEN)
+            for gn in order:
+                if gn[0] in accounted_genomes:
+                    continue
+                skani_search_result = skder_lm_workspace + 'current_search_results.tsv'
+                rc = _lib.lib().skder_amd_search(db._h, gn[0].encode(), SKANI_DEFAULT_MIN_AF, SKANI_DEFAULT_SCREEN,
+                                                 skani_search_result.encode(), err, _lib.ERRLEN)
+                if rc != 0 or not os.path.isfile(skani_search_result):
+                    raise RuntimeError('Had an issue running: skder_amd_search %s: %s' % (gn[0], err.value.decode()))
+                with open(skani_search_result) as ossr:
+                    for i, line in enumerate(ossr):
+                        if i == 0:
+                            continue
+                        line = line.strip('\n')
+                        ref_file, query_file, ani, align_frac_query, align_frac_ref, ref_name, query_name = line.split('\t')
+                        if float(ani) >= ani_cutoff and float(align_frac_ref) >= af_cutoff:
+                            accounted_genomes.add(ref_file)
+                emit(gn[0])
+        else:
+            width = search_batch if search_batch > 1 else 4       # 0: adaptive, starting at 4
+            pos = 0
+            while pos < len(order):
+                batch = []
+                while pos < len(order) and len(batch) < width:
+                    if order[pos][0] not in accounted_genomes:
+                        batch.append(order[pos][0])
+                    pos += 1
+                if not batch:
+                    break
+                rows = db.search_batch(batch)
+                lo, kept = 0, 0
+                for k, genome in enumerate(batch):
+                    hi = lo
+                    while hi < len(rows) and rows[hi]['query'] == k:
+                        hi += 1
+                    if genome not in accounted_genomes:
+                        for e in rows[lo:hi]:
+                            # column 5 of the table (Align_fraction_query), as skder.py:126-128 reads it
+                            if text_value(e['ani']) >= ani_cutoff and text_value(e['af_query']) >= af_cutoff:
+                                accounted_genomes.add(db.paths[int(e['ref'])])
+                        emit(genome)
+                        kept += 1
+                    lo = hi
+                if search_batch == 0:
+                    if kept == len(batch):
+                        width = min(width * 2, 64)
+                    elif kept * 2 < len(batch):
+                        width = max(width // 2, 1)
         skder_result_handle.close()
     finally:
-        _lib.lib().skder_amd_db_free(db)
+        if database is None:
+            db.close()

@@ -464,3 +464,156 @@ def test_properties_at_scale(gpu):
     diff = [float(e["ani"]) for (i, j), e in tri.items() if (i % per) % 10 != (j % per) % 10]
     assert min(same) > max(diff) and min(same) > 0.98 and 0.85 < np.mean(diff) < 0.99
     assert all(0.0 < float(e["af_ref"]) <= 1.0 and 0.0 < float(e["af_query"]) <= 1.0 for e in e1)
+
+
+def _golden_listing(tmp_path, which="skder_gtdb_results"):
+    gdir = os.path.join(GOLDEN, "genomes")
+    rows = [l.rstrip("\n").split("\t") for l in open(os.path.join(GOLDEN, "downstream", which + "__Concatenated_N50.txt"))]
+    have = set(os.listdir(gdir))
+    mapping = dict(line.rstrip("\n").split("\t") for line in open(os.path.join(GOLDEN, "plain_to_gz.tsv")))
+    paths, n50 = [], []
+    for name, v in rows:
+        if name in have:
+            paths.append(os.path.join(gdir, name))
+        else:                                     # the 7 plain-FASTA inputs of the reference's first test run
+            plain = tmp_path / name
+            if not plain.exists():
+                with gzip.open(os.path.join(gdir, mapping[name]), "rb") as f:
+                    plain.write_bytes(f.read())
+            paths.append(str(plain))
+        n50.append(int(v))
+    listing = tmp_path / (which + "_listing.txt")
+    listing.write_text("".join(p + "\n" for p in paths))
+    return str(listing), paths, n50
+
+
+def test_n50_from_the_ingest_pass(gpu, tmp_path):
+    """Concatenated_N50.txt comes out of the pass that uploads the FASTA files and holds the
+    reference's golden values (34 gz genomes and the 7 plain ones), listing order kept"""
+    import skder_amd
+    from skder_amd.skder import Database
+    for which in ("skder_gtdb_results", "skder_results"):
+        listing, paths, gold = _golden_listing(tmp_path, which)
+        n50_file = tmp_path / (which + "_n50.txt")
+        tri = tmp_path / (which + "_tri.tsv")
+        skder_amd.runSkaniTriangle(listing, str(tri), "-s 89.5", 50.0, "greedy", False, None, n50_file=str(n50_file))
+        got = [l.rstrip("\n").split("\t") for l in open(n50_file)]
+        assert [g[0] for g in got] == paths
+        assert [int(g[1]) for g in got] == gold
+        with Database.from_listing(listing) as db:
+            assert db.paths == paths and db.n50 == gold
+    # util.n50_calc's corner cases: inner blanks count, empty records do not, text before the first header does
+    odd = tmp_path / "odd.fasta"
+    odd.write_text("ACGT\n>r1\n" + "ACGTACGTAC GTAC\n" * 50 + ">empty\n\n>r2\n  " + "A" * 300 + "  \r\n>r3\n" + "C" * 700 + "\n")
+    lst = tmp_path / "odd.txt"
+    lst.write_text(str(odd) + "\n")
+    with Database.from_listing(str(lst)) as db:
+        lens = sorted([4, 15 * 50, 300, 700], reverse=True)
+        half, cum, want = int(sum(lens) / 2), 0, None
+        for l in lens:
+            cum += l
+            if cum >= half:
+                want = l
+                break
+        assert db.n50 == [want]
+
+
+def test_database_table_in_memory_equals_text(gpu, tmp_path):
+    """the rows handed over in memory are the rows of the text table (same order, same
+    orientation, same 2-decimal values), for a listing that is NOT in path order"""
+    import skder_amd
+    from skder_amd import selection
+    from skder_amd.skder import Database
+    listing, paths, _ = _golden_listing(tmp_path)
+    tri = tmp_path / "tri.tsv"
+    skder_amd.runSkaniTriangle(listing, str(tri), "-s 89.5", 10.0, "greedy", False, None)
+    with Database.from_listing(listing) as db:
+        tsv = tmp_path / "db_tri.tsv"
+        rows = db.triangle(10.0, 89.5, out_tsv=str(tsv))
+        assert tsv.read_text() == tri.read_text()
+        assert selection.edges_from_engine(rows, db.paths) == selection.edges_from_table(str(tri))
+        rows2 = db.triangle(10.0, 89.5)                      # no text at all
+        assert rows2.tobytes() == rows.tobytes()
+    hdr, trows = load_table(str(tri))
+    assert all(r[0] < r[1] for r in trows)                   # Ref = the path that sorts first (SURVEY V2)
+
+
+def test_speculative_search_batches_equal_the_sequential_loop(gpu, tmp_path):
+    """low_mem_greedy with speculative batches of searches gives the listing of the one-search-
+    per-representative loop (skder.py:116-133), for every batch width; a batch's per-query tables are the
+    single searches' tables"""
+    import skder_amd
+    from skder_amd.skder import Database
+    listing, paths, gold = _golden_listing(tmp_path)
+    n50_file = tmp_path / "n50.txt"
+    n50_file.write_text("".join("%s\t%d\n" % kv for kv in zip(paths, gold)))
+    results = {}
+    for ani in (99.5, 98.0):
+        for width in (1, 0, 2, 5, 64):
+            ws = tmp_path / ("ws_%s_%d" % (ani, width))
+            ws.mkdir()
+            res = ws / "res.txt"
+            skder_amd.lowMemGreedyDerep(listing, str(ws) + "/", str(n50_file), str(res), str(ws) + "/", ani, 50.0, None,
+                                        search_batch=width)
+            results[(ani, width)] = res.read_text()
+        assert len(set(results[(ani, w)] for w in (1, 0, 2, 5, 64))) == 1
+        assert 0 < results[(ani, 1)].count("\n") < len(paths)
+    assert results[(99.5, 1)] != results[(98.0, 1)]
+    with Database.from_listing(listing) as db:
+        qs = [paths[3], paths[20], paths[3], paths[11]]
+        outs = [str(tmp_path / ("b%d.tsv" % i)) for i in range(len(qs))]
+        rows = db.search_batch(qs, out_tsvs=outs)
+        assert list(rows["query"]) == sorted(rows["query"])
+        import ctypes as C
+        from skder_amd import _lib
+        err = C.create_string_buffer(2048)
+        for q, o in zip(qs, outs):
+            single = tmp_path / "single.tsv"
+            assert _lib.lib().skder_amd_search(db._h, q.encode(), 15.0, 80.0, str(single).encode(), err, 2048) == 0, err.value
+            assert open(o).read() == single.read_text()
+        assert len(db.search_batch([])) == 0
+
+
+def test_sketch_store_round_trip(gpu, tmp_path):
+    """a database saved to the sketch store and loaded again gives bit-identical tables,
+    paths and N50s; damaged or foreign files are refused"""
+    from skder_amd import driver
+    from skder_amd.skder import Database
+    listing, paths, gold = _golden_listing(tmp_path)
+    store = tmp_path / "sketches.skdb"
+    with Database.from_listing(listing) as db:
+        rows = db.triangle(10.0, 89.5)
+        srows = db.search_batch([paths[5]])
+        db.save(str(store))
+    with Database.load(str(store)) as db2:
+        assert db2.paths == paths and db2.n50 == gold
+        assert db2.triangle(10.0, 89.5).tobytes() == rows.tobytes()
+        assert db2.search_batch([paths[5]]).tobytes() == srows.tobytes()
+    blob = bytearray(store.read_bytes())
+    bad = tmp_path / "bad.skdb"
+    flipped = bytearray(blob)
+    flipped[len(blob) // 2] ^= 0x40
+    bad.write_bytes(flipped)
+    with pytest.raises(RuntimeError, match="checksum"):
+        Database.load(str(bad))
+    bad.write_bytes(blob[: len(blob) - 1000])
+    with pytest.raises(RuntimeError, match="truncated|size"):
+        Database.load(str(bad))
+    bad.write_bytes(b"not a store at all" * 10)
+    with pytest.raises(RuntimeError, match="not a libskder_amd sketch store"):
+        Database.load(str(bad))
+    # the driver resumes from the store: same representatives, FASTA files not needed any more
+    import shutil
+    gcopy = tmp_path / "gcopy"
+    gcopy.mkdir()
+    genomes = []
+    for p in paths[:12]:
+        shutil.copy(p, gcopy / os.path.basename(p))
+        genomes.append(str(gcopy / os.path.basename(p)))
+    r1 = driver.run(genomes, str(tmp_path / "run1"), "greedy", 99.5, 50.0, store=str(tmp_path / "drv.skdb"))
+    shutil.rmtree(gcopy)
+    r2 = driver.run(genomes, str(tmp_path / "run2"), "greedy", 99.5, 50.0, store=str(tmp_path / "drv.skdb"))
+    assert r1 == r2 and len(r1) > 0
+    assert (tmp_path / "run1" / "Concatenated_N50.txt").read_text() == (tmp_path / "run2" / "Concatenated_N50.txt").read_text()
+    assert (tmp_path / "run1" / "Skani_Triangle_Edge_Output.txt").read_text() == \
+        (tmp_path / "run2" / "Skani_Triangle_Edge_Output.txt").read_text()
