@@ -220,7 +220,7 @@ struct Run {
     uint32_t seg;                     // summary key: changes along a path only at score-lowering indels
 };
 
-__global__ __launch_bounds__(256, 4) void chain_fast_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs, uint32_t npairs,
+__global__ __launch_bounds__(256, 3) void chain_fast_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs, uint32_t npairs,
                                                          uint32_t total_chunks, const uint32_t *__restrict__ hits,
                                                          const uint4 *__restrict__ multi, ChainRec *__restrict__ fast_chains,
                                                          uint32_t *__restrict__ chunk_state, uint32_t *__restrict__ slow_list,
@@ -235,8 +235,9 @@ __global__ __launch_bounds__(256, 4) void chain_fast_kernel(SetView A, SetView B
         wg = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + idx;
     }
     const uint32_t t = wg * 256u + threadIdx.x;
-    // lane-private LDS strips: one 64-byte line of each stream (see the refill below)
-    __shared__ uint32_t lb_hit[16][256], lb_qp[16][256];
+    // lane-private LDS rings: two 64-byte lines of each stream (see the staging below)
+    __shared__ uint32_t lb_hit[32][256];
+    __shared__ uint16_t lb_qp[32][256];   // positions relative to the chunk's first seed (a chunk spans < 20 kb)
     if (t >= total_chunks) return;
     const uint32_t pi = find_pair(pairs, npairs, t);
     const PairDesc pd = pairs[pi];
@@ -310,57 +311,84 @@ __global__ __launch_bounds__(256, 4) void chain_fast_kernel(SetView A, SetView B
     const uint32_t tidx = threadIdx.x;
     const uint64_t hbase = pd.hit_base;          // absolute entry index of seed 0 in the hit array
     const uint32_t *qg_abs = QS.pgpos;           // absolute base of the position array
-    // Control structure against wave divergence: in the INNER loop every lane advances through its
-    // own seeds for as long as they are misses or plain extensions of its current run (a handful of
-    // instructions); a lane that meets anything else parks.  When all 64 lanes have parked or finished,
-    // the general step below runs once for the parked lanes, and the inner loop resumes.  The general
-    // code is therefore executed a few times per chunk instead of once per seed.
-    uint32_t s = s0, rf_h = s0, rf_q = s0;   // rf_*: first seed NOT covered by the lane's LDS strip
+    const uint32_t qphase = (uint32_t)(qoff & 15u);
+    uint32_t s = s0;
     bool dom = false;   // "r0 dominates": no other run or summary can out-score an extension of r0
+    // Control structure against wave divergence.  Work proceeds in ROUNDS that are uniform across the
+    // wave: (1) every lane walks at most 16 seeds of its chunk -- misses and plain extensions of its
+    // current run cost a handful of instructions -- and parks at the first seed that is anything else;
+    // (2) the general step runs once for the lanes that parked.  Nobody waits for more than 16 walk
+    // trips per round, and all loop exits are votes, so the wave stays converged.
+    // Input staging: the hit words of a pair start at an entry congruent (mod 16) to the genome's seed
+    // offset, so 64-byte line k of both streams covers the same 16 seeds.  Each lane keeps the two
+    // lines around its position in a private LDS ring (32 entries per stream) and the following line
+    // in registers: the loads for line k+1 are issued when line k is moved into LDS, a whole round
+    // before they are needed.
+    uint32_t rfa = (s0 + qphase) & ~15u;            // aligned index (seed + qphase) of the line held in registers
+    const uint32_t *hline = hits + (hbase - qphase);  // line k of the hit stream starts at hline + 16 k
+    const uint32_t *qline = qg_abs + (qoff - qphase);
+    const uint32_t qbase = s0 < s1 ? qg[s0] : 0u;
+    uint32_t cur_w = cur_hi - cur_lo;
+    // the record interval must be in registers before the prefetch is issued: a later wait on it
+    // would drain the prefetch as well (vmcnt counts in order)
+    asm volatile("" ::"v"(cur_lo), "v"(cur_w), "v"(qbase));
+    uint4 h0, h1, h2, h3, q0, q1, q2, q3;
+    {
+        const uint4 *srh = reinterpret_cast<const uint4 *>(hline + rfa);
+        const uint4 *srq = reinterpret_cast<const uint4 *>(qline + rfa);
+        h0 = srh[0]; h1 = srh[1]; h2 = srh[2]; h3 = srh[3];
+        q0 = srq[0]; q1 = srq[1]; q2 = srq[2]; q3 = srq[3];
+    }
     for (;;) {
-        bool park = false;
-        uint32_t hw = HIT_NONE;
-        int32_t qp = 0;
-        // refill round: every lane whose LDS strip is used up pulls the next 64-byte line (16 entries,
-        // 4 x 16-B loads) of that stream.  All lanes that need one refill together, so the wave pays
-        // one memory round trip per round, not one per seed
-        if (!cplx && s < s1) {
-            if (s >= rf_h) {
-                const uint64_t ah = hbase + s;
-                const uint4 *src = reinterpret_cast<const uint4 *>(hits + (ah & ~(uint64_t)15));
-                const uint4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
-                lb_hit[0][tidx] = v0.x; lb_hit[1][tidx] = v0.y; lb_hit[2][tidx] = v0.z; lb_hit[3][tidx] = v0.w;
-                lb_hit[4][tidx] = v1.x; lb_hit[5][tidx] = v1.y; lb_hit[6][tidx] = v1.z; lb_hit[7][tidx] = v1.w;
-                lb_hit[8][tidx] = v2.x; lb_hit[9][tidx] = v2.y; lb_hit[10][tidx] = v2.z; lb_hit[11][tidx] = v2.w;
-                lb_hit[12][tidx] = v3.x; lb_hit[13][tidx] = v3.y; lb_hit[14][tidx] = v3.z; lb_hit[15][tidx] = v3.w;
-                rf_h = s + 16u - (uint32_t)(ah & 15u);
-            }
-            if (s >= rf_q) {
-                const uint64_t aq = qoff + s;
-                const uint4 *src = reinterpret_cast<const uint4 *>(qg_abs + (aq & ~(uint64_t)15));
-                const uint4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
-                lb_qp[0][tidx] = v0.x; lb_qp[1][tidx] = v0.y; lb_qp[2][tidx] = v0.z; lb_qp[3][tidx] = v0.w;
-                lb_qp[4][tidx] = v1.x; lb_qp[5][tidx] = v1.y; lb_qp[6][tidx] = v1.z; lb_qp[7][tidx] = v1.w;
-                lb_qp[8][tidx] = v2.x; lb_qp[9][tidx] = v2.y; lb_qp[10][tidx] = v2.z; lb_qp[11][tidx] = v2.w;
-                lb_qp[12][tidx] = v3.x; lb_qp[13][tidx] = v3.y; lb_qp[14][tidx] = v3.z; lb_qp[15][tidx] = v3.w;
-                rf_q = s + 16u - (uint32_t)(aq & 15u);
+        const bool live = !cplx && s < s1;
+        if (live && s + qphase + 16u > rfa) {
+            const uint32_t o = rfa & 16u;
+            lb_hit[o + 0][tidx] = h0.x; lb_hit[o + 1][tidx] = h0.y; lb_hit[o + 2][tidx] = h0.z; lb_hit[o + 3][tidx] = h0.w;
+            lb_hit[o + 4][tidx] = h1.x; lb_hit[o + 5][tidx] = h1.y; lb_hit[o + 6][tidx] = h1.z; lb_hit[o + 7][tidx] = h1.w;
+            lb_hit[o + 8][tidx] = h2.x; lb_hit[o + 9][tidx] = h2.y; lb_hit[o + 10][tidx] = h2.z; lb_hit[o + 11][tidx] = h2.w;
+            lb_hit[o + 12][tidx] = h3.x; lb_hit[o + 13][tidx] = h3.y; lb_hit[o + 14][tidx] = h3.z; lb_hit[o + 15][tidx] = h3.w;
+            lb_qp[o + 0][tidx] = (uint16_t)(q0.x - qbase); lb_qp[o + 1][tidx] = (uint16_t)(q0.y - qbase); lb_qp[o + 2][tidx] = (uint16_t)(q0.z - qbase); lb_qp[o + 3][tidx] = (uint16_t)(q0.w - qbase);
+            lb_qp[o + 4][tidx] = (uint16_t)(q1.x - qbase); lb_qp[o + 5][tidx] = (uint16_t)(q1.y - qbase); lb_qp[o + 6][tidx] = (uint16_t)(q1.z - qbase); lb_qp[o + 7][tidx] = (uint16_t)(q1.w - qbase);
+            lb_qp[o + 8][tidx] = (uint16_t)(q2.x - qbase); lb_qp[o + 9][tidx] = (uint16_t)(q2.y - qbase); lb_qp[o + 10][tidx] = (uint16_t)(q2.z - qbase); lb_qp[o + 11][tidx] = (uint16_t)(q2.w - qbase);
+            lb_qp[o + 12][tidx] = (uint16_t)(q3.x - qbase); lb_qp[o + 13][tidx] = (uint16_t)(q3.y - qbase); lb_qp[o + 14][tidx] = (uint16_t)(q3.z - qbase); lb_qp[o + 15][tidx] = (uint16_t)(q3.w - qbase);
+            rfa += 16u;
+            if (rfa < s1 + qphase) {             // the next line still holds seeds of this chunk
+                const uint4 *srh = reinterpret_cast<const uint4 *>(hline + rfa);
+                const uint4 *srq = reinterpret_cast<const uint4 *>(qline + rfa);
+                h0 = srh[0]; h1 = srh[1]; h2 = srh[2]; h3 = srh[3];
+                q0 = srq[0]; q1 = srq[1]; q2 = srq[2]; q3 = srq[3];
             }
         }
-        while (!cplx && s < s1) {
-            if (s >= rf_h || s >= rf_q) break;    // strip used up: leave for the next refill round
-            const uint64_t ah = hbase + s, aq = qoff + s;
-            hw = lb_hit[ah & 15u][tidx];
-            if (hw == HIT_NONE) { s++; continue; }
-            qp = (int32_t)lb_qp[aq & 15u][tidx];
+#ifdef SKDER_PROFILE_COUNTERS
+        if ((threadIdx.x & 63u) == __ffsll(__ballot(1)) - 1) atomicAdd(slow_count + 13, 1u);      // rounds (per wave)
+#endif
+        {
+            bool park = false;
+            uint32_t hw = HIT_NONE;
+            int32_t qp = 0;
+            uint32_t lim = s + 16u;
+            lim = lim < rfa - qphase ? lim : rfa - qphase;
+            lim = lim < s1 ? lim : s1;
+            lim = cplx ? s : lim;
             // plain extension of the current run: single hit, same record and strand, zero gap cost,
             // inside the 2500-base band, and r0 dominates every other possible predecessor.  r0's last
             // anchor is anchor ia-1, the nearest candidate, and scores r0.f + 20 >= everything else.
-            const uint32_t rpu = hw & 0x7FFFFFFFu;
-            if (dom && (hw & 0xFF000000u) != HIT_MULTI && rpu >= cur_lo && rpu < cur_hi && (hw >> 31) == (r0.rr_last >> 31)) {
+            // (Evaluated without short-circuit branches; a miss fails the record-interval test.)
+            while (s < lim) {
+#ifdef SKDER_PROFILE_COUNTERS
+                if ((threadIdx.x & 63u) == __ffsll(__ballot(1)) - 1) atomicAdd(slow_count + 12, 1u);  // walk trips (per wave)
+#endif
+                const uint32_t row = (qphase + s) & 31u;
+                hw = lb_hit[row][tidx];
+                qp = (int32_t)(qbase + lb_qp[row][tidx]);
+                const uint32_t rpu = hw & 0x7FFFFFFFu;
                 const int32_t dq = qp - (int32_t)r0.q_last;
-                const int32_t rpj = (int32_t)(r0.rr_last & 0x7FFFFFFFu);
-                const int32_t dr = (hw >> 31) ? rpj - (int32_t)rpu : (int32_t)rpu - rpj;
-                if (dq > 0 && dq == dr && dq <= ANI_BP_BAND) {
+                const int32_t d1 = (int32_t)rpu - (int32_t)(r0.rr_last & 0x7FFFFFFFu);
+                const int32_t dr = (int32_t)hw < 0 ? -d1 : d1;
+                const bool plain = dom & ((hw & 0xFF000000u) != HIT_MULTI) & (rpu - cur_lo < cur_w) & ((int32_t)(hw ^ r0.rr_last) >= 0) &
+                                   ((uint32_t)(dq - 1) < (uint32_t)ANI_BP_BAND) & (dq == dr);
+                if ((hw != HIT_NONE) & !plain) { park = true; break; }
+                if (plain) {
                     r0.pmax = r0.f > r0.pmax ? r0.f : r0.pmax;
                     r0.f += ANI_ANCHOR_SCORE;
                     runmax = r0.f > runmax ? r0.f : runmax;
@@ -368,146 +396,151 @@ __global__ __launch_bounds__(256, 4) void chain_fast_kernel(SetView A, SetView B
                     r0.rmin = rpu < r0.rmin ? rpu : r0.rmin;
                     r0.rmax = rpu > r0.rmax ? rpu : r0.rmax;
                     r0.qi_last = s; r0.idx_last = ia;
-                    ia++; s++;
-                    continue;
+                    ia++;
                 }
+                s++;
             }
-            park = true;
-            break;
-        }
-        if (!park) { if (cplx || s >= s1) break; continue; }   // finished / declined, or just a refill
-        // ---- general step for seed s (all of its hits)
-        if (hw == HIT_MANY) { cplx = true; cause = 2; break; }
-        uint32_t m = 1, g0 = hw, g1 = HIT_NONE, g2 = HIT_NONE, g3 = HIT_NONE;
-        if ((hw & 0xFF000000u) == HIT_MULTI) {   // 2..4 occurrences, ascending gpos
-            const uint4 mv = multi[pd.multi_base + (hw & 0x00FFFFFFu)];
-            g0 = mv.x; g1 = mv.y; g2 = mv.z; g3 = mv.w;
-            m = 2u + (g2 != HIT_NONE) + (g3 != HIT_NONE);
-        }
-        dom = false;
-        for (uint32_t u = 0; u < m && !cplx; u++) {
-            const uint32_t rr = g0;
-            g0 = g1; g1 = g2; g2 = g3;
-            const int32_t rp = (int32_t)(rr & 0x7FFFFFFFu);
-            if ((uint32_t)rp < cur_lo || (uint32_t)rp >= cur_hi) {   // record of this hit: binary search
-                uint32_t lo = 0, hi = rnrec;
-                while (hi - lo > 1) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (rgo[mid] <= (uint32_t)rp) lo = mid; else hi = mid;
+#ifdef SKDER_PROFILE_COUNTERS
+            if (park) atomicAdd(slow_count + 10, 1u);                                               // parks (per lane)
+            if (__any(park) && (threadIdx.x & 63u) == __ffsll(__ballot(1)) - 1) atomicAdd(slow_count + 11, 1u);   // general passes (per wave)
+#endif
+            if (park) do {
+                // ---- general step for seed s (all of its hits)
+                if (hw == HIT_MANY) { cplx = true; cause = 2; break; }
+                uint32_t m = 1, g0 = hw, g1 = HIT_NONE, g2 = HIT_NONE, g3 = HIT_NONE;
+                if ((hw & 0xFF000000u) == HIT_MULTI) {   // 2..4 occurrences, ascending gpos
+                    const uint4 mv = multi[pd.multi_base + (hw & 0x00FFFFFFu)];
+                    g0 = mv.x; g1 = mv.y; g2 = mv.z; g3 = mv.w;
+                    m = 2u + (g2 != HIT_NONE) + (g3 != HIT_NONE);
                 }
-                cur_rec = lo; cur_lo = rgo[lo]; cur_hi = rgo[lo + 1];
-            }
-            const uint32_t rc = cur_rec;
-            const uint32_t rev = rr >> 31;
-            const uint32_t key = rc | (rev << 31);
-            const int32_t dg = rev ? rp + qp : rp - qp;
+                dom = false;
+                for (uint32_t u = 0; u < m && !cplx; u++) {
+                    const uint32_t rr = g0;
+                    g0 = g1; g1 = g2; g2 = g3;
+                    const int32_t rp = (int32_t)(rr & 0x7FFFFFFFu);
+                    if ((uint32_t)rp < cur_lo || (uint32_t)rp >= cur_hi) {   // record of this hit: binary search
+                        uint32_t lo = 0, hi = rnrec;
+                        while (hi - lo > 1) {
+                            const uint32_t mid = (lo + hi) >> 1;
+                            if (rgo[mid] <= (uint32_t)rp) lo = mid; else hi = mid;
+                        }
+                        cur_rec = lo; cur_lo = rgo[lo]; cur_hi = rgo[lo + 1]; cur_w = cur_hi - cur_lo;
+                    }
+                    const uint32_t rc = cur_rec;
+                    const uint32_t rev = rr >> 31;
+                    const uint32_t key = rc | (rev << 31);
+                    const int32_t dg = rev ? rp + qp : rp - qp;
 
-            // ---- general case: the oracle's look-back over the last anchors of the ring's runs
-            int32_t best = ANI_ANCHOR_SCORE, pgap = 0;
-            int bj = -1;
-            bool exact = false;
-#define TRY(K, E)                                                                                   \
-            if (!exact && !cplx) {                                                                  \
-                if (!(E).cnt) exact = true;                       /* no older anchors at all */     \
-                else if (best >= runmax + ANI_ANCHOR_SCORE) exact = true;                           \
-                else if (ia - (E).idx_last > ANI_BAND) exact = true;                                \
-                else {                                                                              \
-                    const int32_t dq = qp - (int32_t)(E).q_last;                                    \
-                    if (dq > ANI_BP_BAND) exact = true;                                             \
-                    else if ((E).rctg == rc && ((E).rr_last >> 31) == rev) {                        \
-                        const int32_t rpj = (int32_t)((E).rr_last & 0x7FFFFFFFu);                   \
-                        const int32_t dr = rev ? rpj - rp : rp - rpj;                               \
-                        const int32_t ed = rev ? rpj + (int32_t)(E).q_last : rpj - (int32_t)(E).q_last; /* run diagonal */ \
-                        const int32_t off = dg > ed ? dg - ed : ed - dg;                            \
-                        if (off <= ANI_MAX_GAP) {                                                   \
-                            /* an INTERIOR anchor of the run could be a valid predecessor where the last one is not */ \
-                            const int32_t rf = (int32_t)(E).r_first;                                \
-                            const bool inside = rev ? (rp < rf && dr <= 0) : (rp > rf && dr <= 0);  \
-                            if (dq <= 0 || inside) { cplx = true; cause = 7; }                      \
-                            else if (dr > 0 && dq <= ANI_MAX_LIN && dr <= ANI_MAX_LIN) {            \
-                                const int32_t sc = (E).f + ANI_ANCHOR_SCORE - off;                  \
-                                if (sc > best) { best = sc; bj = (K); pgap = off; }                 \
-                            }                                                                       \
-                        }                                                                           \
-                    }                                                                               \
-                }                                                                                   \
-            }
-            TRY(0, r0) TRY(1, r1) TRY(2, r2) TRY(3, r3)
-#undef TRY
-            if (cplx) break;
-            if (!exact && nevict) {
-                // the look-back would continue into evicted runs: accept only if none of them can matter
-                bool ok = true;
-#define SUMMARY_BLOCKS(SF, SQ, DLO, DHI, KEYOK)                                                                  \
-                if ((KEYOK) && qp - (int32_t)(SQ) <= ANI_BP_BAND) {                                              \
-                    const int32_t off = dg < (DLO) ? (DLO) - dg : (dg > (DHI) ? dg - (DHI) : 0);                  \
-                    if (off <= ANI_MAX_GAP && !(best >= (SF) + ANI_ANCHOR_SCORE - off)) ok = false;               \
+                    // ---- general case: the oracle's look-back over the last anchors of the ring's runs
+                    int32_t best = ANI_ANCHOR_SCORE, pgap = 0;
+                    int bj = -1;
+                    bool exact = false;
+        #define TRY(K, E)                                                                                   \
+                    if (!exact && !cplx) {                                                                  \
+                        if (!(E).cnt) exact = true;                       /* no older anchors at all */     \
+                        else if (best >= runmax + ANI_ANCHOR_SCORE) exact = true;                           \
+                        else if (ia - (E).idx_last > ANI_BAND) exact = true;                                \
+                        else {                                                                              \
+                            const int32_t dq = qp - (int32_t)(E).q_last;                                    \
+                            if (dq > ANI_BP_BAND) exact = true;                                             \
+                            else if ((E).rctg == rc && ((E).rr_last >> 31) == rev) {                        \
+                                const int32_t rpj = (int32_t)((E).rr_last & 0x7FFFFFFFu);                   \
+                                const int32_t dr = rev ? rpj - rp : rp - rpj;                               \
+                                const int32_t ed = rev ? rpj + (int32_t)(E).q_last : rpj - (int32_t)(E).q_last; /* run diagonal */ \
+                                const int32_t off = dg > ed ? dg - ed : ed - dg;                            \
+                                if (off <= ANI_MAX_GAP) {                                                   \
+                                    /* an INTERIOR anchor of the run could be a valid predecessor where the last one is not */ \
+                                    const int32_t rf = (int32_t)(E).r_first;                                \
+                                    const bool inside = rev ? (rp < rf && dr <= 0) : (rp > rf && dr <= 0);  \
+                                    if (dq <= 0 || inside) { cplx = true; cause = 7; }                      \
+                                    else if (dr > 0 && dq <= ANI_MAX_LIN && dr <= ANI_MAX_LIN) {            \
+                                        const int32_t sc = (E).f + ANI_ANCHOR_SCORE - off;                  \
+                                        if (sc > best) { best = sc; bj = (K); pgap = off; }                 \
+                                    }                                                                       \
+                                }                                                                           \
+                            }                                                                               \
+                        }                                                                                   \
+                    }
+                    TRY(0, r0) TRY(1, r1) TRY(2, r2) TRY(3, r3)
+        #undef TRY
+                    if (cplx) break;
+                    if (!exact && nevict) {
+                        // the look-back would continue into evicted runs: accept only if none of them can matter
+                        bool ok = true;
+        #define SUMMARY_BLOCKS(SF, SQ, DLO, DHI, KEYOK)                                                                  \
+                        if ((KEYOK) && qp - (int32_t)(SQ) <= ANI_BP_BAND) {                                              \
+                            const int32_t off = dg < (DLO) ? (DLO) - dg : (dg > (DHI) ? dg - (DHI) : 0);                  \
+                            if (off <= ANI_MAX_GAP && !(best >= (SF) + ANI_ANCHOR_SCORE - off)) ok = false;               \
+                        }
+                        SUMMARY_BLOCKS(s0_f, s0_q, s0_dlo, s0_dhi, s0_seg != 0xFFFFFFFFu && s0_key == key)
+                        SUMMARY_BLOCKS(lost_f, lost_q, lost_dlo, lost_dhi, lost_f != NEG)
+        #undef SUMMARY_BLOCKS
+                        if (!ok) { cplx = true; cause = 3; break; }
+                    }
+                    if (bj >= 0) {
+                        // bring the predecessor run to the front (ring order = recency of the last anchor)
+                        if (bj == 1) { const Run tr = r1; r1 = r0; r0 = tr; }
+                        else if (bj == 2) { const Run tr = r2; r2 = r1; r1 = r0; r0 = tr; }
+                        else if (bj == 3) { const Run tr = r3; r3 = r2; r2 = r1; r1 = r0; r0 = tr; }
+                        if (r0.cnt & SUCC_BIT) { cplx = true; cause = 4; break; }   // two anchors chain to one predecessor
+                        if (pgap == 0) {
+                            // same diagonal: the run simply grows
+                            r0.pmax = r0.f > r0.pmax ? r0.f : r0.pmax;
+                            r0.f = best;
+                            r0.q_last = (uint32_t)qp; r0.rr_last = rr; r0.cnt += 1u;
+                            r0.rmin = (uint32_t)rp < r0.rmin ? (uint32_t)rp : r0.rmin;
+                            r0.rmax = (uint32_t)rp > r0.rmax ? (uint32_t)rp : r0.rmax;
+                            r0.qi_last = s; r0.idx_last = ia;
+                        } else {
+                            // an indel: new run on the same path; the old run's last anchor now has a successor
+                            Run e;
+                            e.q_last = (uint32_t)qp; e.rr_last = rr; e.rctg = rc; e.f = best;
+                            e.cnt = (r0.cnt & 0x7FFFFFFFu) + 1u; e.first_qi = r0.first_qi;
+                            e.rmin = (uint32_t)rp < r0.rmin ? (uint32_t)rp : r0.rmin;
+                            e.rmax = (uint32_t)rp > r0.rmax ? (uint32_t)rp : r0.rmax;
+                            e.qi_last = s; e.idx_last = ia; e.pmax = r0.f > r0.pmax ? r0.f : r0.pmax;
+                            e.r_first = (uint32_t)rp; e.seg = pgap >= ANI_ANCHOR_SCORE ? ia : r0.seg;
+                            r0.cnt |= SUCC_BIT;
+                            EVICT(r3);
+                            r3 = r2; r2 = r1; r1 = r0; r0 = e;
+                        }
+                    } else {
+                        Run e;
+                        e.q_last = (uint32_t)qp; e.rr_last = rr; e.rctg = rc; e.f = best;
+                        e.cnt = 1; e.first_qi = s; e.rmin = e.rmax = (uint32_t)rp;
+                        e.qi_last = s; e.idx_last = ia; e.pmax = NEG; e.r_first = (uint32_t)rp; e.seg = ia;
+                        EVICT(r3);
+                        r3 = r2; r2 = r1; r1 = r0; r0 = e;
+                    }
+                    ia++;
+                    runmax = best > runmax ? best : runmax;
                 }
-                SUMMARY_BLOCKS(s0_f, s0_q, s0_dlo, s0_dhi, s0_seg != 0xFFFFFFFFu && s0_key == key)
-                SUMMARY_BLOCKS(lost_f, lost_q, lost_dlo, lost_dhi, lost_f != NEG)
-#undef SUMMARY_BLOCKS
-                if (!ok) { cplx = true; cause = 3; break; }
-            }
-            if (bj >= 0) {
-                // bring the predecessor run to the front (ring order = recency of the last anchor)
-                if (bj == 1) { const Run tr = r1; r1 = r0; r0 = tr; }
-                else if (bj == 2) { const Run tr = r2; r2 = r1; r1 = r0; r0 = tr; }
-                else if (bj == 3) { const Run tr = r3; r3 = r2; r2 = r1; r1 = r0; r0 = tr; }
-                if (r0.cnt & SUCC_BIT) { cplx = true; cause = 4; break; }   // two anchors chain to one predecessor
-                if (pgap == 0) {
-                    // same diagonal: the run simply grows
-                    r0.pmax = r0.f > r0.pmax ? r0.f : r0.pmax;
-                    r0.f = best;
-                    r0.q_last = (uint32_t)qp; r0.rr_last = rr; r0.cnt += 1u;
-                    r0.rmin = (uint32_t)rp < r0.rmin ? (uint32_t)rp : r0.rmin;
-                    r0.rmax = (uint32_t)rp > r0.rmax ? (uint32_t)rp : r0.rmax;
-                    r0.qi_last = s; r0.idx_last = ia;
-                } else {
-                    // an indel: new run on the same path; the old run's last anchor now has a successor
-                    Run e;
-                    e.q_last = (uint32_t)qp; e.rr_last = rr; e.rctg = rc; e.f = best;
-                    e.cnt = (r0.cnt & 0x7FFFFFFFu) + 1u; e.first_qi = r0.first_qi;
-                    e.rmin = (uint32_t)rp < r0.rmin ? (uint32_t)rp : r0.rmin;
-                    e.rmax = (uint32_t)rp > r0.rmax ? (uint32_t)rp : r0.rmax;
-                    e.qi_last = s; e.idx_last = ia; e.pmax = r0.f > r0.pmax ? r0.f : r0.pmax;
-                    e.r_first = (uint32_t)rp; e.seg = pgap >= ANI_ANCHOR_SCORE ? ia : r0.seg;
-                    r0.cnt |= SUCC_BIT;
-                    EVICT(r3);
-                    r3 = r2; r2 = r1; r1 = r0; r0 = e;
+                if (cplx) break;
+                s++;
+                // does r0 now dominate?  every other run / summary must be unable to offer more than r0.f + 20
+                // to an anchor that extends r0: other record or strand, more than max_gap off r0's diagonal,
+                // out of the 2500-base band for good, or simply not scoring higher than r0
+                if (r0.cnt && !(r0.cnt & SUCC_BIT)) {
+                    const uint32_t k0 = r0.rctg | ((r0.rr_last >> 31) << 31);
+                    const int32_t q0l = (int32_t)r0.q_last;
+                    const int32_t d0 = (r0.rr_last >> 31) ? (int32_t)(r0.rr_last & 0x7FFFFFFFu) + q0l : (int32_t)(r0.rr_last & 0x7FFFFFFFu) - q0l;
+        #define CANNOT_BEAT(E)                                                                              \
+                    (!(E).cnt || ((E).rctg | (((E).rr_last >> 31) << 31)) != k0 || (E).f <= r0.f || q0l - (int32_t)(E).q_last > ANI_BP_BAND || \
+                     abs((((E).rr_last >> 31) ? (int32_t)((E).rr_last & 0x7FFFFFFFu) + (int32_t)(E).q_last                                       \
+                                              : (int32_t)((E).rr_last & 0x7FFFFFFFu) - (int32_t)(E).q_last) - d0) > ANI_MAX_GAP)
+                    dom = CANNOT_BEAT(r1) && CANNOT_BEAT(r2) && CANNOT_BEAT(r3);
+        #undef CANNOT_BEAT
+                    if (dom && s0_seg != 0xFFFFFFFFu)
+                        dom = s0_key != k0 || s0_f <= r0.f || q0l - (int32_t)s0_q > ANI_BP_BAND || d0 < s0_dlo - ANI_MAX_GAP || d0 > s0_dhi + ANI_MAX_GAP;
+                    if (dom && lost_f != NEG)
+                        dom = lost_f <= r0.f || q0l - (int32_t)lost_q > ANI_BP_BAND || d0 < lost_dlo - ANI_MAX_GAP || d0 > lost_dhi + ANI_MAX_GAP;
+                    // the plain-extension test compares the next hit with r0's record interval
+                    if (dom) { const uint32_t rl = r0.rr_last & 0x7FFFFFFFu; if (rl < cur_lo || rl >= cur_hi) dom = false; }
                 }
-            } else {
-                Run e;
-                e.q_last = (uint32_t)qp; e.rr_last = rr; e.rctg = rc; e.f = best;
-                e.cnt = 1; e.first_qi = s; e.rmin = e.rmax = (uint32_t)rp;
-                e.qi_last = s; e.idx_last = ia; e.pmax = NEG; e.r_first = (uint32_t)rp; e.seg = ia;
-                EVICT(r3);
-                r3 = r2; r2 = r1; r1 = r0; r0 = e;
-            }
-            ia++;
-            runmax = best > runmax ? best : runmax;
+            } while (0);
+            asm volatile("" ::"v"(cur_lo), "v"(cur_w));
         }
-        if (cplx) break;
-        s++;
-        // does r0 now dominate?  every other run / summary must be unable to offer more than r0.f + 20
-        // to an anchor that extends r0: other record or strand, more than max_gap off r0's diagonal,
-        // out of the 2500-base band for good, or simply not scoring higher than r0
-        if (r0.cnt && !(r0.cnt & SUCC_BIT)) {
-            const uint32_t k0 = r0.rctg | ((r0.rr_last >> 31) << 31);
-            const int32_t q0l = (int32_t)r0.q_last;
-            const int32_t d0 = (r0.rr_last >> 31) ? (int32_t)(r0.rr_last & 0x7FFFFFFFu) + q0l : (int32_t)(r0.rr_last & 0x7FFFFFFFu) - q0l;
-#define CANNOT_BEAT(E)                                                                              \
-            (!(E).cnt || ((E).rctg | (((E).rr_last >> 31) << 31)) != k0 || (E).f <= r0.f || q0l - (int32_t)(E).q_last > ANI_BP_BAND || \
-             abs((((E).rr_last >> 31) ? (int32_t)((E).rr_last & 0x7FFFFFFFu) + (int32_t)(E).q_last                                       \
-                                      : (int32_t)((E).rr_last & 0x7FFFFFFFu) - (int32_t)(E).q_last) - d0) > ANI_MAX_GAP)
-            dom = CANNOT_BEAT(r1) && CANNOT_BEAT(r2) && CANNOT_BEAT(r3);
-#undef CANNOT_BEAT
-            if (dom && s0_seg != 0xFFFFFFFFu)
-                dom = s0_key != k0 || s0_f <= r0.f || q0l - (int32_t)s0_q > ANI_BP_BAND || d0 < s0_dlo - ANI_MAX_GAP || d0 > s0_dhi + ANI_MAX_GAP;
-            if (dom && lost_f != NEG)
-                dom = lost_f <= r0.f || q0l - (int32_t)lost_q > ANI_BP_BAND || d0 < lost_dlo - ANI_MAX_GAP || d0 > lost_dhi + ANI_MAX_GAP;
-            // the plain-extension test compares the next hit with r0's record interval
-            if (dom) { const uint32_t rl = r0.rr_last & 0x7FFFFFFFu; if (rl < cur_lo || rl >= cur_hi) dom = false; }
-        }
+        if (!__any(!cplx && s < s1)) break;     // the whole wave is finished
     }
     if (!cplx) EMIT_PATH(r3);
     if (!cplx) EMIT_PATH(r2);
@@ -1214,10 +1247,13 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
             d.multi_cap = 256u + Q.n_seeds / 8u;
             if (d.multi_cap > 0x00FFFFF0u) d.multi_cap = 0x00FFFFF0u;
             if (!hp.empty() && nchunks + d.n_chunks > budget) break;
-            if (nchunks + d.n_chunks > 0x7FFF0000ull || ccap + d.c_cap > 0xFFFF0000ull || nhits + Q.n_seeds > 0xFFFF0000ull ||
+            if (nchunks + d.n_chunks > 0x7FFF0000ull || ccap + d.c_cap > 0xFFFF0000ull || nhits + Q.n_seeds + 32u > 0xFFFF0000ull ||
                 nmulti + d.multi_cap > 0xFFFF0000ull) break;
-            d.chunk_base = (uint32_t)nchunks; d.c_base = (uint32_t)ccap; d.hit_base = (uint32_t)nhits; d.multi_base = (uint32_t)nmulti;
-            nchunks += d.n_chunks; ccap += d.c_cap; nhits += (Q.n_seeds + 15u) & ~15u; nmulti += d.multi_cap;
+            // hit words of the pair start at an entry congruent (mod 16) to the genome's seed offset:
+            // chain_fast_kernel's two input streams then change their 64-byte line at the same seeds
+            const uint64_t hb = nhits + ((Q.seed_off - nhits) & 15u);
+            d.chunk_base = (uint32_t)nchunks; d.c_base = (uint32_t)ccap; d.hit_base = (uint32_t)hb; d.multi_base = (uint32_t)nmulti;
+            nchunks += d.n_chunks; ccap += d.c_cap; nhits = (hb + Q.n_seeds + 15u) & ~(uint64_t)15u; nmulti += d.multi_cap;
             hp.push_back(d);
         }
         const uint32_t nb = (uint32_t)hp.size();
@@ -1270,8 +1306,8 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         HIPCHECK(hipStreamSynchronize(st));
         const uint32_t nslow = hcnt[0];
         if (getenv("SKDER_AMD_DEBUG"))
-            fprintf(stderr, "[skder_amd] batch: %u pairs %llu chunks, slow %u (none %u, slots %u, hits %u, ring %u, branch %u, score %u, qrep %u, inside %u)\n",
-                    nb, (unsigned long long)nchunks, nslow, hcnt[1], hcnt[2], hcnt[3], hcnt[4], hcnt[5], hcnt[6], hcnt[7], hcnt[8]);
+            fprintf(stderr, "[skder_amd] batch: %u pairs %llu chunks, slow %u (none %u, slots %u, hits %u, ring %u, branch %u, score %u, qrep %u, inside %u) parks %u passes %u walk-trips %u rounds %u\n",
+                    nb, (unsigned long long)nchunks, nslow, hcnt[1], hcnt[2], hcnt[3], hcnt[4], hcnt[5], hcnt[6], hcnt[7], hcnt[8], hcnt[10], hcnt[11], hcnt[12], hcnt[13]);
         if (nslow) {
             // declined chunks: one wavefront each, in LDS; the rare chunk with more than 1024 anchors is
             // handed on to the global-memory kernels
