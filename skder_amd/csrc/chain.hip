@@ -26,6 +26,7 @@ struct SetView {
     const uint32_t *boff;
     const uint32_t *chunk_start;
     const uint32_t *rec_goff;
+    const uint16_t *rec_lut;
 };
 
 struct PairDesc {
@@ -249,6 +250,7 @@ __global__ __launch_bounds__(256, 3) void chain_fast_kernel(SetView A, SetView B
     const uint32_t *qg = QS.pgpos + qoff;
     const uint32_t s0 = QS.chunk_start[Qm->chunk_off + c], s1 = QS.chunk_start[Qm->chunk_off + c + 1];
     const uint32_t *rgo = RS.rec_goff + Rm->rec_goff_off;
+    const uint16_t *rlut = RS.rec_lut + Rm->rec_lut_off;
     const uint32_t rnrec = Rm->n_rec;
     uint32_t cur_rec = 0, cur_lo = rgo[0], cur_hi = rgo[1];   // record interval of the last hit (hits cluster)
     bool cplx = Qm->rep_cut != 0xFFFFFFFFu;   // own-multiplicity filter active: leave it to the slow path
@@ -374,31 +376,37 @@ __global__ __launch_bounds__(256, 3) void chain_fast_kernel(SetView A, SetView B
             // inside the 2500-base band, and r0 dominates every other possible predecessor.  r0's last
             // anchor is anchor ia-1, the nearest candidate, and scores r0.f + 20 >= everything else.
             // (Evaluated without short-circuit branches; a miss fails the record-interval test.)
-            while (s < lim) {
+            // uniform trip count (scalar loop control); lanes drop out of `act` when they park or reach lim
+            bool act = s < lim;
+            for (int trip = 0; trip < 16; trip++) {
+                if (!__any(act)) break;
 #ifdef SKDER_PROFILE_COUNTERS
                 if ((threadIdx.x & 63u) == __ffsll(__ballot(1)) - 1) atomicAdd(slow_count + 12, 1u);  // walk trips (per wave)
 #endif
-                const uint32_t row = (qphase + s) & 31u;
-                hw = lb_hit[row][tidx];
-                qp = (int32_t)(qbase + lb_qp[row][tidx]);
-                const uint32_t rpu = hw & 0x7FFFFFFFu;
-                const int32_t dq = qp - (int32_t)r0.q_last;
-                const int32_t d1 = (int32_t)rpu - (int32_t)(r0.rr_last & 0x7FFFFFFFu);
-                const int32_t dr = (int32_t)hw < 0 ? -d1 : d1;
-                const bool plain = dom & ((hw & 0xFF000000u) != HIT_MULTI) & (rpu - cur_lo < cur_w) & ((int32_t)(hw ^ r0.rr_last) >= 0) &
-                                   ((uint32_t)(dq - 1) < (uint32_t)ANI_BP_BAND) & (dq == dr);
-                if ((hw != HIT_NONE) & !plain) { park = true; break; }
-                if (plain) {
-                    r0.pmax = r0.f > r0.pmax ? r0.f : r0.pmax;
-                    r0.f += ANI_ANCHOR_SCORE;
-                    runmax = r0.f > runmax ? r0.f : runmax;
-                    r0.q_last = (uint32_t)qp; r0.rr_last = hw; r0.cnt += 1u;
-                    r0.rmin = rpu < r0.rmin ? rpu : r0.rmin;
-                    r0.rmax = rpu > r0.rmax ? rpu : r0.rmax;
-                    r0.qi_last = s; r0.idx_last = ia;
-                    ia++;
+                if (act) {
+                    const uint32_t row = (qphase + s) & 31u;
+                    hw = lb_hit[row][tidx];
+                    qp = (int32_t)(qbase + lb_qp[row][tidx]);
+                    const uint32_t rpu = hw & 0x7FFFFFFFu;
+                    const int32_t dq = qp - (int32_t)r0.q_last;
+                    const int32_t d1 = (int32_t)rpu - (int32_t)(r0.rr_last & 0x7FFFFFFFu);
+                    const int32_t dr = (int32_t)hw < 0 ? -d1 : d1;
+                    const bool plain = dom & ((hw & 0xFF000000u) != HIT_MULTI) & (rpu - cur_lo < cur_w) & ((int32_t)(hw ^ r0.rr_last) >= 0) &
+                                       ((uint32_t)(dq - 1) < (uint32_t)ANI_BP_BAND) & (dq == dr);
+                    park = (hw != HIT_NONE) & !plain;
+                    if (plain) {
+                        r0.pmax = r0.f > r0.pmax ? r0.f : r0.pmax;
+                        r0.f += ANI_ANCHOR_SCORE;
+                        runmax = r0.f > runmax ? r0.f : runmax;
+                        r0.q_last = (uint32_t)qp; r0.rr_last = hw; r0.cnt += 1u;
+                        r0.rmin = rpu < r0.rmin ? rpu : r0.rmin;
+                        r0.rmax = rpu > r0.rmax ? rpu : r0.rmax;
+                        r0.qi_last = s; r0.idx_last = ia;
+                        ia++;
+                    }
+                    s += park ? 0u : 1u;
+                    act = !park & (s < lim);
                 }
-                s++;
             }
 #ifdef SKDER_PROFILE_COUNTERS
             if (park) atomicAdd(slow_count + 10, 1u);                                               // parks (per lane)
@@ -418,13 +426,23 @@ __global__ __launch_bounds__(256, 3) void chain_fast_kernel(SetView A, SetView B
                     const uint32_t rr = g0;
                     g0 = g1; g1 = g2; g2 = g3;
                     const int32_t rp = (int32_t)(rr & 0x7FFFFFFFu);
-                    if ((uint32_t)rp < cur_lo || (uint32_t)rp >= cur_hi) {   // record of this hit: binary search
-                        uint32_t lo = 0, hi = rnrec;
-                        while (hi - lo > 1) {
-                            const uint32_t mid = (lo + hi) >> 1;
-                            if (rgo[mid] <= (uint32_t)rp) lo = mid; else hi = mid;
+#ifdef SKDER_PROFILE_COUNTERS
+                    if (!r0.cnt) atomicAdd(slow_count + 14, 1u);                                   // parks with an empty ring
+                    else if ((uint32_t)rp < cur_lo || (uint32_t)rp >= cur_hi) atomicAdd(slow_count + 9, 1u);   // record change
+#endif
+                    if ((uint32_t)rp < cur_lo || (uint32_t)rp >= cur_hi) {
+                        // record of this hit: look-up table entry of its 2 kb block, then a short forward scan
+                        uint32_t lo = rlut[(uint32_t)rp >> REC_LUT_SHIFT];
+                        if (lo == 65535u) {          // more than 65534 records: finish with a binary search
+                            uint32_t hi = rnrec;
+                            while (hi - lo > 1) {
+                                const uint32_t mid = (lo + hi) >> 1;
+                                if (rgo[mid] <= (uint32_t)rp) lo = mid; else hi = mid;
+                            }
                         }
-                        cur_rec = lo; cur_lo = rgo[lo]; cur_hi = rgo[lo + 1]; cur_w = cur_hi - cur_lo;
+                        uint32_t b0 = rgo[lo], b1 = rgo[lo + 1];
+                        while (b1 <= (uint32_t)rp) { lo++; b0 = b1; b1 = rgo[lo + 1]; }
+                        cur_rec = lo; cur_lo = b0; cur_hi = b1; cur_w = cur_hi - cur_lo;
                     }
                     const uint32_t rc = cur_rec;
                     const uint32_t rev = rr >> 31;
@@ -1146,7 +1164,7 @@ static SetView view_of(skder_sketches *s)
     v.meta = s->d_meta.p;
     v.pkmer = s->seed_kmer.p; v.pgpos = s->seed_gpos.p; v.pchunk = s->pchunk.p;
     v.skmer = s->skmer.p; v.sgpos = s->sgpos.p; v.sctg = s->sctg.p; v.boff = s->boff.p;
-    v.chunk_start = s->chunk_start.p; v.rec_goff = s->d_rec_goff.p;
+    v.chunk_start = s->chunk_start.p; v.rec_goff = s->d_rec_goff.p; v.rec_lut = s->rec_lut.p;
     return v;
 }
 
@@ -1306,8 +1324,8 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         HIPCHECK(hipStreamSynchronize(st));
         const uint32_t nslow = hcnt[0];
         if (getenv("SKDER_AMD_DEBUG"))
-            fprintf(stderr, "[skder_amd] batch: %u pairs %llu chunks, slow %u (none %u, slots %u, hits %u, ring %u, branch %u, score %u, qrep %u, inside %u) parks %u passes %u walk-trips %u rounds %u\n",
-                    nb, (unsigned long long)nchunks, nslow, hcnt[1], hcnt[2], hcnt[3], hcnt[4], hcnt[5], hcnt[6], hcnt[7], hcnt[8], hcnt[10], hcnt[11], hcnt[12], hcnt[13]);
+            fprintf(stderr, "[skder_amd] batch: %u pairs %llu chunks, slow %u (none %u, slots %u, hits %u, ring %u, branch %u, score %u, qrep %u, inside %u) parks %u passes %u walk-trips %u rounds %u empty-ring %u rec-change %u\n",
+                    nb, (unsigned long long)nchunks, nslow, hcnt[1], hcnt[2], hcnt[3], hcnt[4], hcnt[5], hcnt[6], hcnt[7], hcnt[8], hcnt[10], hcnt[11], hcnt[12], hcnt[13], hcnt[14], hcnt[9]);
         if (nslow) {
             // declined chunks: one wavefront each, in LDS; the rare chunk with more than 1024 anchors is
             // handed on to the global-memory kernels

@@ -4,6 +4,7 @@
 
 #define IDX_MAX_BUCKET_BITS 15
 #define IDX_REP_HIST ANI_REP_HIST
+#define REC_LUT_SHIFT 11      /* record look-up table: one entry per 2048 genome positions */
 
 // per-genome record on the device (index stage)
 struct GenomeMeta {
@@ -13,6 +14,7 @@ struct GenomeMeta {
     uint64_t total_len;     // sum of kept record lengths
     uint64_t rec_goff_off;  // offset into d_rec_goff (n_rec+1 entries)
     uint64_t chunk_off;     // offset of its chunk_start table (n_chunks+1 entries)
+    uint64_t rec_lut_off;   // offset of its record look-up table (total_len >> REC_LUT_SHIFT) + 1 entries
     uint32_t n_seeds;
     uint32_t n_markers;
     uint32_t n_rec;
@@ -34,6 +36,7 @@ struct skder_sketches {
     DevBuf<GenomeMeta> d_meta;
     std::vector<GenomeMeta> h_meta;
     DevBuf<uint32_t> d_rec_goff;
+    DevBuf<uint16_t> rec_lut;              // record holding position b << REC_LUT_SHIFT, per genome (clamped to 65535)
     DevBuf<uint32_t> skmer, sgpos, sctg;   // by-(kmer,gpos) order inside each hash bucket
     DevBuf<uint32_t> boff;                 // bucket offset tables
     DevBuf<uint32_t> pchunk;               // chunk id of every seed (position order)

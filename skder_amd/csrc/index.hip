@@ -118,6 +118,26 @@ __global__ __launch_bounds__(256) void index_genome_kernel(
     if (tid == 0) { meta[g].n_chunks = crun; chunk_start_all[m.chunk_off + crun] = n; }
 }
 
+// record look-up table: lut[b] = index of the kept record that holds genome position b << REC_LUT_SHIFT
+// (records are >= 500 bp, so the wanted record is at most a few steps after lut[pos >> REC_LUT_SHIFT])
+__global__ __launch_bounds__(256) void rec_lut_kernel(const GenomeMeta *__restrict__ meta, const uint32_t *__restrict__ rec_goff,
+                                                     uint16_t *__restrict__ lut_all)
+{
+    const GenomeMeta m = meta[blockIdx.x];
+    const uint32_t *rg = rec_goff + m.rec_goff_off;
+    const uint32_t n = (uint32_t)(m.total_len >> REC_LUT_SHIFT) + 1u;
+    uint16_t *lut = lut_all + m.rec_lut_off;
+    for (uint32_t b = threadIdx.x; b < n; b += blockDim.x) {
+        const uint32_t pos = b << REC_LUT_SHIFT;
+        uint32_t lo = 0, hi = m.n_rec;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (rg[mid] <= pos) lo = mid; else hi = mid;
+        }
+        lut[b] = (uint16_t)(lo < 65535u ? lo : 65535u);
+    }
+}
+
 void index_impl(skder_sketches *s)
 {
     if (s->indexed) return;
@@ -125,7 +145,7 @@ void index_impl(skder_sketches *s)
     hipStream_t st = ctx->stream;
     const uint32_t G = s->n_genomes;
     s->h_meta.resize(G);
-    uint64_t boff_total = 0, rg = 0, chunk_total = 0;
+    uint64_t boff_total = 0, rg = 0, chunk_total = 0, lut_total = 0;
     for (uint32_t g = 0; g < G; g++) {
         GenomeMeta &m = s->h_meta[g];
         m.seed_off = s->h_seed_off[g];
@@ -144,6 +164,8 @@ void index_impl(skder_sketches *s)
         m.n_chunks = 0;
         m.rep_cut = 0xFFFFFFFFu;
         m.chunk_off = chunk_total;
+        m.rec_lut_off = lut_total;
+        lut_total += (m.total_len >> REC_LUT_SHIFT) + 1;
         chunk_total += m.total_len / ANI_CHUNK_LEN + m.n_rec + 2;   // upper bound on chunks + sentinel
     }
     const uint64_t ns = s->h_seed_off[G];
@@ -153,6 +175,7 @@ void index_impl(skder_sketches *s)
     s->pchunk.resize(ns + 1, st);
     s->boff.resize(boff_total + 1, st);
     s->chunk_start.resize(chunk_total + 1, st);
+    s->rec_lut.resize(lut_total + 1, st);
     if (G) {
         HIPCHECK(hipMemcpyAsync(s->d_meta.p, s->h_meta.data(), G * sizeof(GenomeMeta), hipMemcpyHostToDevice, st));
         HIPCHECK(hipMemcpyAsync(s->d_rec_goff.p, s->h_rec_goff.data(), s->h_rec_goff.size() * 4, hipMemcpyHostToDevice, st));
@@ -162,6 +185,7 @@ void index_impl(skder_sketches *s)
         hipLaunchKernelGGL(index_genome_kernel, dim3(G), dim3(256), (1u << max_bits) * 4, st, s->d_meta.p,
                            s->d_rec_goff.p, s->seed_kmer.p, s->seed_gpos.p, s->seed_ctg.p, s->skmer.p, s->sgpos.p,
                            s->sctg.p, s->boff.p, s->pchunk.p, s->chunk_start.p);
+        hipLaunchKernelGGL(rec_lut_kernel, dim3(G), dim3(256), 0, st, s->d_meta.p, s->d_rec_goff.p, s->rec_lut.p);
         HIPCHECK(hipEventRecord(ctx->ev[4], st));
         HIPCHECK(hipMemcpyAsync(s->h_meta.data(), s->d_meta.p, G * sizeof(GenomeMeta), hipMemcpyDeviceToHost, st));
         HIPCHECK(hipStreamSynchronize(st));
