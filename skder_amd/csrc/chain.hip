@@ -777,7 +777,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 }
 
 __global__ __launch_bounds__(64 * SLOWW_WAVES) void slow_wave_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs, uint32_t npairs,
-                                                                    const uint32_t *__restrict__ slow_list, uint32_t nslow,
+                                                                    const uint32_t *__restrict__ slow_list, const uint32_t *__restrict__ nslow_ptr,
                                                                     ChainRec *__restrict__ chains, uint32_t *__restrict__ pair_nch,
                                                                     uint32_t *__restrict__ pair_na, uint32_t *__restrict__ over_list,
                                                                     uint32_t *__restrict__ over_count, uint32_t *__restrict__ flags)
@@ -786,10 +786,13 @@ __global__ __launch_bounds__(64 * SLOWW_WAVES) void slow_wave_kernel(SetView A, 
     __shared__ uint32_t s_rc[SLOWW_WAVES][SLOWW_MAXA], s_bp[SLOWW_WAVES][SLOWW_MAXA];
     __shared__ int32_t s_f[SLOWW_WAVES][SLOWW_MAXA];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t w = blockIdx.x * SLOWW_WAVES + wv;
-    if (w >= nslow) return;
+    // the number of declined chunks is only known on the device (no host round trip between the fast
+    // path and this kernel): a fixed grid strides over the list
+    const uint32_t nslow = *nslow_ptr;
     uint32_t *qi = s_qi[wv], *qp = s_qp[wv], *ar = s_rr[wv], *ac = s_rc[wv], *bp = s_bp[wv];
     int32_t *f = s_f[wv];
+    for (uint32_t w = blockIdx.x * SLOWW_WAVES + wv; w < nslow; w += gridDim.x * SLOWW_WAVES) {
+    __builtin_amdgcn_wave_barrier();
     const uint32_t t = slow_list[w];
     const uint32_t pi = find_pair(pairs, npairs, t);
     const PairDesc pd = pairs[pi];
@@ -840,9 +843,9 @@ __global__ __launch_bounds__(64 * SLOWW_WAVES) void slow_wave_kernel(SetView A, 
     }
     if (over) {   // too many anchors for LDS: hand the chunk to the global-memory kernels
         if (lane == 0) over_list[atomicAdd(over_count, 1u)] = t;
-        return;
+        continue;
     }
-    if (!n) return;
+    if (!n) continue;
     if (lane == 0) atomicAdd(&pair_na[pi], n);
     __builtin_amdgcn_wave_barrier();
 
@@ -927,6 +930,7 @@ __global__ __launch_bounds__(64 * SLOWW_WAVES) void slow_wave_kernel(SetView A, 
         }
         __builtin_amdgcn_wave_barrier();
     }
+    }   // declined chunks of this wave
 }
 
 // round(2^32 * (num/den)^(1/15)): Newton on doubles, + - * / only (oracle_root_fx)
@@ -1181,16 +1185,39 @@ static bool chunk_the_query(const GenomeMeta &ref, const GenomeMeta &query)
     return true;
 }
 
-// work buffers of chain_pairs, kept across calls (grow-only) so that steady-state calls allocate nothing
-struct ChainWork {
+// work buffers of chain_pairs, kept across calls (grow-only) so that steady-state calls allocate nothing.
+// Two complete sets (slots): while the device works on the batch of one slot, the host reads back and
+// post-processes the other slot's results and prepares the descriptors of the next batch.
+struct ChainSlot {
     DevBuf<PairDesc> d_pairs;
-    DevBuf<uint32_t> chunk_state, slow_list, counters, pair_na, pair_nch, cap, abase, slow_n, a_qi, a_r, a_rctg, BP;
-    DevBuf<uint32_t> hits, pair_nmulti, groups, over_list;
-    std::vector<JoinGroup> h_groups;
+    DevBuf<uint32_t> chunk_state, slow_list, counters, pair_na, pair_nch;
+    DevBuf<uint32_t> hits, pair_nmulti, groups, over_list, flags;
     DevBuf<uint4> multi;
-    DevBuf<int32_t> F;
     DevBuf<ChainRec> fast_chains, chains;
     DevBuf<PairOut> d_out;
+    std::vector<PairDesc> hp;
+    std::vector<JoinGroup> h_groups;
+    // pinned host mirrors of the small results
+    PairOut *h_out = nullptr;
+    size_t h_out_cap = 0;
+    uint32_t *h_cnt = nullptr;      // [0..15] counters, [16] flags
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // start, join, fast, slow, finalize, results on host
+    size_t p0 = 0;
+    uint32_t nb = 0, lds_cap = 0;
+    uint64_t nchunks = 0;
+    bool busy = false;
+    ~ChainSlot()
+    {
+        if (h_out) (void)hipHostFree(h_out);
+        if (h_cnt) (void)hipHostFree(h_cnt);
+        for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+    }
+};
+struct ChainWork {
+    ChainSlot slot[2];
+    // rare path (chunks with more anchors than the wave kernel holds in LDS)
+    DevBuf<uint32_t> cap, abase, slow_n, a_qi, a_r, a_rctg, BP;
+    DevBuf<int32_t> F;
     DevBuf<uint32_t> root_lut;
     ScanWorkspace ws;
 };
@@ -1217,9 +1244,8 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         W.root_lut.resize(ROOT_LUT * ROOT_LUT, st);
         hipLaunchKernelGGL(root_lut_kernel, dim3(ROOT_LUT * ROOT_LUT / 256), dim3(256), 0, st, W.root_lut.p);
     }
-    std::vector<PairDesc> hp;
-    std::vector<PairOut> ho;
     const SetView VA = view_of(SA), VB = view_of(SB);
+    const int xcd_remap = getenv("SKDER_AMD_NO_XCD") ? 0 : 1;
     double t_fast = 0, t_slow = 0, t_fin = 0, t_join = 0;
     uint64_t tot_anchors = 0, tot_slow = 0, tot_chunks = 0, tot_over = 0;
     // orientation of every pair, then order the work by the probed genome (R): consecutive
@@ -1249,8 +1275,9 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
     if (getenv("SKDER_AMD_DEBUG"))
         fprintf(stderr, "[skder_amd] host: orient+sort of %zu pairs %.2f ms\n", np,
                 std::chrono::duration<double, std::milli>(t_host1 - t_host0).count());
-    size_t p0 = 0;
-    while (p0 < np) {
+    // ---- one batch: descriptors (host), then everything on the stream without a host round trip
+    auto enqueue = [&](ChainSlot &S, size_t p0) -> size_t {
+        std::vector<PairDesc> &hp = S.hp;
         hp.clear();
         uint64_t nchunks = 0, ccap = 0, nhits = 0, nmulti = 0;
         size_t p = p0;
@@ -1275,24 +1302,33 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
             hp.push_back(d);
         }
         const uint32_t nb = (uint32_t)hp.size();
-        W.d_pairs.resize(nb, st);
-        W.chunk_state.resize(nchunks + 1, st); W.slow_list.resize(nchunks + 1, st);
-        W.fast_chains.resize(nchunks * FAST_SLOTS + 1, st);
-        W.counters.resize(16, st);
-        W.pair_na.resize(nb, st); W.pair_nch.resize(nb, st); W.pair_nmulti.resize(nb, st);
-        W.hits.resize(nhits + 32, st); W.multi.resize(nmulti + 1, st);
-        W.chains.resize(ccap + 1, st);
-        W.d_out.resize(nb, st);
-        HIPCHECK(hipMemcpyAsync(W.d_pairs.p, hp.data(), nb * sizeof(PairDesc), hipMemcpyHostToDevice, st));
-        HIPCHECK(hipMemsetAsync(W.pair_nch.p, 0, nb * 4, st));
-        HIPCHECK(hipMemsetAsync(W.pair_na.p, 0, nb * 4, st));
-        HIPCHECK(hipMemsetAsync(W.pair_nmulti.p, 0, nb * 4, st));
-        HIPCHECK(hipMemsetAsync(W.counters.p, 0, 64, st));
-        HIPCHECK(hipMemsetAsync(ctx->d_flags, 0, 64, st));
-        HIPCHECK(hipEventRecord(ctx->ev[11], st));
+        S.p0 = p0; S.nb = nb; S.nchunks = nchunks; S.busy = true;
+        for (auto &e : S.ev) if (!e) HIPCHECK(hipEventCreate(&e));
+        if (!S.h_cnt) HIPCHECK(hipHostMalloc(&S.h_cnt, 32 * sizeof(uint32_t)));
+        if (S.h_out_cap < nb) {
+            if (S.h_out) (void)hipHostFree(S.h_out);
+            S.h_out = nullptr;
+            S.h_out_cap = (size_t)nb + nb / 4 + 1024;
+            HIPCHECK(hipHostMalloc(&S.h_out, S.h_out_cap * sizeof(PairOut)));
+        }
+        S.d_pairs.resize(nb, st);
+        S.chunk_state.resize(nchunks + 1, st); S.slow_list.resize(nchunks + 1, st); S.over_list.resize(nchunks + 1, st);
+        S.fast_chains.resize(nchunks * FAST_SLOTS + 1, st);
+        S.counters.resize(16, st); S.flags.resize(16, st);
+        S.pair_na.resize(nb, st); S.pair_nch.resize(nb, st); S.pair_nmulti.resize(nb, st);
+        S.hits.resize(nhits + 64, st); S.multi.resize(nmulti + 1, st);
+        S.chains.resize(ccap + 1, st);
+        S.d_out.resize(nb, st);
+        HIPCHECK(hipMemcpyAsync(S.d_pairs.p, hp.data(), nb * sizeof(PairDesc), hipMemcpyHostToDevice, st));
+        HIPCHECK(hipMemsetAsync(S.pair_nch.p, 0, nb * 4, st));
+        HIPCHECK(hipMemsetAsync(S.pair_na.p, 0, nb * 4, st));
+        HIPCHECK(hipMemsetAsync(S.pair_nmulti.p, 0, nb * 4, st));
+        HIPCHECK(hipMemsetAsync(S.counters.p, 0, 64, st));
+        HIPCHECK(hipMemsetAsync(S.flags.p, 0, 64, st));
+        HIPCHECK(hipEventRecord(S.ev[0], st));
         {
             // groups of consecutive pairs that probe the same genome, at most 16 pairs each (load balance)
-            std::vector<JoinGroup> &hg = W.h_groups;
+            std::vector<JoinGroup> &hg = S.h_groups;
             hg.clear();
             for (uint32_t i = 0; i < nb;) {
                 uint32_t j = i;
@@ -1302,88 +1338,104 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
                 hg.push_back(g);
                 i = j;
             }
-            W.groups.resize(hg.size() * 2, st);
-            HIPCHECK(hipMemcpyAsync(W.groups.p, hg.data(), hg.size() * sizeof(JoinGroup), hipMemcpyHostToDevice, st));
+            S.groups.resize(hg.size() * 2, st);
+            HIPCHECK(hipMemcpyAsync(S.groups.p, hg.data(), hg.size() * sizeof(JoinGroup), hipMemcpyHostToDevice, st));
             static bool join_attr_set = false;
             if (!join_attr_set) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(join_probe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           JOIN_SMEM_BYTES);
                 join_attr_set = true;
             }
-            hipLaunchKernelGGL(join_probe_kernel, dim3((unsigned)hg.size()), dim3(JOIN_THREADS), JOIN_SMEM_BYTES, st, VA, VB, W.d_pairs.p,
-                               reinterpret_cast<const JoinGroup *>(W.groups.p), W.hits.p, W.multi.p, W.pair_nmulti.p);
+            hipLaunchKernelGGL(join_probe_kernel, dim3((unsigned)hg.size()), dim3(JOIN_THREADS), JOIN_SMEM_BYTES, st, VA, VB, S.d_pairs.p,
+                               reinterpret_cast<const JoinGroup *>(S.groups.p), S.hits.p, S.multi.p, S.pair_nmulti.p);
         }
-        HIPCHECK(hipEventRecord(ctx->ev[5], st));
+        HIPCHECK(hipEventRecord(S.ev[1], st));
         if (nchunks)
-            hipLaunchKernelGGL(chain_fast_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, st, VA, VB, W.d_pairs.p, nb,
-                               (uint32_t)nchunks, W.hits.p, W.multi.p, W.fast_chains.p, W.chunk_state.p, W.slow_list.p, W.counters.p, W.pair_na.p,
-                               getenv("SKDER_AMD_NO_XCD") ? 0 : 1);
-        HIPCHECK(hipEventRecord(ctx->ev[6], st));
-        uint32_t hcnt[16] = {0};
-        HIPCHECK(hipMemcpyAsync(hcnt, W.counters.p, 64, hipMemcpyDeviceToHost, st));
-        HIPCHECK(hipStreamSynchronize(st));
-        const uint32_t nslow = hcnt[0];
-        if (getenv("SKDER_AMD_DEBUG"))
-            fprintf(stderr, "[skder_amd] batch: %u pairs %llu chunks, slow %u (none %u, slots %u, hits %u, ring %u, branch %u, score %u, qrep %u, inside %u) parks %u passes %u walk-trips %u rounds %u empty-ring %u rec-change %u\n",
-                    nb, (unsigned long long)nchunks, nslow, hcnt[1], hcnt[2], hcnt[3], hcnt[4], hcnt[5], hcnt[6], hcnt[7], hcnt[8], hcnt[10], hcnt[11], hcnt[12], hcnt[13], hcnt[14], hcnt[9]);
-        if (nslow) {
-            // declined chunks: one wavefront each, in LDS; the rare chunk with more than 1024 anchors is
-            // handed on to the global-memory kernels
-            W.over_list.resize(nslow + 1, st);
-            hipLaunchKernelGGL(slow_wave_kernel, dim3((nslow + SLOWW_WAVES - 1) / SLOWW_WAVES), dim3(64 * SLOWW_WAVES), 0, st, VA, VB, W.d_pairs.p,
-                               nb, W.slow_list.p, nslow, W.chains.p, W.pair_nch.p, W.pair_na.p, W.over_list.p, W.counters.p + 15, ctx->d_flags);
-            uint32_t nover = 0;
-            HIPCHECK(hipMemcpyAsync(&nover, W.counters.p + 15, 4, hipMemcpyDeviceToHost, st));
-            HIPCHECK(hipStreamSynchronize(st));
-            if (nover) {
-                W.cap.resize(nover + 1, st); W.abase.resize(nover + 1, st); W.slow_n.resize(nover + 1, st);
-                hipLaunchKernelGGL(slow_caps_kernel, dim3((nover + 256) / 256), dim3(256), 0, st, VA, VB, W.d_pairs.p, nb, W.over_list.p,
-                                   nover, W.cap.p);
-                exclusive_scan_u32(W.cap.p, W.abase.p, nover + 1, W.ws, st);
-                uint32_t atotal = 0;
-                HIPCHECK(hipMemcpyAsync(&atotal, W.abase.p + nover, 4, hipMemcpyDeviceToHost, st));
-                HIPCHECK(hipStreamSynchronize(st));
-                W.a_qi.resize(atotal + 1, st); W.a_r.resize(atotal + 1, st); W.a_rctg.resize(atotal + 1, st);
-                W.F.resize(atotal + 1, st); W.BP.resize(atotal + 1, st);
-                hipLaunchKernelGGL(slow_anchors_kernel, dim3((nover + 3) / 4), dim3(256), 0, st, VA, VB, W.d_pairs.p, nb, W.over_list.p, nover,
-                                   W.abase.p, W.a_qi.p, W.a_r.p, W.a_rctg.p, W.slow_n.p, ctx->d_flags);
-                hipLaunchKernelGGL(slow_chain_kernel, dim3((nover + 255) / 256), dim3(256), 0, st, VA, VB, W.d_pairs.p, nb, W.over_list.p, nover,
-                                   W.abase.p, W.slow_n.p, W.a_qi.p, W.a_r.p, W.a_rctg.p, W.F.p, W.BP.p, W.chains.p, W.pair_nch.p,
-                                   W.pair_na.p, ctx->d_flags);
-            }
-            tot_over += nover;
+            hipLaunchKernelGGL(chain_fast_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, st, VA, VB, S.d_pairs.p, nb,
+                               (uint32_t)nchunks, S.hits.p, S.multi.p, S.fast_chains.p, S.chunk_state.p, S.slow_list.p, S.counters.p, S.pair_na.p,
+                               xcd_remap);
+        HIPCHECK(hipEventRecord(S.ev[2], st));
+        // declined chunks: one wavefront each, in LDS (count read on the device); the rare chunk with more
+        // than 1024 anchors is put on over_list and dealt with after the batch's results are back
+        if (nchunks) {
+            const uint64_t want = (nchunks + SLOWW_WAVES - 1) / SLOWW_WAVES;
+            hipLaunchKernelGGL(slow_wave_kernel, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(64 * SLOWW_WAVES), 0, st, VA, VB,
+                               S.d_pairs.p, nb, S.slow_list.p, S.counters.p, S.chains.p, S.pair_nch.p, S.pair_na.p, S.over_list.p,
+                               S.counters.p + 15, S.flags.p);
         }
-        HIPCHECK(hipEventRecord(ctx->ev[7], st));
+        HIPCHECK(hipEventRecord(S.ev[3], st));
         // LDS capacity of the finalize step: the most chains any pair of the batch can plausibly have
         // (3 per chunk on the fast path + slack), rounded up, at most 4096 (132 KB)
         uint32_t max_chunks = 0;
         for (const PairDesc &d : hp) max_chunks = d.n_chunks > max_chunks ? d.n_chunks : max_chunks;
         uint32_t lds_cap = 512;
         while (lds_cap < FAST_SLOTS * max_chunks / 2 + 128 && lds_cap < 4096) lds_cap <<= 1;
-        hipLaunchKernelGGL(finalize_kernel, dim3(nb), dim3(256), lds_cap * 35u, st, VA, VB, W.d_pairs.p, W.fast_chains.p, W.chunk_state.p,
-                           W.chains.p, W.pair_nch.p, W.pair_na.p, W.d_out.p, ctx->d_flags, W.root_lut.p, lds_cap);
-        HIPCHECK(hipEventRecord(ctx->ev[8], st));
-        ho.resize(nb);
-        uint32_t h_flags = 0;
-        HIPCHECK(hipMemcpyAsync(ho.data(), W.d_out.p, nb * sizeof(PairOut), hipMemcpyDeviceToHost, st));
-        HIPCHECK(hipMemcpyAsync(&h_flags, ctx->d_flags, 4, hipMemcpyDeviceToHost, st));
-        HIPCHECK(hipStreamSynchronize(st));
+        S.lds_cap = lds_cap;
+        if (nb)
+            hipLaunchKernelGGL(finalize_kernel, dim3(nb), dim3(256), lds_cap * 35u, st, VA, VB, S.d_pairs.p, S.fast_chains.p, S.chunk_state.p,
+                               S.chains.p, S.pair_nch.p, S.pair_na.p, S.d_out.p, S.flags.p, W.root_lut.p, lds_cap);
+        HIPCHECK(hipEventRecord(S.ev[4], st));
+        HIPCHECK(hipMemcpyAsync(S.h_out, S.d_out.p, nb * sizeof(PairOut), hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipMemcpyAsync(S.h_cnt, S.counters.p, 64, hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipMemcpyAsync(S.h_cnt + 16, S.flags.p, 4, hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipEventRecord(S.ev[5], st));
+        return p;
+    };
+    auto check_flags = [](uint32_t h_flags) {
         if (h_flags & 4u) throw SkError("anchor buffer overflow in the slow path (a chunk has more than 4*seeds+64 anchors)");
         if (h_flags & 8u) throw SkError("chain buffer overflow (a pair has more than 4*chunks+64 slow-path chains)");
         if (h_flags & 16u) throw SkError("pair with more chains than the finalize step holds in LDS (1.5 per chunk + 128, at most 4096)");
+    };
+    // ---- results of a batch: wait for its last copy, rare-path fix-up, edge records
+    auto consume = [&](ChainSlot &S) {
+        HIPCHECK(hipEventSynchronize(S.ev[5]));
+        S.busy = false;
+        const uint32_t nb = S.nb, nslow = S.h_cnt[0], nover = S.h_cnt[15];
         float ms;
-        HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[6])); t_fast += ms;
-        HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[11], ctx->ev[5])); t_join += ms;
-        HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7])); t_slow += ms;
-        HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[7], ctx->ev[8])); t_fin += ms;
-        tot_slow += nslow; tot_chunks += nchunks;
+        HIPCHECK(hipEventElapsedTime(&ms, S.ev[0], S.ev[1])); t_join += ms;
+        HIPCHECK(hipEventElapsedTime(&ms, S.ev[1], S.ev[2])); t_fast += ms;
+        HIPCHECK(hipEventElapsedTime(&ms, S.ev[2], S.ev[3])); t_slow += ms;
+        HIPCHECK(hipEventElapsedTime(&ms, S.ev[3], S.ev[4])); t_fin += ms;
+        if (getenv("SKDER_AMD_DEBUG")) {
+            const uint32_t *hcnt = S.h_cnt;
+            fprintf(stderr, "[skder_amd] batch: %u pairs %llu chunks, slow %u (none %u, slots %u, hits %u, ring %u, branch %u, score %u, qrep %u, inside %u) parks %u passes %u walk-trips %u rounds %u empty-ring %u rec-change %u\n",
+                    nb, (unsigned long long)S.nchunks, nslow, hcnt[1], hcnt[2], hcnt[3], hcnt[4], hcnt[5], hcnt[6], hcnt[7], hcnt[8], hcnt[10], hcnt[11], hcnt[12], hcnt[13], hcnt[14], hcnt[9]);
+        }
+        check_flags(S.h_cnt[16]);
+        if (nover) {
+            // chunks the wave kernel could not hold: global-memory kernels, then the finalize step again.
+            // The slot's buffers are untouched since (the batch in flight uses the other slot).
+            W.cap.resize(nover + 1, st); W.abase.resize(nover + 1, st); W.slow_n.resize(nover + 1, st);
+            HIPCHECK(hipMemsetAsync(S.flags.p, 0, 64, st));
+            hipLaunchKernelGGL(slow_caps_kernel, dim3((nover + 256) / 256), dim3(256), 0, st, VA, VB, S.d_pairs.p, nb, S.over_list.p,
+                               nover, W.cap.p);
+            exclusive_scan_u32(W.cap.p, W.abase.p, nover + 1, W.ws, st);
+            uint32_t atotal = 0;
+            HIPCHECK(hipMemcpyAsync(&atotal, W.abase.p + nover, 4, hipMemcpyDeviceToHost, st));
+            HIPCHECK(hipStreamSynchronize(st));
+            W.a_qi.resize(atotal + 1, st); W.a_r.resize(atotal + 1, st); W.a_rctg.resize(atotal + 1, st);
+            W.F.resize(atotal + 1, st); W.BP.resize(atotal + 1, st);
+            hipLaunchKernelGGL(slow_anchors_kernel, dim3((nover + 3) / 4), dim3(256), 0, st, VA, VB, S.d_pairs.p, nb, S.over_list.p, nover,
+                               W.abase.p, W.a_qi.p, W.a_r.p, W.a_rctg.p, W.slow_n.p, S.flags.p);
+            hipLaunchKernelGGL(slow_chain_kernel, dim3((nover + 255) / 256), dim3(256), 0, st, VA, VB, S.d_pairs.p, nb, S.over_list.p, nover,
+                               W.abase.p, W.slow_n.p, W.a_qi.p, W.a_r.p, W.a_rctg.p, W.F.p, W.BP.p, S.chains.p, S.pair_nch.p,
+                               S.pair_na.p, S.flags.p);
+            hipLaunchKernelGGL(finalize_kernel, dim3(nb), dim3(256), S.lds_cap * 35u, st, VA, VB, S.d_pairs.p, S.fast_chains.p, S.chunk_state.p,
+                               S.chains.p, S.pair_nch.p, S.pair_na.p, S.d_out.p, S.flags.p, W.root_lut.p, S.lds_cap);
+            HIPCHECK(hipMemcpyAsync(S.h_out, S.d_out.p, nb * sizeof(PairOut), hipMemcpyDeviceToHost, st));
+            HIPCHECK(hipMemcpyAsync(S.h_cnt + 16, S.flags.p, 4, hipMemcpyDeviceToHost, st));
+            HIPCHECK(hipStreamSynchronize(st));
+            check_flags(S.h_cnt[16]);
+            tot_over += nover;
+        }
+        tot_slow += nslow; tot_chunks += S.nchunks;
         for (uint32_t i = 0; i < nb; i++) {
-            const PairOut &o = ho[i];
+            const PairOut &o = S.h_out[i];
             tot_anchors += o.n_anchors;
             if (!o.n_chains || !(o.ani > 0.0)) continue;
-            const bool cq = hp[i].flags & 1u;
+            const bool cq = S.hp[i].flags & 1u;
             skder_edge_t e;
-            e.ref = pref[jobs[p0 + i].orig]; e.query = pquery[jobs[p0 + i].orig];
+            e.ref = pref[jobs[S.p0 + i].orig]; e.query = pquery[jobs[S.p0 + i].orig];
             e.ani = o.ani;
             e.af_query = cq ? o.af_q : o.af_r;
             e.af_ref = cq ? o.af_r : o.af_q;
@@ -1392,8 +1444,26 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
             e.ani_fx_sum = o.fx_sum; e.sum_seeds = o.sum_seeds;
             edges.push_back(e);
         }
-        p0 = p;
+    };
+    // ---- two batches in flight: the next one is enqueued before the previous one's results are read
+    const auto t_loop0 = std::chrono::steady_clock::now();
+    try {
+        size_t p0 = 0;
+        int cur = 0;
+        while (p0 < np) {
+            p0 = enqueue(W.slot[cur], p0);
+            if (W.slot[cur ^ 1].busy) consume(W.slot[cur ^ 1]);
+            cur ^= 1;
+        }
+        if (W.slot[cur ^ 1].busy) consume(W.slot[cur ^ 1]);
+    } catch (...) {
+        (void)hipStreamSynchronize(st);
+        W.slot[0].busy = W.slot[1].busy = false;
+        throw;
     }
+    if (getenv("SKDER_AMD_DEBUG"))
+        fprintf(stderr, "[skder_amd] host: batch loop %.2f ms wall (kernels: join %.2f fast %.2f slow %.2f finalize %.2f)\n",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop0).count(), t_join, t_fast, t_slow, t_fin);
     ctx->timing[3] = t_fast; ctx->timing[4] = t_slow; ctx->timing[5] = t_fin;
     ctx->timing[6] = (double)np; ctx->timing[7] = (double)tot_anchors;
     ctx->counters[0] = tot_chunks; ctx->counters[1] = tot_slow; ctx->counters[3] = tot_over;
@@ -1416,7 +1486,11 @@ void triangle_rows_impl(skder_sketches *s, uint32_t row_begin, uint32_t row_stri
     HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[9], ctx->ev[10]));
     ctx->timing[2] = ms;
     // triangle row (i, j): Ref = i, Query = j
+    const auto t0 = std::chrono::steady_clock::now();
     chain_pairs(s, s, prow, ppart, ctx->edges);
+    if (getenv("SKDER_AMD_DEBUG"))
+        fprintf(stderr, "[skder_amd] host: screen %.2f ms (device), chain_pairs %.2f ms wall, %zu edges\n", ms,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), ctx->edges.size());
 }
 
 void rectangle_impl(skder_sketches *refs, skder_sketches *queries, double screen_pct)
