@@ -32,6 +32,23 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t *ws
     return ex + off;
 }
 
+// exclusive scan across a workgroup of NW waves (NW <= 16). wsum: __shared__ uint32_t[NW].
+template <int NW>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *wsum, uint32_t &total)
+{
+    uint32_t wt;
+    uint32_t ex = wave_excl_scan(v, wt);
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    __syncthreads();                 // previous users of wsum are done
+    if (lane == 63u) wsum[wave] = wt;
+    __syncthreads();
+    // every wave scans the NW wave totals itself (NW <= 64 lanes)
+    uint32_t t = lane < (uint32_t)NW ? wsum[lane] : 0u, tt;
+    const uint32_t tex = wave_excl_scan(t, tt);
+    total = tt;
+    return ex + __shfl(tex, (int)wave, 64);
+}
+
 // ---------------------------------------------------------------------------------------------
 // device-wide exclusive scan (u32), three-pass, recursive on the block sums
 

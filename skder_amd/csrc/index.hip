@@ -4,22 +4,24 @@
 //     hashed digit + in-bucket insertion sort; buckets hold ~4 seeds);
 //   * repetitive k-mer cut-off (ani_oracle.c genome_finish);
 //   * chunk id of every seed: (record, (gpos - record_off) / 20000) numbered in position order.
-// One 256-thread workgroup per genome; all counters live in LDS.
+// One 1024-thread workgroup per genome (the 2^15 LDS counters allow one workgroup per CU, so the
+// latency of the global-memory phases is hidden by 16 wavefronts); all counters live in LDS.
 #include "device_utils.h"
 #include "engine.h"
 
-__global__ __launch_bounds__(256) void index_genome_kernel(
-    GenomeMeta *__restrict__ meta, const uint32_t *__restrict__ rec_goff, const uint32_t *__restrict__ seed_kmer,
-    const uint32_t *__restrict__ seed_gpos, const uint32_t *__restrict__ seed_ctg, uint32_t *__restrict__ skmer,
-    uint32_t *__restrict__ sgpos, uint32_t *__restrict__ sctg, uint32_t *__restrict__ boff_all,
+#define IDX_THREADS 1024
+__global__ __launch_bounds__(IDX_THREADS) void index_genome_kernel(
+    GenomeMeta *__restrict__ meta, const uint32_t *__restrict__ list, const uint32_t *__restrict__ rec_goff,
+    const uint32_t *__restrict__ seed_kmer, const uint32_t *__restrict__ seed_gpos, const uint32_t *__restrict__ seed_ctg,
+    uint32_t *__restrict__ skmer, uint32_t *__restrict__ sgpos, uint32_t *__restrict__ sctg, uint32_t *__restrict__ boff_all,
     uint32_t *__restrict__ pchunk, uint32_t *__restrict__ chunk_start_all)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t *cnt = reinterpret_cast<uint32_t *>(smem_raw);   // 2^bits counters, later cursor, later histogram
-    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t wsum[IDX_THREADS / 64];
     __shared__ uint32_t s_distinct;
 
-    const uint32_t g = blockIdx.x, tid = threadIdx.x;
+    const uint32_t g = list[blockIdx.x], tid = threadIdx.x;
     GenomeMeta m = meta[g];
     const uint32_t n = m.n_seeds, bits = m.bucket_bits, nb = 1u << bits;
     const uint32_t *pk = seed_kmer + m.seed_off, *pg = seed_gpos + m.seed_off, *pc = seed_ctg + m.seed_off;
@@ -27,24 +29,24 @@ __global__ __launch_bounds__(256) void index_genome_kernel(
     uint32_t *boff = boff_all + m.bucket_off;
     const uint32_t *rg = rec_goff + m.rec_goff_off;
 
-    for (uint32_t b = tid; b < nb; b += 256) cnt[b] = 0;
+    for (uint32_t b = tid; b < nb; b += IDX_THREADS) cnt[b] = 0;
     if (tid == 0) s_distinct = 0;
     __syncthreads();
-    for (uint32_t s = tid; s < n; s += 256) atomicAdd(&cnt[kmer_bucket(pk[s] & SK_SEED_MASK, bits)], 1u);
+    for (uint32_t s = tid; s < n; s += IDX_THREADS) atomicAdd(&cnt[kmer_bucket(pk[s] & SK_SEED_MASK, bits)], 1u);
     __syncthreads();
     // exclusive scan of the bucket counts -> boff (global); counters are reset for the scatter cursor
     uint32_t running = 0;
-    for (uint32_t base = 0; base < nb; base += 256) {
+    for (uint32_t base = 0; base < nb; base += IDX_THREADS) {
         uint32_t b = base + tid;
         uint32_t v = b < nb ? cnt[b] : 0u;
         uint32_t total;
-        uint32_t ex = block_excl_scan_256(v, wsum, total);
+        uint32_t ex = block_excl_scan<IDX_THREADS / 64>(v, wsum, total);
         if (b < nb) { boff[b] = running + ex; cnt[b] = 0; }
         running += total;
     }
     if (tid == 0) boff[nb] = n;
     __syncthreads();
-    for (uint32_t s = tid; s < n; s += 256) {
+    for (uint32_t s = tid; s < n; s += IDX_THREADS) {
         uint32_t km = pk[s];
         uint32_t b = kmer_bucket(km & SK_SEED_MASK, bits);
         uint32_t pos = boff[b] + atomicAdd(&cnt[b], 1u);
@@ -52,10 +54,10 @@ __global__ __launch_bounds__(256) void index_genome_kernel(
     }
     __syncthreads();   // global writes of this workgroup are visible to it after the barrier
     // histogram of multiplicities reuses the counter array
-    for (uint32_t b = tid; b < IDX_REP_HIST; b += 256) cnt[b] = 0;
+    for (uint32_t b = tid; b < IDX_REP_HIST; b += IDX_THREADS) cnt[b] = 0;
     __syncthreads();
     uint32_t my_distinct = 0;
-    for (uint32_t b = tid; b < nb; b += 256) {
+    for (uint32_t b = tid; b < nb; b += IDX_THREADS) {
         const uint32_t lo = boff[b], hi = (b + 1 == nb) ? n : boff[b + 1];
         // insertion sort by (kmer, gpos); gpos is unique inside a genome, so the order is total
         for (uint32_t i = lo + 1; i < hi; i++) {
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(256) void index_genome_kernel(
     }
     // chunk ids in position order
     uint32_t crun = 0;
-    for (uint32_t base = 0; base < n; base += 256) {
+    for (uint32_t base = 0; base < n; base += IDX_THREADS) {
         uint32_t s = base + tid;
         uint32_t flag = 0;
         if (s < n) {
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(256) void index_genome_kernel(
             }
         }
         uint32_t total;
-        uint32_t ex = block_excl_scan_256(flag, wsum, total);
+        uint32_t ex = block_excl_scan<IDX_THREADS / 64>(flag, wsum, total);
         if (s < n) {
             pchunk[m.seed_off + s] = crun + ex + flag - 1u;
             if (flag) chunk_start_all[m.chunk_off + crun + ex] = s;
@@ -116,6 +118,202 @@ __global__ __launch_bounds__(256) void index_genome_kernel(
         crun += total;
     }
     if (tid == 0) { meta[g].n_chunks = crun; chunk_start_all[m.chunk_off + crun] = n; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS-resident variant for genomes with fewer than 65536 seeds whose tables fit (the normal case):
+// 16-bit bucket counters/cursors packed two per word, a 16-bit permutation of the seed indices, and
+// the multiplicity histogram all live in LDS; global memory sees only coalesced reads of the
+// position-ordered arrays, gathers through the finished permutation and coalesced writes.
+#define IDXF_THREADS 1024
+#define IDXF_FIXED_BYTES (IDX_REP_HIST * 4)
+__host__ __device__ inline size_t idxf_smem_bytes(uint32_t nb, uint32_t n)
+{
+    size_t body = (size_t)nb * 2 + (((size_t)n * 2 + 15) & ~(size_t)15);   // counters/cursors + permutation
+    if (body < 12 * IDXF_THREADS) body = 12 * IDXF_THREADS;                   // phase F: 1024 ballots + 1024 offsets
+    return body + IDXF_FIXED_BYTES;
+}
+static_assert(IDX_REP_HIST == 4 * IDXF_THREADS, "rep-cut scan assumes four histogram bins per thread");
+
+__global__ __launch_bounds__(IDXF_THREADS) void index_genome_lds_kernel(
+    GenomeMeta *__restrict__ meta, const uint32_t *__restrict__ list, const uint32_t *__restrict__ rec_goff,
+    const uint32_t *__restrict__ seed_kmer, const uint32_t *__restrict__ seed_gpos, const uint32_t *__restrict__ seed_ctg,
+    uint32_t *__restrict__ skmer, uint32_t *__restrict__ sgpos, uint32_t *__restrict__ sctg, uint32_t *__restrict__ boff_all,
+    uint32_t *__restrict__ pchunk, uint32_t *__restrict__ chunk_start_all)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ uint32_t wsum[IDXF_THREADS / 64];
+    __shared__ uint32_t s_distinct, s_cut;
+    const uint32_t g = list[blockIdx.x], tid = threadIdx.x;
+    const GenomeMeta m = meta[g];
+    const uint32_t n = m.n_seeds, bits = m.bucket_bits, nb = 1u << bits;
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem_raw);                       // IDX_REP_HIST
+    uint32_t *cntp = hist + IDX_REP_HIST;                                          // nb / 2 words: two 16-bit fields each
+    uint16_t *cur16 = reinterpret_cast<uint16_t *>(cntp);                          // the same fields, one per bucket
+    uint16_t *perm = reinterpret_cast<uint16_t *>(cntp + nb / 2);                  // n
+    const uint32_t *pk = seed_kmer + m.seed_off, *pg = seed_gpos + m.seed_off, *pc = seed_ctg + m.seed_off;
+    uint32_t *ok = skmer + m.seed_off, *og = sgpos + m.seed_off, *oc = sctg + m.seed_off;
+    uint32_t *boff = boff_all + m.bucket_off;
+    const uint32_t *rg = rec_goff + m.rec_goff_off;
+
+    for (uint32_t b = tid; b < nb / 2; b += IDXF_THREADS) cntp[b] = 0;
+    for (uint32_t b = tid; b < IDX_REP_HIST; b += IDXF_THREADS) hist[b] = 0;
+    if (tid == 0) s_distinct = 0;
+    __syncthreads();
+    // A. bucket sizes
+    for (uint32_t s = tid; s < n; s += IDXF_THREADS) {
+        const uint32_t b = kmer_bucket(pk[s] & SK_SEED_MASK, bits);
+        atomicAdd(&cntp[b >> 1], 1u << ((b & 1u) * 16u));
+    }
+    __syncthreads();
+    // B. exclusive scan: every thread owns nb/1024 consecutive 16-bit fields, handled as whole words
+    // (16-byte LDS accesses); sizes become cursors.  Tables with fewer than 2048 buckets: one word per
+    // thread.
+    {
+        const uint32_t nw = nb / 2;                                   // words
+        const uint32_t wper = (nw + IDXF_THREADS - 1) / IDXF_THREADS; // 16 for 2^15 buckets
+        const uint32_t w0 = tid * wper < nw ? tid * wper : nw, w1 = w0 + wper < nw ? w0 + wper : nw;
+        uint32_t loc = 0;
+        if (wper % 4 == 0) {
+            for (uint32_t w = w0; w < w1; w += 4) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(cntp + w);
+                loc += (v.x & 0xFFFFu) + (v.x >> 16) + (v.y & 0xFFFFu) + (v.y >> 16) + (v.z & 0xFFFFu) + (v.z >> 16) + (v.w & 0xFFFFu) + (v.w >> 16);
+            }
+        } else {
+            for (uint32_t w = w0; w < w1; w++) { const uint32_t v = cntp[w]; loc += (v & 0xFFFFu) + (v >> 16); }
+        }
+        uint32_t total;
+        uint32_t run = block_excl_scan<IDXF_THREADS / 64>(loc, wsum, total);
+        auto step = [&run](uint32_t v) {          // two sizes -> two cursors
+            const uint32_t c0 = v & 0xFFFFu, c1 = v >> 16;
+            const uint32_t r = run | ((run + c0) << 16);
+            run += c0 + c1;
+            return r;
+        };
+        if (wper % 4 == 0) {
+            for (uint32_t w = w0; w < w1; w += 4) {
+                uint4 v = *reinterpret_cast<const uint4 *>(cntp + w);
+                v.x = step(v.x); v.y = step(v.y); v.z = step(v.z); v.w = step(v.w);
+                *reinterpret_cast<uint4 *>(cntp + w) = v;
+            }
+        } else {
+            for (uint32_t w = w0; w < w1; w++) cntp[w] = step(cntp[w]);
+        }
+    }
+    __syncthreads();
+    for (uint32_t b = tid; b < nb; b += IDXF_THREADS) boff[b] = cur16[b];
+    if (tid == 0) boff[nb] = n;
+    __syncthreads();
+    // C. permutation: seed indices grouped by bucket (order inside a bucket fixed in D).  A cursor ends
+    // at the start of the next bucket (<= n < 65536), so a field never carries into its neighbour
+    for (uint32_t s = tid; s < n; s += IDXF_THREADS) {
+        const uint32_t b = kmer_bucket(pk[s] & SK_SEED_MASK, bits), sh = (b & 1u) * 16u;
+        const uint32_t pos = (atomicAdd(&cntp[b >> 1], 1u << sh) >> sh) & 0xFFFFu;
+        perm[pos] = (uint16_t)s;
+    }
+    __syncthreads();
+    // D. order inside every bucket by (k-mer, gpos); multiplicity histogram.  Buckets are independent:
+    // strided over the threads (cursor b now holds the END of bucket b)
+    uint32_t my_distinct = 0, ones = 0;
+    for (uint32_t b = tid; b < nb; b += IDXF_THREADS) {
+        const uint32_t lo = b ? cur16[b - 1] : 0u, hi = cur16[b], k = hi - lo;
+        if (k == 1) { ones++; }
+        else if (k == 2) {
+            const uint32_t sa = perm[lo], sb = perm[lo + 1];
+            const uint32_t ka = pk[sa] & SK_SEED_MASK, kb = pk[sb] & SK_SEED_MASK;
+            if (ka == kb) {
+                if (pg[sb] < pg[sa]) { perm[lo] = (uint16_t)sb; perm[lo + 1] = (uint16_t)sa; }
+                atomicAdd(&hist[2], 1u);
+                my_distinct++;
+            } else {
+                if (kb < ka) { perm[lo] = (uint16_t)sb; perm[lo + 1] = (uint16_t)sa; }
+                ones += 2;
+            }
+        } else if (k > 2) {
+            for (uint32_t i = lo + 1; i < hi; i++) {
+                const uint32_t si = perm[i], kk = pk[si] & SK_SEED_MASK, gp = pg[si];
+                uint32_t j = i;
+                while (j > lo) {
+                    const uint32_t sj = perm[j - 1], k2 = pk[sj] & SK_SEED_MASK;
+                    if (k2 < kk || (k2 == kk && pg[sj] < gp)) break;
+                    perm[j] = (uint16_t)sj;
+                    j--;
+                }
+                perm[j] = (uint16_t)si;
+            }
+            for (uint32_t i = lo; i < hi;) {
+                const uint32_t kk = pk[perm[i]] & SK_SEED_MASK;
+                uint32_t j = i + 1;
+                while (j < hi && (pk[perm[j]] & SK_SEED_MASK) == kk) j++;
+                const uint32_t mult = j - i;
+                if (mult == 1) ones++;
+                else { atomicAdd(&hist[mult < IDX_REP_HIST - 1 ? mult : IDX_REP_HIST - 1], 1u); my_distinct++; }
+                i = j;
+            }
+        }
+    }
+    if (ones) atomicAdd(&hist[1], ones);
+    atomicAdd(&s_distinct, my_distinct + ones);
+    __syncthreads();
+    // repetitive cut-off: multiplicity of ascending rank D - D/1000 - 1 == the (D/1000 + 1)-th largest.
+    // Thread t sums bins [4 (T-1-t), +4): a scan in thread order runs from the highest multiplicity down
+    {
+        const uint32_t D = s_distinct, need = D / 1000u + 1u;
+        const uint32_t hb = 4u * (IDXF_THREADS - 1u - tid);
+        const uint32_t c3 = hist[hb + 3], c2 = hist[hb + 2], c1 = hist[hb + 1], c0 = hb ? hist[hb] : 0u;
+        uint32_t total;
+        const uint32_t before = block_excl_scan<IDXF_THREADS / 64>(c3 + c2 + c1 + c0, wsum, total);
+        if (tid == 0) s_cut = 0;
+        __syncthreads();
+        if (D && before < need && before + c3 + c2 + c1 + c0 >= need) {
+            uint32_t cum = before, mval = 0;
+            cum += c3; if (!mval && cum >= need) mval = hb + 3;
+            cum += c2; if (!mval && cum >= need) mval = hb + 2;
+            cum += c1; if (!mval && cum >= need) mval = hb + 1;
+            cum += c0; if (!mval && cum >= need) mval = hb;
+            s_cut = mval;
+        }
+        __syncthreads();
+        if (tid == 0) meta[g].rep_cut = (D && s_cut >= ANI_REP_FLOOR) ? s_cut : 0xFFFFFFFFu;
+    }
+    // E. bucket-ordered arrays: gathers through the permutation, coalesced writes
+    for (uint32_t pos = tid; pos < n; pos += IDXF_THREADS) {
+        const uint32_t s = perm[pos];
+        ok[pos] = pk[s]; og[pos] = pg[s]; oc[pos] = pc[s];
+    }
+    __syncthreads();   // the permutation is dead from here on
+    // F. chunk ids in position order.  Seed s starts a chunk when its (record, 20 kb window) differs
+    // from seed s-1's.  Coalesced passes: ballots of the start flags per 64 seeds (kept in the counter
+    // area, free by now), one scan over the per-ballot counts, ids from ballot prefixes.
+    {
+        unsigned long long *ballots = reinterpret_cast<unsigned long long *>(cntp);     // <= 1024 (n < 65536)
+        uint32_t *blk_off = reinterpret_cast<uint32_t *>(ballots + IDXF_THREADS);      // 1024
+        const uint32_t nblk = (n + 63u) / 64u, lane = tid & 63u;
+        auto start_flag = [&](uint32_t s) -> bool {
+            if (s >= n) return false;
+            if (s == 0) return true;
+            const uint32_t c = pc[s], c2 = pc[s - 1];
+            return c != c2 || (pg[s] - rg[c]) / ANI_CHUNK_LEN != (pg[s - 1] - rg[c2]) / ANI_CHUNK_LEN;
+        };
+        for (uint32_t base = 0; base < nblk * 64u; base += IDXF_THREADS) {
+            const unsigned long long bal = __ballot(start_flag(base + tid));
+            if (lane == 0 && (base + tid) / 64u < nblk) ballots[(base + tid) / 64u] = bal;
+        }
+        __syncthreads();
+        uint32_t total;
+        const uint32_t mine = tid < nblk ? (uint32_t)__popcll(ballots[tid]) : 0u;
+        const uint32_t ex = block_excl_scan<IDXF_THREADS / 64>(mine, wsum, total);
+        if (tid < nblk) blk_off[tid] = ex;
+        __syncthreads();
+        for (uint32_t s = tid; s < n; s += IDXF_THREADS) {
+            const unsigned long long bal = ballots[s / 64u];
+            const uint32_t upto = (uint32_t)__popcll(bal & (~0ull >> (63u - lane)));   // flags at lanes <= mine
+            const uint32_t id = blk_off[s / 64u] + upto;                                // chunks started up to and including s
+            pchunk[m.seed_off + s] = id - 1u;
+            if ((bal >> lane) & 1ull) chunk_start_all[m.chunk_off + id - 1u] = s;
+        }
+        if (tid == 0) { meta[g].n_chunks = total; chunk_start_all[m.chunk_off + total] = n; }
+    }
 }
 
 // record look-up table: lut[b] = index of the kept record that holds genome position b << REC_LUT_SHIFT
@@ -180,11 +378,41 @@ void index_impl(skder_sketches *s)
         HIPCHECK(hipMemcpyAsync(s->d_meta.p, s->h_meta.data(), G * sizeof(GenomeMeta), hipMemcpyHostToDevice, st));
         HIPCHECK(hipMemcpyAsync(s->d_rec_goff.p, s->h_rec_goff.data(), s->h_rec_goff.size() * 4, hipMemcpyHostToDevice, st));
         HIPCHECK(hipEventRecord(ctx->ev[3], st));
-        uint32_t max_bits = 12;   // the multiplicity histogram needs 4096 counters
-        for (uint32_t g = 0; g < G; g++) max_bits = s->h_meta[g].bucket_bits > max_bits ? s->h_meta[g].bucket_bits : max_bits;
-        hipLaunchKernelGGL(index_genome_kernel, dim3(G), dim3(256), (1u << max_bits) * 4, st, s->d_meta.p,
-                           s->d_rec_goff.p, s->seed_kmer.p, s->seed_gpos.p, s->seed_ctg.p, s->skmer.p, s->sgpos.p,
-                           s->sctg.p, s->boff.p, s->pchunk.p, s->chunk_start.p);
+        // genomes whose tables fit in LDS take the LDS-resident kernel, the others the general one
+        const size_t lds_limit = 150 * 1024;
+        std::vector<uint32_t> small, big;
+        size_t small_bytes = 0;
+        uint32_t max_bits = 12;   // the general kernel's multiplicity histogram needs 4096 counters
+        for (uint32_t g = 0; g < G; g++) {
+            const GenomeMeta &m = s->h_meta[g];
+            const size_t need = idxf_smem_bytes(1u << m.bucket_bits, m.n_seeds);
+            if (m.n_seeds < 65536u && need <= lds_limit) {
+                small.push_back(g);
+                small_bytes = need > small_bytes ? need : small_bytes;
+            } else {
+                big.push_back(g);
+                max_bits = m.bucket_bits > max_bits ? m.bucket_bits : max_bits;
+            }
+        }
+        DevBuf<uint32_t> d_list;
+        d_list.resize(G + 1, st);
+        if (!small.empty()) HIPCHECK(hipMemcpyAsync(d_list.p, small.data(), small.size() * 4, hipMemcpyHostToDevice, st));
+        if (!big.empty()) HIPCHECK(hipMemcpyAsync(d_list.p + small.size(), big.data(), big.size() * 4, hipMemcpyHostToDevice, st));
+        if (!small.empty()) {
+            HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(index_genome_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds_limit));
+            hipLaunchKernelGGL(index_genome_lds_kernel, dim3((unsigned)small.size()), dim3(IDXF_THREADS), small_bytes, st, s->d_meta.p, d_list.p,
+                               s->d_rec_goff.p, s->seed_kmer.p, s->seed_gpos.p, s->seed_ctg.p, s->skmer.p, s->sgpos.p, s->sctg.p, s->boff.p,
+                               s->pchunk.p, s->chunk_start.p);
+        }
+        if (!big.empty()) {
+            HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(index_genome_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)((1u << max_bits) * 4)));
+            hipLaunchKernelGGL(index_genome_kernel, dim3((unsigned)big.size()), dim3(IDX_THREADS), (1u << max_bits) * 4, st, s->d_meta.p,
+                               d_list.p + small.size(), s->d_rec_goff.p, s->seed_kmer.p, s->seed_gpos.p, s->seed_ctg.p, s->skmer.p, s->sgpos.p,
+                               s->sctg.p, s->boff.p, s->pchunk.p, s->chunk_start.p);
+        }
+        HIPCHECK(hipStreamSynchronize(st));   // d_list and the host vectors go out of scope
         hipLaunchKernelGGL(rec_lut_kernel, dim3(G), dim3(256), 0, st, s->d_meta.p, s->d_rec_goff.p, s->rec_lut.p);
         HIPCHECK(hipEventRecord(ctx->ev[4], st));
         HIPCHECK(hipMemcpyAsync(s->h_meta.data(), s->d_meta.p, G * sizeof(GenomeMeta), hipMemcpyDeviceToHost, st));
