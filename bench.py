@@ -99,6 +99,7 @@ def main():
         tm = np.zeros(8)
         t0 = time.perf_counter()
         sk = engine.Sketches(ctx)
+        sk.reserve(total_bases // 120, total_bases // 900)     # densities are 1/125 and 1/1000: a few % of slack
         for layout, d in batches:
             sk.sketch_batch(d.data_ptr(), layout)
             t = ctx.timing()

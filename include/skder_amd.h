@@ -88,6 +88,9 @@ skder_sketches_t *skder_amd_sketches_new(skder_ctx_t *ctx);
 void skder_amd_sketches_free(skder_sketches_t *s);
 /* HOT KERNEL: sketch `batch` (bases already on the device) and append the genomes to `s`. */
 int skder_amd_sketch_batch(skder_sketches_t *s, const uint8_t *d_bases, const skder_batch_t *batch);
+/* capacity hint (expected totals over all batches): the seed and marker arrays are allocated once
+ * instead of growing batch by batch.  Purely an optimisation; smaller or larger totals still work. */
+int skder_amd_sketches_reserve(skder_sketches_t *s, uint64_t n_seeds, uint64_t n_markers);
 /* sizes / raw device arrays (position-ordered seeds; sorted unique markers), for all-gather:
  *   seed_off[n_genomes+1], seed_kmer/gpos/ctg[n_seeds]; marker_off[n_genomes+1], markers[n_markers];
  *   genome_len[n_genomes] (sum of kept record lengths), genome_nrec[n_genomes],

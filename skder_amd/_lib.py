@@ -46,6 +46,7 @@ SYMBOLS = {
     "skder_amd_sketches_new": (C.c_void_p, [C.c_void_p]),
     "skder_amd_sketches_free": (None, [C.c_void_p]),
     "skder_amd_sketch_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Batch)]),
+    "skder_amd_sketches_reserve": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64]),
     "skder_amd_sketches_view": (C.c_int, [C.c_void_p, C.POINTER(RawView)]),
     "skder_amd_sketches_append_raw": (C.c_int, [C.c_void_p, C.POINTER(RawView)]),
     "skder_amd_sketches_index": (C.c_int, [C.c_void_p]),

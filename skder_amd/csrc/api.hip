@@ -103,6 +103,20 @@ extern "C" int skder_amd_sketch_batch(skder_sketches_t *s, const uint8_t *d_base
     API_CATCH_CTX(s->ctx, 2)
 }
 
+extern "C" int skder_amd_sketches_reserve(skder_sketches_t *s, uint64_t n_seeds, uint64_t n_markers)
+{
+    if (!s) return 1;
+    API_TRY
+    HIPCHECK(hipSetDevice(s->ctx->device));
+    hipStream_t st = s->ctx->stream;
+    s->seed_kmer.reserve(n_seeds, s->seed_kmer.n, st);
+    s->seed_gpos.reserve(n_seeds + 32, s->seed_gpos.n, st);
+    s->seed_ctg.reserve(n_seeds, s->seed_ctg.n, st);
+    s->markers.reserve(n_markers, s->markers.n, st);
+    return 0;
+    API_CATCH_CTX(s->ctx, 2)
+}
+
 extern "C" int skder_amd_sketches_view(skder_sketches_t *s, skder_raw_view_t *out)
 {
     if (!s || !out) return 1;

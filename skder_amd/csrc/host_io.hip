@@ -184,6 +184,11 @@ void sketch_files(skder_sketches *s, const std::vector<std::string> &paths, Geno
         for (auto &g : gs) {
             names.path.push_back(g.path); names.first_name.push_back(g.first_name); names.n50.push_back(g.n50);
         }
+        if (i0 == 0 && i1 < paths.size()) {
+            // more batches follow: size the seed and marker arrays once, extrapolating from this batch
+            const double f = 1.1 * (double)paths.size() / (double)i1;
+            (void)skder_amd_sketches_reserve(s, (uint64_t)(s->seed_kmer.n * f) + 4096, (uint64_t)(s->markers.n * f) + 4096);
+        }
         i0 = i1;
     }
 }

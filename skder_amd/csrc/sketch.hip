@@ -14,6 +14,8 @@
 //     -> scan of per-tile counts, gather_* kernels -> position-ordered seed arrays per genome
 //     -> marker_sort_kernel    per genome: bitonic sort in LDS + dedup -> sorted unique markers
 // HBM traffic per base: 1 B read (+ 32/8192 halo) ; per seed 12 B written twice, 8 B read once.
+#include <algorithm>
+
 #include "common.h"
 #include "device_utils.h"
 #include "engine.h"
@@ -249,13 +251,11 @@ __global__ __launch_bounds__(256) void marker_sort_kernel(uint64_t *__restrict__
     __syncthreads();
     for (uint32_t k = 2; k <= m; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = threadIdx.x; i < m; i += 256) {
-                uint32_t ixj = i ^ j;
-                if (ixj > i) {
-                    uint64_t a = key[i], b = key[ixj];
-                    bool up = (i & k) == 0;
-                    if ((a > b) == up) { key[i] = b; key[ixj] = a; }
-                }
+            for (uint32_t t = threadIdx.x; t < m / 2; t += 256) {     // one compare-exchange per thread and trip
+                const uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), ixj = i | j;
+                const uint64_t a = key[i], b = key[ixj];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) { key[i] = b; key[ixj] = a; }
             }
             __syncthreads();
         }
@@ -418,7 +418,17 @@ void sketch_batch_impl(skder_sketches *s, const uint8_t *d_bases, const skder_ba
     d_uoff.resize(b->n_genomes + 1, st);
     HIPCHECK(hipMemcpyAsync(d_goff.p, h_goff.data(), (b->n_genomes + 1) * 4, hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemsetAsync(d_nuniq.p, 0, (b->n_genomes + 1) * 4, st));
-    hipLaunchKernelGGL(marker_sort_kernel, dim3(b->n_genomes), dim3(256), MARK_SORT_CAP * 8, st, raw_marks.p, d_goff.p,
+    // LDS for the largest genome of the batch only (32 KB for 3 Mb genomes): several workgroups per CU
+    uint32_t max_raw = 1024;
+    for (uint32_t g = 0; g < b->n_genomes; g++) max_raw = std::max(max_raw, h_goff[g + 1] - h_goff[g]);
+    uint32_t sort_cap = 1024;
+    while (sort_cap < max_raw && sort_cap < MARK_SORT_CAP) sort_cap <<= 1;
+    static bool sort_attr_set = false;
+    if (!sort_attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(marker_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MARK_SORT_CAP * 8);
+        sort_attr_set = true;
+    }
+    hipLaunchKernelGGL(marker_sort_kernel, dim3(b->n_genomes), dim3(256), sort_cap * 8, st, raw_marks.p, d_goff.p,
                        d_nuniq.p, ctx->d_flags);
     exclusive_scan_u32(d_nuniq.p, d_uoff.p, b->n_genomes + 1, ws, st);
     std::vector<uint32_t> h_uoff(b->n_genomes + 1);

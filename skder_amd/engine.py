@@ -136,6 +136,10 @@ class Sketches:
     def __del__(self):
         self.close()
 
+    def reserve(self, n_seeds: int, n_markers: int):
+        """capacity hint for the totals over all batches (avoids re-allocation while batches are appended)"""
+        self.ctx.check(_lib.lib().skder_amd_sketches_reserve(self.h, int(n_seeds), int(n_markers)), "sketches_reserve")
+
     def sketch_batch(self, d_bases_ptr: int, layout: BatchLayout):
         b = layout.c_batch()
         self.ctx.check(_lib.lib().skder_amd_sketch_batch(self.h, d_bases_ptr, C.byref(b)), "sketch_batch")
