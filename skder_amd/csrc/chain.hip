@@ -86,6 +86,7 @@ __device__ __forceinline__ uint32_t find_pair(const PairDesc *__restrict__ pairs
 // Genomes whose index does not fit in LDS are probed in several passes over bucket ranges.
 struct JoinGroup { uint32_t pair_begin, pair_end; };
 #define JOIN_THREADS 1024
+#define JOIN_U 4             // seeds per thread and trip
 #define JOIN_BCAP 16400      // bucket offsets (16-bit, relative to the pass) held in LDS per pass
 #define JOIN_KCAP 30720      // k-mers held in LDS per pass
 #define JOIN_SMEM_BYTES (JOIN_BCAP * 2 + (JOIN_KCAP + 8) * 4)
@@ -137,58 +138,92 @@ __global__ __launch_bounds__(JOIN_THREADS) void join_probe_kernel(SetView A, Set
             const uint32_t *pk = QS.pkmer + Qm->seed_off;
             const uint32_t nq = Qm->n_seeds;
             uint32_t *hit = hits + pd.hit_base;
-            // four independent seeds per thread and iteration: their loads and probes overlap
-            for (uint32_t s0 = tid; s0 < nq; s0 += 4 * JOIN_THREADS) {
-                uint32_t kqv[4], lov[4], hiv[4];
-                bool mine[4];
+            // JOIN_U independent seeds per thread and trip, handled in phases so that the memory operations
+            // of all of them are in flight together: k-mer loads, LDS probes, then ALL position gathers, then
+            // the coalesced hit-word stores; the rare multi-occurrence seeds come last
+            for (uint32_t s0 = tid; s0 < nq; s0 += JOIN_U * JOIN_THREADS) {
+                uint32_t kqv[JOIN_U], lov[JOIN_U], hiv[JOIN_U], firstv[JOIN_U], cntv[JOIN_U], hvv[JOIN_U];
+                bool mine[JOIN_U];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < JOIN_U; u++) {
                     const uint32_t s = s0 + u * JOIN_THREADS;
                     kqv[u] = s < nq ? pk[s] : 0u;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < JOIN_U; u++) {
                     const uint32_t s = s0 + u * JOIN_THREADS;
                     const uint32_t b = kmer_bucket(kqv[u] & SK_SEED_MASK, bits);
                     mine[u] = s < nq && b >= bb0 && b < bb1;      // else: this seed's bucket belongs to another pass
                     lov[u] = mine[u] ? s_boff[b - bb0] : 0u;
                     hiv[u] = mine[u] ? s_boff[b - bb0 + 1] : 0u;
                 }
+                bool any_multi = false;
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    if (!mine[u]) continue;
-                    const uint32_t s = s0 + u * JOIN_THREADS;
-                    const uint32_t kq = kqv[u], kmer = kq & SK_SEED_MASK, lo = lov[u], hi = hiv[u];
+                for (int u = 0; u < JOIN_U; u++) {
+                    const uint32_t kmer = kqv[u] & SK_SEED_MASK;
                     uint32_t cnt = 0, first = 0;
-                    for (uint32_t e = lo; e < hi; e++) {
-                        const uint32_t k2 = (fits ? s_rk[e] : rk[base + e]) & SK_SEED_MASK;
-                        if (k2 == kmer) { if (!cnt) first = e; cnt++; }
-                        else if (k2 > kmer) break;
-                    }
-                    uint32_t hv = HIT_NONE;
-                    if (cnt && cnt <= rrep) {
-                        if (cnt == 1) {
-                            const uint32_t rkm = fits ? s_rk[first] : rk[base + first];
-                            hv = rg[base + first] | (((kq >> 31) != (rkm >> 31)) ? USED_BIT : 0u);
-                        } else if (cnt <= 4) {
-                            const uint32_t slot = atomicAdd(&pair_nmulti[p], 1u);
-                            if (slot < pd.multi_cap) {
-                                uint32_t v[4] = {HIT_NONE, HIT_NONE, HIT_NONE, HIT_NONE};
-                                for (uint32_t w = 0; w < cnt; w++) {
-                                    const uint32_t rkm = fits ? s_rk[first + w] : rk[base + first + w];
-                                    v[w] = rg[base + first + w] | (((kq >> 31) != (rkm >> 31)) ? USED_BIT : 0u);
-                                }
-                                multi[pd.multi_base + slot] = make_uint4(v[0], v[1], v[2], v[3]);
-                                hv = HIT_MULTI | slot;
-                            } else {
-                                hv = HIT_MANY;
+                    if (fits) {
+                        // buckets hold 1-2 seeds on average, ordered by k-mer: the first two entries are
+                        // compared without a loop (reads clamped into the table), longer buckets continue
+                        const uint32_t lo = lov[u], ne = hiv[u] - lo;
+                        const uint32_t k0 = s_rk[lo] & SK_SEED_MASK, k1 = s_rk[lo + 1] & SK_SEED_MASK;   // s_rk has slack behind nk
+                        const bool m0 = ne > 0 && k0 == kmer, m1 = ne > 1 && k1 == kmer;
+                        cnt = (uint32_t)m0 + (uint32_t)m1;
+                        first = m0 ? lo : lo + 1;
+                        if (ne > 2 && !(k1 > kmer)) {
+                            for (uint32_t e = lo + 2; e < hiv[u]; e++) {
+                                const uint32_t k2 = s_rk[e] & SK_SEED_MASK;
+                                if (k2 == kmer) { if (!cnt) first = e; cnt++; }
+                                else if (k2 > kmer) break;
                             }
-                        } else {
-                            hv = HIT_MANY;
+                        }
+                    } else {
+                        for (uint32_t e = lov[u]; e < hiv[u]; e++) {
+                            const uint32_t k2 = rk[base + e] & SK_SEED_MASK;
+                            if (k2 == kmer) { if (!cnt) first = e; cnt++; }
+                            else if (k2 > kmer) break;
                         }
                     }
-                    hit[s] = hv;
+                    if (cnt > rrep) cnt = 0;
+                    cntv[u] = cnt; firstv[u] = first;
+                    any_multi |= cnt > 1;
                 }
+                // all position gathers in flight together: unconditional loads (seeds without a single hit read
+                // the genome's first entry, one broadcast address), combined only after the last one is issued
+                uint32_t gv[JOIN_U], rkmv[JOIN_U];
+#pragma unroll
+                for (int u = 0; u < JOIN_U; u++) {
+                    const uint32_t e = cntv[u] == 1 ? firstv[u] : 0u;
+                    gv[u] = rg[base + e];
+                    rkmv[u] = fits ? s_rk[e] : rk[base + e];
+                }
+#pragma unroll
+                for (int u = 0; u < JOIN_U; u++) {
+                    hvv[u] = cntv[u] == 1 ? (gv[u] | (((kqv[u] >> 31) != (rkmv[u] >> 31)) ? USED_BIT : 0u))
+                                          : (cntv[u] > 4 ? HIT_MANY : HIT_NONE);
+                }
+                if (any_multi) {
+#pragma unroll
+                    for (int u = 0; u < JOIN_U; u++) {
+                        const uint32_t cnt = cntv[u], first = firstv[u];
+                        if (cnt < 2 || cnt > 4) continue;
+                        const uint32_t slot = atomicAdd(&pair_nmulti[p], 1u);
+                        if (slot < pd.multi_cap) {
+                            uint32_t v[4] = {HIT_NONE, HIT_NONE, HIT_NONE, HIT_NONE};
+                            for (uint32_t w = 0; w < cnt; w++) {
+                                const uint32_t rkm = fits ? s_rk[first + w] : rk[base + first + w];
+                                v[w] = rg[base + first + w] | (((kqv[u] >> 31) != (rkm >> 31)) ? USED_BIT : 0u);
+                            }
+                            multi[pd.multi_base + slot] = make_uint4(v[0], v[1], v[2], v[3]);
+                            hvv[u] = HIT_MULTI | slot;
+                        } else {
+                            hvv[u] = HIT_MANY;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < JOIN_U; u++)
+                    if (mine[u]) hit[s0 + u * JOIN_THREADS] = hvv[u];
             }
         }
         bb0 = bb1;
