@@ -113,7 +113,7 @@ def main():
         sk.index()
         tm[1] += ctx.timing()[1] - (0 if world > 1 else 0)
         t3 = time.perf_counter()
-        edges = sk.triangle_rows(rank, world, args.screen)
+        edges = sk.triangle_rows(rank, world, args.screen, copy=False)   # a view of the library's host buffer
         t4 = time.perf_counter()
         wall["sketch"] += t1 - t0; wall["exchange"] += t2 - t1; wall["index"] += t3 - t2; wall["triangle"] += t4 - t3
         t = ctx.timing()

@@ -178,24 +178,25 @@ class Sketches:
     def index(self):
         self.ctx.check(_lib.lib().skder_amd_sketches_index(self.h), "sketches_index")
 
-    def _edges(self, p, n) -> np.ndarray:
+    def _edges(self, p, n, copy=True) -> np.ndarray:
         if not n.value:
             return np.zeros(0, EDGE_DTYPE)
         raw = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n.value * EDGE_DTYPE.itemsize,))
-        return raw.view(EDGE_DTYPE).copy()
+        return raw.view(EDGE_DTYPE).copy() if copy else raw.view(EDGE_DTYPE)
 
-    def triangle_rows(self, row_begin: int = 0, row_stride: int = 1, screen_pct: float = 80.0) -> np.ndarray:
+    def triangle_rows(self, row_begin: int = 0, row_stride: int = 1, screen_pct: float = 80.0, copy: bool = True) -> np.ndarray:
+        """copy=False: a view of the library's edge buffer, valid until the next call on this context"""
         p = C.POINTER(Edge)()
         n = C.c_uint64(0)
         self.ctx.check(_lib.lib().skder_amd_triangle_rows(self.h, row_begin, row_stride, screen_pct, C.byref(p), C.byref(n)),
                        "triangle_rows")
-        return self._edges(p, n)
+        return self._edges(p, n, copy)
 
-    def rectangle(self, queries: "Sketches", screen_pct: float = 80.0) -> np.ndarray:
+    def rectangle(self, queries: "Sketches", screen_pct: float = 80.0, copy: bool = True) -> np.ndarray:
         p = C.POINTER(Edge)()
         n = C.c_uint64(0)
         self.ctx.check(_lib.lib().skder_amd_rectangle(self.h, queries.h, screen_pct, C.byref(p), C.byref(n)), "rectangle")
-        return self._edges(p, n)
+        return self._edges(p, n, copy)
 
     def debug_genome(self, g: int, n_seeds: int) -> dict:
         nch, rep, bits = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
