@@ -1480,6 +1480,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
             edges.push_back(e);
         }
     };
+    edges.reserve(edges.size() + np);
     // ---- two batches in flight: the next one is enqueued before the previous one's results are read
     const auto t_loop0 = std::chrono::steady_clock::now();
     try {
