@@ -798,8 +798,8 @@ __global__ __launch_bounds__(256) void slow_chain_kernel(SetView A, SetView B, c
 // candidates of one anchor (packed max-reduce: score first, nearest predecessor on ties), then extracts
 // chains best end first with back-tracking by lane 0.  Chunks with more than SLOWW_MAXA anchors are
 // passed on to the global-memory kernels above.
-#define SLOWW_MAXA 1024
-#define SLOWW_WAVES 2        // wavefronts (chunks) per workgroup
+#define SLOWW_MAXA 384
+#define SLOWW_WAVES 4        // wavefronts (chunks) per workgroup
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 {
@@ -1433,8 +1433,8 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         HIPCHECK(hipEventElapsedTime(&ms, S.ev[3], S.ev[4])); t_fin += ms;
         if (getenv("SKDER_AMD_DEBUG")) {
             const uint32_t *hcnt = S.h_cnt;
-            fprintf(stderr, "[skder_amd] batch: %u pairs %llu chunks, slow %u (none %u, slots %u, hits %u, ring %u, branch %u, score %u, qrep %u, inside %u) parks %u passes %u walk-trips %u rounds %u empty-ring %u rec-change %u\n",
-                    nb, (unsigned long long)S.nchunks, nslow, hcnt[1], hcnt[2], hcnt[3], hcnt[4], hcnt[5], hcnt[6], hcnt[7], hcnt[8], hcnt[10], hcnt[11], hcnt[12], hcnt[13], hcnt[14], hcnt[9]);
+            fprintf(stderr, "[skder_amd] batch: over %u; %u pairs %llu chunks, slow %u (none %u, slots %u, hits %u, ring %u, branch %u, score %u, qrep %u, inside %u) parks %u passes %u walk-trips %u rounds %u empty-ring %u rec-change %u\n",
+                    nover, nb, (unsigned long long)S.nchunks, nslow, hcnt[1], hcnt[2], hcnt[3], hcnt[4], hcnt[5], hcnt[6], hcnt[7], hcnt[8], hcnt[10], hcnt[11], hcnt[12], hcnt[13], hcnt[14], hcnt[9]);
         }
         check_flags(S.h_cnt[16]);
         if (nover) {
