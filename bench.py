@@ -175,7 +175,8 @@ def main():
         try:
             if N == 5000 and world == 1:
                 pm = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")))[dom]
-                traffic = (pm["FETCH_SIZE"]["sum_counter_kb"] + pm["WRITE_SIZE"]["sum_counter_kb"]) * 1024.0
+                # counter values corrected by the calibration of profiles/calib (profiles/summarise.py)
+                traffic = sum(pm[c].get("corrected_bytes", pm[c]["sum_counter_kb"] * 1024.0) for c in ("FETCH_SIZE", "WRITE_SIZE"))
         except Exception:
             traffic = None
         out = {
