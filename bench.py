@@ -70,7 +70,10 @@ def main():
     backend = os.environ.get("SKDER_AMD_DIST_BACKEND", "nccl")
     ndev = torch.cuda.device_count()
     dev = local_rank % max(ndev, 1)
-    if world > 1:
+    # SKDER_AMD_FORCE_DIST=1 (under torch.distributed.run with one process) drives the whole N > 1 code
+    # path -- RCCL process group, sketch all-gather on device tensors, edge gather -- on a single GPU
+    dist_on = world > 1 or (os.environ.get("SKDER_AMD_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ)
+    if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
@@ -105,13 +108,13 @@ def main():
             t = ctx.timing()
             tm[0] += t[0]; tm[1] += t[1]
         t1 = time.perf_counter()
-        if world > 1:
+        if dist_on:
             raw = multigpu.exchange_raw(multigpu.raw_from_sketches(sk), staging="cpu" if backend != "nccl" else None)
             sk.close()
             sk = multigpu.sketches_from_raw(ctx, raw)
         t2 = time.perf_counter()
         sk.index()
-        tm[1] += ctx.timing()[1] - (0 if world > 1 else 0)
+        tm[1] += ctx.timing()[1]
         t3 = time.perf_counter()
         edges = sk.triangle_rows(rank, world, args.screen, copy=False)   # a view of the library's host buffer
         t4 = time.perf_counter()
@@ -119,14 +122,14 @@ def main():
         t = ctx.timing()
         tm[2:] = t[2:]
         step.counters = ctx.counters()
-        if world > 1:
+        if dist_on:
             edges = multigpu.gather_edges(edges)
         sk.close()
         return edges, tm
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -139,7 +142,7 @@ def main():
         tms.append(tm)
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -147,7 +150,7 @@ def main():
     pairs = N * (N - 1) // 2
     tm = np.mean(tms, axis=0)
     n_chained_all = float(tm[6])
-    if world > 1:
+    if dist_on:
         t = torch.tensor([tm[6]], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         n_chained_all = float(t.item())
@@ -206,7 +209,7 @@ def main():
                                              % (t_sk, t_pair, npair, N, int(n_chain_total))}
         print(json.dumps(out))
     ctx.close()
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -66,14 +66,27 @@ def exchange_raw(raw: Dict, group=None, staging: str = None) -> Dict:
 
 
 def gather_edges(edges: np.ndarray, group=None) -> np.ndarray:
-    """edge records of all ranks on rank 0 (others get an empty array)"""
+    """edge records of all ranks on rank 0 (others get an empty array).  The records travel as raw bytes
+    in one padded all-gather (device tensors under RCCL, host tensors under gloo), rank order kept."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    bufs = [None] * world if rank == 0 else None
-    dist.gather_object(edges, bufs, dst=0, group=group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    item = edges.dtype.itemsize
+    n = torch.tensor([len(edges)], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    counts = [int(x.item()) for x in sizes]
+    mx = max(max(counts), 1)
+    buf = torch.zeros(mx * item, dtype=torch.uint8, device=dev)
+    if len(edges):
+        raw = np.ascontiguousarray(edges).view(np.uint8).reshape(-1)
+        buf[: raw.size] = torch.from_numpy(raw.copy()).to(dev)
+    out = [torch.empty(mx * item, dtype=torch.uint8, device=dev) for _ in range(world)]
+    dist.all_gather(out, buf, group=group)
     if rank != 0:
-        return edges[:0]
-    return np.concatenate(bufs) if bufs else edges
+        return edges[:0].copy()
+    parts = [out[r][: counts[r] * item].cpu().numpy().view(edges.dtype) for r in range(world)]
+    return np.concatenate(parts) if parts else edges[:0].copy()
 
 
 def raw_from_sketches(sk) -> Dict:

@@ -617,3 +617,25 @@ def test_sketch_store_round_trip(gpu, tmp_path):
     assert (tmp_path / "run1" / "Concatenated_N50.txt").read_text() == (tmp_path / "run2" / "Concatenated_N50.txt").read_text()
     assert (tmp_path / "run1" / "Skani_Triangle_Edge_Output.txt").read_text() == \
         (tmp_path / "run2" / "Skani_Triangle_Edge_Output.txt").read_text()
+
+
+def test_rccl_process_group_on_one_gpu(gpu):
+    """the N > 1 code path with the REAL backend (nccl = RCCL): one rank under torch.distributed.run, device
+    tensors through all_gather / all_gather_object / gather_object; same edges as the plain path"""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    common = ["--genomes", "40", "--genome-len", "200000", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    env = dict(os.environ, SKDER_AMD_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("SKDER_AMD_DIST_BACKEND", None)
+    rc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                         "127.0.0.1", "--master-port", str(29900 + os.getpid() % 90), os.path.join(ROOT, "bench.py"), "--gpus", "1"]
+                        + common, capture_output=True, text=True, env=env, timeout=900)
+    assert rc.returncode == 0, rc.stderr[-3000:]
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    j2 = json.loads([l for l in rc.stdout.splitlines() if l.startswith("{")][-1])
+    assert j1["config"]["edges"] == j2["config"]["edges"] > 0
+    assert j1["config"]["chained_pairs"] == j2["config"]["chained_pairs"]
