@@ -23,6 +23,15 @@ struct GenomeMeta {
     uint32_t rep_cut;       // filled by the index kernel
 };
 
+// marker -> genome-list inverted index of a sketch set (screen.hip); built on the first screen against
+// the set and kept, so the per-representative searches of low_mem_greedy do not rebuild it
+struct ScreenIndex {
+    bool built = false;
+    uint64_t ts = 0;                       // table size (power of two)
+    DevBuf<uint64_t> keys;                 // open-addressing table of marker k-mers
+    DevBuf<uint32_t> loff, list, slot_of;  // per slot: offset of its genome list; lists; slot of every marker occurrence
+};
+
 struct skder_sketches {
     skder_ctx *ctx = nullptr;
     uint32_t n_genomes = 0;
@@ -41,6 +50,7 @@ struct skder_sketches {
     DevBuf<uint32_t> boff;                 // bucket offset tables
     DevBuf<uint32_t> pchunk;               // chunk id of every seed (position order)
     DevBuf<uint32_t> chunk_start;          // first seed of every chunk (+ end sentinel), per genome
+    ScreenIndex screen;
 };
 
 void sketch_batch_impl(skder_sketches *s, const uint8_t *d_bases, const skder_batch_t *b);

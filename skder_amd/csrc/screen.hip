@@ -172,22 +172,30 @@ void screen_pairs(skder_sketches *refs, skder_sketches *queries, const std::vect
     const uint32_t nrows = (uint32_t)rows.size(), nref = refs->n_genomes;
     if (!nrows || !nref) return;
     const uint64_t total_marks = refs->h_marker_off[nref];
-    uint64_t ts = 1024;
-    while (ts < 2 * total_marks) ts <<= 1;
-    if (ts > 0x80000000ull) throw SkError("marker table too large");
-    DevBuf<uint64_t> keys;
-    DevBuf<uint32_t> cnt, loff, cursor, slot_of, list, d_rows, row_count, row_off, q_slot;
-    DevBuf<unsigned long long> pass_bits;
-    keys.resize(ts, st); cnt.resize(ts + 1, st); loff.resize(ts + 1, st); cursor.resize(ts, st);
-    slot_of.resize(total_marks + 1, st); list.resize(total_marks + 1, st);
-    hipLaunchKernelGGL(table_clear_kernel, dim3(2048), dim3(256), 0, st, keys.p, cnt.p, ts);
-    HIPCHECK(hipMemsetAsync(cnt.p + ts, 0, 4, st));
-    HIPCHECK(hipMemsetAsync(cursor.p, 0, ts * 4, st));
-    hipLaunchKernelGGL(table_insert_kernel, dim3(nref), dim3(256), 0, st, refs->d_meta.p, refs->markers.p,
-                       reinterpret_cast<unsigned long long *>(keys.p), cnt.p, ts - 1, slot_of.p);
+    ScreenIndex &X = refs->screen;
     ScanWorkspace ws;
-    exclusive_scan_u32(cnt.p, loff.p, ts + 1, ws, st);
-    hipLaunchKernelGGL(table_fill_kernel, dim3(nref), dim3(256), 0, st, refs->d_meta.p, slot_of.p, loff.p, cursor.p, list.p);
+    if (!X.built) {
+        uint64_t ts = 1024;
+        while (ts < 2 * total_marks) ts <<= 1;
+        if (ts > 0x80000000ull) throw SkError("marker table too large");
+        DevBuf<uint32_t> cnt, cursor;
+        X.keys.resize(ts, st); cnt.resize(ts + 1, st); X.loff.resize(ts + 1, st); cursor.resize(ts, st);
+        X.slot_of.resize(total_marks + 1, st); X.list.resize(total_marks + 1, st);
+        hipLaunchKernelGGL(table_clear_kernel, dim3(2048), dim3(256), 0, st, X.keys.p, cnt.p, ts);
+        HIPCHECK(hipMemsetAsync(cnt.p + ts, 0, 4, st));
+        HIPCHECK(hipMemsetAsync(cursor.p, 0, ts * 4, st));
+        hipLaunchKernelGGL(table_insert_kernel, dim3(nref), dim3(256), 0, st, refs->d_meta.p, refs->markers.p,
+                           reinterpret_cast<unsigned long long *>(X.keys.p), cnt.p, ts - 1, X.slot_of.p);
+        exclusive_scan_u32(cnt.p, X.loff.p, ts + 1, ws, st);
+        hipLaunchKernelGGL(table_fill_kernel, dim3(nref), dim3(256), 0, st, refs->d_meta.p, X.slot_of.p, X.loff.p, cursor.p, X.list.p);
+        X.ts = ts;
+        X.built = true;
+    }
+    const uint64_t ts = X.ts;
+    DevBuf<uint32_t> d_rows, row_count, row_off, q_slot;
+    DevBuf<unsigned long long> pass_bits;
+    DevBuf<uint64_t> &keys = X.keys;
+    DevBuf<uint32_t> &loff = X.loff, &list = X.list, &slot_of = X.slot_of;
     const uint32_t *q_slot_ptr = slot_of.p;
     if (queries != refs) {
         q_slot.resize(queries->h_marker_off[queries->n_genomes] + 1, st);
