@@ -46,6 +46,56 @@ def cpu_baseline(recipe, n_sample=10):
     return (t2 - t1) / n_sample, (t3 - t2) / max(npair, 1), npair
 
 
+def end_to_end_sample(recipe, batches, n_sample, device):
+    """The file-based drop-in on a bounded sample (second clock): the first n_sample genomes
+    are written as FASTA files (from the device-resident bases), then skder_amd_triangle runs listing ->
+    ingest (read, parse, N50, PCIe copy) -> sketch -> index -> screen -> chain -> TSV on disk."""
+    import shutil
+    import tempfile
+    import ctypes as C
+    import torch
+    from skder_amd import _lib
+    layout, d = batches[0]
+    n_sample = min(n_sample, layout.n_genomes)
+    host = d.cpu().numpy()
+    tmp = tempfile.mkdtemp(prefix="skder_amd_e2e_")
+    try:
+        paths, nbytes, r = [], 0, 0
+        for g in range(n_sample):
+            parts = []
+            for k in range(int(layout.genome_rec_begin[g]), int(layout.genome_rec_begin[g + 1])):
+                o, l = int(layout.rec_off[k]), int(layout.rec_len[k])
+                seq = host[o:o + l]
+                pad = (-l) % 80
+                lines = np.concatenate([seq, np.full(pad, ord("\n"), np.uint8)]).reshape(-1, 80)
+                body = np.concatenate([lines, np.full((lines.shape[0], 1), ord("\n"), np.uint8)], axis=1).reshape(-1)
+                body = body[: l + (l + 79) // 80] if pad == 0 else np.concatenate([body[: (l // 80) * 81], seq[(l // 80) * 80:], [ord("\n")]]).astype(np.uint8)
+                parts.append((">g%d_rec%d synthetic\n" % (g, k)).encode())
+                parts.append(body.tobytes())
+            p = os.path.join(tmp, "g%05d.fasta" % g)
+            with open(p, "wb") as f:
+                blob = b"".join(parts)
+                f.write(blob)
+            nbytes += len(blob)
+            paths.append(p)
+        listing = os.path.join(tmp, "listing.txt")
+        open(listing, "w").write("".join(p + "\n" for p in paths))
+        out = os.path.join(tmp, "edges.tsv")
+        n50 = os.path.join(tmp, "n50.tsv")
+        err = C.create_string_buffer(_lib.ERRLEN)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rc = _lib.lib().skder_amd_triangle_n50(listing.encode(), 50.0, 80.0, device, out.encode(), n50.encode(), err, _lib.ERRLEN)
+        dt = time.perf_counter() - t0
+        if rc != 0:
+            raise RuntimeError(err.value.decode())
+        rows = sum(1 for _ in open(out)) - 1
+        return {"genomes": n_sample, "fasta_bytes": nbytes, "seconds": dt, "rows": rows,
+                "ingest_MB_per_s": nbytes / dt / 1e6}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -56,6 +106,7 @@ def main():
     ap.add_argument("--screen", type=float, default=80.0)
     ap.add_argument("--batch-genomes", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--e2e-genomes", type=int, default=128, help="genomes in the file-based end-to-end sample (0: skip)")
     args = ap.parse_args()
 
     import torch
@@ -207,6 +258,15 @@ def main():
                                    "sample": "oracle (CPU restatement) on 10 genomes of one species: %.3f s/genome sketch, "
                                              "%.4f s/chained pair (%d pairs); extrapolated to %d genomes + %d chained pairs"
                                              % (t_sk, t_pair, npair, N, int(n_chain_total))}
+        if world == 1 and not args.no_cpu_baseline and args.e2e_genomes > 0:
+            # second clock: listing file -> TSV on disk through the drop-in entry point, on a
+            # bounded sample; never part of `value`
+            e = end_to_end_sample(recipe, batches, args.e2e_genomes, dev)
+            e["extrapolated_full_workload_s"] = total_bases * 1.0125 / (e["fasta_bytes"] / e["seconds"]) + ms_per_step * 1e-3
+            e["sample"] = ("skder_amd_triangle_n50 on %d FASTA files written from the resident bases (page cache hot): read, parse, "
+                           "N50, PCIe copy, sketch, index, screen, chain, TSV; extrapolation = full workload's FASTA bytes at the "
+                           "sample's rate + one device step" % e["genomes"])
+            out["end_to_end"] = e
         print(json.dumps(out))
     ctx.close()
     if dist_on:

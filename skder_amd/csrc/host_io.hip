@@ -40,34 +40,58 @@ void read_fasta(const std::string &path, HostGenome &g)
             g.bases.resize(rec_start);   // records below 500 bp are ignored entirely
         }
     };
+    // line-oriented scan of the inflated stream: sequence lines are appended in bulk (memchr for the
+    // line end, one pass that drops blanks only when a line has any), header lines are collected whole
     bool at_line_start = true;
     for (;;) {
         int n = gzread(f, buf.data(), (unsigned)buf.size());
         if (n < 0) { gzclose(f); throw SkError("read error in " + path); }
         if (n == 0) break;
-        for (int i = 0; i < n; i++) {
-            char c = buf[i];
+        const char *p = buf.data(), *end = p + n;
+        while (p < end) {
+            const char *nl = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
+            const char *le = nl ? nl : end;                    // end of this piece of the line
             if (in_header) {
-                if (c == '\n') { in_header = false; at_line_start = true; }
-                else if (c != '\r') cur_name.push_back(c);
+                for (const char *q = p; q < le; q++) if (*q != '\r') cur_name.push_back(*q);
+                if (nl) { in_header = false; at_line_start = true; }
+                p = nl ? nl + 1 : end;
                 continue;
             }
-            if (c == '\n') { at_line_start = true; n50_ws = 0; n50_line_has = false; continue; }
-            if (at_line_start && c == '>') {
+            if (at_line_start && p < le && *p == '>') {
                 close_rec();
                 have_rec = true;
                 rec_start = g.bases.size();
                 cur_name.clear();
                 in_header = true;
+                at_line_start = false;
+                p++;
                 continue;
             }
-            at_line_start = false;
-            if (c == '\r' || c == ' ' || c == '\t' || c == '\v' || c == '\f') {
-                if (n50_line_has) n50_ws++;
-                continue;
+            if (p < le) {
+                at_line_start = false;
+                // fast path: no blank of any kind inside the piece (the normal case)
+                bool clean = true;
+                for (const char *q = p; q < le; q++) {
+                    const char c = *q;
+                    if (c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f') { clean = false; break; }
+                }
+                if (clean) {
+                    n50_cur += n50_ws + (uint64_t)(le - p); n50_ws = 0; n50_line_has = true;
+                    if (have_rec) g.bases.insert(g.bases.end(), reinterpret_cast<const uint8_t *>(p), reinterpret_cast<const uint8_t *>(le));
+                } else {
+                    for (const char *q = p; q < le; q++) {
+                        const char c = *q;
+                        if (c == '\r' || c == ' ' || c == '\t' || c == '\v' || c == '\f') {
+                            if (n50_line_has) n50_ws++;
+                            continue;
+                        }
+                        n50_cur += n50_ws + 1; n50_ws = 0; n50_line_has = true;
+                        if (have_rec) g.bases.push_back((uint8_t)c);
+                    }
+                }
             }
-            n50_cur += n50_ws + 1; n50_ws = 0; n50_line_has = true;
-            if (have_rec) g.bases.push_back((uint8_t)c);
+            if (nl) { at_line_start = true; n50_ws = 0; n50_line_has = false; }
+            p = nl ? nl + 1 : end;
         }
     }
     close_rec();
@@ -102,38 +126,55 @@ std::vector<std::string> read_listing(const std::string &path)
     return v;
 }
 
+// run fn(k) for k in [0, n) on up to nthreads host threads; the first exception is re-thrown
+template <class F>
+static void parallel_for(size_t n, unsigned nthreads, F fn)
+{
+    std::atomic<size_t> next(0);
+    std::atomic<bool> failed(false);
+    std::string first_err;
+    std::vector<std::thread> th;
+    const unsigned nt = (unsigned)std::min<size_t>(nthreads, n ? n : 1);
+    for (unsigned t = 0; t < nt; t++)
+        th.emplace_back([&]() {
+            for (;;) {
+                const size_t k = next.fetch_add(1);
+                if (k >= n || failed.load()) break;
+                try { fn(k); }
+                catch (const std::exception &e) {
+                    if (!failed.exchange(true)) first_err = e.what();
+                }
+            }
+        });
+    for (auto &t : th) t.join();
+    if (failed) throw SkError(first_err);
+}
+
 void sketch_files(skder_sketches *s, const std::vector<std::string> &paths, GenomeNames &names)
 {
     skder_ctx *ctx = s->ctx;
     hipStream_t st = ctx->stream;
-    const size_t batch_bytes = 1ull << 30;
+    size_t batch_bytes = 256ull << 20;   // per batch of bases: small enough that pinning the staging buffer is cheap
+    if (const char *e = getenv("SKDER_AMD_IO_BATCH_MB")) batch_bytes = (size_t)std::max(1, atoi(e)) << 20;
+    unsigned nthreads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    if (const char *e = getenv("SKDER_AMD_IO_THREADS")) nthreads = (unsigned)std::max(1, atoi(e));
+    // staging buffers are kept across batches (pinned host + device), grown when a batch needs more
+    uint8_t *h = nullptr, *d = nullptr;
+    size_t h_cap = 0;
+    struct Staging {
+        uint8_t *&h, *&d;
+        ~Staging() { if (d) (void)hipFree(d); if (h) (void)hipHostFree(h); }
+    } staging{h, d};
     size_t i0 = 0;
-    unsigned nthreads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     while (i0 < paths.size()) {
         // read files in parallel until the batch holds ~1 GB of bases
         std::vector<HostGenome> gs;
         size_t i1 = i0, bytes = 0;
         while (i1 < paths.size() && bytes < batch_bytes) {
-            size_t chunk = std::min<size_t>(paths.size() - i1, 64);
-            size_t base = gs.size();
+            const size_t chunk = std::min<size_t>(paths.size() - i1, 2 * (size_t)nthreads);
+            const size_t base = gs.size();
             gs.resize(base + chunk);
-            std::atomic<size_t> next(0);
-            std::string first_err;
-            std::atomic<bool> failed(false);
-            std::vector<std::thread> th;
-            for (unsigned t = 0; t < nthreads; t++)
-                th.emplace_back([&]() {
-                    for (;;) {
-                        size_t k = next.fetch_add(1);
-                        if (k >= chunk) break;
-                        try { read_fasta(paths[i1 + k], gs[base + k]); }
-                        catch (const std::exception &e) {
-                            if (!failed.exchange(true)) first_err = e.what();
-                        }
-                    }
-                });
-            for (auto &t : th) t.join();
-            if (failed) throw SkError(first_err);
+            parallel_for(chunk, nthreads, [&](size_t k) { read_fasta(paths[i1 + k], gs[base + k]); });
             for (size_t k = 0; k < chunk; k++) bytes += gs[base + k].bases.size();
             i1 += chunk;
         }
@@ -151,36 +192,33 @@ void sketch_files(skder_sketches *s, const std::vector<std::string> &paths, Geno
         }
         gbegin.push_back((uint32_t)rec_len.size());
         const uint64_t total = off + SKDER_TILE + 64;
-        uint8_t *h = nullptr, *d = nullptr;
-        HIPCHECK(hipHostMalloc(&h, total));
-        memset(h, 'A', 32);
-        {
-            size_t r = 0;
-            for (auto &g : gs) {
-                size_t src = 0;
-                for (uint32_t l : g.rec_len) {
-                    memcpy(h + rec_off[r], g.bases.data() + src, l);
-                    uint64_t padded = (l + 31ull) & ~31ull;
-                    memset(h + rec_off[r] + l, 'A', padded - l);
-                    src += l; r++;
-                }
-            }
-            memset(h + off, 'A', SKDER_TILE + 64);
+        if (total > h_cap) {
+            if (d) (void)hipFree(d);
+            if (h) (void)hipHostFree(h);
+            h = d = nullptr;
+            h_cap = total + total / 8;
+            HIPCHECK(hipHostMalloc(&h, h_cap));
+            HIPCHECK(hipMalloc(&d, h_cap));
         }
-        HIPCHECK(hipMalloc(&d, total));
+        memset(h, 'A', 32);
+        parallel_for(gs.size(), nthreads, [&](size_t gi) {        // every genome's records into the pinned buffer
+            const HostGenome &g = gs[gi];
+            size_t src = 0, r = gbegin[gi];
+            for (uint32_t l : g.rec_len) {
+                memcpy(h + rec_off[r], g.bases.data() + src, l);
+                const uint64_t padded = (l + 31ull) & ~31ull;
+                memset(h + rec_off[r] + l, 'A', padded - l);
+                src += l; r++;
+            }
+        });
+        memset(h + off, 'A', SKDER_TILE + 64);
         HIPCHECK(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, st));
         skder_batch_t b;
         b.n_genomes = (uint32_t)gs.size();
         b.n_records = (uint32_t)rec_len.size();
         b.rec_off = rec_off.data(); b.rec_len = rec_len.data(); b.genome_rec_begin = gbegin.data();
-        try {
-            sketch_batch_impl(s, d, &b);
-        } catch (...) {
-            (void)hipFree(d); (void)hipHostFree(h);
-            throw;
-        }
+        sketch_batch_impl(s, d, &b);
         HIPCHECK(hipStreamSynchronize(st));
-        (void)hipFree(d); (void)hipHostFree(h);
         for (auto &g : gs) {
             names.path.push_back(g.path); names.first_name.push_back(g.first_name); names.n50.push_back(g.n50);
         }
