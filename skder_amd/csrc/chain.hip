@@ -23,10 +23,10 @@ struct SetView {
     const GenomeMeta *meta;
     const uint32_t *pkmer, *pgpos, *pchunk;   // position order
     const uint32_t *skmer, *sgpos, *sctg;     // bucket order
+    const uint32_t *stag;                     // bucket order: sgpos | (sctg & 63) << 24
     const uint32_t *boff;
     const uint32_t *chunk_start;
     const uint32_t *rec_goff;
-    const uint16_t *rec_lut;
 };
 
 struct PairDesc {
@@ -81,7 +81,7 @@ __device__ __forceinline__ uint32_t find_pair(const PairDesc *__restrict__ pairs
 // share R, loads R's bucket offsets and bucket-ordered k-mers into LDS once (132 KB for a 3 Mb genome),
 // and then streams the position-ordered k-mers of every chunked genome of the group past it: one
 // coalesced 4-byte read per seed, a probe of the LDS-resident bucket (about 5 LDS reads), a gather of
-// the matched position from R's sgpos array (L2-resident), and one coalesced 4-byte hit word written
+// the matched position (with its record tag) from R's stag array (L2-resident), and one coalesced 4-byte hit word written
 // per seed -- in position order, so nothing is scattered into HBM and no memset is needed.
 // Genomes whose index does not fit in LDS are probed in several passes over bucket ranges.
 struct JoinGroup { uint32_t pair_begin, pair_end; };
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(JOIN_THREADS) void join_probe_kernel(SetView A, Set
     const SetView &RS = (pd0.flags & 4u) ? B : A;
     const GenomeMeta *Rm = RS.meta + pd0.r;
     const uint32_t bits = Rm->bucket_bits, nbk = 1u << bits, rrep = Rm->rep_cut;
-    const uint32_t *rk = RS.skmer + Rm->seed_off, *rg = RS.sgpos + Rm->seed_off, *rb = RS.boff + Rm->bucket_off;
+    const uint32_t *rk = RS.skmer + Rm->seed_off, *rg = RS.stag + Rm->seed_off, *rb = RS.boff + Rm->bucket_off;   // rg: position | record tag
 
     for (uint32_t bb0 = 0; bb0 < nbk;) {
         __syncthreads();
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(JOIN_THREADS) void join_probe_kernel(SetView A, Set
 // reach the current best.  The lane proves as it goes that its result is the oracle's; a chunk where
 // the proof fails (branching chains, best end not last, too many hits or chains) goes to the slow path.
 struct Run {
-    uint32_t q_last, rr_last, rctg;   // last anchor: query pos, ref pos | rev<<31, ref record
+    uint32_t q_last, rr_last;         // last anchor: query pos; hit word (ref pos | record tag << 24 | rev << 31)
     int32_t f;                        // score of the last anchor
     uint32_t cnt;                     // anchors on the PATH ending at the last anchor | SUCC_BIT
     uint32_t first_qi, rmin, rmax;    // path aggregates: first seed index, ref extent
@@ -284,11 +284,9 @@ __global__ __launch_bounds__(256, 3) void chain_fast_kernel(SetView A, SetView B
     const uint64_t qoff = Qm->seed_off;
     const uint32_t *qg = QS.pgpos + qoff;
     const uint32_t s0 = QS.chunk_start[Qm->chunk_off + c], s1 = QS.chunk_start[Qm->chunk_off + c + 1];
-    const uint32_t *rgo = RS.rec_goff + Rm->rec_goff_off;
-    const uint16_t *rlut = RS.rec_lut + Rm->rec_lut_off;
-    const uint32_t rnrec = Rm->n_rec;
-    uint32_t cur_rec = 0, cur_lo = rgo[0], cur_hi = rgo[1];   // record interval of the last hit (hits cluster)
-    bool cplx = Qm->rep_cut != 0xFFFFFFFFu;   // own-multiplicity filter active: leave it to the slow path
+    // own-multiplicity filter active, or positions of the probed genome do not fit a hit word's 24 bits:
+    // leave the chunk to the slow path
+    bool cplx = Qm->rep_cut != 0xFFFFFFFFu || Rm->total_len > (uint64_t)HIT_POS_MASK;
     uint32_t cause = cplx ? 6u : 0u;
 
     const int32_t NEG = -0x40000000;
@@ -296,7 +294,7 @@ __global__ __launch_bounds__(256, 3) void chain_fast_kernel(SetView A, SetView B
     r0.cnt = r1.cnt = r2.cnt = r3.cnt = 0;          // cnt == 0: empty ring position
     r0.f = r1.f = r2.f = r3.f = NEG;
     r0.q_last = r1.q_last = r2.q_last = r3.q_last = 0; r0.rr_last = r1.rr_last = r2.rr_last = r3.rr_last = 0;
-    r0.rctg = r1.rctg = r2.rctg = r3.rctg = 0; r0.first_qi = r1.first_qi = r2.first_qi = r3.first_qi = 0;
+    r0.first_qi = r1.first_qi = r2.first_qi = r3.first_qi = 0;
     r0.rmin = r1.rmin = r2.rmin = r3.rmin = 0; r0.rmax = r1.rmax = r2.rmax = r3.rmax = 0;
     r0.qi_last = r1.qi_last = r2.qi_last = r3.qi_last = 0; r0.idx_last = r1.idx_last = r2.idx_last = r3.idx_last = 0;
     r0.pmax = r1.pmax = r2.pmax = r3.pmax = NEG; r0.r_first = r1.r_first = r2.r_first = r3.r_first = 0;
@@ -316,7 +314,7 @@ __global__ __launch_bounds__(256, 3) void chain_fast_kernel(SetView A, SetView B
             else {                                                                           \
                 ChainRec cr;                                                                 \
                 cr.score = (E).f; cr.n = (E).cnt; cr.n_seeds = (E).qi_last - (E).first_qi + 1; \
-                cr.q0 = qg[(E).first_qi]; cr.q1 = (E).q_last; cr.r0 = (E).rmin; cr.r1 = (E).rmax; cr.rctg = (E).rctg; \
+                cr.q0 = qg[(E).first_qi]; cr.q1 = (E).q_last; cr.r0 = (E).rmin; cr.r1 = (E).rmax; cr.rctg = ((E).rr_last >> HIT_POS_BITS) & 63u; \
                 slots[nfin++] = cr;                                                          \
             }                                                                                \
         }                                                                                    \
@@ -328,9 +326,9 @@ __global__ __launch_bounds__(256, 3) void chain_fast_kernel(SetView A, SetView B
         if ((E).cnt) {                                                                       \
             EMIT_PATH(E);                                                                    \
             nevict++;                                                                        \
-            const uint32_t k3 = (E).rctg | (((E).rr_last >> 31) << 31);                      \
-            const int32_t d3 = ((E).rr_last >> 31) ? (int32_t)((E).rr_last & 0x7FFFFFFFu) + (int32_t)(E).q_last \
-                                                   : (int32_t)((E).rr_last & 0x7FFFFFFFu) - (int32_t)(E).q_last; \
+            const uint32_t k3 = (E).rr_last & HIT_KEY_MASK;                                   \
+            const int32_t d3 = ((E).rr_last >> 31) ? (int32_t)((E).rr_last & HIT_POS_MASK) + (int32_t)(E).q_last \
+                                                   : (int32_t)((E).rr_last & HIT_POS_MASK) - (int32_t)(E).q_last; \
             if ((E).seg == s0_seg) {                                                         \
                 s0_f = (E).f > s0_f ? (E).f : s0_f; s0_q = (E).q_last > s0_q ? (E).q_last : s0_q; \
                 s0_dlo = d3 < s0_dlo ? d3 : s0_dlo; s0_dhi = d3 > s0_dhi ? d3 : s0_dhi;      \
@@ -365,10 +363,9 @@ __global__ __launch_bounds__(256, 3) void chain_fast_kernel(SetView A, SetView B
     const uint32_t *hline = hits + (hbase - qphase);  // line k of the hit stream starts at hline + 16 k
     const uint32_t *qline = qg_abs + (qoff - qphase);
     const uint32_t qbase = s0 < s1 ? qg[s0] : 0u;
-    uint32_t cur_w = cur_hi - cur_lo;
-    // the record interval must be in registers before the prefetch is issued: a later wait on it
-    // would drain the prefetch as well (vmcnt counts in order)
-    asm volatile("" ::"v"(cur_lo), "v"(cur_w), "v"(qbase));
+    // the chunk's first position must be in a register before the prefetch is issued: a later wait on
+    // it would drain the prefetch as well (vmcnt counts in order)
+    asm volatile("" ::"v"(qbase));
     uint4 h0, h1, h2, h3, q0, q1, q2, q3;
     {
         const uint4 *srh = reinterpret_cast<const uint4 *>(hline + rfa);
@@ -422,11 +419,13 @@ __global__ __launch_bounds__(256, 3) void chain_fast_kernel(SetView A, SetView B
                     const uint32_t row = (qphase + s) & 31u;
                     hw = lb_hit[row][tidx];
                     qp = (int32_t)(qbase + lb_qp[row][tidx]);
-                    const uint32_t rpu = hw & 0x7FFFFFFFu;
+                    const uint32_t rpu = hw & HIT_POS_MASK;
                     const int32_t dq = qp - (int32_t)r0.q_last;
-                    const int32_t d1 = (int32_t)rpu - (int32_t)(r0.rr_last & 0x7FFFFFFFu);
+                    const int32_t d1 = (int32_t)rpu - (int32_t)(r0.rr_last & HIT_POS_MASK);
                     const int32_t dr = (int32_t)hw < 0 ? -d1 : d1;
-                    const bool plain = dom & ((hw & 0xFF000000u) != HIT_MULTI) & (rpu - cur_lo < cur_w) & ((int32_t)(hw ^ r0.rr_last) >= 0) &
+                    // same strand and record tag (a miss, a multi word and a too-many word all differ from a
+                    // position word in bit 30), same diagonal, inside the band
+                    const bool plain = dom & (((hw ^ r0.rr_last) & (HIT_KEY_MASK | 0x40000000u)) == 0u) &
                                        ((uint32_t)(dq - 1) < (uint32_t)ANI_BP_BAND) & (dq == dr);
                     park = (hw != HIT_NONE) & !plain;
                     if (plain) {
@@ -460,28 +459,13 @@ __global__ __launch_bounds__(256, 3) void chain_fast_kernel(SetView A, SetView B
                 for (uint32_t u = 0; u < m && !cplx; u++) {
                     const uint32_t rr = g0;
                     g0 = g1; g1 = g2; g2 = g3;
-                    const int32_t rp = (int32_t)(rr & 0x7FFFFFFFu);
+                    const int32_t rp = (int32_t)(rr & HIT_POS_MASK);
 #ifdef SKDER_PROFILE_COUNTERS
                     if (!r0.cnt) atomicAdd(slow_count + 14, 1u);                                   // parks with an empty ring
-                    else if ((uint32_t)rp < cur_lo || (uint32_t)rp >= cur_hi) atomicAdd(slow_count + 9, 1u);   // record change
+                    else if ((rr ^ r0.rr_last) & HIT_KEY_MASK) atomicAdd(slow_count + 9, 1u);                    // strand or record change
 #endif
-                    if ((uint32_t)rp < cur_lo || (uint32_t)rp >= cur_hi) {
-                        // record of this hit: look-up table entry of its 2 kb block, then a short forward scan
-                        uint32_t lo = rlut[(uint32_t)rp >> REC_LUT_SHIFT];
-                        if (lo == 65535u) {          // more than 65534 records: finish with a binary search
-                            uint32_t hi = rnrec;
-                            while (hi - lo > 1) {
-                                const uint32_t mid = (lo + hi) >> 1;
-                                if (rgo[mid] <= (uint32_t)rp) lo = mid; else hi = mid;
-                            }
-                        }
-                        uint32_t b0 = rgo[lo], b1 = rgo[lo + 1];
-                        while (b1 <= (uint32_t)rp) { lo++; b0 = b1; b1 = rgo[lo + 1]; }
-                        cur_rec = lo; cur_lo = b0; cur_hi = b1; cur_w = cur_hi - cur_lo;
-                    }
-                    const uint32_t rc = cur_rec;
                     const uint32_t rev = rr >> 31;
-                    const uint32_t key = rc | (rev << 31);
+                    const uint32_t key = rr & HIT_KEY_MASK;     // strand + record tag
                     const int32_t dg = rev ? rp + qp : rp - qp;
 
                     // ---- general case: the oracle's look-back over the last anchors of the ring's runs
@@ -496,8 +480,8 @@ __global__ __launch_bounds__(256, 3) void chain_fast_kernel(SetView A, SetView B
                         else {                                                                              \
                             const int32_t dq = qp - (int32_t)(E).q_last;                                    \
                             if (dq > ANI_BP_BAND) exact = true;                                             \
-                            else if ((E).rctg == rc && ((E).rr_last >> 31) == rev) {                        \
-                                const int32_t rpj = (int32_t)((E).rr_last & 0x7FFFFFFFu);                   \
+                            else if (((E).rr_last & HIT_KEY_MASK) == key) {                                 \
+                                const int32_t rpj = (int32_t)((E).rr_last & HIT_POS_MASK);                   \
                                 const int32_t dr = rev ? rpj - rp : rp - rpj;                               \
                                 const int32_t ed = rev ? rpj + (int32_t)(E).q_last : rpj - (int32_t)(E).q_last; /* run diagonal */ \
                                 const int32_t off = dg > ed ? dg - ed : ed - dg;                            \
@@ -547,8 +531,8 @@ __global__ __launch_bounds__(256, 3) void chain_fast_kernel(SetView A, SetView B
                         } else {
                             // an indel: new run on the same path; the old run's last anchor now has a successor
                             Run e;
-                            e.q_last = (uint32_t)qp; e.rr_last = rr; e.rctg = rc; e.f = best;
-                            e.cnt = (r0.cnt & 0x7FFFFFFFu) + 1u; e.first_qi = r0.first_qi;
+                            e.q_last = (uint32_t)qp; e.rr_last = rr; e.f = best;
+                            e.cnt = (r0.cnt & HIT_POS_MASK) + 1u; e.first_qi = r0.first_qi;
                             e.rmin = (uint32_t)rp < r0.rmin ? (uint32_t)rp : r0.rmin;
                             e.rmax = (uint32_t)rp > r0.rmax ? (uint32_t)rp : r0.rmax;
                             e.qi_last = s; e.idx_last = ia; e.pmax = r0.f > r0.pmax ? r0.f : r0.pmax;
@@ -559,7 +543,7 @@ __global__ __launch_bounds__(256, 3) void chain_fast_kernel(SetView A, SetView B
                         }
                     } else {
                         Run e;
-                        e.q_last = (uint32_t)qp; e.rr_last = rr; e.rctg = rc; e.f = best;
+                        e.q_last = (uint32_t)qp; e.rr_last = rr; e.f = best;
                         e.cnt = 1; e.first_qi = s; e.rmin = e.rmax = (uint32_t)rp;
                         e.qi_last = s; e.idx_last = ia; e.pmax = NEG; e.r_first = (uint32_t)rp; e.seg = ia;
                         EVICT(r3);
@@ -574,24 +558,21 @@ __global__ __launch_bounds__(256, 3) void chain_fast_kernel(SetView A, SetView B
                 // to an anchor that extends r0: other record or strand, more than max_gap off r0's diagonal,
                 // out of the 2500-base band for good, or simply not scoring higher than r0
                 if (r0.cnt && !(r0.cnt & SUCC_BIT)) {
-                    const uint32_t k0 = r0.rctg | ((r0.rr_last >> 31) << 31);
+                    const uint32_t k0 = r0.rr_last & HIT_KEY_MASK;
                     const int32_t q0l = (int32_t)r0.q_last;
-                    const int32_t d0 = (r0.rr_last >> 31) ? (int32_t)(r0.rr_last & 0x7FFFFFFFu) + q0l : (int32_t)(r0.rr_last & 0x7FFFFFFFu) - q0l;
+                    const int32_t d0 = (r0.rr_last >> 31) ? (int32_t)(r0.rr_last & HIT_POS_MASK) + q0l : (int32_t)(r0.rr_last & HIT_POS_MASK) - q0l;
         #define CANNOT_BEAT(E)                                                                              \
-                    (!(E).cnt || ((E).rctg | (((E).rr_last >> 31) << 31)) != k0 || (E).f <= r0.f || q0l - (int32_t)(E).q_last > ANI_BP_BAND || \
-                     abs((((E).rr_last >> 31) ? (int32_t)((E).rr_last & 0x7FFFFFFFu) + (int32_t)(E).q_last                                       \
-                                              : (int32_t)((E).rr_last & 0x7FFFFFFFu) - (int32_t)(E).q_last) - d0) > ANI_MAX_GAP)
+                    (!(E).cnt || ((E).rr_last & HIT_KEY_MASK) != k0 || (E).f <= r0.f || q0l - (int32_t)(E).q_last > ANI_BP_BAND || \
+                     abs((((E).rr_last >> 31) ? (int32_t)((E).rr_last & HIT_POS_MASK) + (int32_t)(E).q_last                                       \
+                                              : (int32_t)((E).rr_last & HIT_POS_MASK) - (int32_t)(E).q_last) - d0) > ANI_MAX_GAP)
                     dom = CANNOT_BEAT(r1) && CANNOT_BEAT(r2) && CANNOT_BEAT(r3);
         #undef CANNOT_BEAT
                     if (dom && s0_seg != 0xFFFFFFFFu)
                         dom = s0_key != k0 || s0_f <= r0.f || q0l - (int32_t)s0_q > ANI_BP_BAND || d0 < s0_dlo - ANI_MAX_GAP || d0 > s0_dhi + ANI_MAX_GAP;
                     if (dom && lost_f != NEG)
                         dom = lost_f <= r0.f || q0l - (int32_t)lost_q > ANI_BP_BAND || d0 < lost_dlo - ANI_MAX_GAP || d0 > lost_dhi + ANI_MAX_GAP;
-                    // the plain-extension test compares the next hit with r0's record interval
-                    if (dom) { const uint32_t rl = r0.rr_last & 0x7FFFFFFFu; if (rl < cur_lo || rl >= cur_hi) dom = false; }
-                }
+                        }
             } while (0);
-            asm volatile("" ::"v"(cur_lo), "v"(cur_w));
         }
         if (!__any(!cplx && s < s1)) break;     // the whole wave is finished
     }
@@ -1128,7 +1109,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(SetView A, SetView B, con
             const uint32_t k0 = bin_start[b ? b - 1 : 0], k1 = bin_start[b + 2 <= FIN_BINS ? b + 2 : FIN_BINS];
             for (uint32_t k = k0; k < k1; k++) {
                 const uint32_t j = order[k];
-                if (rc[j] != rc[i] || j == i) continue;
+                if (j == i) continue;     // chains lie inside one record and positions are genome-linear: overlap implies the same record
                 const uint32_t lo = r0[i] > r0[j] ? r0[i] : r0[j];
                 const uint32_t hi = r1[i] < r1[j] ? r1[i] : r1[j];
                 if (hi <= lo) continue;
@@ -1202,8 +1183,8 @@ static SetView view_of(skder_sketches *s)
     SetView v;
     v.meta = s->d_meta.p;
     v.pkmer = s->seed_kmer.p; v.pgpos = s->seed_gpos.p; v.pchunk = s->pchunk.p;
-    v.skmer = s->skmer.p; v.sgpos = s->sgpos.p; v.sctg = s->sctg.p; v.boff = s->boff.p;
-    v.chunk_start = s->chunk_start.p; v.rec_goff = s->d_rec_goff.p; v.rec_lut = s->rec_lut.p;
+    v.skmer = s->skmer.p; v.sgpos = s->sgpos.p; v.sctg = s->sctg.p; v.stag = s->stag.p; v.boff = s->boff.p;
+    v.chunk_start = s->chunk_start.p; v.rec_goff = s->d_rec_goff.p;
     return v;
 }
 

@@ -4,7 +4,9 @@
 
 #define IDX_MAX_BUCKET_BITS 15
 #define IDX_REP_HIST ANI_REP_HIST
-#define REC_LUT_SHIFT 11      /* record look-up table: one entry per 2048 genome positions */
+#define HIT_POS_BITS 24        /* hit words: position in the low 24 bits, record index mod 64 in bits 24..29 */
+#define HIT_POS_MASK 0x00FFFFFFu
+#define HIT_KEY_MASK 0xBF000000u   /* strand (bit 31) and record tag (bits 24..29) */
 
 // per-genome record on the device (index stage)
 struct GenomeMeta {
@@ -14,7 +16,6 @@ struct GenomeMeta {
     uint64_t total_len;     // sum of kept record lengths
     uint64_t rec_goff_off;  // offset into d_rec_goff (n_rec+1 entries)
     uint64_t chunk_off;     // offset of its chunk_start table (n_chunks+1 entries)
-    uint64_t rec_lut_off;   // offset of its record look-up table (total_len >> REC_LUT_SHIFT) + 1 entries
     uint32_t n_seeds;
     uint32_t n_markers;
     uint32_t n_rec;
@@ -45,8 +46,8 @@ struct skder_sketches {
     DevBuf<GenomeMeta> d_meta;
     std::vector<GenomeMeta> h_meta;
     DevBuf<uint32_t> d_rec_goff;
-    DevBuf<uint16_t> rec_lut;              // record holding position b << REC_LUT_SHIFT, per genome (clamped to 65535)
     DevBuf<uint32_t> skmer, sgpos, sctg;   // by-(kmer,gpos) order inside each hash bucket
+    DevBuf<uint32_t> stag;                 // sgpos | (sctg & 63) << 24: the word the join hands to the chaining kernel
     DevBuf<uint32_t> boff;                 // bucket offset tables
     DevBuf<uint32_t> pchunk;               // chunk id of every seed (position order)
     DevBuf<uint32_t> chunk_start;          // first seed of every chunk (+ end sentinel), per genome

@@ -13,8 +13,8 @@
 __global__ __launch_bounds__(IDX_THREADS) void index_genome_kernel(
     GenomeMeta *__restrict__ meta, const uint32_t *__restrict__ list, const uint32_t *__restrict__ rec_goff,
     const uint32_t *__restrict__ seed_kmer, const uint32_t *__restrict__ seed_gpos, const uint32_t *__restrict__ seed_ctg,
-    uint32_t *__restrict__ skmer, uint32_t *__restrict__ sgpos, uint32_t *__restrict__ sctg, uint32_t *__restrict__ boff_all,
-    uint32_t *__restrict__ pchunk, uint32_t *__restrict__ chunk_start_all)
+    uint32_t *__restrict__ skmer, uint32_t *__restrict__ sgpos, uint32_t *__restrict__ sctg, uint32_t *__restrict__ stag,
+    uint32_t *__restrict__ boff_all, uint32_t *__restrict__ pchunk, uint32_t *__restrict__ chunk_start_all)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t *cnt = reinterpret_cast<uint32_t *>(smem_raw);   // 2^bits counters, later cursor, later histogram
@@ -25,7 +25,7 @@ __global__ __launch_bounds__(IDX_THREADS) void index_genome_kernel(
     GenomeMeta m = meta[g];
     const uint32_t n = m.n_seeds, bits = m.bucket_bits, nb = 1u << bits;
     const uint32_t *pk = seed_kmer + m.seed_off, *pg = seed_gpos + m.seed_off, *pc = seed_ctg + m.seed_off;
-    uint32_t *ok = skmer + m.seed_off, *og = sgpos + m.seed_off, *oc = sctg + m.seed_off;
+    uint32_t *ok = skmer + m.seed_off, *og = sgpos + m.seed_off, *oc = sctg + m.seed_off, *ot = stag + m.seed_off;
     uint32_t *boff = boff_all + m.bucket_off;
     const uint32_t *rg = rec_goff + m.rec_goff_off;
 
@@ -83,6 +83,7 @@ __global__ __launch_bounds__(IDX_THREADS) void index_genome_kernel(
     }
     atomicAdd(&s_distinct, my_distinct);
     __syncthreads();
+    for (uint32_t e = tid; e < n; e += IDX_THREADS) ot[e] = og[e] | ((oc[e] & 63u) << HIT_POS_BITS);
     if (tid == 0) {
         // multiplicity of ascending rank D - D/1000 - 1 == the (D/1000 + 1)-th largest
         uint32_t D = s_distinct, cut = 0xFFFFFFFFu;
@@ -138,8 +139,8 @@ static_assert(IDX_REP_HIST == 4 * IDXF_THREADS, "rep-cut scan assumes four histo
 __global__ __launch_bounds__(IDXF_THREADS) void index_genome_lds_kernel(
     GenomeMeta *__restrict__ meta, const uint32_t *__restrict__ list, const uint32_t *__restrict__ rec_goff,
     const uint32_t *__restrict__ seed_kmer, const uint32_t *__restrict__ seed_gpos, const uint32_t *__restrict__ seed_ctg,
-    uint32_t *__restrict__ skmer, uint32_t *__restrict__ sgpos, uint32_t *__restrict__ sctg, uint32_t *__restrict__ boff_all,
-    uint32_t *__restrict__ pchunk, uint32_t *__restrict__ chunk_start_all)
+    uint32_t *__restrict__ skmer, uint32_t *__restrict__ sgpos, uint32_t *__restrict__ sctg, uint32_t *__restrict__ stag,
+    uint32_t *__restrict__ boff_all, uint32_t *__restrict__ pchunk, uint32_t *__restrict__ chunk_start_all)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ uint32_t wsum[IDXF_THREADS / 64];
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(IDXF_THREADS) void index_genome_lds_kernel(
     uint16_t *cur16 = reinterpret_cast<uint16_t *>(cntp);                          // the same fields, one per bucket
     uint16_t *perm = reinterpret_cast<uint16_t *>(cntp + nb / 2);                  // n
     const uint32_t *pk = seed_kmer + m.seed_off, *pg = seed_gpos + m.seed_off, *pc = seed_ctg + m.seed_off;
-    uint32_t *ok = skmer + m.seed_off, *og = sgpos + m.seed_off, *oc = sctg + m.seed_off;
+    uint32_t *ok = skmer + m.seed_off, *og = sgpos + m.seed_off, *oc = sctg + m.seed_off, *ot = stag + m.seed_off;
     uint32_t *boff = boff_all + m.bucket_off;
     const uint32_t *rg = rec_goff + m.rec_goff_off;
 
@@ -279,7 +280,8 @@ __global__ __launch_bounds__(IDXF_THREADS) void index_genome_lds_kernel(
     // E. bucket-ordered arrays: gathers through the permutation, coalesced writes
     for (uint32_t pos = tid; pos < n; pos += IDXF_THREADS) {
         const uint32_t s = perm[pos];
-        ok[pos] = pk[s]; og[pos] = pg[s]; oc[pos] = pc[s];
+        const uint32_t gp = pg[s], ct = pc[s];
+        ok[pos] = pk[s]; og[pos] = gp; oc[pos] = ct; ot[pos] = gp | ((ct & 63u) << HIT_POS_BITS);
     }
     __syncthreads();   // the permutation is dead from here on
     // F. chunk ids in position order.  Seed s starts a chunk when its (record, 20 kb window) differs
@@ -316,26 +318,6 @@ __global__ __launch_bounds__(IDXF_THREADS) void index_genome_lds_kernel(
     }
 }
 
-// record look-up table: lut[b] = index of the kept record that holds genome position b << REC_LUT_SHIFT
-// (records are >= 500 bp, so the wanted record is at most a few steps after lut[pos >> REC_LUT_SHIFT])
-__global__ __launch_bounds__(256) void rec_lut_kernel(const GenomeMeta *__restrict__ meta, const uint32_t *__restrict__ rec_goff,
-                                                     uint16_t *__restrict__ lut_all)
-{
-    const GenomeMeta m = meta[blockIdx.x];
-    const uint32_t *rg = rec_goff + m.rec_goff_off;
-    const uint32_t n = (uint32_t)(m.total_len >> REC_LUT_SHIFT) + 1u;
-    uint16_t *lut = lut_all + m.rec_lut_off;
-    for (uint32_t b = threadIdx.x; b < n; b += blockDim.x) {
-        const uint32_t pos = b << REC_LUT_SHIFT;
-        uint32_t lo = 0, hi = m.n_rec;
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (rg[mid] <= pos) lo = mid; else hi = mid;
-        }
-        lut[b] = (uint16_t)(lo < 65535u ? lo : 65535u);
-    }
-}
-
 void index_impl(skder_sketches *s)
 {
     if (s->indexed) return;
@@ -343,7 +325,7 @@ void index_impl(skder_sketches *s)
     hipStream_t st = ctx->stream;
     const uint32_t G = s->n_genomes;
     s->h_meta.resize(G);
-    uint64_t boff_total = 0, rg = 0, chunk_total = 0, lut_total = 0;
+    uint64_t boff_total = 0, rg = 0, chunk_total = 0;
     for (uint32_t g = 0; g < G; g++) {
         GenomeMeta &m = s->h_meta[g];
         m.seed_off = s->h_seed_off[g];
@@ -362,18 +344,15 @@ void index_impl(skder_sketches *s)
         m.n_chunks = 0;
         m.rep_cut = 0xFFFFFFFFu;
         m.chunk_off = chunk_total;
-        m.rec_lut_off = lut_total;
-        lut_total += (m.total_len >> REC_LUT_SHIFT) + 1;
         chunk_total += m.total_len / ANI_CHUNK_LEN + m.n_rec + 2;   // upper bound on chunks + sentinel
     }
     const uint64_t ns = s->h_seed_off[G];
     s->d_meta.resize(G, st);
     s->d_rec_goff.resize(s->h_rec_goff.size() + 1, st);
-    s->skmer.resize(ns + 1, st); s->sgpos.resize(ns + 1, st); s->sctg.resize(ns + 1, st);
+    s->skmer.resize(ns + 1, st); s->sgpos.resize(ns + 1, st); s->sctg.resize(ns + 1, st); s->stag.resize(ns + 1, st);
     s->pchunk.resize(ns + 1, st);
     s->boff.resize(boff_total + 1, st);
     s->chunk_start.resize(chunk_total + 1, st);
-    s->rec_lut.resize(lut_total + 1, st);
     if (G) {
         HIPCHECK(hipMemcpyAsync(s->d_meta.p, s->h_meta.data(), G * sizeof(GenomeMeta), hipMemcpyHostToDevice, st));
         HIPCHECK(hipMemcpyAsync(s->d_rec_goff.p, s->h_rec_goff.data(), s->h_rec_goff.size() * 4, hipMemcpyHostToDevice, st));
@@ -402,7 +381,7 @@ void index_impl(skder_sketches *s)
             HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(index_genome_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds_limit));
             hipLaunchKernelGGL(index_genome_lds_kernel, dim3((unsigned)small.size()), dim3(IDXF_THREADS), small_bytes, st, s->d_meta.p, d_list.p,
-                               s->d_rec_goff.p, s->seed_kmer.p, s->seed_gpos.p, s->seed_ctg.p, s->skmer.p, s->sgpos.p, s->sctg.p, s->boff.p,
+                               s->d_rec_goff.p, s->seed_kmer.p, s->seed_gpos.p, s->seed_ctg.p, s->skmer.p, s->sgpos.p, s->sctg.p, s->stag.p, s->boff.p,
                                s->pchunk.p, s->chunk_start.p);
         }
         if (!big.empty()) {
@@ -410,10 +389,9 @@ void index_impl(skder_sketches *s)
                                          (int)((1u << max_bits) * 4)));
             hipLaunchKernelGGL(index_genome_kernel, dim3((unsigned)big.size()), dim3(IDX_THREADS), (1u << max_bits) * 4, st, s->d_meta.p,
                                d_list.p + small.size(), s->d_rec_goff.p, s->seed_kmer.p, s->seed_gpos.p, s->seed_ctg.p, s->skmer.p, s->sgpos.p,
-                               s->sctg.p, s->boff.p, s->pchunk.p, s->chunk_start.p);
+                               s->sctg.p, s->stag.p, s->boff.p, s->pchunk.p, s->chunk_start.p);
         }
         HIPCHECK(hipStreamSynchronize(st));   // d_list and the host vectors go out of scope
-        hipLaunchKernelGGL(rec_lut_kernel, dim3(G), dim3(256), 0, st, s->d_meta.p, s->d_rec_goff.p, s->rec_lut.p);
         HIPCHECK(hipEventRecord(ctx->ev[4], st));
         HIPCHECK(hipMemcpyAsync(s->h_meta.data(), s->d_meta.p, G * sizeof(GenomeMeta), hipMemcpyDeviceToHost, st));
         HIPCHECK(hipStreamSynchronize(st));
