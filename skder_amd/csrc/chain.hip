@@ -91,6 +91,113 @@ struct JoinGroup { uint32_t pair_begin, pair_end; };
 #define JOIN_KCAP 30720      // k-mers held in LDS per pass
 #define JOIN_SMEM_BYTES (JOIN_BCAP * 2 + (JOIN_KCAP + 8) * 4)
 
+// the probe loop of one staged bucket range for all pairs of a group.  FITS: the range's k-mers are in
+// LDS (false only for a single bucket with more than JOIN_KCAP seeds); WHOLE: the range is the whole
+// table, so every seed belongs to this pass (the normal case: both true, no per-seed tests for either)
+template <bool FITS, bool WHOLE>
+__device__ __forceinline__ void join_pass(const SetView &A, const SetView &B, const PairDesc *__restrict__ pairs, const JoinGroup g,
+                                          uint32_t *__restrict__ hits, uint4 *__restrict__ multi, uint32_t *__restrict__ pair_nmulti,
+                                          const uint32_t *s_rk, const uint16_t *s_boff, const uint32_t *__restrict__ rk,
+                                          const uint32_t *__restrict__ rg, uint32_t base, uint32_t bits, uint32_t bb0, uint32_t bb1,
+                                          uint32_t rrep, uint32_t tid)
+{
+    for (uint32_t p = g.pair_begin; p < g.pair_end; p++) {
+        const PairDesc pd = pairs[p];
+        const SetView &QS = (pd.flags & 2u) ? B : A;
+        const GenomeMeta *Qm = QS.meta + pd.q;
+        const uint32_t *pk = QS.pkmer + Qm->seed_off;
+        const uint32_t nq = Qm->n_seeds;
+        uint32_t *hit = hits + pd.hit_base;
+        // JOIN_U independent seeds per thread and trip, handled in phases so that the memory operations
+        // of all of them are in flight together: k-mer loads, LDS probes, then ALL position gathers, then
+        // the coalesced hit-word stores; the rare multi-occurrence seeds come last
+        for (uint32_t s0 = tid; s0 < nq; s0 += JOIN_U * JOIN_THREADS) {
+            uint32_t kqv[JOIN_U], lov[JOIN_U], hiv[JOIN_U], firstv[JOIN_U], cntv[JOIN_U], hvv[JOIN_U];
+            bool mine[JOIN_U];
+#pragma unroll
+            for (int u = 0; u < JOIN_U; u++) {
+                const uint32_t s = s0 + u * JOIN_THREADS;
+                kqv[u] = s < nq ? pk[s] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < JOIN_U; u++) {
+                const uint32_t s = s0 + u * JOIN_THREADS;
+                const uint32_t b = kmer_bucket(kqv[u] & SK_SEED_MASK, bits);
+                mine[u] = s < nq && (WHOLE || (b >= bb0 && b < bb1));      // else: this seed's bucket belongs to another pass
+                lov[u] = mine[u] ? s_boff[b - bb0] : 0u;
+                hiv[u] = mine[u] ? s_boff[b - bb0 + 1] : 0u;
+            }
+            bool any_multi = false;
+#pragma unroll
+            for (int u = 0; u < JOIN_U; u++) {
+                const uint32_t kmer = kqv[u] & SK_SEED_MASK;
+                uint32_t cnt = 0, first = 0;
+                if (FITS) {
+                    // buckets hold 1-2 seeds on average, ordered by k-mer: the first two entries are
+                    // compared without a loop (reads clamped into the table), longer buckets continue
+                    const uint32_t lo = lov[u], ne = hiv[u] - lo;
+                    const uint32_t k0 = s_rk[lo] & SK_SEED_MASK, k1 = s_rk[lo + 1] & SK_SEED_MASK;   // s_rk has slack behind nk
+                    const bool m0 = ne > 0 && k0 == kmer, m1 = ne > 1 && k1 == kmer;
+                    cnt = (uint32_t)m0 + (uint32_t)m1;
+                    first = m0 ? lo : lo + 1;
+                    if (ne > 2 && !(k1 > kmer)) {
+                        for (uint32_t e = lo + 2; e < hiv[u]; e++) {
+                            const uint32_t k2 = s_rk[e] & SK_SEED_MASK;
+                            if (k2 == kmer) { if (!cnt) first = e; cnt++; }
+                            else if (k2 > kmer) break;
+                        }
+                    }
+                } else {
+                    for (uint32_t e = lov[u]; e < hiv[u]; e++) {
+                        const uint32_t k2 = rk[base + e] & SK_SEED_MASK;
+                        if (k2 == kmer) { if (!cnt) first = e; cnt++; }
+                        else if (k2 > kmer) break;
+                    }
+                }
+                if (cnt > rrep) cnt = 0;
+                cntv[u] = cnt; firstv[u] = first;
+                any_multi |= cnt > 1;
+            }
+            // all position gathers in flight together: unconditional loads (seeds without a single hit read
+            // the genome's first entry, one broadcast address), combined only after the last one is issued
+            uint32_t gv[JOIN_U], rkmv[JOIN_U];
+#pragma unroll
+            for (int u = 0; u < JOIN_U; u++) {
+                const uint32_t e = cntv[u] == 1 ? firstv[u] : 0u;
+                gv[u] = rg[base + e];
+                rkmv[u] = FITS ? s_rk[e] : rk[base + e];
+            }
+#pragma unroll
+            for (int u = 0; u < JOIN_U; u++) {
+                hvv[u] = cntv[u] == 1 ? (gv[u] | (((kqv[u] >> 31) != (rkmv[u] >> 31)) ? USED_BIT : 0u))
+                                      : (cntv[u] > 4 ? HIT_MANY : HIT_NONE);
+            }
+            if (any_multi) {
+#pragma unroll
+                for (int u = 0; u < JOIN_U; u++) {
+                    const uint32_t cnt = cntv[u], first = firstv[u];
+                    if (cnt < 2 || cnt > 4) continue;
+                    const uint32_t slot = atomicAdd(&pair_nmulti[p], 1u);
+                    if (slot < pd.multi_cap) {
+                        uint32_t v[4] = {HIT_NONE, HIT_NONE, HIT_NONE, HIT_NONE};
+                        for (uint32_t w = 0; w < cnt; w++) {
+                            const uint32_t rkm = FITS ? s_rk[first + w] : rk[base + first + w];
+                            v[w] = rg[base + first + w] | (((kqv[u] >> 31) != (rkm >> 31)) ? USED_BIT : 0u);
+                        }
+                        multi[pd.multi_base + slot] = make_uint4(v[0], v[1], v[2], v[3]);
+                        hvv[u] = HIT_MULTI | slot;
+                    } else {
+                        hvv[u] = HIT_MANY;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < JOIN_U; u++)
+                if (mine[u]) hit[s0 + u * JOIN_THREADS] = hvv[u];
+        }
+    }
+}
+
 __global__ __launch_bounds__(JOIN_THREADS) void join_probe_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs,
                                                                   const JoinGroup *__restrict__ groups,
                                                                   uint32_t *__restrict__ hits, uint4 *__restrict__ multi,
@@ -131,101 +238,10 @@ __global__ __launch_bounds__(JOIN_THREADS) void join_probe_kernel(SetView A, Set
         if (fits)
             for (uint32_t i = tid; i < nk; i += JOIN_THREADS) s_rk[i] = rk[base + i];
         __syncthreads();
-        for (uint32_t p = g.pair_begin; p < g.pair_end; p++) {
-            const PairDesc pd = pairs[p];
-            const SetView &QS = (pd.flags & 2u) ? B : A;
-            const GenomeMeta *Qm = QS.meta + pd.q;
-            const uint32_t *pk = QS.pkmer + Qm->seed_off;
-            const uint32_t nq = Qm->n_seeds;
-            uint32_t *hit = hits + pd.hit_base;
-            // JOIN_U independent seeds per thread and trip, handled in phases so that the memory operations
-            // of all of them are in flight together: k-mer loads, LDS probes, then ALL position gathers, then
-            // the coalesced hit-word stores; the rare multi-occurrence seeds come last
-            for (uint32_t s0 = tid; s0 < nq; s0 += JOIN_U * JOIN_THREADS) {
-                uint32_t kqv[JOIN_U], lov[JOIN_U], hiv[JOIN_U], firstv[JOIN_U], cntv[JOIN_U], hvv[JOIN_U];
-                bool mine[JOIN_U];
-#pragma unroll
-                for (int u = 0; u < JOIN_U; u++) {
-                    const uint32_t s = s0 + u * JOIN_THREADS;
-                    kqv[u] = s < nq ? pk[s] : 0u;
-                }
-#pragma unroll
-                for (int u = 0; u < JOIN_U; u++) {
-                    const uint32_t s = s0 + u * JOIN_THREADS;
-                    const uint32_t b = kmer_bucket(kqv[u] & SK_SEED_MASK, bits);
-                    mine[u] = s < nq && b >= bb0 && b < bb1;      // else: this seed's bucket belongs to another pass
-                    lov[u] = mine[u] ? s_boff[b - bb0] : 0u;
-                    hiv[u] = mine[u] ? s_boff[b - bb0 + 1] : 0u;
-                }
-                bool any_multi = false;
-#pragma unroll
-                for (int u = 0; u < JOIN_U; u++) {
-                    const uint32_t kmer = kqv[u] & SK_SEED_MASK;
-                    uint32_t cnt = 0, first = 0;
-                    if (fits) {
-                        // buckets hold 1-2 seeds on average, ordered by k-mer: the first two entries are
-                        // compared without a loop (reads clamped into the table), longer buckets continue
-                        const uint32_t lo = lov[u], ne = hiv[u] - lo;
-                        const uint32_t k0 = s_rk[lo] & SK_SEED_MASK, k1 = s_rk[lo + 1] & SK_SEED_MASK;   // s_rk has slack behind nk
-                        const bool m0 = ne > 0 && k0 == kmer, m1 = ne > 1 && k1 == kmer;
-                        cnt = (uint32_t)m0 + (uint32_t)m1;
-                        first = m0 ? lo : lo + 1;
-                        if (ne > 2 && !(k1 > kmer)) {
-                            for (uint32_t e = lo + 2; e < hiv[u]; e++) {
-                                const uint32_t k2 = s_rk[e] & SK_SEED_MASK;
-                                if (k2 == kmer) { if (!cnt) first = e; cnt++; }
-                                else if (k2 > kmer) break;
-                            }
-                        }
-                    } else {
-                        for (uint32_t e = lov[u]; e < hiv[u]; e++) {
-                            const uint32_t k2 = rk[base + e] & SK_SEED_MASK;
-                            if (k2 == kmer) { if (!cnt) first = e; cnt++; }
-                            else if (k2 > kmer) break;
-                        }
-                    }
-                    if (cnt > rrep) cnt = 0;
-                    cntv[u] = cnt; firstv[u] = first;
-                    any_multi |= cnt > 1;
-                }
-                // all position gathers in flight together: unconditional loads (seeds without a single hit read
-                // the genome's first entry, one broadcast address), combined only after the last one is issued
-                uint32_t gv[JOIN_U], rkmv[JOIN_U];
-#pragma unroll
-                for (int u = 0; u < JOIN_U; u++) {
-                    const uint32_t e = cntv[u] == 1 ? firstv[u] : 0u;
-                    gv[u] = rg[base + e];
-                    rkmv[u] = fits ? s_rk[e] : rk[base + e];
-                }
-#pragma unroll
-                for (int u = 0; u < JOIN_U; u++) {
-                    hvv[u] = cntv[u] == 1 ? (gv[u] | (((kqv[u] >> 31) != (rkmv[u] >> 31)) ? USED_BIT : 0u))
-                                          : (cntv[u] > 4 ? HIT_MANY : HIT_NONE);
-                }
-                if (any_multi) {
-#pragma unroll
-                    for (int u = 0; u < JOIN_U; u++) {
-                        const uint32_t cnt = cntv[u], first = firstv[u];
-                        if (cnt < 2 || cnt > 4) continue;
-                        const uint32_t slot = atomicAdd(&pair_nmulti[p], 1u);
-                        if (slot < pd.multi_cap) {
-                            uint32_t v[4] = {HIT_NONE, HIT_NONE, HIT_NONE, HIT_NONE};
-                            for (uint32_t w = 0; w < cnt; w++) {
-                                const uint32_t rkm = fits ? s_rk[first + w] : rk[base + first + w];
-                                v[w] = rg[base + first + w] | (((kqv[u] >> 31) != (rkm >> 31)) ? USED_BIT : 0u);
-                            }
-                            multi[pd.multi_base + slot] = make_uint4(v[0], v[1], v[2], v[3]);
-                            hvv[u] = HIT_MULTI | slot;
-                        } else {
-                            hvv[u] = HIT_MANY;
-                        }
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < JOIN_U; u++)
-                    if (mine[u]) hit[s0 + u * JOIN_THREADS] = hvv[u];
-            }
-        }
+        const bool whole = bb0 == 0 && bb1 == nbk;
+        if (fits && whole) join_pass<true, true>(A, B, pairs, g, hits, multi, pair_nmulti, s_rk, s_boff, rk, rg, base, bits, bb0, bb1, rrep, tid);
+        else if (fits) join_pass<true, false>(A, B, pairs, g, hits, multi, pair_nmulti, s_rk, s_boff, rk, rg, base, bits, bb0, bb1, rrep, tid);
+        else join_pass<false, false>(A, B, pairs, g, hits, multi, pair_nmulti, s_rk, s_boff, rk, rg, base, bits, bb0, bb1, rrep, tid);
         bb0 = bb1;
     }
 }
