@@ -265,7 +265,8 @@ struct Run {
     uint32_t q_last, rr_last;         // last anchor: query pos; hit word (ref pos | record tag << 24 | rev << 31)
     int32_t f;                        // score of the last anchor
     uint32_t cnt;                     // anchors on the PATH ending at the last anchor | SUCC_BIT
-    uint32_t first_qi, rmin, rmax;    // path aggregates: first seed index, ref extent
+    uint32_t first_qi, q_first, rmin, rmax;   // path aggregates: first seed index and its position (kept so that emitting a
+                                      // chain needs no load: a wait on one would also drain the input prefetch), ref extent
     uint32_t qi_last, idx_last;       // seed index / anchor ordinal of the last anchor
     int32_t pmax;                     // highest score among the earlier anchors of the path
     uint32_t r_first;                 // ref pos of the run's first anchor
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(256, 3) void chain_fast_kernel(SetView A, SetView B
     r0.cnt = r1.cnt = r2.cnt = r3.cnt = 0;          // cnt == 0: empty ring position
     r0.f = r1.f = r2.f = r3.f = NEG;
     r0.q_last = r1.q_last = r2.q_last = r3.q_last = 0; r0.rr_last = r1.rr_last = r2.rr_last = r3.rr_last = 0;
-    r0.first_qi = r1.first_qi = r2.first_qi = r3.first_qi = 0;
+    r0.first_qi = r1.first_qi = r2.first_qi = r3.first_qi = 0; r0.q_first = r1.q_first = r2.q_first = r3.q_first = 0;
     r0.rmin = r1.rmin = r2.rmin = r3.rmin = 0; r0.rmax = r1.rmax = r2.rmax = r3.rmax = 0;
     r0.qi_last = r1.qi_last = r2.qi_last = r3.qi_last = 0; r0.idx_last = r1.idx_last = r2.idx_last = r3.idx_last = 0;
     r0.pmax = r1.pmax = r2.pmax = r3.pmax = NEG; r0.r_first = r1.r_first = r2.r_first = r3.r_first = 0;
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(256, 3) void chain_fast_kernel(SetView A, SetView B
             else {                                                                           \
                 ChainRec cr;                                                                 \
                 cr.score = (E).f; cr.n = (E).cnt; cr.n_seeds = (E).qi_last - (E).first_qi + 1; \
-                cr.q0 = qg[(E).first_qi]; cr.q1 = (E).q_last; cr.r0 = (E).rmin; cr.r1 = (E).rmax; cr.rctg = ((E).rr_last >> HIT_POS_BITS) & 63u; \
+                cr.q0 = (E).q_first; cr.q1 = (E).q_last; cr.r0 = (E).rmin; cr.r1 = (E).rmax; cr.rctg = ((E).rr_last >> HIT_POS_BITS) & 63u; \
                 slots[nfin++] = cr;                                                          \
             }                                                                                \
         }                                                                                    \
@@ -548,7 +549,7 @@ __global__ __launch_bounds__(256, 3) void chain_fast_kernel(SetView A, SetView B
                             // an indel: new run on the same path; the old run's last anchor now has a successor
                             Run e;
                             e.q_last = (uint32_t)qp; e.rr_last = rr; e.f = best;
-                            e.cnt = (r0.cnt & HIT_POS_MASK) + 1u; e.first_qi = r0.first_qi;
+                            e.cnt = (r0.cnt & ~SUCC_BIT) + 1u; e.first_qi = r0.first_qi; e.q_first = r0.q_first;
                             e.rmin = (uint32_t)rp < r0.rmin ? (uint32_t)rp : r0.rmin;
                             e.rmax = (uint32_t)rp > r0.rmax ? (uint32_t)rp : r0.rmax;
                             e.qi_last = s; e.idx_last = ia; e.pmax = r0.f > r0.pmax ? r0.f : r0.pmax;
@@ -560,7 +561,7 @@ __global__ __launch_bounds__(256, 3) void chain_fast_kernel(SetView A, SetView B
                     } else {
                         Run e;
                         e.q_last = (uint32_t)qp; e.rr_last = rr; e.f = best;
-                        e.cnt = 1; e.first_qi = s; e.rmin = e.rmax = (uint32_t)rp;
+                        e.cnt = 1; e.first_qi = s; e.q_first = (uint32_t)qp; e.rmin = e.rmax = (uint32_t)rp;
                         e.qi_last = s; e.idx_last = ia; e.pmax = NEG; e.r_first = (uint32_t)rp; e.seg = ia;
                         EVICT(r3);
                         r3 = r2; r2 = r1; r1 = r0; r0 = e;
