@@ -23,77 +23,91 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(recipe, n_sample=10):
-    """oracle (CPU restatement, 1 thread) on a bounded sample of the same workload: per-genome
-    sketch time and per-chained-pair time, extrapolated to the full pair matrix."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import oracle_py
-    from skder_amd import synth
-    p = oracle_py.default_params()
-    gs = list(range(n_sample))          # one species: every pair is chained
-    t0 = time.perf_counter()
-    bases = [synth.bases_numpy(recipe, g) for g in gs]
-    t1 = time.perf_counter()
-    og = [oracle_py.Genome.from_bases(b, recipe.rec_lens[g], p) for g, b in zip(gs, bases)]
-    t2 = time.perf_counter()
-    npair = 0
-    for i in range(n_sample):
-        for j in range(i + 1, n_sample):
-            if oracle_py.screen(og[i], og[j], 80.0, p)[0]:
-                oracle_py.pair(og[i], og[j], p)
-            npair += 1
-    t3 = time.perf_counter()
-    return (t2 - t1) / n_sample, (t3 - t2) / max(npair, 1), npair
-
-
-def end_to_end_sample(recipe, batches, n_sample, device):
-    """The file-based drop-in on a bounded sample (second clock): the first n_sample genomes
-    are written as FASTA files (from the device-resident bases), then skder_amd_triangle runs listing ->
-    ingest (read, parse, N50, PCIe copy) -> sketch -> index -> screen -> chain -> TSV on disk."""
-    import shutil
+def write_sample_files(batches, n_sample):
+    """FASTA files of the first n_sample genomes, written from the device-resident bases (80 columns)"""
     import tempfile
-    import ctypes as C
-    import torch
-    from skder_amd import _lib
     layout, d = batches[0]
     n_sample = min(n_sample, layout.n_genomes)
     host = d.cpu().numpy()
-    tmp = tempfile.mkdtemp(prefix="skder_amd_e2e_")
-    try:
-        paths, nbytes, r = [], 0, 0
-        for g in range(n_sample):
-            parts = []
-            for k in range(int(layout.genome_rec_begin[g]), int(layout.genome_rec_begin[g + 1])):
-                o, l = int(layout.rec_off[k]), int(layout.rec_len[k])
-                seq = host[o:o + l]
-                pad = (-l) % 80
-                lines = np.concatenate([seq, np.full(pad, ord("\n"), np.uint8)]).reshape(-1, 80)
-                body = np.concatenate([lines, np.full((lines.shape[0], 1), ord("\n"), np.uint8)], axis=1).reshape(-1)
-                body = body[: l + (l + 79) // 80] if pad == 0 else np.concatenate([body[: (l // 80) * 81], seq[(l // 80) * 80:], [ord("\n")]]).astype(np.uint8)
-                parts.append((">g%d_rec%d synthetic\n" % (g, k)).encode())
-                parts.append(body.tobytes())
-            p = os.path.join(tmp, "g%05d.fasta" % g)
-            with open(p, "wb") as f:
-                blob = b"".join(parts)
-                f.write(blob)
-            nbytes += len(blob)
-            paths.append(p)
-        listing = os.path.join(tmp, "listing.txt")
-        open(listing, "w").write("".join(p + "\n" for p in paths))
-        out = os.path.join(tmp, "edges.tsv")
-        n50 = os.path.join(tmp, "n50.tsv")
-        err = C.create_string_buffer(_lib.ERRLEN)
-        torch.cuda.synchronize()
+    tmp = tempfile.mkdtemp(prefix="skder_amd_sample_")
+    paths, nbytes = [], 0
+    for g in range(n_sample):
+        parts = []
+        for k in range(int(layout.genome_rec_begin[g]), int(layout.genome_rec_begin[g + 1])):
+            o, l = int(layout.rec_off[k]), int(layout.rec_len[k])
+            seq = host[o:o + l]
+            full = (l // 80) * 80
+            body = np.concatenate([seq[:full].reshape(-1, 80), np.full((full // 80, 1), ord("\n"), np.uint8)], axis=1).reshape(-1)
+            parts.append((">g%d_rec%d synthetic\n" % (g, k)).encode())
+            parts.append(body.tobytes())
+            if l > full:
+                parts.append(seq[full:].tobytes() + b"\n")
+        p = os.path.join(tmp, "g%05d.fasta" % g)
+        blob = b"".join(parts)
+        with open(p, "wb") as f:
+            f.write(blob)
+        nbytes += len(blob)
+        paths.append(p)
+    return tmp, paths, nbytes
+
+
+def end_to_end_sample(tmp, paths, nbytes, device):
+    """The file-based drop-in on a bounded sample (second clock): skder_amd_triangle runs
+    listing -> ingest (read, parse, N50, PCIe copy) -> sketch -> index -> screen -> chain -> TSV on disk."""
+    import ctypes as C
+    import torch
+    from skder_amd import _lib
+    listing = os.path.join(tmp, "listing.txt")
+    open(listing, "w").write("".join(p + "\n" for p in paths))
+    out = os.path.join(tmp, "edges.tsv")
+    n50 = os.path.join(tmp, "n50.tsv")
+    err = C.create_string_buffer(_lib.ERRLEN)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rc = _lib.lib().skder_amd_triangle_n50(listing.encode(), 50.0, 80.0, device, out.encode(), n50.encode(), err, _lib.ERRLEN)
+    dt = time.perf_counter() - t0
+    if rc != 0:
+        raise RuntimeError(err.value.decode())
+    rows = sum(1 for _ in open(out)) - 1
+    return {"genomes": len(paths), "fasta_bytes": nbytes, "seconds": dt, "rows": rows, "ingest_MB_per_s": nbytes / dt / 1e6}
+
+
+def cpu_baseline_files(tmp, paths, threads):
+    """oracle (CPU restatement, OpenMP) on the sample files, wall clock on `threads` host threads:
+      per genome   : read + sketch, from a triangle whose 101 % screen lets no pair through;
+      per pair     : the pairwise marker screen, timed on one thread over cross-genome pairs and divided
+                     by `threads` (perfect scaling assumed: the optimistic choice for the CPU);
+      per chained  : the full triangle's extra time per pair that passes the screen."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py
+    p = oracle_py.default_params()
+
+    def run(sub, screen):
+        listing = os.path.join(tmp, "cpu_listing.txt")
+        open(listing, "w").write("".join(q + "\n" for q in sub))
+        out = os.path.join(tmp, "cpu_edges.tsv")
         t0 = time.perf_counter()
-        rc = _lib.lib().skder_amd_triangle_n50(listing.encode(), 50.0, 80.0, device, out.encode(), n50.encode(), err, _lib.ERRLEN)
+        oracle_py.triangle(listing, 0.0, screen, threads, out, p)
         dt = time.perf_counter() - t0
-        if rc != 0:
-            raise RuntimeError(err.value.decode())
-        rows = sum(1 for _ in open(out)) - 1
-        return {"genomes": n_sample, "fasta_bytes": nbytes, "seconds": dt, "rows": rows,
-                "ingest_MB_per_s": nbytes / dt / 1e6}
-    finally:
-        shutil.rmtree(tmp, ignore_errors=True)
+        return dt, sum(1 for _ in open(out)) - 1
+
+    n = len(paths)
+    t_load, _ = run(paths, 101.0)
+    t_full, chained = run(paths, 80.0)
+    k = min(n, 24)
+    gs = [oracle_py.Genome.load(q, p) for q in paths[:k]]
+    t0 = time.perf_counter()
+    npair = 0
+    for rep in range(4):
+        for i in range(k):
+            for j in range(i + 1, k):
+                oracle_py.screen(gs[i], gs[j], 80.0, p)
+                npair += 1
+    t_screen = (time.perf_counter() - t0) / max(npair, 1)
+    per_pair = t_screen / threads
+    per_genome = t_load / n
+    per_chained = max(t_full - t_load, 0.0) / max(chained, 1)
+    return per_genome, per_pair, per_chained, chained, t_load + t_full + t_screen * npair
 
 
 def main():
@@ -250,23 +264,28 @@ def main():
                          "other_ms": {"sketch_post": float(tm[1]), "screen": float(tm[2]), "chain_slow_path": float(tm[4]),
                                       "finalize": float(tm[5])}},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            t_sk, t_pair, npair = cpu_baseline(recipe)
-            n_chain_total = n_chained
-            est = N * t_sk + n_chain_total * t_pair
-            out["cpu_baseline"] = {"value": pairs / est, "unit": "genome-pairs/s", "cores": 1, "kind": "port",
-                                   "sample": "oracle (CPU restatement) on 10 genomes of one species: %.3f s/genome sketch, "
-                                             "%.4f s/chained pair (%d pairs); extrapolated to %d genomes + %d chained pairs"
-                                             % (t_sk, t_pair, npair, N, int(n_chain_total))}
         if world == 1 and not args.no_cpu_baseline and args.e2e_genomes > 0:
-            # second clock: listing file -> TSV on disk through the drop-in entry point, on a
-            # bounded sample; never part of `value`
-            e = end_to_end_sample(recipe, batches, args.e2e_genomes, dev)
-            e["extrapolated_full_workload_s"] = total_bases * 1.0125 / (e["fasta_bytes"] / e["seconds"]) + ms_per_step * 1e-3
-            e["sample"] = ("skder_amd_triangle_n50 on %d FASTA files written from the resident bases (page cache hot): read, parse, "
-                           "N50, PCIe copy, sketch, index, screen, chain, TSV; extrapolation = full workload's FASTA bytes at the "
-                           "sample's rate + one device step" % e["genomes"])
-            out["end_to_end"] = e
+            import shutil
+            tmp, paths, nbytes = write_sample_files(batches, args.e2e_genomes)
+            try:
+                # second clock: listing file -> TSV on disk through the drop-in entry point, on a
+                # bounded sample; never part of `value`
+                e = end_to_end_sample(tmp, paths, nbytes, dev)
+                e["extrapolated_full_workload_s"] = total_bases * 1.0125 / (e["fasta_bytes"] / e["seconds"]) + ms_per_step * 1e-3
+                e["sample"] = ("skder_amd_triangle_n50 on %d FASTA files written from the resident bases (page cache hot): read, parse, "
+                               "N50, PCIe copy, sketch, index, screen, chain, TSV; extrapolation = full workload's FASTA bytes at the "
+                               "sample's rate + one device step" % e["genomes"])
+                out["end_to_end"] = e
+                threads = max(1, min(32, os.cpu_count() or 1))
+                pg, pp, pc, chained, spent = cpu_baseline_files(tmp, paths, threads)
+                est = N * pg + pairs * pp + n_chained * pc
+                out["cpu_baseline"] = {"value": pairs / est, "unit": "genome-pairs/s", "cores": threads, "kind": "port",
+                                       "sample": "oracle (CPU restatement, OpenMP, %d threads, wall clock) on the same %d FASTA files: "
+                                                 "%.4f s/genome read+sketch, %.2e s/pair marker screen, %.5f s/chained pair (%d pairs); "
+                                                 "%.1f s of wall time spent; extrapolated to %d genomes, %d pairs, %d chained pairs"
+                                                 % (threads, len(paths), pg, pp, pc, chained, spent, N, pairs, int(n_chained))}
+            finally:
+                shutil.rmtree(tmp, ignore_errors=True)
         print(json.dumps(out))
     ctx.close()
     if dist_on:
