@@ -799,18 +799,24 @@ __global__ __launch_bounds__(256) void slow_chain_kernel(SetView A, SetView B, c
 #define SLOWW_MAXA 384
 #define SLOWW_WAVES 4        // wavefronts (chunks) per workgroup
 
+// maximum over the 64 lanes of a fully active wavefront, in every lane: DPP row shifts inside the four
+// 16-lane rows, two row broadcasts, one readlane (7 instructions; the shuffle form costs six LDS
+// crossbar round trips)
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const uint32_t y = __shfl_xor(v, o, 64);
-        v = y > v ? y : v;
-    }
-    return v;
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true); v = t > v ? t : v;   // row_shr:1
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true); v = t > v ? t : v;   // row_shr:2
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true); v = t > v ? t : v;   // row_shr:4
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true); v = t > v ? t : v;   // row_shr:8
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, true); v = t > v ? t : v;   // row_bcast:15 -> rows 1, 3
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true); v = t > v ? t : v;   // row_bcast:31 -> rows 2, 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 __global__ __launch_bounds__(64 * SLOWW_WAVES) void slow_wave_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs, uint32_t npairs,
                                                                     const uint32_t *__restrict__ slow_list, const uint32_t *__restrict__ nslow_ptr,
+                                                                    const uint32_t *__restrict__ hits, const uint4 *__restrict__ multi,
                                                                     ChainRec *__restrict__ chains, uint32_t *__restrict__ pair_nch,
                                                                     uint32_t *__restrict__ pair_na, uint32_t *__restrict__ over_list,
                                                                     uint32_t *__restrict__ over_count, uint32_t *__restrict__ flags)
@@ -839,13 +845,29 @@ __global__ __launch_bounds__(64 * SLOWW_WAVES) void slow_wave_kernel(SetView A, 
     const uint32_t *rb = RS.boff + R.bucket_off;
     const uint32_t *qsk = QS.skmer + Q.seed_off, *qb = QS.boff + Q.bucket_off;
 
-    // 1. ordered anchors
+    // 1. ordered anchors.  The join has already found the occurrences of every seed: single hits and the
+    // 2..4-occurrence lists are taken from its hit words (one coalesced read per 64 seeds); only seeds
+    // marked "too many" -- or all seeds, when the chunked genome's own multiplicity filter is active --
+    // are looked up again through the bucket index.  Records are compared by their 6-bit tags, exact
+    // under the DP's distance limits like in the fast path.
+    const bool qfilter = Q.rep_cut != 0xFFFFFFFFu;
+    const uint32_t *hw_of = hits + pd.hit_base;
     uint32_t n = 0;
     bool over = false;
     for (uint32_t sb = s0; sb < s1; sb += 64) {
         const uint32_t s = sb + lane;
-        uint32_t cnt = 0, first = 0, km = 0;
+        uint32_t cnt = 0, first = 0, km = 0, hw = HIT_NONE;
+        uint4 mv = make_uint4(HIT_NONE, HIT_NONE, HIT_NONE, HIT_NONE);
+        bool probe = false;
         if (s < s1) {
+            hw = hw_of[s];
+            if (qfilter || hw == HIT_MANY) probe = hw != HIT_NONE;
+            else if ((hw & 0xFF000000u) == HIT_MULTI) {
+                mv = multi[pd.multi_base + (hw & 0x00FFFFFFu)];
+                cnt = 2u + (mv.z != HIT_NONE) + (mv.w != HIT_NONE);
+            } else if (hw != HIT_NONE) { mv.x = hw; cnt = 1; }
+        }
+        if (probe) {
             km = qk[s];
             const uint32_t kmer = km & SK_SEED_MASK;
             const uint32_t b = kmer_bucket(kmer, R.bucket_bits);
@@ -856,7 +878,7 @@ __global__ __launch_bounds__(64 * SLOWW_WAVES) void slow_wave_kernel(SetView A, 
                 else if (k2 > kmer) break;
             }
             if (cnt > R.rep_cut) cnt = 0;
-            if (cnt && Q.rep_cut != 0xFFFFFFFFu) {   // multiplicity inside the chunked genome itself
+            if (cnt && qfilter) {   // multiplicity inside the chunked genome itself
                 const uint32_t b2 = kmer_bucket(kmer, Q.bucket_bits);
                 uint32_t m2 = 0;
                 for (uint32_t e = qb[b2]; e < qb[b2 + 1]; e++) m2 += ((qsk[e] & SK_SEED_MASK) == kmer);
@@ -866,11 +888,23 @@ __global__ __launch_bounds__(64 * SLOWW_WAVES) void slow_wave_kernel(SetView A, 
         uint32_t total;
         const uint32_t at = n + wave_excl_scan(cnt, total);
         if (n + total > SLOWW_MAXA) { over = true; break; }     // wave-uniform
-        for (uint32_t u = 0; u < cnt; u++) {
-            const uint32_t idx = at + u, rkm = rk[first + u];
-            qi[idx] = s; qp[idx] = qg[s];
-            ar[idx] = rg[first + u] | (((km >> 31) != (rkm >> 31)) ? USED_BIT : 0u);
-            ac[idx] = rcg[first + u];
+        if (cnt) {
+            const uint32_t qpos = qg[s];
+            if (probe) {
+                for (uint32_t u = 0; u < cnt; u++) {
+                    const uint32_t idx = at + u, rkm = rk[first + u];
+                    qi[idx] = s; qp[idx] = qpos;
+                    ar[idx] = rg[first + u] | (((km >> 31) != (rkm >> 31)) ? USED_BIT : 0u);
+                    ac[idx] = rcg[first + u] & 63u;
+                }
+            } else {
+                for (uint32_t u = 0; u < cnt; u++) {
+                    const uint32_t idx = at + u, w = u == 0 ? mv.x : (u == 1 ? mv.y : (u == 2 ? mv.z : mv.w));
+                    qi[idx] = s; qp[idx] = qpos;
+                    ar[idx] = w & (HIT_POS_MASK | USED_BIT);
+                    ac[idx] = (w >> HIT_POS_BITS) & 63u;
+                }
+            }
         }
         n += total;
     }
@@ -1393,7 +1427,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         if (nchunks) {
             const uint64_t want = (nchunks + SLOWW_WAVES - 1) / SLOWW_WAVES;
             hipLaunchKernelGGL(slow_wave_kernel, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(64 * SLOWW_WAVES), 0, st, VA, VB,
-                               S.d_pairs.p, nb, S.slow_list.p, S.counters.p, S.chains.p, S.pair_nch.p, S.pair_na.p, S.over_list.p,
+                               S.d_pairs.p, nb, S.slow_list.p, S.counters.p, S.hits.p, S.multi.p, S.chains.p, S.pair_nch.p, S.pair_na.p, S.over_list.p,
                                S.counters.p + 15, S.flags.p);
         }
         HIPCHECK(hipEventRecord(S.ev[3], st));
