@@ -14,6 +14,7 @@
 //                    parallel fix-point, fixed-point containment ANI, aligned fraction.
 #include <algorithm>
 #include <chrono>
+#include <thread>
 
 #include "device_utils.h"
 #include "engine.h"
@@ -1280,8 +1281,11 @@ struct ChainSlot {
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
     }
 };
+struct PairJob { uint32_t q, r, flags, orig; };
 struct ChainWork {
     ChainSlot slot[2];
+    std::vector<PairJob> jobs, jobs_sorted;
+    std::vector<uint32_t> sort_start;
     // rare path (chunks with more anchors than the wave kernel holds in LDS)
     DevBuf<uint32_t> cap, abase, slow_n, a_qi, a_r, a_rctg, BP;
     DevBuf<int32_t> F;
@@ -1318,24 +1322,55 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
     // orientation of every pair, then order the work by the probed genome (R): consecutive
     // workgroups probe the same hash table, which keeps it in the XCD's L2
     const auto t_host0 = std::chrono::steady_clock::now();
-    struct PairJob { uint32_t q, r, flags, orig; };
-    std::vector<PairJob> jobs(np);
-    for (size_t p = 0; p < np; p++) {
-        const GenomeMeta &mr = SA->h_meta[pref[p]], &mq = SB->h_meta[pquery[p]];
-        const bool cq = chunk_the_query(mr, mq);
-        jobs[p].q = cq ? pquery[p] : pref[p];
-        jobs[p].r = cq ? pref[p] : pquery[p];
-        jobs[p].flags = (cq ? 1u : 0u) | (cq ? 2u : 0u) | (cq ? 0u : 4u);   // Q in B iff cq; R in B iff !cq
-        jobs[p].orig = (uint32_t)p;
-    }
-    {   // stable counting sort by (set of R, R): O(n), the order inside a group stays the screen's
+    std::vector<PairJob> &jobs = W.jobs, &sorted = W.jobs_sorted;     // kept across calls: no fresh pages to fault in
+    jobs.resize(np); sorted.resize(np);
+    {
+        // orientation + stable counting sort by (set of R, R) on a few host threads: every thread owns a
+        // contiguous range of pairs, counts its keys, and scatters into the slots that the prefix over
+        // (key, thread) reserves for it -- the order inside a group stays the screen's
         const size_t na = SA->n_genomes, nbk = na + SB->n_genomes + 1;
-        std::vector<uint32_t> start(nbk + 1, 0);
+        const unsigned T = np >= 65536 ? 4u : 1u;
+        std::vector<uint32_t> &cnt = W.sort_start;
+        cnt.assign((size_t)T * nbk, 0);
         auto keyof = [&](const PairJob &j) { return (size_t)((j.flags & 4u) ? na + j.r : j.r); };
-        for (const PairJob &j : jobs) start[keyof(j) + 1]++;
-        for (size_t k = 0; k < nbk; k++) start[k + 1] += start[k];
-        std::vector<PairJob> sorted(np);
-        for (const PairJob &j : jobs) sorted[start[keyof(j)]++] = j;
+        auto range = [&](unsigned t) { return std::make_pair(np * t / T, np * (t + 1) / T); };
+        auto orient = [&](unsigned t) {
+            const auto rg = range(t);
+            uint32_t *c = cnt.data() + (size_t)t * nbk;
+            for (size_t p = rg.first; p < rg.second; p++) {
+                const GenomeMeta &mr = SA->h_meta[pref[p]], &mq = SB->h_meta[pquery[p]];
+                const bool cq = chunk_the_query(mr, mq);
+                PairJob j;
+                j.q = cq ? pquery[p] : pref[p];
+                j.r = cq ? pref[p] : pquery[p];
+                j.flags = (cq ? 1u : 0u) | (cq ? 2u : 0u) | (cq ? 0u : 4u);   // Q in B iff cq; R in B iff !cq
+                j.orig = (uint32_t)p;
+                jobs[p] = j;
+                c[keyof(j)]++;
+            }
+        };
+        auto scatter = [&](unsigned t) {
+            const auto rg = range(t);
+            uint32_t *c = cnt.data() + (size_t)t * nbk;
+            for (size_t p = rg.first; p < rg.second; p++) sorted[c[keyof(jobs[p])]++] = jobs[p];
+        };
+        auto run = [&](auto fn) {
+            if (T == 1) { fn(0u); return; }
+            std::vector<std::thread> th;
+            for (unsigned t = 1; t < T; t++) th.emplace_back(fn, t);
+            fn(0u);
+            for (auto &x : th) x.join();
+        };
+        run(orient);
+        uint32_t running = 0;
+        for (size_t k = 0; k < nbk; k++)
+            for (unsigned t = 0; t < T; t++) {
+                uint32_t &c = cnt[(size_t)t * nbk + k];
+                const uint32_t v = c;
+                c = running;
+                running += v;
+            }
+        run(scatter);
         jobs.swap(sorted);
     }
     const auto t_host1 = std::chrono::steady_clock::now();
