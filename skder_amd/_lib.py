@@ -77,6 +77,26 @@ SYMBOLS = {
 _LIB = None
 
 
+def _preload_pytorch_hip_runtime():
+    """PyTorch wheels ship their own copy of libamdhip64; libskder_amd.so links the system one.  Two
+    copies of the HIP runtime in one process cannot both own the GPU (the second sees no device), and
+    which one came first would depend on import order.  When PyTorch is installed its copy is loaded
+    first and globally, so that this library's dependency resolves to the same runtime PyTorch uses."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    p = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.isfile(p):
+        try:
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Load libskder_amd.so; raises RuntimeError if it has not been built."""
     global _LIB
@@ -84,6 +104,7 @@ def lib():
         if not os.path.isfile(LIB_PATH):
             raise RuntimeError("libskder_amd.so is missing (run `make -C skder_amd/csrc`); "
                                "skder_amd has no CPU fallback")
+        _preload_pytorch_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             f = getattr(L, name)      # AttributeError if a declared symbol is not exported
