@@ -138,6 +138,10 @@ int skder_amd_triangle_rows(skder_sketches_t *s, uint32_t row_begin, uint32_t ro
 int skder_amd_rectangle(skder_sketches_t *refs, skder_sketches_t *queries, double screen_pct,
                         const skder_edge_t **edges, uint64_t *n_edges);
 
+/* device-to-device copy on the context's stream, complete on return (lets a caller that holds device
+ * memory of its own -- e.g. a torch tensor for the RCCL exchange -- take a copy of the raw arrays) */
+int skder_amd_copy_d2d(skder_ctx_t *ctx, void *dst, const void *src, size_t bytes);
+
 /* timing of the last triangle_rows/rectangle/sketch_batch call, milliseconds by HIP events on the
  * context's stream: [0] sketch kernel, [1] sketch post-processing + index, [2] screen,
  * [3] chaining fast path, [4] chaining slow path, [5] finalize; counts: [6] pairs screened in, [7] anchors */

@@ -67,6 +67,17 @@ extern "C" int skder_amd_last_timing(skder_ctx_t *ctx, double *out8)
     for (int i = 0; i < 8; i++) out8[i] = ctx->timing[i];
     return 0;
 }
+extern "C" int skder_amd_copy_d2d(skder_ctx_t *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (!ctx || (bytes && (!dst || !src))) return 1;
+    API_TRY
+    HIPCHECK(hipSetDevice(ctx->device));
+    if (bytes) HIPCHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+    API_CATCH_CTX(ctx, 2)
+}
+
 extern "C" int skder_amd_last_counters(skder_ctx_t *ctx, uint64_t *out4)
 {
     if (!ctx || !out4) return 1;

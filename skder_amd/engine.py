@@ -208,7 +208,22 @@ class Sketches:
         return dict(n_chunks=nch.value, rep_cut=rep.value, bucket_bits=bits.value, skmer=sk, sgpos=sg, sctg=sc, pchunk=pc)
 
 
-def download(ptr: int, n: int, dtype) -> np.ndarray:
+def _copy_d2d(dst_ptr: int, src_ptr: int, nbytes: int, ctx=None):
+    """device-to-device copy, complete on return: through the library (its own stream) when a context
+    is given, else through the HIP runtime this process already has loaded"""
+    if ctx is not None:
+        ctx.check(_lib.lib().skder_amd_copy_d2d(ctx.h, dst_ptr, src_ptr, nbytes), "copy_d2d")
+        return
+    hip = C.CDLL(None)                      # the runtime loaded globally by _lib (never a second copy)
+    if not hasattr(hip, "hipMemcpy"):
+        hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    rc = hip.hipMemcpy(dst_ptr, src_ptr, nbytes, 3)
+    if rc != 0:
+        raise RuntimeError("hipMemcpy failed: %d" % rc)
+
+
+def download(ptr: int, n: int, dtype, ctx=None) -> np.ndarray:
     """copy n elements from a device pointer (torch as the allocator/copier)"""
     import torch
     nbytes = n * np.dtype(dtype).itemsize
@@ -216,23 +231,15 @@ def download(ptr: int, n: int, dtype) -> np.ndarray:
         return np.zeros(0, dtype)
     t = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
-    hip = C.CDLL("libamdhip64.so")
-    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-    rc = hip.hipMemcpy(t.data_ptr(), ptr, nbytes, 3)   # device to device
-    if rc != 0:
-        raise RuntimeError("hipMemcpy failed: %d" % rc)
-    return t.cpu().numpy().view(dtype).copy()
+    _copy_d2d(t.data_ptr(), ptr, nbytes, ctx)
+    return t.cpu().numpy().view(dtype)
 
 
-def download_tensor(ptr: int, n: int, torch_dtype):
+def download_tensor(ptr: int, n: int, torch_dtype, ctx=None):
     """copy n elements from a raw device pointer into a new torch tensor on the current device"""
     import torch
     t = torch.empty(max(n, 0), dtype=torch_dtype, device="cuda")
     if n:
         torch.cuda.synchronize()
-        hip = C.CDLL("libamdhip64.so")
-        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-        rc = hip.hipMemcpy(t.data_ptr(), ptr, n * t.element_size(), 3)
-        if rc != 0:
-            raise RuntimeError("hipMemcpy failed: %d" % rc)
+        _copy_d2d(t.data_ptr(), ptr, n * t.element_size(), ctx)
     return t

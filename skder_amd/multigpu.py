@@ -94,10 +94,10 @@ def raw_from_sketches(sk) -> Dict:
     from .engine import download_tensor
     v = sk.view()
     return dict(n_genomes=v["n_genomes"],
-                seed_kmer=download_tensor(v["d_seed_kmer"], v["n_seeds"], torch.int32),
-                seed_gpos=download_tensor(v["d_seed_gpos"], v["n_seeds"], torch.int32),
-                seed_ctg=download_tensor(v["d_seed_ctg"], v["n_seeds"], torch.int32),
-                markers=download_tensor(v["d_markers"], v["n_markers"], torch.int64),
+                seed_kmer=download_tensor(v["d_seed_kmer"], v["n_seeds"], torch.int32, sk.ctx),
+                seed_gpos=download_tensor(v["d_seed_gpos"], v["n_seeds"], torch.int32, sk.ctx),
+                seed_ctg=download_tensor(v["d_seed_ctg"], v["n_seeds"], torch.int32, sk.ctx),
+                markers=download_tensor(v["d_markers"], v["n_markers"], torch.int64, sk.ctx),
                 seed_off=v["seed_off"], marker_off=v["marker_off"], genome_len=v["genome_len"],
                 genome_nrec=v["genome_nrec"], rec_goff=v["rec_goff"])
 
