@@ -613,20 +613,47 @@ __global__ __launch_bounds__(256, 3) void chain_fast_kernel(SetView A, SetView B
 // ---------------------------------------------------------------------------------------------
 // SLOW PATH (unabridged algorithm) for the chunks the fast path declined
 
+// one wavefront per slow chunk: the exact number of anchors of the chunk (a seed may occur any number of
+// times on the other genome as long as the repetitive cut-off is inactive, so no a-priori bound exists)
 __global__ __launch_bounds__(256) void slow_caps_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs, uint32_t npairs,
                                                         const uint32_t *__restrict__ slow_list, uint32_t nslow,
                                                         uint32_t *__restrict__ cap)
 {
-    const uint32_t w = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (w > nslow) return;
-    if (w == nslow) { cap[w] = 0; return; }
+    if (w == nslow) { if (lane == 0) cap[w] = 0; return; }
     const uint32_t t = slow_list[w];
     const PairDesc pd = pairs[find_pair(pairs, npairs, t)];
     const SetView &QS = (pd.flags & 2u) ? B : A;
-    const GenomeMeta *Qm = QS.meta + pd.q;
+    const SetView &RS = (pd.flags & 4u) ? B : A;
+    const GenomeMeta Q = QS.meta[pd.q], R = RS.meta[pd.r];
     const uint32_t c = t - pd.chunk_base;
-    const uint32_t s0 = QS.chunk_start[Qm->chunk_off + c], s1 = QS.chunk_start[Qm->chunk_off + c + 1];
-    cap[w] = 4u * (s1 - s0) + 64u;
+    const uint32_t s0 = QS.chunk_start[Q.chunk_off + c], s1 = QS.chunk_start[Q.chunk_off + c + 1];
+    const uint32_t *qk = QS.pkmer + Q.seed_off;
+    const uint32_t *rk = RS.skmer + R.seed_off, *rb = RS.boff + R.bucket_off;
+    const uint32_t *qsk = QS.skmer + Q.seed_off, *qb = QS.boff + Q.bucket_off;
+    uint32_t mine = 0;
+    for (uint32_t s = s0 + lane; s < s1; s += 64) {
+        const uint32_t kmer = qk[s] & SK_SEED_MASK;
+        const uint32_t b = kmer_bucket(kmer, R.bucket_bits);
+        uint32_t cnt = 0;
+        for (uint32_t e = rb[b]; e < rb[b + 1]; e++) {
+            const uint32_t k2 = rk[e] & SK_SEED_MASK;
+            if (k2 == kmer) cnt++;
+            else if (k2 > kmer) break;
+        }
+        if (cnt > R.rep_cut) cnt = 0;
+        if (cnt && Q.rep_cut != 0xFFFFFFFFu) {
+            const uint32_t b2 = kmer_bucket(kmer, Q.bucket_bits);
+            uint32_t m2 = 0;
+            for (uint32_t e = qb[b2]; e < qb[b2 + 1]; e++) m2 += ((qsk[e] & SK_SEED_MASK) == kmer);
+            if (m2 > Q.rep_cut) cnt = 0;
+        }
+        mine += cnt;
+    }
+    uint32_t total;
+    (void)wave_excl_scan(mine, total);
+    if (lane == 0) cap[w] = total;
 }
 
 // one wavefront per slow chunk: ordered anchors through the bucket index (hits in ascending gpos)
@@ -1390,7 +1417,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
             memset(&d, 0, sizeof d);
             d.q = jb.q; d.r = jb.r; d.flags = jb.flags;
             d.n_chunks = Q.n_chunks;
-            d.c_cap = 4u * Q.n_chunks + 64u;
+            d.c_cap = 16u * Q.n_chunks + 256u;     // slow-path chains of the pair (repeat-rich chunks yield many)
             d.multi_cap = 256u + Q.n_seeds / 8u;
             if (d.multi_cap > 0x00FFFFF0u) d.multi_cap = 0x00FFFFF0u;
             if (!hp.empty() && nchunks + d.n_chunks > budget) break;
@@ -1444,8 +1471,10 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
             HIPCHECK(hipMemcpyAsync(S.groups.p, hg.data(), hg.size() * sizeof(JoinGroup), hipMemcpyHostToDevice, st));
             static bool join_attr_set = false;
             if (!join_attr_set) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(join_probe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          JOIN_SMEM_BYTES);
+                HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(join_probe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             JOIN_SMEM_BYTES));
+                HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(finalize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             4096 * 35));
                 join_attr_set = true;
             }
             hipLaunchKernelGGL(join_probe_kernel, dim3((unsigned)hg.size()), dim3(JOIN_THREADS), JOIN_SMEM_BYTES, st, VA, VB, S.d_pairs.p,
@@ -1467,15 +1496,17 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         }
         HIPCHECK(hipEventRecord(S.ev[3], st));
         // LDS capacity of the finalize step: the most chains any pair of the batch can plausibly have
-        // (3 per chunk on the fast path + slack), rounded up, at most 4096 (132 KB)
+        // (1.5 per chunk + slack), rounded up; a batch in which some pair has more is finalized again with
+        // the full 4096 (140 KB) when its results are read
         uint32_t max_chunks = 0;
         for (const PairDesc &d : hp) max_chunks = d.n_chunks > max_chunks ? d.n_chunks : max_chunks;
         uint32_t lds_cap = 512;
-        while (lds_cap < FAST_SLOTS * max_chunks / 2 + 128 && lds_cap < 4096) lds_cap <<= 1;
+        while (lds_cap < FAST_SLOTS * max_chunks / 2 + 128 && lds_cap < 4096) lds_cap <<= 1;   // retried with more if a pair needs it
         S.lds_cap = lds_cap;
         if (nb)
             hipLaunchKernelGGL(finalize_kernel, dim3(nb), dim3(256), lds_cap * 35u, st, VA, VB, S.d_pairs.p, S.fast_chains.p, S.chunk_state.p,
                                S.chains.p, S.pair_nch.p, S.pair_na.p, S.d_out.p, S.flags.p, W.root_lut.p, lds_cap);
+        HIPCHECK(hipGetLastError());     // a rejected launch (resources) must not pass as an empty result
         HIPCHECK(hipEventRecord(S.ev[4], st));
         HIPCHECK(hipMemcpyAsync(S.h_out, S.d_out.p, nb * sizeof(PairOut), hipMemcpyDeviceToHost, st));
         HIPCHECK(hipMemcpyAsync(S.h_cnt, S.counters.p, 64, hipMemcpyDeviceToHost, st));
@@ -1484,9 +1515,9 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         return p;
     };
     auto check_flags = [](uint32_t h_flags) {
-        if (h_flags & 4u) throw SkError("anchor buffer overflow in the slow path (a chunk has more than 4*seeds+64 anchors)");
-        if (h_flags & 8u) throw SkError("chain buffer overflow (a pair has more than 4*chunks+64 slow-path chains)");
-        if (h_flags & 16u) throw SkError("pair with more chains than the finalize step holds in LDS (1.5 per chunk + 128, at most 4096)");
+        if (h_flags & 4u) throw SkError("anchor buffer overflow in the slow path (internal error: counts and anchors disagree)");
+        if (h_flags & 8u) throw SkError("chain buffer overflow (a pair has more than 16*chunks+256 slow-path chains)");
+        if (h_flags & 16u) throw SkError("pair with more than 4096 chains: more than the finalize step holds in LDS");
     };
     // ---- results of a batch: wait for its last copy, rare-path fix-up, edge records
     auto consume = [&](ChainSlot &S) {
@@ -1503,13 +1534,26 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
             fprintf(stderr, "[skder_amd] batch: over %u; %u pairs %llu chunks, slow %u (none %u, slots %u, hits %u, ring %u, branch %u, score %u, qrep %u, inside %u) parks %u passes %u walk-trips %u rounds %u empty-ring %u rec-change %u\n",
                     nover, nb, (unsigned long long)S.nchunks, nslow, hcnt[1], hcnt[2], hcnt[3], hcnt[4], hcnt[5], hcnt[6], hcnt[7], hcnt[8], hcnt[10], hcnt[11], hcnt[12], hcnt[13], hcnt[14], hcnt[9]);
         }
+        bool refinalize = (S.h_cnt[16] & 16u) && S.lds_cap < 4096;   // a pair with more chains than the LDS capacity chosen
+        if (refinalize) S.h_cnt[16] &= ~16u;
         check_flags(S.h_cnt[16]);
+        if (refinalize && !nover) {
+            S.lds_cap = 4096;
+            HIPCHECK(hipMemsetAsync(S.flags.p, 0, 64, st));
+            hipLaunchKernelGGL(finalize_kernel, dim3(nb), dim3(256), S.lds_cap * 35u, st, VA, VB, S.d_pairs.p, S.fast_chains.p, S.chunk_state.p,
+                               S.chains.p, S.pair_nch.p, S.pair_na.p, S.d_out.p, S.flags.p, W.root_lut.p, S.lds_cap);
+            HIPCHECK(hipMemcpyAsync(S.h_out, S.d_out.p, nb * sizeof(PairOut), hipMemcpyDeviceToHost, st));
+            HIPCHECK(hipMemcpyAsync(S.h_cnt + 16, S.flags.p, 4, hipMemcpyDeviceToHost, st));
+            HIPCHECK(hipStreamSynchronize(st));
+            check_flags(S.h_cnt[16]);
+        }
         if (nover) {
+            if (refinalize) S.lds_cap = 4096;
             // chunks the wave kernel could not hold: global-memory kernels, then the finalize step again.
             // The slot's buffers are untouched since (the batch in flight uses the other slot).
             W.cap.resize(nover + 1, st); W.abase.resize(nover + 1, st); W.slow_n.resize(nover + 1, st);
             HIPCHECK(hipMemsetAsync(S.flags.p, 0, 64, st));
-            hipLaunchKernelGGL(slow_caps_kernel, dim3((nover + 256) / 256), dim3(256), 0, st, VA, VB, S.d_pairs.p, nb, S.over_list.p,
+            hipLaunchKernelGGL(slow_caps_kernel, dim3((nover + 4) / 4), dim3(256), 0, st, VA, VB, S.d_pairs.p, nb, S.over_list.p,
                                nover, W.cap.p);
             exclusive_scan_u32(W.cap.p, W.abase.p, nover + 1, W.ws, st);
             uint32_t atotal = 0;

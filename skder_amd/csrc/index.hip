@@ -391,6 +391,7 @@ void index_impl(skder_sketches *s)
                                d_list.p + small.size(), s->d_rec_goff.p, s->seed_kmer.p, s->seed_gpos.p, s->seed_ctg.p, s->skmer.p, s->sgpos.p,
                                s->sctg.p, s->stag.p, s->boff.p, s->pchunk.p, s->chunk_start.p);
         }
+        HIPCHECK(hipGetLastError());
         HIPCHECK(hipStreamSynchronize(st));   // d_list and the host vectors go out of scope
         HIPCHECK(hipEventRecord(ctx->ev[4], st));
         HIPCHECK(hipMemcpyAsync(s->h_meta.data(), s->d_meta.p, G * sizeof(GenomeMeta), hipMemcpyDeviceToHost, st));

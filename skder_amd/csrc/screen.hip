@@ -213,6 +213,7 @@ void screen_pairs(skder_sketches *refs, skder_sketches *queries, const std::vect
     hipLaunchKernelGGL(screen_rows_kernel, dim3(nrows), dim3(256), 0, st, queries->d_meta.p, q_slot_ptr, refs->d_meta.p, nref,
                        loff.p, list.p, d_rows.p, triangle ? 1 : 0, cutoff, screen_pct > 0.0 ? 1 : 0, pass_bits.p, wpr,
                        row_count.p);
+    HIPCHECK(hipGetLastError());
     exclusive_scan_u32(row_count.p, row_off.p, nrows + 1, ws, st);
     uint32_t npairs = 0;
     HIPCHECK(hipMemcpyAsync(&npairs, row_off.p + nrows, 4, hipMemcpyDeviceToHost, st));

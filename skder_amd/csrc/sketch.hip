@@ -440,6 +440,7 @@ void sketch_batch_impl(skder_sketches *s, const uint8_t *d_bases, const skder_ba
     s->markers.resize(mark_base + h_uoff[b->n_genomes], st);
     hipLaunchKernelGGL(marker_compact_kernel, dim3(b->n_genomes), dim3(256), 0, st, raw_marks.p, d_goff.p, d_nuniq.p,
                        d_uoff.p, mark_base, s->markers.p);
+    HIPCHECK(hipGetLastError());
     HIPCHECK(hipEventRecord(ctx->ev[2], st));
     HIPCHECK(hipStreamSynchronize(st));
     float ms0 = 0, ms1 = 0;

@@ -639,3 +639,65 @@ def test_rccl_process_group_on_one_gpu(gpu):
     j2 = json.loads([l for l in rc.stdout.splitlines() if l.startswith("{")][-1])
     assert j1["config"]["edges"] == j2["config"]["edges"] > 0
     assert j1["config"]["chained_pairs"] == j2["config"]["chained_pairs"]
+
+
+def test_repeats_indels_and_inversions(gpu, oracle):
+    """adversarial small genomes: a library of segments reused up to 8 times per genome (multi-occurrence
+    seeds, 'too many' hit words, repetitive cut-off), random strand flips, substitutions and short indels
+    every few hundred bases (branching / ring-overflow chunks on the slow path), 90 records of 500-3000 bp
+    among them (record tags wrap around 64).  Every pair, no screen: bit-equal with the oracle."""
+    engine, ctx, torch = gpu
+    p = oracle.default_params()
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    comp = np.zeros(256, np.uint8)
+    comp[ord("A")], comp[ord("C")], comp[ord("G")], comp[ord("T")] = ord("T"), ord("G"), ord("C"), ord("A")
+    rng = np.random.RandomState(20251)
+    library = [alpha[rng.randint(0, 4, rng.randint(2500, 9000))] for _ in range(24)]
+
+    def mutate(seq, sub, indel_every):
+        seq = seq.copy()
+        k = rng.binomial(len(seq), sub)
+        if k:
+            idx = rng.choice(len(seq), k, replace=False)
+            seq[idx] = alpha[(np.searchsorted(alpha, seq[idx]) + 1 + rng.randint(0, 3, k)) % 4]
+        out, pos = [], 0
+        while pos < len(seq):
+            step = rng.randint(indel_every // 2, indel_every * 2)
+            out.append(seq[pos:pos + step])
+            pos += step
+            if rng.rand() < 0.5:
+                out.append(alpha[rng.randint(0, 4, rng.randint(1, 40))])      # insertion
+            else:
+                pos += rng.randint(1, 40)                                     # deletion
+        return np.concatenate(out)
+
+    rec_lens_list, bases_list = [], []
+    for g in range(7):
+        picks = list(rng.randint(0, len(library), 70))
+        picks += [picks[0]] * 7                                               # one segment 8 times
+        pieces = []
+        for k in picks:
+            seg = mutate(library[k], 0.004 * (1 + g % 3), 300 + 200 * (g % 4))
+            if rng.rand() < 0.3:
+                seg = comp[seg[::-1]]
+            pieces.append(seg)
+        genome = np.concatenate(pieces)
+        cuts, pos = [], 0
+        for r in range(90):                                                   # many short records first
+            pos += rng.randint(500, 3000)
+            cuts.append(pos)
+        cuts = [c for c in cuts if c < len(genome) - 600]
+        bounds = [0] + cuts + [len(genome)]
+        lens = np.diff(bounds).astype(np.uint32)
+        assert lens.min() >= 500
+        rec_lens_list.append(lens)
+        bases_list.append(genome)
+    s, _ = _sketch(gpu, rec_lens_list, bases_list)
+    og = [oracle.Genome.from_bases(b, l, p) for b, l in zip(bases_list, rec_lens_list)]
+    edges = s.triangle_rows(0, 1, 0.0)
+    want = _oracle_edges(oracle, og, p, 0.0)
+    assert len(want) >= 15
+    _check_edges(edges, want)
+    c = ctx.counters()
+    assert c[1] > 0 and c[0] > c[1]                                           # both chaining paths were exercised
+    s.close()
