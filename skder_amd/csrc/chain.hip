@@ -1404,6 +1404,46 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
     if (getenv("SKDER_AMD_DEBUG"))
         fprintf(stderr, "[skder_amd] host: orient+sort of %zu pairs %.2f ms\n", np,
                 std::chrono::duration<double, std::milli>(t_host1 - t_host0).count());
+    // ---- the chaining stage of a batch whose hit words exist: fast path, slow path, finalize, results
+    auto chain_stage = [&](ChainSlot &S) {
+        const uint32_t nb = S.nb;
+        HIPCHECK(hipMemsetAsync(S.pair_nch.p, 0, nb * 4, st));
+        HIPCHECK(hipMemsetAsync(S.pair_na.p, 0, nb * 4, st));
+        HIPCHECK(hipMemsetAsync(S.counters.p, 0, 64, st));
+        HIPCHECK(hipMemsetAsync(S.flags.p, 0, 64, st));
+        HIPCHECK(hipEventRecord(S.ev[1], st));
+        if (S.nchunks)
+            hipLaunchKernelGGL(chain_fast_kernel, dim3((unsigned)((S.nchunks + 255) / 256)), dim3(256), 0, st, VA, VB, S.d_pairs.p, nb,
+                               (uint32_t)S.nchunks, S.hits.p, S.multi.p, S.fast_chains.p, S.chunk_state.p, S.slow_list.p, S.counters.p, S.pair_na.p,
+                               xcd_remap);
+        HIPCHECK(hipEventRecord(S.ev[2], st));
+        // declined chunks: one wavefront each, in LDS (count read on the device); the rare chunk with more
+        // than 1024 anchors is put on over_list and dealt with after the batch's results are back
+        if (S.nchunks) {
+            const uint64_t want = (S.nchunks + SLOWW_WAVES - 1) / SLOWW_WAVES;
+            hipLaunchKernelGGL(slow_wave_kernel, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(64 * SLOWW_WAVES), 0, st, VA, VB,
+                               S.d_pairs.p, nb, S.slow_list.p, S.counters.p, S.hits.p, S.multi.p, S.chains.p, S.pair_nch.p, S.pair_na.p, S.over_list.p,
+                               S.counters.p + 15, S.flags.p);
+        }
+        HIPCHECK(hipEventRecord(S.ev[3], st));
+        // LDS capacity of the finalize step: the most chains any pair of the batch can plausibly have
+        // (1.5 per chunk + slack), rounded up; a batch in which some pair has more is finalized again with
+        // the full 4096 (140 KB) when its results are read
+        uint32_t max_chunks = 0;
+        for (const PairDesc &d : S.hp) max_chunks = d.n_chunks > max_chunks ? d.n_chunks : max_chunks;
+        uint32_t lds_cap = 512;
+        while (lds_cap < FAST_SLOTS * max_chunks / 2 + 128 && lds_cap < 4096) lds_cap <<= 1;   // retried with more if a pair needs it
+        S.lds_cap = lds_cap;
+        if (nb)
+            hipLaunchKernelGGL(finalize_kernel, dim3(nb), dim3(256), lds_cap * 35u, st, VA, VB, S.d_pairs.p, S.fast_chains.p, S.chunk_state.p,
+                               S.chains.p, S.pair_nch.p, S.pair_na.p, S.d_out.p, S.flags.p, W.root_lut.p, lds_cap);
+        HIPCHECK(hipGetLastError());     // a rejected launch (resources) must not pass as an empty result
+        HIPCHECK(hipEventRecord(S.ev[4], st));
+        HIPCHECK(hipMemcpyAsync(S.h_out, S.d_out.p, nb * sizeof(PairOut), hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipMemcpyAsync(S.h_cnt, S.counters.p, 64, hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipMemcpyAsync(S.h_cnt + 16, S.flags.p, 4, hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipEventRecord(S.ev[5], st));
+    };
     // ---- one batch: descriptors (host), then everything on the stream without a host round trip
     auto enqueue = [&](ChainSlot &S, size_t p0) -> size_t {
         std::vector<PairDesc> &hp = S.hp;
@@ -1449,11 +1489,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         S.chains.resize(ccap + 1, st);
         S.d_out.resize(nb, st);
         HIPCHECK(hipMemcpyAsync(S.d_pairs.p, hp.data(), nb * sizeof(PairDesc), hipMemcpyHostToDevice, st));
-        HIPCHECK(hipMemsetAsync(S.pair_nch.p, 0, nb * 4, st));
-        HIPCHECK(hipMemsetAsync(S.pair_na.p, 0, nb * 4, st));
         HIPCHECK(hipMemsetAsync(S.pair_nmulti.p, 0, nb * 4, st));
-        HIPCHECK(hipMemsetAsync(S.counters.p, 0, 64, st));
-        HIPCHECK(hipMemsetAsync(S.flags.p, 0, 64, st));
         HIPCHECK(hipEventRecord(S.ev[0], st));
         {
             // groups of consecutive pairs that probe the same genome, at most 16 pairs each (load balance)
@@ -1480,43 +1516,12 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
             hipLaunchKernelGGL(join_probe_kernel, dim3((unsigned)hg.size()), dim3(JOIN_THREADS), JOIN_SMEM_BYTES, st, VA, VB, S.d_pairs.p,
                                reinterpret_cast<const JoinGroup *>(S.groups.p), S.hits.p, S.multi.p, S.pair_nmulti.p);
         }
-        HIPCHECK(hipEventRecord(S.ev[1], st));
-        if (nchunks)
-            hipLaunchKernelGGL(chain_fast_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, st, VA, VB, S.d_pairs.p, nb,
-                               (uint32_t)nchunks, S.hits.p, S.multi.p, S.fast_chains.p, S.chunk_state.p, S.slow_list.p, S.counters.p, S.pair_na.p,
-                               xcd_remap);
-        HIPCHECK(hipEventRecord(S.ev[2], st));
-        // declined chunks: one wavefront each, in LDS (count read on the device); the rare chunk with more
-        // than 1024 anchors is put on over_list and dealt with after the batch's results are back
-        if (nchunks) {
-            const uint64_t want = (nchunks + SLOWW_WAVES - 1) / SLOWW_WAVES;
-            hipLaunchKernelGGL(slow_wave_kernel, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(64 * SLOWW_WAVES), 0, st, VA, VB,
-                               S.d_pairs.p, nb, S.slow_list.p, S.counters.p, S.hits.p, S.multi.p, S.chains.p, S.pair_nch.p, S.pair_na.p, S.over_list.p,
-                               S.counters.p + 15, S.flags.p);
-        }
-        HIPCHECK(hipEventRecord(S.ev[3], st));
-        // LDS capacity of the finalize step: the most chains any pair of the batch can plausibly have
-        // (1.5 per chunk + slack), rounded up; a batch in which some pair has more is finalized again with
-        // the full 4096 (140 KB) when its results are read
-        uint32_t max_chunks = 0;
-        for (const PairDesc &d : hp) max_chunks = d.n_chunks > max_chunks ? d.n_chunks : max_chunks;
-        uint32_t lds_cap = 512;
-        while (lds_cap < FAST_SLOTS * max_chunks / 2 + 128 && lds_cap < 4096) lds_cap <<= 1;   // retried with more if a pair needs it
-        S.lds_cap = lds_cap;
-        if (nb)
-            hipLaunchKernelGGL(finalize_kernel, dim3(nb), dim3(256), lds_cap * 35u, st, VA, VB, S.d_pairs.p, S.fast_chains.p, S.chunk_state.p,
-                               S.chains.p, S.pair_nch.p, S.pair_na.p, S.d_out.p, S.flags.p, W.root_lut.p, lds_cap);
-        HIPCHECK(hipGetLastError());     // a rejected launch (resources) must not pass as an empty result
-        HIPCHECK(hipEventRecord(S.ev[4], st));
-        HIPCHECK(hipMemcpyAsync(S.h_out, S.d_out.p, nb * sizeof(PairOut), hipMemcpyDeviceToHost, st));
-        HIPCHECK(hipMemcpyAsync(S.h_cnt, S.counters.p, 64, hipMemcpyDeviceToHost, st));
-        HIPCHECK(hipMemcpyAsync(S.h_cnt + 16, S.flags.p, 4, hipMemcpyDeviceToHost, st));
-        HIPCHECK(hipEventRecord(S.ev[5], st));
+        chain_stage(S);
         return p;
     };
     auto check_flags = [](uint32_t h_flags) {
         if (h_flags & 4u) throw SkError("anchor buffer overflow in the slow path (internal error: counts and anchors disagree)");
-        if (h_flags & 8u) throw SkError("chain buffer overflow (a pair has more than 16*chunks+256 slow-path chains)");
+        if (h_flags & 8u) throw SkError("chain buffer overflow after the capacities were made exact (internal error)");
         if (h_flags & 16u) throw SkError("pair with more than 4096 chains: more than the finalize step holds in LDS");
     };
     // ---- results of a batch: wait for its last copy, rare-path fix-up, edge records
@@ -1534,45 +1539,69 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
             fprintf(stderr, "[skder_amd] batch: over %u; %u pairs %llu chunks, slow %u (none %u, slots %u, hits %u, ring %u, branch %u, score %u, qrep %u, inside %u) parks %u passes %u walk-trips %u rounds %u empty-ring %u rec-change %u\n",
                     nover, nb, (unsigned long long)S.nchunks, nslow, hcnt[1], hcnt[2], hcnt[3], hcnt[4], hcnt[5], hcnt[6], hcnt[7], hcnt[8], hcnt[10], hcnt[11], hcnt[12], hcnt[13], hcnt[14], hcnt[9]);
         }
-        bool refinalize = (S.h_cnt[16] & 16u) && S.lds_cap < 4096;   // a pair with more chains than the LDS capacity chosen
-        if (refinalize) S.h_cnt[16] &= ~16u;
-        check_flags(S.h_cnt[16]);
-        if (refinalize && !nover) {
-            S.lds_cap = 4096;
-            HIPCHECK(hipMemsetAsync(S.flags.p, 0, 64, st));
+        // Rare-path fix-ups; the slot's buffers are untouched since (the batch in flight uses the other slot).
+        //  * nover: chunks the wave kernel could not hold go through the global-memory kernels;
+        //  * flag 8: a pair produced more slow-path chains than its region holds (repeats: one chunk can
+        //    chain to every copy).  pair_nch keeps counting past the capacity, so after a complete attempt it
+        //    holds the number wanted: every pair gets exactly that and the chaining stage runs again;
+        //  * flag 16: a pair has more chains than the LDS capacity chosen for finalize: again at 4096.
+        auto finalize_and_fetch = [&]() {
             hipLaunchKernelGGL(finalize_kernel, dim3(nb), dim3(256), S.lds_cap * 35u, st, VA, VB, S.d_pairs.p, S.fast_chains.p, S.chunk_state.p,
                                S.chains.p, S.pair_nch.p, S.pair_na.p, S.d_out.p, S.flags.p, W.root_lut.p, S.lds_cap);
+            HIPCHECK(hipGetLastError());
             HIPCHECK(hipMemcpyAsync(S.h_out, S.d_out.p, nb * sizeof(PairOut), hipMemcpyDeviceToHost, st));
             HIPCHECK(hipMemcpyAsync(S.h_cnt + 16, S.flags.p, 4, hipMemcpyDeviceToHost, st));
             HIPCHECK(hipStreamSynchronize(st));
-            check_flags(S.h_cnt[16]);
-        }
-        if (nover) {
-            if (refinalize) S.lds_cap = 4096;
-            // chunks the wave kernel could not hold: global-memory kernels, then the finalize step again.
-            // The slot's buffers are untouched since (the batch in flight uses the other slot).
-            W.cap.resize(nover + 1, st); W.abase.resize(nover + 1, st); W.slow_n.resize(nover + 1, st);
-            HIPCHECK(hipMemsetAsync(S.flags.p, 0, 64, st));
-            hipLaunchKernelGGL(slow_caps_kernel, dim3((nover + 4) / 4), dim3(256), 0, st, VA, VB, S.d_pairs.p, nb, S.over_list.p,
-                               nover, W.cap.p);
-            exclusive_scan_u32(W.cap.p, W.abase.p, nover + 1, W.ws, st);
-            uint32_t atotal = 0;
-            HIPCHECK(hipMemcpyAsync(&atotal, W.abase.p + nover, 4, hipMemcpyDeviceToHost, st));
-            HIPCHECK(hipStreamSynchronize(st));
-            W.a_qi.resize(atotal + 1, st); W.a_r.resize(atotal + 1, st); W.a_rctg.resize(atotal + 1, st);
-            W.F.resize(atotal + 1, st); W.BP.resize(atotal + 1, st);
-            hipLaunchKernelGGL(slow_anchors_kernel, dim3((nover + 3) / 4), dim3(256), 0, st, VA, VB, S.d_pairs.p, nb, S.over_list.p, nover,
-                               W.abase.p, W.a_qi.p, W.a_r.p, W.a_rctg.p, W.slow_n.p, S.flags.p);
-            hipLaunchKernelGGL(slow_chain_kernel, dim3((nover + 255) / 256), dim3(256), 0, st, VA, VB, S.d_pairs.p, nb, S.over_list.p, nover,
-                               W.abase.p, W.slow_n.p, W.a_qi.p, W.a_r.p, W.a_rctg.p, W.F.p, W.BP.p, S.chains.p, S.pair_nch.p,
-                               S.pair_na.p, S.flags.p);
-            hipLaunchKernelGGL(finalize_kernel, dim3(nb), dim3(256), S.lds_cap * 35u, st, VA, VB, S.d_pairs.p, S.fast_chains.p, S.chunk_state.p,
-                               S.chains.p, S.pair_nch.p, S.pair_na.p, S.d_out.p, S.flags.p, W.root_lut.p, S.lds_cap);
-            HIPCHECK(hipMemcpyAsync(S.h_out, S.d_out.p, nb * sizeof(PairOut), hipMemcpyDeviceToHost, st));
-            HIPCHECK(hipMemcpyAsync(S.h_cnt + 16, S.flags.p, 4, hipMemcpyDeviceToHost, st));
-            HIPCHECK(hipStreamSynchronize(st));
-            check_flags(S.h_cnt[16]);
-            tot_over += nover;
+        };
+        for (int attempt = 0;; attempt++) {
+            uint32_t flags_seen = S.h_cnt[16];
+            const uint32_t nover_now = S.h_cnt[15];
+            if (nover_now) {
+                W.cap.resize(nover_now + 1, st); W.abase.resize(nover_now + 1, st); W.slow_n.resize(nover_now + 1, st);
+                HIPCHECK(hipMemsetAsync(S.flags.p, 0, 64, st));
+                hipLaunchKernelGGL(slow_caps_kernel, dim3((nover_now + 4) / 4), dim3(256), 0, st, VA, VB, S.d_pairs.p, nb, S.over_list.p,
+                                   nover_now, W.cap.p);
+                exclusive_scan_u32(W.cap.p, W.abase.p, nover_now + 1, W.ws, st);
+                uint32_t atotal = 0;
+                HIPCHECK(hipMemcpyAsync(&atotal, W.abase.p + nover_now, 4, hipMemcpyDeviceToHost, st));
+                HIPCHECK(hipStreamSynchronize(st));
+                W.a_qi.resize(atotal + 1, st); W.a_r.resize(atotal + 1, st); W.a_rctg.resize(atotal + 1, st);
+                W.F.resize(atotal + 1, st); W.BP.resize(atotal + 1, st);
+                hipLaunchKernelGGL(slow_anchors_kernel, dim3((nover_now + 3) / 4), dim3(256), 0, st, VA, VB, S.d_pairs.p, nb, S.over_list.p,
+                                   nover_now, W.abase.p, W.a_qi.p, W.a_r.p, W.a_rctg.p, W.slow_n.p, S.flags.p);
+                hipLaunchKernelGGL(slow_chain_kernel, dim3((nover_now + 255) / 256), dim3(256), 0, st, VA, VB, S.d_pairs.p, nb, S.over_list.p,
+                                   nover_now, W.abase.p, W.slow_n.p, W.a_qi.p, W.a_r.p, W.a_rctg.p, W.F.p, W.BP.p, S.chains.p, S.pair_nch.p,
+                                   S.pair_na.p, S.flags.p);
+                finalize_and_fetch();
+                flags_seen = (flags_seen & 8u) | S.h_cnt[16];     // the wave kernel's overflow stays known
+            }
+            if ((flags_seen & 8u) && attempt == 0) {
+                std::vector<uint32_t> want(nb);
+                HIPCHECK(hipMemcpyAsync(want.data(), S.pair_nch.p, nb * 4ull, hipMemcpyDeviceToHost, st));
+                HIPCHECK(hipStreamSynchronize(st));
+                uint64_t ccap = 0;
+                for (uint32_t i = 0; i < nb; i++) {
+                    PairDesc &d = S.hp[i];
+                    if (want[i] + 64u > d.c_cap) d.c_cap = want[i] + 64u;
+                    d.c_base = (uint32_t)ccap;
+                    ccap += d.c_cap;
+                    if (ccap > 0xFFFF0000ull) throw SkError("chain buffer overflow: more than 2^32 slow-path chains in one batch of pairs");
+                }
+                S.chains.resize(ccap + 1, st);
+                HIPCHECK(hipMemcpyAsync(S.d_pairs.p, S.hp.data(), nb * sizeof(PairDesc), hipMemcpyHostToDevice, st));
+                chain_stage(S);
+                HIPCHECK(hipEventSynchronize(S.ev[5]));
+                continue;     // the over-list part runs again against the new regions
+            }
+            if ((flags_seen & 16u) && S.lds_cap < 4096) {
+                S.lds_cap = 4096;
+                HIPCHECK(hipMemsetAsync(S.flags.p, 0, 64, st));
+                finalize_and_fetch();
+                flags_seen = (flags_seen & ~16u) | S.h_cnt[16];
+            }
+            check_flags(flags_seen);
+            tot_over += nover_now;
+            break;
         }
         tot_slow += nslow; tot_chunks += S.nchunks;
         for (uint32_t i = 0; i < nb; i++) {

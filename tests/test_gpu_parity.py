@@ -701,3 +701,48 @@ def test_repeats_indels_and_inversions(gpu, oracle):
     c = ctx.counters()
     assert c[1] > 0 and c[0] > c[1]                                           # both chaining paths were exercised
     s.close()
+
+
+def test_repetitive_cutoff_and_large_genome(gpu, oracle):
+    """(a) genomes in which one 4 kb segment occurs 32 times: the repetitive cut-off becomes active (own
+    multiplicity filter, every chunk on the slow path, look-ups through the bucket index); (b) a 15 Mb
+    genome against a mutated copy: more than 65535 seeds (general index kernel), several LDS passes of the
+    join, positions close to the 24 bits of a hit word.  Bit-equal with the oracle."""
+    engine, ctx, torch = gpu
+    p = oracle.default_params()
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    rng = np.random.RandomState(77)
+
+    def subst(seq, rate):
+        seq = seq.copy()
+        k = rng.binomial(len(seq), rate)
+        idx = rng.choice(len(seq), k, replace=False)
+        seq[idx] = alpha[(np.searchsorted(alpha, seq[idx]) + 1 + rng.randint(0, 3, k)) % 4]
+        return seq
+
+    rep = alpha[rng.randint(0, 4, 4000)]
+    uniq = alpha[rng.randint(0, 4, 150000)]
+    def assemble(rep_g, uniq_g):        # the copies of the repeat stay identical inside a genome
+        return np.concatenate([np.concatenate([rep_g, uniq_g[i * 3000:(i + 1) * 3000]]) for i in range(32)] + [uniq_g[96000:]])
+
+    small = [assemble(rep, uniq), assemble(subst(rep, 0.01), subst(uniq, 0.01)), assemble(subst(rep, 0.03), subst(uniq, 0.03))]
+    lens_small = [np.array([len(x) // 2, len(x) - len(x) // 2], np.uint32) for x in small]
+    s, _ = _sketch(gpu, lens_small, small)
+    og = [oracle.Genome.from_bases(b, l, p) for b, l in zip(small, lens_small)]
+    assert all(o.rep_cut != 0xFFFFFFFF for o in og)                      # the cut-off is active
+    edges = s.triangle_rows(0, 1, 0.0)
+    _check_edges(edges, _oracle_edges(oracle, og, p, 0.0))
+    assert ctx.counters()[1] == ctx.counters()[0] > 0                    # every chunk took the slow path
+    s.close()
+
+    big = alpha[rng.randint(0, 4, 15_000_000)]
+    big2 = subst(big, 0.02)
+    lens_big = [np.array([9_000_000, 6_000_000], np.uint32), np.array([15_000_000], np.uint32)]
+    s, _ = _sketch(gpu, lens_big, [big, big2])
+    og = [oracle.Genome.from_bases(b, l, p) for b, l in zip([big, big2], lens_big)]
+    assert og[0].n_seeds > 65535
+    edges = s.triangle_rows(0, 1, 80.0)
+    want = _oracle_edges(oracle, og, p, 80.0)
+    assert len(want) == 1
+    _check_edges(edges, want)
+    s.close()
