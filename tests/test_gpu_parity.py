@@ -746,3 +746,27 @@ def test_repetitive_cutoff_and_large_genome(gpu, oracle):
     assert len(want) == 1
     _check_edges(edges, want)
     s.close()
+
+
+def test_listing_edge_cases(gpu, tmp_path):
+    """empty listing (header-only table), duplicate lines (one row, the self pair of identical files), blank
+    lines ignored; a database over duplicate lines answers a search with both entries"""
+    import skder_amd
+    from skder_amd.skder import Database
+    gdir = os.path.join(GOLDEN, "genomes")
+    fs = [os.path.join(gdir, n) for n in GENOMES[:3]]
+
+    def rows(lines, name):
+        l = tmp_path / (name + ".txt")
+        l.write_text("".join(x + "\n" for x in lines))
+        o = tmp_path / (name + ".tsv")
+        skder_amd.runSkaniTriangle(str(l), str(o), "-s 80", 15.0, "greedy", False, None)
+        return load_table(str(o))[1]
+
+    assert rows([], "empty") == []
+    dup = rows([fs[0], fs[0]], "dup")
+    assert len(dup) == 1 and dup[0][0] == dup[0][1] == fs[0] and dup[0][2] == "100.00"
+    assert len(rows(fs + [""], "blank")) == 3
+    with Database.from_listing(str(tmp_path / "dup.txt")) as db:
+        assert db.paths == [fs[0], fs[0]]
+        assert len(db.search_batch([fs[0]])) == 2
