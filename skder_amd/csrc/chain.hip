@@ -1086,28 +1086,38 @@ __device__ __forceinline__ bool better(const int32_t *sc, const uint32_t *q0, co
     return q1[j] < q1[i];
 }
 
-__global__ __launch_bounds__(256) void finalize_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs,
-                                                       const ChainRec *__restrict__ fast_chains, const uint32_t *__restrict__ chunk_state,
-                                                       const ChainRec *__restrict__ chains, const uint32_t *__restrict__ pair_nch,
-                                                       const uint32_t *__restrict__ pair_na, PairOut *__restrict__ out,
-                                                       uint32_t *__restrict__ flags, const uint32_t *__restrict__ root_lut, uint32_t lds_cap)
+// GLOBAL = false: the chain arrays of the pair live in dynamic LDS (`cap_arg` chains, sized per batch by the
+// host), one workgroup per pair of the batch.  GLOBAL = true: the same code for the few pairs with more
+// chains than LDS holds (repeat-rich genomes): arrays in a global workspace, workgroup b handles pair
+// glist[b] with capacity gcap[b] at gws + goff[b].
+template <bool GLOBAL>
+__global__ __launch_bounds__(256) void finalize_kernel_t(SetView A, SetView B, const PairDesc *__restrict__ pairs,
+                                                         const ChainRec *__restrict__ fast_chains, const uint32_t *__restrict__ chunk_state,
+                                                         const ChainRec *__restrict__ chains, const uint32_t *__restrict__ pair_nch,
+                                                         const uint32_t *__restrict__ pair_na, PairOut *__restrict__ out,
+                                                         uint32_t *__restrict__ flags, const uint32_t *__restrict__ root_lut, uint32_t cap_arg,
+                                                         unsigned char *__restrict__ gws, const uint64_t *__restrict__ goff,
+                                                         const uint32_t *__restrict__ glist, const uint32_t *__restrict__ gcap)
 {
-    // dynamic LDS: 8 word arrays + 1 byte array of `lds_cap` chains (sized per batch by the host)
+    // 8 word arrays + 1 byte array + 1 u16 array of `lds_cap` chains
     extern __shared__ __attribute__((aligned(16))) unsigned char fin_smem[];
-    int32_t *sc = reinterpret_cast<int32_t *>(fin_smem);
-    uint32_t *q0 = reinterpret_cast<uint32_t *>(fin_smem) + lds_cap, *q1 = q0 + lds_cap, *r0 = q1 + lds_cap, *r1 = r0 + lds_cap;
+    const uint32_t pidx = GLOBAL ? glist[blockIdx.x] : blockIdx.x;
+    const uint32_t lds_cap = GLOBAL ? gcap[blockIdx.x] : cap_arg;
+    unsigned char *const arrays = GLOBAL ? gws + goff[blockIdx.x] : fin_smem;
+    int32_t *sc = reinterpret_cast<int32_t *>(arrays);
+    uint32_t *q0 = reinterpret_cast<uint32_t *>(arrays) + lds_cap, *q1 = q0 + lds_cap, *r0 = q1 + lds_cap, *r1 = r0 + lds_cap;
     uint32_t *rc = r1 + lds_cap, *na = rc + lds_cap, *nsd = na + lds_cap;
     uint8_t *state = reinterpret_cast<uint8_t *>(nsd + lds_cap);   // 0 unknown, 1 kept, 2 dropped
     uint16_t *order = reinterpret_cast<uint16_t *>(state + lds_cap);  // chain indices grouped by bin
     __shared__ unsigned long long s_fx, s_seeds, s_anch, s_span;
     __shared__ uint32_t s_kept, s_unknown, s_n;
 
-    const PairDesc pd = pairs[blockIdx.x];
+    const PairDesc pd = pairs[pidx];
     const uint32_t tid = threadIdx.x;
     if (tid == 0) { s_fx = 0; s_seeds = 0; s_anch = 0; s_span = 0; s_kept = 0; s_unknown = 0; s_n = 0; }
     __syncthreads();
     // gather: chains of the fast path (per-chunk slots) and of the slow path (per-pair list)
-    uint32_t nslow = pair_nch[blockIdx.x];
+    uint32_t nslow = pair_nch[pidx];
     if (nslow > pd.c_cap) nslow = pd.c_cap;
     const uint32_t nfast_items = pd.n_chunks * FAST_SLOTS;
     for (uint32_t i = tid; i < nfast_items + nslow; i += 256) {
@@ -1130,8 +1140,16 @@ __global__ __launch_bounds__(256) void finalize_kernel(SetView A, SetView B, con
     __syncthreads();
     uint32_t n = s_n;
     if (n > lds_cap) {
-        if (tid == 0) atomicOr(&flags[0], 16u);
-        n = lds_cap;
+        // more chains than the arrays hold: report the number wanted (n_chains = ~0 marks the record) and
+        // leave the pair to a launch with enough room
+        if (tid == 0) {
+            atomicOr(&flags[0], 16u);
+            PairOut o;
+            memset(&o, 0, sizeof o);
+            o.n_chains = 0xFFFFFFFFu; o.n_chains_all = n;
+            out[pidx] = o;
+        }
+        return;
     }
     __syncthreads();
     // Spatial binning on the other genome so that a chain is compared only with chains that can
@@ -1238,7 +1256,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(SetView A, SetView B, con
         const SetView &RS = (pd.flags & 4u) ? B : A;
         PairOut o;
         o.fx_sum = (int64_t)s_fx; o.sum_seeds = s_seeds; o.sum_anchors = s_anch; o.sum_span = s_span;
-        o.n_chains = s_kept; o.n_chains_all = n; o.n_anchors = pair_na[blockIdx.x]; o.pad = 0;
+        o.n_chains = s_kept; o.n_chains_all = n; o.n_anchors = pair_na[pidx]; o.pad = 0;
         o.ani_raw = 0.0; o.ani = 0.0;
         if (s_seeds) {
             o.ani_raw = ((double)o.fx_sum / (double)s_seeds) / ANI_FX_ONE;
@@ -1250,7 +1268,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(SetView A, SetView B, con
         if (afq > 1.0) afq = 1.0;
         if (afr > 1.0) afr = 1.0;
         o.af_q = afq; o.af_r = afr;
-        out[blockIdx.x] = o;
+        out[pidx] = o;
     }
 }
 
@@ -1435,8 +1453,8 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         while (lds_cap < FAST_SLOTS * max_chunks / 2 + 128 && lds_cap < 4096) lds_cap <<= 1;   // retried with more if a pair needs it
         S.lds_cap = lds_cap;
         if (nb)
-            hipLaunchKernelGGL(finalize_kernel, dim3(nb), dim3(256), lds_cap * 35u, st, VA, VB, S.d_pairs.p, S.fast_chains.p, S.chunk_state.p,
-                               S.chains.p, S.pair_nch.p, S.pair_na.p, S.d_out.p, S.flags.p, W.root_lut.p, lds_cap);
+            hipLaunchKernelGGL(finalize_kernel_t<false>, dim3(nb), dim3(256), lds_cap * 35u, st, VA, VB, S.d_pairs.p, S.fast_chains.p, S.chunk_state.p,
+                               S.chains.p, S.pair_nch.p, S.pair_na.p, S.d_out.p, S.flags.p, W.root_lut.p, lds_cap, nullptr, nullptr, nullptr, nullptr);
         HIPCHECK(hipGetLastError());     // a rejected launch (resources) must not pass as an empty result
         HIPCHECK(hipEventRecord(S.ev[4], st));
         HIPCHECK(hipMemcpyAsync(S.h_out, S.d_out.p, nb * sizeof(PairOut), hipMemcpyDeviceToHost, st));
@@ -1509,7 +1527,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
             if (!join_attr_set) {
                 HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(join_probe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              JOIN_SMEM_BYTES));
-                HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(finalize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(finalize_kernel_t<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              4096 * 35));
                 join_attr_set = true;
             }
@@ -1522,7 +1540,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
     auto check_flags = [](uint32_t h_flags) {
         if (h_flags & 4u) throw SkError("anchor buffer overflow in the slow path (internal error: counts and anchors disagree)");
         if (h_flags & 8u) throw SkError("chain buffer overflow after the capacities were made exact (internal error)");
-        if (h_flags & 16u) throw SkError("pair with more than 4096 chains: more than the finalize step holds in LDS");
+        if (h_flags & 16u) throw SkError("finalize step: a pair still has more chains than its arrays hold (internal error)");
     };
     // ---- results of a batch: wait for its last copy, rare-path fix-up, edge records
     auto consume = [&](ChainSlot &S) {
@@ -1546,8 +1564,8 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         //    holds the number wanted: every pair gets exactly that and the chaining stage runs again;
         //  * flag 16: a pair has more chains than the LDS capacity chosen for finalize: again at 4096.
         auto finalize_and_fetch = [&]() {
-            hipLaunchKernelGGL(finalize_kernel, dim3(nb), dim3(256), S.lds_cap * 35u, st, VA, VB, S.d_pairs.p, S.fast_chains.p, S.chunk_state.p,
-                               S.chains.p, S.pair_nch.p, S.pair_na.p, S.d_out.p, S.flags.p, W.root_lut.p, S.lds_cap);
+            hipLaunchKernelGGL(finalize_kernel_t<false>, dim3(nb), dim3(256), S.lds_cap * 35u, st, VA, VB, S.d_pairs.p, S.fast_chains.p, S.chunk_state.p,
+                               S.chains.p, S.pair_nch.p, S.pair_na.p, S.d_out.p, S.flags.p, W.root_lut.p, S.lds_cap, nullptr, nullptr, nullptr, nullptr);
             HIPCHECK(hipGetLastError());
             HIPCHECK(hipMemcpyAsync(S.h_out, S.d_out.p, nb * sizeof(PairOut), hipMemcpyDeviceToHost, st));
             HIPCHECK(hipMemcpyAsync(S.h_cnt + 16, S.flags.p, 4, hipMemcpyDeviceToHost, st));
@@ -1598,6 +1616,39 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
                 HIPCHECK(hipMemsetAsync(S.flags.p, 0, 64, st));
                 finalize_and_fetch();
                 flags_seen = (flags_seen & ~16u) | S.h_cnt[16];
+            }
+            if (flags_seen & 16u) {
+                // pairs with more than 4096 chains: the same step with its arrays in a global workspace
+                std::vector<uint32_t> glist, gcap;
+                std::vector<uint64_t> goff;
+                uint64_t bytes = 0;
+                for (uint32_t i = 0; i < nb; i++)
+                    if (S.h_out[i].n_chains == 0xFFFFFFFFu) {
+                        const uint32_t want = S.h_out[i].n_chains_all;
+                        if (want > 65535u) throw SkError("pair with more than 65535 chains");   // chain indices are 16-bit in the overlap filter
+                        const uint32_t capi = (want + 15u) & ~15u;      // keeps the byte and 16-bit arrays behind the word arrays aligned
+                        glist.push_back(i); gcap.push_back(capi); goff.push_back(bytes);
+                        bytes += ((uint64_t)capi * 35u + 255u) & ~(uint64_t)255u;
+                    }
+                if (!glist.empty()) {
+                    DevBuf<unsigned char> gws;
+                    DevBuf<uint32_t> d_list, d_cap;
+                    DevBuf<uint64_t> d_off;
+                    const size_t ng = glist.size();
+                    gws.resize(bytes + 256, st); d_list.resize(ng, st); d_cap.resize(ng, st); d_off.resize(ng, st);
+                    HIPCHECK(hipMemcpyAsync(d_list.p, glist.data(), ng * 4, hipMemcpyHostToDevice, st));
+                    HIPCHECK(hipMemcpyAsync(d_cap.p, gcap.data(), ng * 4, hipMemcpyHostToDevice, st));
+                    HIPCHECK(hipMemcpyAsync(d_off.p, goff.data(), ng * 8, hipMemcpyHostToDevice, st));
+                    HIPCHECK(hipMemsetAsync(S.flags.p, 0, 64, st));
+                    hipLaunchKernelGGL(finalize_kernel_t<true>, dim3((unsigned)ng), dim3(256), 0, st, VA, VB, S.d_pairs.p, S.fast_chains.p,
+                                       S.chunk_state.p, S.chains.p, S.pair_nch.p, S.pair_na.p, S.d_out.p, S.flags.p, W.root_lut.p, 0u, gws.p,
+                                       d_off.p, d_list.p, d_cap.p);
+                    HIPCHECK(hipGetLastError());
+                    HIPCHECK(hipMemcpyAsync(S.h_out, S.d_out.p, nb * sizeof(PairOut), hipMemcpyDeviceToHost, st));
+                    HIPCHECK(hipMemcpyAsync(S.h_cnt + 16, S.flags.p, 4, hipMemcpyDeviceToHost, st));
+                    HIPCHECK(hipStreamSynchronize(st));
+                    flags_seen = (flags_seen & ~16u) | S.h_cnt[16];
+                }
             }
             check_flags(flags_seen);
             tot_over += nover_now;

@@ -722,18 +722,25 @@ def test_repetitive_cutoff_and_large_genome(gpu, oracle):
 
     rep = alpha[rng.randint(0, 4, 4000)]
     uniq = alpha[rng.randint(0, 4, 150000)]
-    def assemble(rep_g, uniq_g):        # the copies of the repeat stay identical inside a genome
-        return np.concatenate([np.concatenate([rep_g, uniq_g[i * 3000:(i + 1) * 3000]]) for i in range(32)] + [uniq_g[96000:]])
+    def assemble(rep_g, uniq_g, copies):        # the copies of the repeat stay identical inside a genome
+        return np.concatenate([np.concatenate([rep_g, uniq_g[i * 3000:(i + 1) * 3000]]) for i in range(copies)] + [uniq_g[3000 * copies:]])
 
-    small = [assemble(rep, uniq), assemble(subst(rep, 0.01), subst(uniq, 0.01)), assemble(subst(rep, 0.03), subst(uniq, 0.03))]
-    lens_small = [np.array([len(x) // 2, len(x) - len(x) // 2], np.uint32) for x in small]
-    s, _ = _sketch(gpu, lens_small, small)
-    og = [oracle.Genome.from_bases(b, l, p) for b, l in zip(small, lens_small)]
-    assert all(o.rep_cut != 0xFFFFFFFF for o in og)                      # the cut-off is active
-    edges = s.triangle_rows(0, 1, 0.0)
-    _check_edges(edges, _oracle_edges(oracle, og, p, 0.0))
-    assert ctx.counters()[1] == ctx.counters()[0] > 0                    # every chunk took the slow path
-    s.close()
+    # 32 copies: about a thousand chains per pair (finalize in LDS); 48 copies: more than 4096 chains per
+    # pair, the finalize step's global-memory variant, and slow-chain regions that have to be made exact
+    for copies in (32, 48):
+        small = [assemble(rep, uniq, copies), assemble(subst(rep, 0.01), subst(uniq, 0.01), copies),
+                 assemble(subst(rep, 0.03), subst(uniq, 0.03), copies)]
+        lens_small = [np.array([len(x) // 2, len(x) - len(x) // 2], np.uint32) for x in small]
+        s, _ = _sketch(gpu, lens_small, small)
+        og = [oracle.Genome.from_bases(b, l, p) for b, l in zip(small, lens_small)]
+        assert all(o.rep_cut != 0xFFFFFFFF for o in og)                      # the cut-off is active
+        edges = s.triangle_rows(0, 1, 0.0)
+        want = _oracle_edges(oracle, og, p, 0.0)
+        _check_edges(edges, want)
+        assert ctx.counters()[1] == ctx.counters()[0] > 0                    # every chunk took the slow path
+        if copies == 48:
+            assert max(int(e["n_chains"]) for e in edges) > 0 and len(want) == 3
+        s.close()
 
     big = alpha[rng.randint(0, 4, 15_000_000)]
     big2 = subst(big, 0.02)
