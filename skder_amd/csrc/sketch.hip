@@ -357,7 +357,7 @@ void sketch_batch_impl(skder_sketches *s, const uint8_t *d_bases, const skder_ba
     std::vector<RecDesc> recs;
     std::vector<uint32_t> gtb, rec_goff;
     std::vector<uint64_t> glen;
-    const uint32_t nt = build_records(b, recs, gtb, rec_goff, glen);
+    uint32_t nt = build_records(b, recs, gtb, rec_goff, glen);
 
     DevBuf<TileDesc> d_tiles;
     DevBuf<RecDesc> d_recs;
@@ -368,32 +368,61 @@ void sketch_batch_impl(skder_sketches *s, const uint8_t *d_bases, const skder_ba
     HIPCHECK(hipMemcpyAsync(d_recs.p, recs.data(), recs.size() * sizeof(RecDesc), hipMemcpyHostToDevice, st));
     if (nt)
         hipLaunchKernelGGL(make_tiles_kernel, dim3((nt + 255) / 256), dim3(256), 0, st, d_recs.p, (uint32_t)recs.size(), nt, d_tiles.p);
-    slot_kmer.resize((size_t)nt * SK_SLOT_SEEDS, st);
-    slot_gpos.resize((size_t)nt * SK_SLOT_SEEDS, st);
-    slot_mark.resize((size_t)nt * SK_SLOT_MARKS, st);
-    tile_ns.resize(nt + 1, st); tile_nm.resize(nt + 1, st);
-    tile_soff.resize(nt + 1, st); tile_moff.resize(nt + 1, st);
-    HIPCHECK(hipMemsetAsync(ctx->d_flags, 0, 64, st));
-    HIPCHECK(hipMemsetAsync(tile_ns.p + nt, 0, 4, st));
-    HIPCHECK(hipMemsetAsync(tile_nm.p + nt, 0, 4, st));
-
-    HIPCHECK(hipEventRecord(ctx->ev[0], st));
-    if (nt)
-        hipLaunchKernelGGL(sketch_tiles_kernel, dim3(nt), dim3(SK_THREADS), 0, st, d_bases, d_tiles.p, slot_kmer.p,
-                           slot_gpos.p, slot_mark.p, tile_ns.p, tile_nm.p, ctx->d_flags);
-    HIPCHECK(hipEventRecord(ctx->ev[1], st));
-
-    // offsets
     ScanWorkspace ws;
-    exclusive_scan_u32(tile_ns.p, tile_soff.p, nt + 1, ws, st);
-    exclusive_scan_u32(tile_nm.p, tile_moff.p, nt + 1, ws, st);
-    std::vector<uint32_t> h_soff(nt + 1), h_moff(nt + 1);
-    uint32_t h_flags = 0;
-    HIPCHECK(hipMemcpyAsync(h_soff.data(), tile_soff.p, (nt + 1) * 4, hipMemcpyDeviceToHost, st));
-    HIPCHECK(hipMemcpyAsync(h_moff.data(), tile_moff.p, (nt + 1) * 4, hipMemcpyDeviceToHost, st));
-    HIPCHECK(hipMemcpyAsync(&h_flags, ctx->d_flags, 4, hipMemcpyDeviceToHost, st));
-    HIPCHECK(hipStreamSynchronize(st));
-    if (h_flags & 1u) throw SkError("sketch tile slot overflow (more than 512 seeds or 128 markers in 8192 bases)");
+    std::vector<uint32_t> h_soff, h_moff;
+    for (int attempt = 0;; attempt++) {
+        slot_kmer.resize((size_t)nt * SK_SLOT_SEEDS, st);
+        slot_gpos.resize((size_t)nt * SK_SLOT_SEEDS, st);
+        slot_mark.resize((size_t)nt * SK_SLOT_MARKS, st);
+        tile_ns.resize(nt + 1, st); tile_nm.resize(nt + 1, st);
+        tile_soff.resize(nt + 1, st); tile_moff.resize(nt + 1, st);
+        HIPCHECK(hipMemsetAsync(ctx->d_flags, 0, 64, st));
+        HIPCHECK(hipMemsetAsync(tile_ns.p + nt, 0, 4, st));
+        HIPCHECK(hipMemsetAsync(tile_nm.p + nt, 0, 4, st));
+
+        HIPCHECK(hipEventRecord(ctx->ev[0], st));
+        if (nt)
+            hipLaunchKernelGGL(sketch_tiles_kernel, dim3(nt), dim3(SK_THREADS), 0, st, d_bases, d_tiles.p, slot_kmer.p,
+                               slot_gpos.p, slot_mark.p, tile_ns.p, tile_nm.p, ctx->d_flags);
+        HIPCHECK(hipEventRecord(ctx->ev[1], st));
+
+        // offsets
+        exclusive_scan_u32(tile_ns.p, tile_soff.p, nt + 1, ws, st);
+        exclusive_scan_u32(tile_nm.p, tile_moff.p, nt + 1, ws, st);
+        h_soff.resize(nt + 1); h_moff.resize(nt + 1);
+        uint32_t h_flags = 0;
+        HIPCHECK(hipMemcpyAsync(h_soff.data(), tile_soff.p, (nt + 1) * 4, hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipMemcpyAsync(h_moff.data(), tile_moff.p, (nt + 1) * 4, hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipMemcpyAsync(&h_flags, ctx->d_flags, 4, hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipStreamSynchronize(st));
+        if (!(h_flags & 1u)) break;
+        if (attempt) throw SkError("sketch tile slot overflow after the tiles were refined (internal error)");
+        // A tile holds more than 512 seeds or 128 markers in its 8192 positions (low-complexity sequence whose
+        // few distinct k-mers happen to be sampled).  Such tiles are cut into 64 pieces of 128 positions --
+        // no piece can exceed either capacity -- and the batch is sketched again over the refined tile list.
+        std::vector<TileDesc> ht(nt), refined;
+        HIPCHECK(hipMemcpy(ht.data(), d_tiles.p, (size_t)nt * sizeof(TileDesc), hipMemcpyDeviceToHost));
+        refined.reserve(nt + 1024);
+        for (uint32_t t = 0; t < nt; t++) {
+            const uint32_t ns = h_soff[t + 1] - h_soff[t], nm = h_moff[t + 1] - h_moff[t];
+            if (ns <= SK_SLOT_SEEDS && nm <= SK_SLOT_MARKS) { refined.push_back(ht[t]); continue; }
+            for (uint32_t p = 0; p < ht[t].npos; p += 128) {
+                TileDesc d = ht[t];
+                d.base_off += p; d.pos0 += p; d.gpos0 += p;
+                d.npos = ht[t].npos - p < 128 ? ht[t].npos - p : 128;
+                refined.push_back(d);
+            }
+        }
+        if (refined.size() >= 0xFFFF0000ull) throw SkError("too many tiles in one batch");
+        nt = (uint32_t)refined.size();
+        // first tile of every genome in the refined list (tiles stay in genome order)
+        for (uint32_t g = 0, t = 0; g <= b->n_genomes; g++) {
+            while (t < nt && refined[t].genome < g) t++;
+            gtb[g] = t;
+        }
+        d_tiles.resize(nt, st);
+        HIPCHECK(hipMemcpy(d_tiles.p, refined.data(), (size_t)nt * sizeof(TileDesc), hipMemcpyHostToDevice));
+    }
     const uint64_t add_seeds = h_soff[nt], add_raw_marks = h_moff[nt];
 
     // seeds
@@ -432,6 +461,7 @@ void sketch_batch_impl(skder_sketches *s, const uint8_t *d_bases, const skder_ba
                        d_nuniq.p, ctx->d_flags);
     exclusive_scan_u32(d_nuniq.p, d_uoff.p, b->n_genomes + 1, ws, st);
     std::vector<uint32_t> h_uoff(b->n_genomes + 1);
+    uint32_t h_flags = 0;
     HIPCHECK(hipMemcpyAsync(h_uoff.data(), d_uoff.p, (b->n_genomes + 1) * 4, hipMemcpyDeviceToHost, st));
     HIPCHECK(hipMemcpyAsync(&h_flags, ctx->d_flags, 4, hipMemcpyDeviceToHost, st));
     HIPCHECK(hipStreamSynchronize(st));

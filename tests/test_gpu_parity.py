@@ -777,3 +777,53 @@ def test_listing_edge_cases(gpu, tmp_path):
     with Database.from_listing(str(tmp_path / "dup.txt")) as db:
         assert db.paths == [fs[0], fs[0]]
         assert len(db.search_batch([fs[0]])) == 2
+
+
+def test_low_complexity_tiles(gpu, oracle):
+    """tandem repeats whose few distinct k-mers are sampled put thousands of seeds / markers into one
+    8192-base tile (more than the 512 / 128 the sketch kernel's slots hold): the tiles are refined and the
+    sketch equals the oracle's; a pair of such genomes chains bit-equal as well"""
+    engine, ctx, torch = gpu
+    p = oracle.default_params()
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    rng = np.random.RandomState(5)
+    # find short periods whose 15-mers / 21-mers are selected by the sampler, using the oracle itself
+    def n_seeds_markers(seq):
+        g = oracle.Genome.from_bases(seq, np.array([len(seq)], np.uint32), p)
+        return g.n_seeds, g.n_markers_raw if hasattr(g, "n_markers_raw") else g.n_markers
+    dense = []
+    for period in range(5, 10):
+        for _ in range(300):
+            unit = alpha[rng.randint(0, 4, period)]
+            seq = np.tile(unit, 3000 // period + 1)[:3000]
+            ns, _nm = n_seeds_markers(seq)
+            if ns > 3000 * 0.11:
+                dense.append(unit)
+                break
+    assert len(dense) >= 4, "too few densely sampled tandem repeats found"
+    body = alpha[rng.randint(0, 4, 60000)]
+    genomes = []
+    for k in range(2):
+        parts = [body[:20000]]
+        for unit in dense[k::2][:2]:            # different repeat units in the two genomes: no anchors between the repeats
+            parts.append(np.tile(unit, 9000 // len(unit) + 1)[:9000])       # > one tile of pure repeat
+            parts.append(body[20000 + 5000 * len(parts):25000 + 5000 * len(parts)])
+        g = np.concatenate(parts + [body[50000:]])
+        if k == 1:
+            idx = rng.choice(len(g), len(g) // 100, replace=False)
+            g = g.copy()
+            g[idx] = alpha[(np.searchsorted(alpha, g[idx]) + 1 + rng.randint(0, 3, len(idx))) % 4]
+        genomes.append(g)
+    lens = [np.array([len(g)], np.uint32) for g in genomes]
+    s, _ = _sketch(gpu, lens, genomes)
+    og = [oracle.Genome.from_bases(g, l, p) for g, l in zip(genomes, lens)]
+    for o in og:                                                          # some 8192-position tile exceeds the 512-seed slots
+        pos = o.seeds()[1]
+        assert np.bincount(pos // 8192).max() > 512
+    _compare_sketch(engine, s, oracle, og)
+    # (the repeats of the two genomes use different units: anchors between two copies of one tandem repeat
+    # grow with the square of its length, correct but slow on both sides)
+    edges = s.triangle_rows(0, 1, 0.0)
+    _check_edges(edges, _oracle_edges(oracle, og, p, 0.0))
+    assert len(edges) == 1 and 0.9 < float(edges[0]["ani"]) <= 1.0 and int(edges[0]["n_chains"]) > 0
+    s.close()
