@@ -719,66 +719,104 @@ __global__ __launch_bounds__(256) void slow_anchors_kernel(SetView A, SetView B,
     if (lane == 0) slow_n[w] = running < cap ? running : cap;
 }
 
+// forward declaration (defined with the wave kernel below)
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v);
+
+// one WAVEFRONT per chunk of the over list; anchors in global memory.  The DP only ever looks back 50
+// anchors, so the last 64 anchors are kept in a per-wave LDS ring and the 64 lanes examine the look-back
+// candidates of one anchor together (as slow_wave_kernel does); f and bp go to global memory for the
+// extraction, which lane 0 runs over the candidate ends sorted once.
 __global__ __launch_bounds__(256) void slow_chain_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs, uint32_t npairs,
                                                          const uint32_t *__restrict__ slow_list, uint32_t nslow,
                                                          const uint32_t *__restrict__ abase, const uint32_t *__restrict__ slow_n,
                                                          const uint32_t *__restrict__ a_qi, const uint32_t *__restrict__ a_r,
                                                          const uint32_t *__restrict__ a_rctg, int32_t *__restrict__ F,
-                                                         uint32_t *__restrict__ BP, ChainRec *__restrict__ chains,
+                                                         uint32_t *__restrict__ BP, uint64_t *__restrict__ ORD, ChainRec *__restrict__ chains,
                                                          uint32_t *__restrict__ pair_nch, uint32_t *__restrict__ pair_na,
                                                          uint32_t *__restrict__ flags)
 {
-    const uint32_t w = blockIdx.x * 256u + threadIdx.x;
+    __shared__ uint32_t ring_qp[4][64], ring_rr[4][64], ring_rc[4][64];
+    __shared__ int32_t ring_f[4][64];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t w = blockIdx.x * 4u + wv;
     if (w >= nslow) return;
     const uint32_t t = slow_list[w];
     const uint32_t lo = find_pair(pairs, npairs, t);
     const PairDesc pd = pairs[lo];
     const uint32_t a0 = abase[w], n = slow_n[w];
     if (!n) return;
-    atomicAdd(&pair_na[lo], n);
+    if (lane == 0) atomicAdd(&pair_na[lo], n);
     const SetView &QS = (pd.flags & 2u) ? B : A;
     const uint32_t *qg = QS.pgpos + QS.meta[pd.q].seed_off;
     const uint32_t *qi = a_qi + a0, *ar = a_r + a0, *ac = a_rctg + a0;
     int32_t *f = F + a0;
     uint32_t *bp = BP + a0;
 
-    // banded chaining; `runmax` bounds every f[j] seen so far, so once best >= runmax + score no
-    // remaining predecessor can beat it (exact early exit, same result as the full band)
-    int32_t runmax = -0x40000000;
+    // banded chaining: lane l examines predecessor i-1-l of anchor i (ring slot (i-1-l) & 63)
     for (uint32_t i = 0; i < n; i++) {
-        const int32_t qp = (int32_t)qg[qi[i]];
+        const int32_t qpi = (int32_t)qg[qi[i]];
         const uint32_t rr = ar[i], rc = ac[i];
         const int32_t rp = (int32_t)(rr & 0x7FFFFFFFu);
         const uint32_t rev = rr >> 31;
-        int32_t best = ANI_ANCHOR_SCORE, bj = -1;
-        const uint32_t jlo = i > ANI_BAND ? i - ANI_BAND : 0u;
-        for (uint32_t j = i; j-- > jlo;) {
-            if (best >= runmax + ANI_ANCHOR_SCORE) break;
-            const int32_t dq = qp - (int32_t)qg[qi[j]];
-            if (dq > ANI_BP_BAND) break;
-            const uint32_t rj = ar[j];
-            if (ac[j] != rc || (rj >> 31) != rev) continue;
-            const int32_t rpj = (int32_t)(rj & 0x7FFFFFFFu);
-            const int32_t dr = rev ? rpj - rp : rp - rpj;
-            if (dq <= 0 || dr <= 0) continue;
-            if (dq > ANI_MAX_LIN || dr > ANI_MAX_LIN) continue;
-            const int32_t gap = dq > dr ? dq - dr : dr - dq;
-            if (gap > ANI_MAX_GAP) continue;
-            const int32_t sc = f[j] + ANI_ANCHOR_SCORE - gap;
-            if (sc > best) { best = sc; bj = (int32_t)j; }
+        uint32_t key = 0;     // (score << 6) | (63 - lane): the maximum is the best score, nearest on ties
+        if (lane < i && lane < ANI_BAND) {
+            const uint32_t sl = (i - 1 - lane) & 63u;
+            const int32_t dq = qpi - (int32_t)ring_qp[wv][sl];
+            const uint32_t rj = ring_rr[wv][sl];
+            if (dq <= ANI_BP_BAND && ring_rc[wv][sl] == rc && (rj >> 31) == rev) {
+                const int32_t rpj = (int32_t)(rj & 0x7FFFFFFFu);
+                const int32_t dr = rev ? rpj - rp : rp - rpj;
+                if (dq > 0 && dr > 0 && dq <= ANI_MAX_LIN && dr <= ANI_MAX_LIN) {
+                    const int32_t gap = dq > dr ? dq - dr : dr - dq;
+                    if (gap <= ANI_MAX_GAP) {
+                        const int32_t sc = ring_f[wv][sl] + ANI_ANCHOR_SCORE - gap;
+                        if (sc > ANI_ANCHOR_SCORE) key = ((uint32_t)sc << 6) | (63u - lane);
+                    }
+                }
+            }
         }
-        f[i] = best;
-        bp[i] = (uint32_t)(bj + 1);
-        runmax = best > runmax ? best : runmax;
+        key = wave_max_u32(key);
+        if (lane == 0) {
+            const int32_t fi = key ? (int32_t)(key >> 6) : ANI_ANCHOR_SCORE;
+            f[i] = fi;
+            bp[i] = key ? i - (63u - (key & 63u)) : 0u;     // predecessor index + 1
+            ring_qp[wv][i & 63u] = (uint32_t)qpi; ring_rr[wv][i & 63u] = rr; ring_rc[wv][i & 63u] = rc; ring_f[wv][i & 63u] = fi;
+        }
+        __builtin_amdgcn_wave_barrier();
     }
-    // chains: best end first (ties: lowest index); back-track until the start or a used anchor
-    for (;;) {
-        int32_t bestv = ANI_ANCHOR_SCORE, besti = -1;
-        for (uint32_t i = 0; i < n; i++) {
-            const int32_t v = f[i];
-            if (v > bestv) { bestv = v; besti = (int32_t)i; }
+    __threadfence();
+    if (lane != 0) return;
+    // chains: best end first (ties: lowest index); back-track until the start or a used anchor.  Scores
+    // never change except by being voided, so the order of the candidate ends is fixed: sort them once
+    // (heap sort of (score, ~index) keys, descending) instead of scanning for the maximum per chain --
+    // a chunk inside a shared tandem repeat has 10^5 anchors and thousands of chains
+    uint64_t *key = ORD + a0;
+    uint32_t m = 0;
+    for (uint32_t i = 0; i < n; i++)
+        if (f[i] > ANI_ANCHOR_SCORE) key[m++] = ((uint64_t)(uint32_t)f[i] << 32) | (uint64_t)(0xFFFFFFFFu - i);
+    {
+        auto sift = [&](uint32_t root, uint32_t end) {      // min-heap: the array ends up in descending order
+            const uint64_t v = key[root];
+            for (;;) {
+                uint32_t c = 2 * root + 1;
+                if (c >= end) break;
+                if (c + 1 < end && key[c + 1] < key[c]) c++;
+                if (!(key[c] < v)) break;
+                key[root] = key[c];
+                root = c;
+            }
+            key[root] = v;
+        };
+        for (uint32_t i = m / 2; i-- > 0;) sift(i, m);
+        for (uint32_t e = m; e-- > 1;) {
+            const uint64_t t2 = key[0]; key[0] = key[e]; key[e] = t2;
+            sift(0, e);
         }
-        if (besti < 0) break;
+    }
+    for (uint32_t kk = 0; kk < m; kk++) {
+        const int32_t besti = (int32_t)(0xFFFFFFFFu - (uint32_t)key[kk]);
+        const int32_t bestv = f[besti];
+        if (bestv <= ANI_ANCHOR_SCORE) continue;      // voided since: inside an extracted chain, or a failed end
         uint32_t cnt = 0, rmin = 0xFFFFFFFFu, rmax = 0;
         int32_t cur = besti, first = besti;
         while (cur >= 0) {
@@ -1334,6 +1372,7 @@ struct ChainWork {
     // rare path (chunks with more anchors than the wave kernel holds in LDS)
     DevBuf<uint32_t> cap, abase, slow_n, a_qi, a_r, a_rctg, BP;
     DevBuf<int32_t> F;
+    DevBuf<uint64_t> ORD;
     DevBuf<uint32_t> root_lut;
     ScanWorkspace ws;
 };
@@ -1584,11 +1623,11 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
                 HIPCHECK(hipMemcpyAsync(&atotal, W.abase.p + nover_now, 4, hipMemcpyDeviceToHost, st));
                 HIPCHECK(hipStreamSynchronize(st));
                 W.a_qi.resize(atotal + 1, st); W.a_r.resize(atotal + 1, st); W.a_rctg.resize(atotal + 1, st);
-                W.F.resize(atotal + 1, st); W.BP.resize(atotal + 1, st);
+                W.F.resize(atotal + 1, st); W.BP.resize(atotal + 1, st); W.ORD.resize(atotal + 1, st);
                 hipLaunchKernelGGL(slow_anchors_kernel, dim3((nover_now + 3) / 4), dim3(256), 0, st, VA, VB, S.d_pairs.p, nb, S.over_list.p,
                                    nover_now, W.abase.p, W.a_qi.p, W.a_r.p, W.a_rctg.p, W.slow_n.p, S.flags.p);
-                hipLaunchKernelGGL(slow_chain_kernel, dim3((nover_now + 255) / 256), dim3(256), 0, st, VA, VB, S.d_pairs.p, nb, S.over_list.p,
-                                   nover_now, W.abase.p, W.slow_n.p, W.a_qi.p, W.a_r.p, W.a_rctg.p, W.F.p, W.BP.p, S.chains.p, S.pair_nch.p,
+                hipLaunchKernelGGL(slow_chain_kernel, dim3((nover_now + 3) / 4), dim3(256), 0, st, VA, VB, S.d_pairs.p, nb, S.over_list.p,
+                                   nover_now, W.abase.p, W.slow_n.p, W.a_qi.p, W.a_r.p, W.a_rctg.p, W.F.p, W.BP.p, W.ORD.p, S.chains.p, S.pair_nch.p,
                                    S.pair_na.p, S.flags.p);
                 finalize_and_fetch();
                 flags_seen = (flags_seen & 8u) | S.h_cnt[16];     // the wave kernel's overflow stays known

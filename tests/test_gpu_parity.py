@@ -827,3 +827,21 @@ def test_low_complexity_tiles(gpu, oracle):
     _check_edges(edges, _oracle_edges(oracle, og, p, 0.0))
     assert len(edges) == 1 and 0.9 < float(edges[0]["ani"]) <= 1.0 and int(edges[0]["n_chains"]) > 0
     s.close()
+    # the same tandem repeat in both genomes: millions of anchors in two chunks (global-memory slow path:
+    # exact counts, wave-parallel DP, candidate ends sorted once)
+    shared = []
+    for k in range(2):
+        rep_part = np.tile(dense[0], 9000 // len(dense[0]) + 1)[:9000]
+        g = np.concatenate([body[:25000], rep_part, body[25000:]])
+        if k == 1:
+            idx2 = rng.choice(len(g), len(g) // 100, replace=False)
+            g = g.copy()
+            g[idx2] = alpha[(np.searchsorted(alpha, g[idx2]) + 1 + rng.randint(0, 3, len(idx2))) % 4]
+        shared.append(g)
+    lens2 = [np.array([len(g)], np.uint32) for g in shared]
+    s, _ = _sketch(gpu, lens2, shared)
+    og2 = [oracle.Genome.from_bases(g, l, p) for g, l in zip(shared, lens2)]
+    edges = s.triangle_rows(0, 1, 0.0)
+    _check_edges(edges, _oracle_edges(oracle, og2, p, 0.0))
+    assert int(edges[0]["n_anchors"]) > 500000 and ctx.counters()[3] > 0     # the over list was used
+    s.close()
