@@ -318,6 +318,14 @@ __global__ __launch_bounds__(256) void make_tiles_kernel(const RecDesc *__restri
     tiles[t] = d;
 }
 
+// dst[i] = src[idx[i]]: the per-genome entries of the per-tile offset tables (the host only needs those)
+__global__ __launch_bounds__(256) void pick_kernel(const uint32_t *__restrict__ src, const uint32_t *__restrict__ idx, uint32_t n,
+                                                   uint32_t *__restrict__ dst)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+
 static uint32_t build_records(const skder_batch_t *b, std::vector<RecDesc> &recs, std::vector<uint32_t> &genome_tile_begin,
                               std::vector<uint32_t> &rec_goff /* per genome nrec+1 */, std::vector<uint64_t> &genome_len)
 {
@@ -369,7 +377,8 @@ void sketch_batch_impl(skder_sketches *s, const uint8_t *d_bases, const skder_ba
     if (nt)
         hipLaunchKernelGGL(make_tiles_kernel, dim3((nt + 255) / 256), dim3(256), 0, st, d_recs.p, (uint32_t)recs.size(), nt, d_tiles.p);
     ScanWorkspace ws;
-    std::vector<uint32_t> h_soff, h_moff;
+    std::vector<uint32_t> h_soff, h_moff, g_soff, g_moff;     // per tile (refinement only) / per genome boundary
+    DevBuf<uint32_t> d_gtb, d_gs, d_gm;
     for (int attempt = 0;; attempt++) {
         slot_kmer.resize((size_t)nt * SK_SLOT_SEEDS, st);
         slot_gpos.resize((size_t)nt * SK_SLOT_SEEDS, st);
@@ -389,13 +398,23 @@ void sketch_batch_impl(skder_sketches *s, const uint8_t *d_bases, const skder_ba
         // offsets
         exclusive_scan_u32(tile_ns.p, tile_soff.p, nt + 1, ws, st);
         exclusive_scan_u32(tile_nm.p, tile_moff.p, nt + 1, ws, st);
-        h_soff.resize(nt + 1); h_moff.resize(nt + 1);
+        // the host needs the offsets at genome boundaries only: pick them on the device (the full per-tile
+        // tables are fetched only when tiles have to be refined)
+        const uint32_t ng1 = b->n_genomes + 1;
+        d_gtb.resize(ng1, st); d_gs.resize(ng1, st); d_gm.resize(ng1, st);
+        HIPCHECK(hipMemcpyAsync(d_gtb.p, gtb.data(), ng1 * 4ull, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(pick_kernel, dim3((ng1 + 255) / 256), dim3(256), 0, st, tile_soff.p, d_gtb.p, ng1, d_gs.p);
+        hipLaunchKernelGGL(pick_kernel, dim3((ng1 + 255) / 256), dim3(256), 0, st, tile_moff.p, d_gtb.p, ng1, d_gm.p);
+        g_soff.resize(ng1); g_moff.resize(ng1);
         uint32_t h_flags = 0;
-        HIPCHECK(hipMemcpyAsync(h_soff.data(), tile_soff.p, (nt + 1) * 4, hipMemcpyDeviceToHost, st));
-        HIPCHECK(hipMemcpyAsync(h_moff.data(), tile_moff.p, (nt + 1) * 4, hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipMemcpyAsync(g_soff.data(), d_gs.p, ng1 * 4ull, hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipMemcpyAsync(g_moff.data(), d_gm.p, ng1 * 4ull, hipMemcpyDeviceToHost, st));
         HIPCHECK(hipMemcpyAsync(&h_flags, ctx->d_flags, 4, hipMemcpyDeviceToHost, st));
         HIPCHECK(hipStreamSynchronize(st));
         if (!(h_flags & 1u)) break;
+        h_soff.resize(nt + 1); h_moff.resize(nt + 1);
+        HIPCHECK(hipMemcpy(h_soff.data(), tile_soff.p, (nt + 1) * 4ull, hipMemcpyDeviceToHost));
+        HIPCHECK(hipMemcpy(h_moff.data(), tile_moff.p, (nt + 1) * 4ull, hipMemcpyDeviceToHost));
         if (attempt) throw SkError("sketch tile slot overflow after the tiles were refined (internal error)");
         // A tile holds more than 512 seeds or 128 markers in its 8192 positions (low-complexity sequence whose
         // few distinct k-mers happen to be sampled).  Such tiles are cut into 64 pieces of 128 positions --
@@ -423,7 +442,7 @@ void sketch_batch_impl(skder_sketches *s, const uint8_t *d_bases, const skder_ba
         d_tiles.resize(nt, st);
         HIPCHECK(hipMemcpy(d_tiles.p, refined.data(), (size_t)nt * sizeof(TileDesc), hipMemcpyHostToDevice));
     }
-    const uint64_t add_seeds = h_soff[nt], add_raw_marks = h_moff[nt];
+    const uint64_t add_seeds = g_soff[b->n_genomes], add_raw_marks = g_moff[b->n_genomes];
 
     // seeds
     const uint64_t seed_base = s->seed_kmer.n;
@@ -440,7 +459,7 @@ void sketch_batch_impl(skder_sketches *s, const uint8_t *d_bases, const skder_ba
     if (nt)
         hipLaunchKernelGGL(gather_marks_kernel, dim3(nt), dim3(64), 0, st, tile_nm.p, tile_moff.p, slot_mark.p, raw_marks.p);
     std::vector<uint32_t> h_goff(b->n_genomes + 1);
-    for (uint32_t g = 0; g <= b->n_genomes; g++) h_goff[g] = h_moff[gtb[g]];
+    for (uint32_t g = 0; g <= b->n_genomes; g++) h_goff[g] = g_moff[g];
     DevBuf<uint32_t> d_goff, d_nuniq, d_uoff;
     d_goff.resize(b->n_genomes + 1, st);
     d_nuniq.resize(b->n_genomes + 1, st);
@@ -481,7 +500,7 @@ void sketch_batch_impl(skder_sketches *s, const uint8_t *d_bases, const skder_ba
 
     // host metadata
     for (uint32_t g = 0; g < b->n_genomes; g++) {
-        s->h_seed_off.push_back(seed_base + h_soff[gtb[g + 1]]);
+        s->h_seed_off.push_back(seed_base + g_soff[g + 1]);
         s->h_marker_off.push_back(mark_base + h_uoff[g + 1]);
         s->h_genome_len.push_back(glen[g]);
         s->h_genome_nrec.push_back(b->genome_rec_begin[g + 1] - b->genome_rec_begin[g]);
