@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <chrono>
 #include <thread>
+#include <type_traits>
 
 #include "device_utils.h"
 #include "engine.h"
@@ -112,19 +113,21 @@ __device__ __forceinline__ void join_pass(const SetView &A, const SetView &B, co
         // JOIN_U independent seeds per thread and trip, handled in phases so that the memory operations
         // of all of them are in flight together: k-mer loads, LDS probes, then ALL position gathers, then
         // the coalesced hit-word stores; the rare multi-occurrence seeds come last
-        for (uint32_t s0 = tid; s0 < nq; s0 += JOIN_U * JOIN_THREADS) {
+        // FULL trips (every seed of every thread exists) carry no bounds tests; one guarded trip finishes the pair
+        auto trip = [&](auto full_tag, const uint32_t s0) {
+            constexpr bool FULL = decltype(full_tag)::value;
             uint32_t kqv[JOIN_U], lov[JOIN_U], hiv[JOIN_U], firstv[JOIN_U], cntv[JOIN_U], hvv[JOIN_U];
             bool mine[JOIN_U];
 #pragma unroll
             for (int u = 0; u < JOIN_U; u++) {
                 const uint32_t s = s0 + u * JOIN_THREADS;
-                kqv[u] = s < nq ? pk[s] : 0u;
+                kqv[u] = (FULL || s < nq) ? pk[s] : 0u;
             }
 #pragma unroll
             for (int u = 0; u < JOIN_U; u++) {
                 const uint32_t s = s0 + u * JOIN_THREADS;
                 const uint32_t b = kmer_bucket(kqv[u] & SK_SEED_MASK, bits);
-                mine[u] = s < nq && (WHOLE || (b >= bb0 && b < bb1));      // else: this seed's bucket belongs to another pass
+                mine[u] = (FULL || s < nq) && (WHOLE || (b >= bb0 && b < bb1));      // else: this seed's bucket belongs to another pass
                 lov[u] = mine[u] ? s_boff[b - bb0] : 0u;
                 hiv[u] = mine[u] ? s_boff[b - bb0 + 1] : 0u;
             }
@@ -195,7 +198,11 @@ __device__ __forceinline__ void join_pass(const SetView &A, const SetView &B, co
 #pragma unroll
             for (int u = 0; u < JOIN_U; u++)
                 if (mine[u]) hit[s0 + u * JOIN_THREADS] = hvv[u];
-        }
+        };
+        const uint32_t per_trip = JOIN_U * JOIN_THREADS, nfull = nq / per_trip * per_trip;
+        uint32_t s0 = tid;
+        for (; s0 < nfull; s0 += per_trip) trip(std::true_type{}, s0);
+        if (s0 < nq) trip(std::false_type{}, s0);
     }
 }
 
