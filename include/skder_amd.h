@@ -109,7 +109,8 @@ typedef struct {
     const uint32_t *h_rec_goff;    /* host */
 } skder_raw_view_t;
 int skder_amd_sketches_view(skder_sketches_t *s, skder_raw_view_t *out);
-/* append genomes from raw arrays (device pointers for seeds/markers, host pointers for the rest) */
+/* append genomes from raw arrays (device pointers for seeds/markers, host pointers for the rest);
+ * d_seed_ctg may be NULL: the record indices are then derived from d_seed_gpos and h_rec_goff */
 int skder_amd_sketches_append_raw(skder_sketches_t *s, const skder_raw_view_t *raw);
 /* build the per-genome lookup structures (k-mer bucket index, chunk tables, repetitive cut-offs) */
 int skder_amd_sketches_index(skder_sketches_t *s);

@@ -143,6 +143,25 @@ extern "C" int skder_amd_sketches_view(skder_sketches_t *s, skder_raw_view_t *ou
     return 0;
 }
 
+// record index of every appended seed from its genome-linear position (binary search in the genome's
+// record offsets): lets the sketch exchange leave the third of its volume that is derivable at home
+struct CtgJob { uint64_t seed_begin, seed_end; uint32_t rec_begin, n_rec; };
+__global__ __launch_bounds__(256) void ctg_from_gpos_kernel(const CtgJob *__restrict__ jobs, const uint32_t *__restrict__ rec_goff,
+                                                            const uint32_t *__restrict__ gpos, uint32_t *__restrict__ ctg)
+{
+    const CtgJob j = jobs[blockIdx.x];
+    const uint32_t *rg = rec_goff + j.rec_begin;
+    for (uint64_t s = j.seed_begin + threadIdx.x; s < j.seed_end; s += 256) {
+        const uint32_t p = gpos[s];
+        uint32_t lo = 0, hi = j.n_rec;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (rg[mid] <= p) lo = mid; else hi = mid;
+        }
+        ctg[s] = lo;
+    }
+}
+
 extern "C" int skder_amd_sketches_append_raw(skder_sketches_t *s, const skder_raw_view_t *raw)
 {
     if (!s || !raw) return 1;
@@ -159,7 +178,29 @@ extern "C" int skder_amd_sketches_append_raw(skder_sketches_t *s, const skder_ra
     if (raw->n_seeds) {
         HIPCHECK(hipMemcpyAsync(s->seed_kmer.p + sb, raw->d_seed_kmer, raw->n_seeds * 4, hipMemcpyDeviceToDevice, st));
         HIPCHECK(hipMemcpyAsync(s->seed_gpos.p + sb, raw->d_seed_gpos, raw->n_seeds * 4, hipMemcpyDeviceToDevice, st));
-        HIPCHECK(hipMemcpyAsync(s->seed_ctg.p + sb, raw->d_seed_ctg, raw->n_seeds * 4, hipMemcpyDeviceToDevice, st));
+        if (raw->d_seed_ctg)
+            HIPCHECK(hipMemcpyAsync(s->seed_ctg.p + sb, raw->d_seed_ctg, raw->n_seeds * 4, hipMemcpyDeviceToDevice, st));
+    }
+    if (raw->n_seeds && !raw->d_seed_ctg) {
+        // no record indices given: derive them from the positions and the record tables
+        std::vector<CtgJob> jobs(raw->n_genomes);
+        std::vector<uint32_t> goff;
+        size_t rgi = 0;
+        for (uint32_t g = 0; g < raw->n_genomes; g++) {
+            CtgJob &j = jobs[g];
+            j.seed_begin = sb + raw->h_seed_off[g] - raw->h_seed_off[0];
+            j.seed_end = sb + raw->h_seed_off[g + 1] - raw->h_seed_off[0];
+            j.rec_begin = (uint32_t)goff.size(); j.n_rec = raw->h_genome_nrec[g];
+            for (uint32_t r = 0; r <= raw->h_genome_nrec[g]; r++) goff.push_back(raw->h_rec_goff[rgi++]);
+        }
+        DevBuf<CtgJob> d_jobs;
+        DevBuf<uint32_t> d_goff;
+        d_jobs.resize(jobs.size(), st); d_goff.resize(goff.size() + 1, st);
+        HIPCHECK(hipMemcpyAsync(d_jobs.p, jobs.data(), jobs.size() * sizeof(CtgJob), hipMemcpyHostToDevice, st));
+        HIPCHECK(hipMemcpyAsync(d_goff.p, goff.data(), goff.size() * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(ctg_from_gpos_kernel, dim3(raw->n_genomes), dim3(256), 0, st, d_jobs.p, d_goff.p, s->seed_gpos.p, s->seed_ctg.p);
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipStreamSynchronize(st));
     }
     if (raw->n_markers)
         HIPCHECK(hipMemcpyAsync(s->markers.p + mb, raw->d_markers, raw->n_markers * 8, hipMemcpyDeviceToDevice, st));

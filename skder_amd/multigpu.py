@@ -1,7 +1,7 @@
 """Row-block sharding of the pair matrix over the GPUs of one node.
 
 One process per GPU.  Each rank sketches a contiguous block of genomes, the raw sketches
-(position-ordered seeds: 12 B/seed, sorted markers: 8 B/marker, record tables) are all-gathered
+(position-ordered seeds: k-mer + position, 8 B/seed; sorted markers: 8 B/marker; record tables) are all-gathered
 with torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests),
 every rank builds the lookup index for ALL genomes (cheap next to sketching) and then computes the
 upper-triangle rows i = rank, rank + world, ... (cyclic, because row i has N-1-i entries).  Edge
@@ -31,7 +31,7 @@ def _allgather_var(t: torch.Tensor, counts: List[int], group=None) -> torch.Tens
 
 
 def exchange_raw(raw: Dict, group=None, staging: str = None) -> Dict:
-    """raw: dict with torch tensors seed_kmer/seed_gpos/seed_ctg (int32 views of u32) and markers
+    """raw: dict with torch tensors seed_kmer/seed_gpos (int32 views of u32) and markers
     (int64 view of u64) of THIS rank's genomes, and numpy metadata seed_off, marker_off, genome_len,
     genome_nrec, rec_goff.  Returns the same dict for the concatenation of all ranks' genomes.
     staging="cpu": move device tensors through host memory (gloo backend)."""
@@ -44,7 +44,8 @@ def exchange_raw(raw: Dict, group=None, staging: str = None) -> Dict:
     metas = [None] * world
     dist.all_gather_object(metas, meta, group=group)
     out = dict(n_genomes=sum(m["n_genomes"] for m in metas))
-    for key, cnt in (("seed_kmer", "n_seeds"), ("seed_gpos", "n_seeds"), ("seed_ctg", "n_seeds"), ("markers", "n_markers")):
+    # the record index of a seed follows from its position and the record table: it is not exchanged
+    for key, cnt in (("seed_kmer", "n_seeds"), ("seed_gpos", "n_seeds"), ("markers", "n_markers")):
         src = raw[key]
         if staging == "cpu" and src.is_cuda:      # gloo functional runs: exchange through host memory
             out[key] = _allgather_var(src.cpu(), [m[cnt] for m in metas], group).to(src.device)
@@ -96,7 +97,6 @@ def raw_from_sketches(sk) -> Dict:
     return dict(n_genomes=v["n_genomes"],
                 seed_kmer=download_tensor(v["d_seed_kmer"], v["n_seeds"], torch.int32, sk.ctx),
                 seed_gpos=download_tensor(v["d_seed_gpos"], v["n_seeds"], torch.int32, sk.ctx),
-                seed_ctg=download_tensor(v["d_seed_ctg"], v["n_seeds"], torch.int32, sk.ctx),
                 markers=download_tensor(v["d_markers"], v["n_markers"], torch.int64, sk.ctx),
                 seed_off=v["seed_off"], marker_off=v["marker_off"], genome_len=v["genome_len"],
                 genome_nrec=v["genome_nrec"], rec_goff=v["rec_goff"])
@@ -107,7 +107,7 @@ def sketches_from_raw(ctx, raw: Dict):
     from .engine import Sketches
     s = Sketches(ctx)
     torch.cuda.synchronize()
-    s.append_raw(raw["n_genomes"], raw["seed_kmer"].data_ptr(), raw["seed_gpos"].data_ptr(), raw["seed_ctg"].data_ptr(),
+    s.append_raw(raw["n_genomes"], raw["seed_kmer"].data_ptr(), raw["seed_gpos"].data_ptr(), None,
                  raw["markers"].data_ptr(), raw["seed_off"], raw["marker_off"], raw["genome_len"], raw["genome_nrec"],
                  raw["rec_goff"])
     return s
