@@ -435,6 +435,7 @@ __global__ __launch_bounds__(256, 3) void chain_fast_kernel(SetView A, SetView B
             // (Evaluated without short-circuit branches; a miss fails the record-interval test.)
             // uniform trip count (scalar loop control); lanes drop out of `act` when they park or reach lim
             bool act = s < lim;
+            uint32_t ext = 0, last_s = 0;      // plain extensions of r0 in this walk, seed of the last one
             for (int trip = 0; trip < 16; trip++) {
                 if (!__any(act)) break;
 #ifdef SKDER_PROFILE_COUNTERS
@@ -453,19 +454,27 @@ __global__ __launch_bounds__(256, 3) void chain_fast_kernel(SetView A, SetView B
                     const bool plain = dom & (((hw ^ r0.rr_last) & (HIT_KEY_MASK | 0x40000000u)) == 0u) &
                                        ((uint32_t)(dq - 1) < (uint32_t)ANI_BP_BAND) & (dq == dr);
                     park = (hw != HIT_NONE) & !plain;
-                    if (plain) {
-                        r0.pmax = r0.f > r0.pmax ? r0.f : r0.pmax;
-                        r0.f += ANI_ANCHOR_SCORE;
-                        runmax = r0.f > runmax ? r0.f : runmax;
-                        r0.q_last = (uint32_t)qp; r0.rr_last = hw; r0.cnt += 1u;
-                        r0.rmin = rpu < r0.rmin ? rpu : r0.rmin;
-                        r0.rmax = rpu > r0.rmax ? rpu : r0.rmax;
-                        r0.qi_last = s; r0.idx_last = ia;
-                        ia++;
+                    if (plain) {       // only what the next trip's test needs; the rest is settled after the walk
+                        r0.q_last = (uint32_t)qp; r0.rr_last = hw;
+                        ext++; last_s = s;
                     }
                     s += park ? 0u : 1u;
                     act = !park & (s < lim);
                 }
+            }
+            if (ext) {
+                // k plain extensions at once: scores rise by 20 per anchor, positions move monotonically along
+                // the run's diagonal, so the aggregates follow from the last anchor alone
+                const int32_t f_prev = r0.f + ANI_ANCHOR_SCORE * (int32_t)(ext - 1u);
+                r0.pmax = f_prev > r0.pmax ? f_prev : r0.pmax;
+                r0.f = f_prev + ANI_ANCHOR_SCORE;
+                runmax = r0.f > runmax ? r0.f : runmax;
+                r0.cnt += ext;
+                r0.idx_last = ia + ext - 1u; ia += ext;
+                r0.qi_last = last_s;
+                const uint32_t rl = r0.rr_last & HIT_POS_MASK;
+                r0.rmin = rl < r0.rmin ? rl : r0.rmin;
+                r0.rmax = rl > r0.rmax ? rl : r0.rmax;
             }
 #ifdef SKDER_PROFILE_COUNTERS
             if (park) atomicAdd(slow_count + 10, 1u);                                               // parks (per lane)
