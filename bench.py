@@ -120,7 +120,7 @@ def main():
     ap.add_argument("--screen", type=float, default=80.0)
     ap.add_argument("--batch-genomes", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--e2e-genomes", type=int, default=128, help="genomes in the file-based end-to-end sample (0: skip)")
+    ap.add_argument("--e2e-genomes", type=int, default=256, help="genomes in the file-based end-to-end sample (0: skip)")
     args = ap.parse_args()
 
     import torch

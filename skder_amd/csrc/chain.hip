@@ -1530,7 +1530,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
             memset(&d, 0, sizeof d);
             d.q = jb.q; d.r = jb.r; d.flags = jb.flags;
             d.n_chunks = Q.n_chunks;
-            d.c_cap = 16u * Q.n_chunks + 256u;     // slow-path chains of the pair (repeat-rich chunks yield many)
+            d.c_cap = 4u * Q.n_chunks + 64u;       // slow-path chains of the pair; made exact and retried when a pair needs more
             d.multi_cap = 256u + Q.n_seeds / 8u;
             if (d.multi_cap > 0x00FFFFF0u) d.multi_cap = 0x00FFFFF0u;
             if (!hp.empty() && nchunks + d.n_chunks > budget) break;
@@ -1553,6 +1553,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
             S.h_out_cap = (size_t)nb + nb / 4 + 1024;
             HIPCHECK(hipHostMalloc(&S.h_out, S.h_out_cap * sizeof(PairOut)));
         }
+        const auto t_al0 = std::chrono::steady_clock::now();
         S.d_pairs.resize(nb, st);
         S.chunk_state.resize(nchunks + 1, st); S.slow_list.resize(nchunks + 1, st); S.over_list.resize(nchunks + 1, st);
         S.fast_chains.resize(nchunks * FAST_SLOTS + 1, st);
@@ -1561,6 +1562,9 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         S.hits.resize(nhits + 64, st); S.multi.resize(nmulti + 1, st);
         S.chains.resize(ccap + 1, st);
         S.d_out.resize(nb, st);
+        if (getenv("SKDER_AMD_DEBUG"))
+            fprintf(stderr, "[skder_amd] host: work buffers of the batch ready after %.2f ms\n",
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_al0).count());
         HIPCHECK(hipMemcpyAsync(S.d_pairs.p, hp.data(), nb * sizeof(PairDesc), hipMemcpyHostToDevice, st));
         HIPCHECK(hipMemsetAsync(S.pair_nmulti.p, 0, nb * 4, st));
         HIPCHECK(hipEventRecord(S.ev[0], st));

@@ -1,20 +1,44 @@
 // host_io.h -- FASTA ingest, listing files, skani-format TSV output (host side of the drop-in)
 #pragma once
+#include <cstdlib>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "engine.h"
 
+// output of the FASTA parser: the genome's kept records already in DEVICE LAYOUT -- every record starts on a
+// 32-byte boundary and is padded with 'A' to the next one -- either in memory owned by the genome (grown
+// as needed: gzip input, whose inflated size is not known beforehand) or in a caller-supplied region of
+// fixed capacity (plain files: straight into the pinned staging buffer, no second copy, no page faults)
 struct HostGenome {
     std::string path;        // as written in the listing (byte for byte)
     std::string first_name;  // header line of the first record >= 500 bp
     std::vector<uint32_t> rec_len;   // kept records only
-    std::vector<uint8_t> bases;      // kept records, back to back
+    std::vector<uint64_t> rec_rel;   // offset of every kept record inside the packed layout (multiples of 32)
+    uint64_t packed_size = 0;        // bytes of the packed layout
+    uint8_t *own = nullptr;          // malloc'ed packed layout when no region was supplied
     uint64_t n50 = 0;                // over ALL records (util.py:686-724)
+    HostGenome() = default;
+    HostGenome(const HostGenome &) = delete;
+    HostGenome &operator=(const HostGenome &) = delete;
+    HostGenome(HostGenome &&o) noexcept { *this = std::move(o); }
+    HostGenome &operator=(HostGenome &&o) noexcept
+    {
+        if (this != &o) {
+            free(own);
+            path = std::move(o.path); first_name = std::move(o.first_name); rec_len = std::move(o.rec_len);
+            rec_rel = std::move(o.rec_rel); packed_size = o.packed_size; own = o.own; n50 = o.n50;
+            o.own = nullptr; o.packed_size = 0;
+        }
+        return *this;
+    }
+    ~HostGenome() { free(own); }
 };
 
-// plain or gzip FASTA -> kept records (>= ANI_MIN_CONTIG). Throws SkError.
-void read_fasta(const std::string &path, HostGenome &g);
+// plain or gzip FASTA -> kept records (>= ANI_MIN_CONTIG) in device layout.  region == nullptr: into g.own;
+// else into region[0 .. region_cap) (SkError "region" if it does not fit).  Throws SkError.
+void read_fasta(const std::string &path, HostGenome &g, uint8_t *region = nullptr, size_t region_cap = 0);
 std::vector<std::string> read_listing(const std::string &path);
 
 // sketch a list of genomes read from disk into `s` (batched H2D copies); names/paths returned

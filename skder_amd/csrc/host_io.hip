@@ -3,25 +3,73 @@
 // No compute happens here: bases go to HBM unmodified (1 byte per base) and the kernels do the rest.
 #include "host_io.h"
 
+#include <fcntl.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <future>
 #include <thread>
 
-void read_fasta(const std::string &path, HostGenome &g)
+// growing or fixed output of the parser
+namespace {
+struct OutBuf {
+    uint8_t *p;
+    size_t n, cap;
+    bool fixed;
+    void need(size_t extra)
+    {
+        if (n + extra <= cap) return;
+        if (fixed) throw SkError("region");
+        size_t nc = cap * 2 > n + extra ? cap * 2 : n + extra + (1u << 20);
+        uint8_t *q = static_cast<uint8_t *>(realloc(p, nc));
+        if (!q) throw SkError("out of host memory");
+        p = q; cap = nc;
+    }
+};
+struct FileCloser {
+    gzFile gz = nullptr;
+    int fd = -1;
+    ~FileCloser() { if (gz) gzclose(gz); if (fd >= 0) close(fd); }
+};
+}   // namespace
+
+static bool looks_gzip(const std::string &path)
+{
+    unsigned char m[2] = {0, 0};
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) throw SkError("cannot open " + path);
+    const size_t k = fread(m, 1, 2, f);
+    fclose(f);
+    return k == 2 && m[0] == 0x1f && m[1] == 0x8b;
+}
+
+void read_fasta(const std::string &path, HostGenome &g, uint8_t *region, size_t region_cap)
 {
     g.path = path;
-    g.first_name.clear(); g.rec_len.clear(); g.bases.clear();
-    gzFile f = gzopen(path.c_str(), "rb");
-    if (!f) throw SkError("cannot open " + path);
-    gzbuffer(f, 1 << 20);
+    g.first_name.clear(); g.rec_len.clear(); g.rec_rel.clear(); g.packed_size = 0;
+    free(g.own); g.own = nullptr;
+    FileCloser fc;
+    const bool gz = looks_gzip(path);
+    if (gz) {
+        fc.gz = gzopen(path.c_str(), "rb");
+        if (!fc.gz) throw SkError("cannot open " + path);
+        gzbuffer(fc.gz, 1 << 20);
+    } else {
+        fc.fd = open(path.c_str(), O_RDONLY);
+        if (fc.fd < 0) throw SkError("cannot open " + path);
+    }
+    OutBuf out{region, 0, region ? region_cap : 0, region != nullptr};
+    struct OwnGuard { OutBuf &o; bool armed; ~OwnGuard() { if (armed && !o.fixed) free(o.p); } } guard{out, true};
     std::vector<uint64_t> all_len;
-    std::vector<char> buf(1 << 20);
+    static thread_local std::vector<char> buf;
+    if (buf.size() < (1u << 20)) buf.resize(1u << 20);
     std::string cur_name;
     bool in_header = false, have_rec = false, have_first = false;
-    size_t rec_start = 0;   // offset in g.bases where the current record starts
+    size_t rec_start = 0;   // offset in the packed layout where the current record starts (multiple of 32)
     // N50 bookkeeping follows util.py:686-724 to the letter: a record's length is the sum of
     // len(line.strip()) over its lines (inner blanks count, empty records are not recorded, text
     // in front of the first header forms a record of its own)
@@ -31,23 +79,36 @@ void read_fasta(const std::string &path, HostGenome &g)
         if (n50_cur) all_len.push_back(n50_cur);
         n50_cur = 0;
         if (!have_rec) return;
-        size_t len = g.bases.size() - rec_start;
+        const size_t len = out.n - rec_start;
         if (len >= ANI_MIN_CONTIG) {
             if (len > 0x7FFFFFFFull) throw SkError("record longer than 2^31 in " + path);
             g.rec_len.push_back((uint32_t)len);
+            g.rec_rel.push_back(rec_start);
             if (!have_first) { g.first_name = cur_name; have_first = true; }
+            const size_t padded = (len + 31) & ~(size_t)31;
+            out.need(padded - len);
+            memset(out.p + out.n, 'A', padded - len);
+            out.n = rec_start + padded;
         } else {
-            g.bases.resize(rec_start);   // records below 500 bp are ignored entirely
+            out.n = rec_start;   // records below 500 bp are ignored entirely
         }
     };
-    // line-oriented scan of the inflated stream: sequence lines are appended in bulk (memchr for the
-    // line end, one pass that drops blanks only when a line has any), header lines are collected whole
     bool at_line_start = true;
     for (;;) {
-        int n = gzread(f, buf.data(), (unsigned)buf.size());
-        if (n < 0) { gzclose(f); throw SkError("read error in " + path); }
+        long n = gz ? (long)gzread(fc.gz, buf.data(), (unsigned)buf.size()) : (long)read(fc.fd, buf.data(), buf.size());
+        if (n < 0) throw SkError("read error in " + path);
         if (n == 0) break;
         const char *p = buf.data(), *end = p + n;
+        // one pass over the buffer decides between the bulk path (no blank characters: lines are copied with
+        // memcpy) and the careful path (CRLF files, blanks inside lines): is any byte below 0x21 not a '\n'?
+        bool buf_clean;
+        {
+            const unsigned char *u = reinterpret_cast<const unsigned char *>(p);
+            unsigned bad = 0;
+            for (long i = 0; i < n; i++) bad |= (unsigned)(u[i] < 0x21) & (unsigned)(u[i] != '\n');   // vectorised by the compiler
+            buf_clean = bad == 0;
+        }
+        out.need((size_t)n + 64);
         while (p < end) {
             const char *nl = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
             const char *le = nl ? nl : end;                    // end of this piece of the line
@@ -60,7 +121,7 @@ void read_fasta(const std::string &path, HostGenome &g)
             if (at_line_start && p < le && *p == '>') {
                 close_rec();
                 have_rec = true;
-                rec_start = g.bases.size();
+                rec_start = out.n;                             // out.n is a multiple of 32 between records
                 cur_name.clear();
                 in_header = true;
                 at_line_start = false;
@@ -69,15 +130,10 @@ void read_fasta(const std::string &path, HostGenome &g)
             }
             if (p < le) {
                 at_line_start = false;
-                // fast path: no blank of any kind inside the piece (the normal case)
-                bool clean = true;
-                for (const char *q = p; q < le; q++) {
-                    const char c = *q;
-                    if (c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f') { clean = false; break; }
-                }
-                if (clean) {
-                    n50_cur += n50_ws + (uint64_t)(le - p); n50_ws = 0; n50_line_has = true;
-                    if (have_rec) g.bases.insert(g.bases.end(), reinterpret_cast<const uint8_t *>(p), reinterpret_cast<const uint8_t *>(le));
+                if (buf_clean) {
+                    const size_t len = (size_t)(le - p);
+                    n50_cur += n50_ws + len; n50_ws = 0; n50_line_has = true;
+                    if (have_rec) { memcpy(out.p + out.n, p, len); out.n += len; }   // room was made for the whole buffer
                 } else {
                     for (const char *q = p; q < le; q++) {
                         const char c = *q;
@@ -86,7 +142,7 @@ void read_fasta(const std::string &path, HostGenome &g)
                             continue;
                         }
                         n50_cur += n50_ws + 1; n50_ws = 0; n50_line_has = true;
-                        if (have_rec) g.bases.push_back((uint8_t)c);
+                        if (have_rec) out.p[out.n++] = (uint8_t)c;
                     }
                 }
             }
@@ -95,8 +151,9 @@ void read_fasta(const std::string &path, HostGenome &g)
         }
     }
     close_rec();
-    gzclose(f);
     if (all_len.empty()) throw SkError("no sequence in " + path);
+    g.packed_size = out.n;
+    if (!out.fixed) { g.own = out.p; guard.armed = false; }
     // N50 as util.py:686-724
     std::sort(all_len.begin(), all_len.end());
     uint64_t tot = 0;
@@ -158,77 +215,142 @@ void sketch_files(skder_sketches *s, const std::vector<std::string> &paths, Geno
     if (const char *e = getenv("SKDER_AMD_IO_BATCH_MB")) batch_bytes = (size_t)std::max(1, atoi(e)) << 20;
     unsigned nthreads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
     if (const char *e = getenv("SKDER_AMD_IO_THREADS")) nthreads = (unsigned)std::max(1, atoi(e));
-    // staging buffers are kept across batches (pinned host + device), grown when a batch needs more
-    uint8_t *h = nullptr, *d = nullptr;
-    size_t h_cap = 0;
+    const bool dbg = getenv("SKDER_AMD_DEBUG") != nullptr;
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
+    // two staging slots (pinned host + device buffer each), kept across batches and grown when a batch needs
+    // more: while the device copies and sketches the batch of one slot, the host threads parse the next batch
+    // into the other
+    struct Slot { uint8_t *h = nullptr, *d = nullptr; size_t cap = 0; };
+    Slot slot[2];
     struct Staging {
-        uint8_t *&h, *&d;
-        ~Staging() { if (d) (void)hipFree(d); if (h) (void)hipHostFree(h); }
-    } staging{h, d};
-    size_t i0 = 0;
-    while (i0 < paths.size()) {
-        // read files in parallel until the batch holds ~1 GB of bases
-        std::vector<HostGenome> gs;
-        size_t i1 = i0, bytes = 0;
-        while (i1 < paths.size() && bytes < batch_bytes) {
-            const size_t chunk = std::min<size_t>(paths.size() - i1, 2 * (size_t)nthreads);
-            const size_t base = gs.size();
-            gs.resize(base + chunk);
-            parallel_for(chunk, nthreads, [&](size_t k) { read_fasta(paths[i1 + k], gs[base + k]); });
-            for (size_t k = 0; k < chunk; k++) bytes += gs[base + k].bases.size();
-            i1 += chunk;
+        Slot *sl;
+        ~Staging() { for (int k = 0; k < 2; k++) { if (sl[k].d) (void)hipFree(sl[k].d); if (sl[k].h) (void)hipHostFree(sl[k].h); } }
+    } staging{slot};
+    // file sizes and kinds up front (parallel stat + 2-byte read): a plain file's packed layout is bounded by
+    // its size (+ 32 bytes of padding per kept record of >= 500 bases), so it can be parsed straight into
+    // its region of the staging buffer; a gzip file is inflated into memory of its own first
+    struct FileInfo { uint64_t size = 0; bool gz = false; };
+    std::vector<FileInfo> info(paths.size());
+    parallel_for(paths.size(), nthreads, [&](size_t k) {
+        struct stat sb;
+        if (stat(paths[k].c_str(), &sb) != 0) throw SkError("cannot open " + paths[k]);
+        info[k].size = (uint64_t)sb.st_size;
+        info[k].gz = looks_gzip(paths[k]);
+    });
+    auto bound = [](uint64_t fsize) { return ((fsize + fsize / 15 + 64) + 31) & ~(uint64_t)31; };
+    // the batch starting at i0: files until ~batch_bytes of layout (gzip files are estimated at 4x their size)
+    auto batch_end = [&](size_t i0) {
+        size_t i1 = i0;
+        uint64_t est = 0;
+        while (i1 < paths.size() && (i1 == i0 || est < batch_bytes)) {
+            est += info[i1].gz ? 4 * info[i1].size : bound(info[i1].size);
+            i1++;
         }
-        // device layout: records 32-B aligned, 32 B in front, SKDER_TILE + 32 behind
+        return i1;
+    };
+    struct Prepared {
+        size_t i0 = 0, i1 = 0;
+        int sl = 0;
+        std::vector<HostGenome> gs;
         std::vector<uint64_t> rec_off;
         std::vector<uint32_t> rec_len, gbegin;
+        uint64_t total = 0;
+        double ms = 0;
+    };
+    auto prepare = [&](size_t i0, size_t i1, int sl) {
+        const double t0 = now();
+        HIPCHECK(hipSetDevice(ctx->device));          // may run on a helper thread
+        Prepared P;
+        P.i0 = i0; P.i1 = i1; P.sl = sl;
+        const size_t ng = i1 - i0;
+        P.gs.resize(ng);
+        std::vector<HostGenome> &gs = P.gs;
+        // phase A: gzip files into memory of their own (exact sizes afterwards)
+        parallel_for(ng, nthreads, [&](size_t k) { if (info[i0 + k].gz) read_fasta(paths[i0 + k], gs[k]); });
+        // regions: 32 readable bytes in front, SKDER_TILE + 64 behind
+        std::vector<uint64_t> gbase(ng + 1);
         uint64_t off = 32;
-        for (auto &g : gs) {
-            gbegin.push_back((uint32_t)rec_len.size());
-            for (uint32_t l : g.rec_len) {
-                rec_off.push_back(off);
-                rec_len.push_back(l);
-                off += (l + 31ull) & ~31ull;
-            }
+        for (size_t k = 0; k < ng; k++) {
+            gbase[k] = off;
+            off += info[i0 + k].gz ? gs[k].packed_size : bound(info[i0 + k].size);
         }
-        gbegin.push_back((uint32_t)rec_len.size());
-        const uint64_t total = off + SKDER_TILE + 64;
-        if (total > h_cap) {
-            if (d) (void)hipFree(d);
-            if (h) (void)hipHostFree(h);
-            h = d = nullptr;
-            h_cap = total + total / 8;
-            HIPCHECK(hipHostMalloc(&h, h_cap));
-            HIPCHECK(hipMalloc(&d, h_cap));
+        gbase[ng] = off;
+        P.total = off + SKDER_TILE + 64;
+        Slot &S = slot[sl];
+        if (P.total > S.cap) {
+            if (S.d) (void)hipFree(S.d);
+            if (S.h) (void)hipHostFree(S.h);
+            S.h = S.d = nullptr;
+            S.cap = P.total + P.total / 8;
+            HIPCHECK(hipHostMalloc(&S.h, S.cap));
+            HIPCHECK(hipMalloc(&S.d, S.cap));
         }
+        uint8_t *h = S.h;
         memset(h, 'A', 32);
-        parallel_for(gs.size(), nthreads, [&](size_t gi) {        // every genome's records into the pinned buffer
-            const HostGenome &g = gs[gi];
-            size_t src = 0, r = gbegin[gi];
-            for (uint32_t l : g.rec_len) {
-                memcpy(h + rec_off[r], g.bases.data() + src, l);
-                const uint64_t padded = (l + 31ull) & ~31ull;
-                memset(h + rec_off[r] + l, 'A', padded - l);
-                src += l; r++;
+        // phase B: plain files are parsed straight into their regions, inflated ones are copied in
+        parallel_for(ng, nthreads, [&](size_t k) {
+            if (info[i0 + k].gz) {
+                if (gs[k].packed_size) memcpy(h + gbase[k], gs[k].own, gs[k].packed_size);
+                free(gs[k].own); gs[k].own = nullptr;
+            } else {
+                read_fasta(paths[i0 + k], gs[k], h + gbase[k], gbase[k + 1] - gbase[k]);
             }
         });
         memset(h + off, 'A', SKDER_TILE + 64);
-        HIPCHECK(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, st));
-        skder_batch_t b;
-        b.n_genomes = (uint32_t)gs.size();
-        b.n_records = (uint32_t)rec_len.size();
-        b.rec_off = rec_off.data(); b.rec_len = rec_len.data(); b.genome_rec_begin = gbegin.data();
-        sketch_batch_impl(s, d, &b);
-        HIPCHECK(hipStreamSynchronize(st));
-        for (auto &g : gs) {
+        for (size_t k = 0; k < ng; k++) {
+            P.gbegin.push_back((uint32_t)P.rec_len.size());
+            for (size_t r = 0; r < gs[k].rec_len.size(); r++) {
+                P.rec_off.push_back(gbase[k] + gs[k].rec_rel[r]);
+                P.rec_len.push_back(gs[k].rec_len[r]);
+            }
+        }
+        P.gbegin.push_back((uint32_t)P.rec_len.size());
+        P.ms = now() - t0;
+        return P;
+    };
+    double t_parse = 0, t_dev = 0;
+    if (paths.empty()) return;
+    Prepared cur = prepare(0, batch_end(0), 0);
+    for (;;) {
+        // the next batch is parsed on a helper thread while this one is copied and sketched
+        std::future<Prepared> next;
+        const bool more = cur.i1 < paths.size();
+        if (more) {
+            const size_t n0 = cur.i1, n1 = batch_end(cur.i1);
+            const int nsl = cur.sl ^ 1;
+            next = std::async(std::launch::async, [&prepare, n0, n1, nsl]() { return prepare(n0, n1, nsl); });
+        }
+        const double t2 = now();
+        t_parse += cur.ms;
+        try {
+            Slot &S = slot[cur.sl];
+            HIPCHECK(hipMemcpyAsync(S.d, S.h, cur.total, hipMemcpyHostToDevice, st));
+            skder_batch_t b;
+            b.n_genomes = (uint32_t)cur.gs.size();
+            b.n_records = (uint32_t)cur.rec_len.size();
+            b.rec_off = cur.rec_off.data(); b.rec_len = cur.rec_len.data(); b.genome_rec_begin = cur.gbegin.data();
+            sketch_batch_impl(s, S.d, &b);
+            HIPCHECK(hipStreamSynchronize(st));
+        } catch (...) {
+            if (more) { try { (void)next.get(); } catch (...) {} }
+            throw;
+        }
+        t_dev += now() - t2;
+        for (auto &g : cur.gs) {
             names.path.push_back(g.path); names.first_name.push_back(g.first_name); names.n50.push_back(g.n50);
         }
-        if (i0 == 0 && i1 < paths.size()) {
+        if (cur.i0 == 0 && more) {
             // more batches follow: size the seed and marker arrays once, extrapolating from this batch
-            const double f = 1.1 * (double)paths.size() / (double)i1;
+            const double f = 1.1 * (double)paths.size() / (double)cur.i1;
             (void)skder_amd_sketches_reserve(s, (uint64_t)(s->seed_kmer.n * f) + 4096, (uint64_t)(s->markers.n * f) + 4096);
         }
-        i0 = i1;
+        if (!more) break;
+        cur = next.get();
     }
+    if (dbg)
+        fprintf(stderr, "[skder_amd] ingest of %zu files: %.1f ms wall (read+parse %.1f ms on helper threads, copy+sketch %.1f ms, overlapped)\n",
+                paths.size(), now() - t_begin, t_parse, t_dev);
 }
 
 // ---------------------------------------------------------------------------------------------
