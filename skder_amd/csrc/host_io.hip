@@ -238,7 +238,7 @@ void sketch_files(skder_sketches *s, const std::vector<std::string> &paths, Geno
         info[k].size = (uint64_t)sb.st_size;
         info[k].gz = looks_gzip(paths[k]);
     });
-    auto bound = [](uint64_t fsize) { return ((fsize + fsize / 15 + 64) + 31) & ~(uint64_t)31; };
+    auto bound = [](uint64_t fsize) { return ((fsize + fsize / 15 + 256) + 31) & ~(uint64_t)31; };
     // the batch starting at i0: files until ~batch_bytes of layout (gzip files are estimated at 4x their size)
     auto batch_end = [&](size_t i0) {
         size_t i1 = i0;

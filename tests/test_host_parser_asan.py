@@ -1,0 +1,71 @@
+"""The FASTA parser of the ingest path under AddressSanitizer + UBSan (CPU build; GPU sanitizers are not
+available on the pool).  Edge cases follow util.n50_calc (/root/reference/src/skDER/util.py:686-724) and the
+reader the reference delegates to skani: CRLF files, blanks inside lines, text before the first header, empty
+records, a last line without newline, thousands of short records, gzip input."""
+import gzip
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+CSRC = os.path.join(ROOT, "skder_amd", "csrc")
+
+
+def _n50(lens):
+    lens = sorted((l for l in lens if l), reverse=True)
+    half, cum = int(sum(lens) / 2), 0
+    for l in lens:
+        cum += l
+        if cum >= half:
+            return l
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
+def test_parser_under_sanitizers(tmp_path):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    subprocess.check_call(["make", "-C", CSRC, "-j8"], stdout=subprocess.DEVNULL)
+    objs = [os.path.join(CSRC, o) for o in ("pool.o", "sketch.o", "scan.o", "index.o", "screen.o", "chain.o", "api.o")]
+    exe = str(tmp_path / "harness")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+                           "-std=c++17", "-I" + CSRC, "-x", "hip", os.path.join(ROOT, "tests", "host_parser_harness.cpp"),
+                           os.path.join(CSRC, "host_io.hip"), "-x", "none"] + objs + ["-o", exe, "-lz", "-lpthread"],
+                          stderr=subprocess.DEVNULL)
+    rng = np.random.RandomState(3)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    seq = lambda n: bytes(alpha[rng.randint(0, 4, n)])
+    wrap = lambda s, w, eol=b"\n": eol.join(s[i:i + w] for i in range(0, len(s), w)) + eol
+    files, want = {}, {}
+    files["plain.fa"] = b">r1 x\n" + wrap(seq(70001), 80) + b">short\n" + wrap(seq(300), 60) + b">r3\n" + wrap(seq(555), 70)
+    want["plain.fa"] = (2, 70556, _n50([70001, 300, 555]), "r1 x")
+    files["crlf.fa"] = b">r1\r\n" + wrap(seq(5000), 60, b"\r\n") + b">r2\r\n" + wrap(seq(499), 60, b"\r\n")
+    want["crlf.fa"] = (1, 5000, _n50([5000, 499]), "r1")
+    body = wrap(seq(3000), 50).replace(b"A", b"A ", 20)
+    files["blanks.fa"] = b"ACGT\n>r1\n" + body + b"\n\n>e\n\n>r2\n  " + seq(700) + b"  \n"
+    want["blanks.fa"] = (2, 3700, _n50([4, 3020, 700]), "r1")          # inner blanks count for N50 (len(line.strip()))
+    files["noeol.fa"] = b">r1\n" + seq(1200)
+    want["noeol.fa"] = (1, 1200, 1200, "r1")
+    lens = [500 + i % 37 for i in range(3000)]
+    files["many.fa"] = b"".join(b">c%d\n" % i + wrap(seq(l), 61) for i, l in enumerate(lens))
+    want["many.fa"] = (3000, sum(lens), _n50(lens), "c0")
+    for k, v in files.items():
+        (tmp_path / k).write_bytes(v)
+    for k in ("plain.fa", "many.fa"):
+        with gzip.open(tmp_path / (k + ".gz"), "wb") as f:
+            f.write(files[k])
+        want[k + ".gz"] = want[k]
+    names = sorted(want)
+    out = subprocess.run([exe] + names, cwd=tmp_path, capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"),
+                         timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "ERROR" not in out.stderr and "runtime error" not in out.stderr, out.stderr[-3000:]
+    lines = [l.split() for l in out.stdout.splitlines()]
+    assert len(lines) == len(names)
+    for l in lines:
+        nrec, nbases, n50, first = want[l[0]]
+        assert int(l[2]) == nrec and int(l[4]) == nbases and int(l[8]) == n50, l
+        assert l[-2:] == ["same", "1"], l                    # own-memory and region layouts agree byte for byte
+        assert ("'" + first + "'") in " ".join(l), l
