@@ -63,6 +63,9 @@ struct PairOut {
 #define FIN_LDS_CHAINS 2048
 #define FIN_BINS 1024
 #define FAST_SLOTS 3
+#ifndef PASS_THRESH
+#define PASS_THRESH 8u       // parked lanes of a wavefront that start a general pass of chain_fast_kernel
+#endif
 #define RING 4
 #define CHUNK_SLOW 0xFFFFFFFFu
 #define SUCC_BIT 0x80000000u
@@ -297,8 +300,8 @@ __global__ __launch_bounds__(256, 3) void chain_fast_kernel(SetView A, SetView B
     }
     const uint32_t t = wg * 256u + threadIdx.x;
     // lane-private LDS rings: two 64-byte lines of each stream (see the staging below)
-    __shared__ uint32_t lb_hit[32][256];
-    __shared__ uint16_t lb_qp[32][256];   // positions relative to the chunk's first seed (a chunk spans < 20 kb)
+    __shared__ uint32_t lb_hit[16][256];
+    __shared__ uint32_t lb_qp[16][256];
     if (t >= total_chunks) return;
     const uint32_t pi = find_pair(pairs, npairs, t);
     const PairDesc pd = pairs[pi];
@@ -307,7 +310,6 @@ __global__ __launch_bounds__(256, 3) void chain_fast_kernel(SetView A, SetView B
     const SetView &RS = (pd.flags & 4u) ? B : A;
     const GenomeMeta *Qm = QS.meta + pd.q, *Rm = RS.meta + pd.r;
     const uint64_t qoff = Qm->seed_off;
-    const uint32_t *qg = QS.pgpos + qoff;
     const uint32_t s0 = QS.chunk_start[Qm->chunk_off + c], s1 = QS.chunk_start[Qm->chunk_off + c + 1];
     // own-multiplicity filter active, or positions of the probed genome do not fit a hit word's 24 bits:
     // leave the chunk to the slow path
@@ -375,22 +377,18 @@ __global__ __launch_bounds__(256, 3) void chain_fast_kernel(SetView A, SetView B
     uint32_t s = s0;
     bool dom = false;   // "r0 dominates": no other run or summary can out-score an extension of r0
     // Control structure against wave divergence.  Work proceeds in ROUNDS that are uniform across the
-    // wave: (1) every lane walks at most 16 seeds of its chunk -- misses and plain extensions of its
-    // current run cost a handful of instructions -- and parks at the first seed that is anything else;
-    // (2) the general step runs once for the lanes that parked.  Nobody waits for more than 16 walk
-    // trips per round, and all loop exits are votes, so the wave stays converged.
+    // wave: (1) every lane disposes of the rest of its current 16-seed line -- misses and plain
+    // extensions of its current run, found by bit operations on the line's class word -- and parks at
+    // the first seed that is anything else; (2) the general step runs once for the lanes that parked.
+    // All loop exits are votes, so the wave stays converged.
     // Input staging: the hit words of a pair start at an entry congruent (mod 16) to the genome's seed
-    // offset, so 64-byte line k of both streams covers the same 16 seeds.  Each lane keeps the two
-    // lines around its position in a private LDS ring (32 entries per stream) and the following line
-    // in registers: the loads for line k+1 are issued when line k is moved into LDS, a whole round
-    // before they are needed.
+    // offset, so 64-byte line k of both streams covers the same 16 seeds.  Each lane keeps its current
+    // line in a private LDS column (16 entries per stream, for the dynamic look-ups at a park) and the
+    // following line in registers: the loads for line k+1 are issued when line k is moved into LDS, a
+    // whole round before they are needed.
     uint32_t rfa = (s0 + qphase) & ~15u;            // aligned index (seed + qphase) of the line held in registers
     const uint32_t *hline = hits + (hbase - qphase);  // line k of the hit stream starts at hline + 16 k
     const uint32_t *qline = qg_abs + (qoff - qphase);
-    const uint32_t qbase = s0 < s1 ? qg[s0] : 0u;
-    // the chunk's first position must be in a register before the prefetch is issued: a later wait on
-    // it would drain the prefetch as well (vmcnt counts in order)
-    asm volatile("" ::"v"(qbase));
     uint4 h0, h1, h2, h3, q0, q1, q2, q3;
     {
         const uint4 *srh = reinterpret_cast<const uint4 *>(hline + rfa);
@@ -398,18 +396,39 @@ __global__ __launch_bounds__(256, 3) void chain_fast_kernel(SetView A, SetView B
         h0 = srh[0]; h1 = srh[1]; h2 = srh[2]; h3 = srh[3];
         q0 = srq[0]; q1 = srq[1]; q2 = srq[2]; q3 = srq[3];
     }
+    // Seed classes of the staged line, two bits per seed: 0 = CONTINUES the previous hit (single position
+    // word with the previous non-miss seed's record, strand and diagonal, 1..2500 bases behind it),
+    // 1 = miss, 2 = anything else.  The classes depend on the data alone, so they are computed for the
+    // 16 seeds of a line in straight-line code when the line is staged; a class-0 seed is a plain
+    // extension of the current run exactly when that run dominates (`dom`), because the hit processed
+    // last is always the last anchor of the front run.  The walk over a line is then a few bit
+    // operations on the class word instead of a loop over the seeds.
+    uint32_t cw = 0;
+    uint32_t pw = 0x40000000u, pq = 0, pdiag = 0;   // previous non-miss seed: hit word, position, diagonal
+    bool park = false;                              // waiting at seed s for the general step
+    uint32_t hw = HIT_NONE;
+    int32_t qp = 0;
     for (;;) {
         const bool live = !cplx && s < s1;
-        if (live && s + qphase + 16u > rfa) {
-            const uint32_t o = rfa & 16u;
-            lb_hit[o + 0][tidx] = h0.x; lb_hit[o + 1][tidx] = h0.y; lb_hit[o + 2][tidx] = h0.z; lb_hit[o + 3][tidx] = h0.w;
-            lb_hit[o + 4][tidx] = h1.x; lb_hit[o + 5][tidx] = h1.y; lb_hit[o + 6][tidx] = h1.z; lb_hit[o + 7][tidx] = h1.w;
-            lb_hit[o + 8][tidx] = h2.x; lb_hit[o + 9][tidx] = h2.y; lb_hit[o + 10][tidx] = h2.z; lb_hit[o + 11][tidx] = h2.w;
-            lb_hit[o + 12][tidx] = h3.x; lb_hit[o + 13][tidx] = h3.y; lb_hit[o + 14][tidx] = h3.z; lb_hit[o + 15][tidx] = h3.w;
-            lb_qp[o + 0][tidx] = (uint16_t)(q0.x - qbase); lb_qp[o + 1][tidx] = (uint16_t)(q0.y - qbase); lb_qp[o + 2][tidx] = (uint16_t)(q0.z - qbase); lb_qp[o + 3][tidx] = (uint16_t)(q0.w - qbase);
-            lb_qp[o + 4][tidx] = (uint16_t)(q1.x - qbase); lb_qp[o + 5][tidx] = (uint16_t)(q1.y - qbase); lb_qp[o + 6][tidx] = (uint16_t)(q1.z - qbase); lb_qp[o + 7][tidx] = (uint16_t)(q1.w - qbase);
-            lb_qp[o + 8][tidx] = (uint16_t)(q2.x - qbase); lb_qp[o + 9][tidx] = (uint16_t)(q2.y - qbase); lb_qp[o + 10][tidx] = (uint16_t)(q2.z - qbase); lb_qp[o + 11][tidx] = (uint16_t)(q2.w - qbase);
-            lb_qp[o + 12][tidx] = (uint16_t)(q3.x - qbase); lb_qp[o + 13][tidx] = (uint16_t)(q3.y - qbase); lb_qp[o + 14][tidx] = (uint16_t)(q3.z - qbase); lb_qp[o + 15][tidx] = (uint16_t)(q3.w - qbase);
+        if (live && s + qphase >= rfa) {           // s has entered the line held in registers
+            cw = 0;
+#define STAGE(K, W, Q)                                                                                   \
+            {                                                                                            \
+                const uint32_t w_ = (W), q_ = (Q);                                                       \
+                lb_hit[K][tidx] = w_; lb_qp[K][tidx] = q_;                                               \
+                const bool none_ = w_ == HIT_NONE;                                                       \
+                const uint32_t sg_ = (uint32_t)((int32_t)w_ >> 31);                                      \
+                const uint32_t dg_ = (w_ & HIT_POS_MASK) - ((q_ ^ sg_) - sg_);   /* pos - q, or pos + q */ \
+                const uint32_t x_ = ((w_ ^ pw) & (HIT_KEY_MASK | 0x40000000u)) | (dg_ ^ pdiag) | (w_ & 0x40000000u); \
+                const bool cont_ = (x_ == 0u) & ((q_ - pq - 1u) < (uint32_t)ANI_BP_BAND);                \
+                cw |= (none_ ? 1u : (cont_ ? 0u : 2u)) << (2 * (K));                                     \
+                pw = none_ ? pw : w_; pq = none_ ? pq : q_; pdiag = none_ ? pdiag : dg_;                 \
+            }
+            STAGE(0, h0.x, q0.x) STAGE(1, h0.y, q0.y) STAGE(2, h0.z, q0.z) STAGE(3, h0.w, q0.w)
+            STAGE(4, h1.x, q1.x) STAGE(5, h1.y, q1.y) STAGE(6, h1.z, q1.z) STAGE(7, h1.w, q1.w)
+            STAGE(8, h2.x, q2.x) STAGE(9, h2.y, q2.y) STAGE(10, h2.z, q2.z) STAGE(11, h2.w, q2.w)
+            STAGE(12, h3.x, q3.x) STAGE(13, h3.y, q3.y) STAGE(14, h3.z, q3.z) STAGE(15, h3.w, q3.w)
+#undef STAGE
             rfa += 16u;
             if (rfa < s1 + qphase) {             // the next line still holds seeds of this chunk
                 const uint4 *srh = reinterpret_cast<const uint4 *>(hline + rfa);
@@ -422,65 +441,95 @@ __global__ __launch_bounds__(256, 3) void chain_fast_kernel(SetView A, SetView B
         if ((threadIdx.x & 63u) == __ffsll(__ballot(1)) - 1) atomicAdd(slow_count + 13, 1u);      // rounds (per wave)
 #endif
         {
-            bool park = false;
-            uint32_t hw = HIT_NONE;
-            int32_t qp = 0;
-            uint32_t lim = s + 16u;
-            lim = lim < rfa - qphase ? lim : rfa - qphase;
-            lim = lim < s1 ? lim : s1;
-            lim = cplx ? s : lim;
-            // plain extension of the current run: single hit, same record and strand, zero gap cost,
-            // inside the 2500-base band, and r0 dominates every other possible predecessor.  r0's last
-            // anchor is anchor ia-1, the nearest candidate, and scores r0.f + 20 >= everything else.
-            // (Evaluated without short-circuit branches; a miss fails the record-interval test.)
-            // uniform trip count (scalar loop control); lanes drop out of `act` when they park or reach lim
-            bool act = s < lim;
-            uint32_t ext = 0, last_s = 0;      // plain extensions of r0 in this walk, seed of the last one
-            for (int trip = 0; trip < 16; trip++) {
-                if (!__any(act)) break;
-#ifdef SKDER_PROFILE_COUNTERS
-                if ((threadIdx.x & 63u) == __ffsll(__ballot(1)) - 1) atomicAdd(slow_count + 12, 1u);  // walk trips (per wave)
-#endif
-                if (act) {
-                    const uint32_t row = (qphase + s) & 31u;
-                    hw = lb_hit[row][tidx];
-                    qp = (int32_t)(qbase + lb_qp[row][tidx]);
-                    const uint32_t rpu = hw & HIT_POS_MASK;
-                    const int32_t dq = qp - (int32_t)r0.q_last;
-                    const int32_t d1 = (int32_t)rpu - (int32_t)(r0.rr_last & HIT_POS_MASK);
-                    const int32_t dr = (int32_t)hw < 0 ? -d1 : d1;
-                    // same strand and record tag (a miss, a multi word and a too-many word all differ from a
-                    // position word in bit 30), same diagonal, inside the band
-                    const bool plain = dom & (((hw ^ r0.rr_last) & (HIT_KEY_MASK | 0x40000000u)) == 0u) &
-                                       ((uint32_t)(dq - 1) < (uint32_t)ANI_BP_BAND) & (dq == dr);
-                    park = (hw != HIT_NONE) & !plain;
-                    if (plain) {       // only what the next trip's test needs; the rest is settled after the walk
-                        r0.q_last = (uint32_t)qp; r0.rr_last = hw;
-                        ext++; last_s = s;
+            // the rest of the staged line: skip misses and (while r0 dominates) continuing seeds, stop at the
+            // first seed that needs a decision.  The most common decision -- the hit starts a new run because no
+            // run of the ring can precede it -- is taken here as well; everything else parks for the general step.
+            for (;;) {
+                const bool actv = !cplx && !park && s < s1 && s + qphase < rfa;
+                if (!__any(actv)) break;
+                if (actv) {
+                    const uint32_t k = (s + qphase) & 15u;
+                    uint32_t nv = 16u - k;
+                    nv = nv < s1 - s ? nv : s1 - s;
+                    const uint32_t rem = cw >> (2u * k);
+                    const uint32_t hi = (rem >> 1) & 0x55555555u, lo = rem & 0x55555555u;
+                    const uint32_t vmask = nv >= 16u ? 0xFFFFFFFFu : (1u << (2u * nv)) - 1u;
+                    const uint32_t stop = (dom ? hi : (~lo & 0x55555555u)) & vmask;
+                    const uint32_t first = stop ? (uint32_t)(__ffs((int)stop) - 1) >> 1 : nv;
+                    const uint32_t rmask = first >= 16u ? 0xFFFFFFFFu : (1u << (2u * first)) - 1u;
+                    const uint32_t contm = ~(hi | lo) & 0x55555555u & rmask;      // plain extensions of r0 among the skipped seeds
+                    if (contm) {
+                        // k plain extensions at once: scores rise by 20 per anchor, positions move monotonically along
+                        // the run's diagonal, so the aggregates follow from the last anchor alone
+                        const uint32_t ext = (uint32_t)__popc(contm);
+                        const uint32_t last_s = s + ((31u - (uint32_t)__clz((int)contm)) >> 1);
+                        const uint32_t lrow = (qphase + last_s) & 15u;
+                        r0.q_last = lb_qp[lrow][tidx]; r0.rr_last = lb_hit[lrow][tidx];
+                        const int32_t f_prev = r0.f + ANI_ANCHOR_SCORE * (int32_t)(ext - 1u);
+                        r0.pmax = f_prev > r0.pmax ? f_prev : r0.pmax;
+                        r0.f = f_prev + ANI_ANCHOR_SCORE;
+                        runmax = r0.f > runmax ? r0.f : runmax;
+                        r0.cnt += ext;
+                        r0.idx_last = ia + ext - 1u; ia += ext;
+                        r0.qi_last = last_s;
+                        const uint32_t rl = r0.rr_last & HIT_POS_MASK;
+                        r0.rmin = rl < r0.rmin ? rl : r0.rmin;
+                        r0.rmax = rl > r0.rmax ? rl : r0.rmax;
                     }
-                    s += park ? 0u : 1u;
-                    act = !park & (s < lim);
+                    s += first;
+                    park = first < nv;
+                    if (park) {
+                        const uint32_t row = (qphase + s) & 15u;
+                        hw = lb_hit[row][tidx];
+                        qp = (int32_t)lb_qp[row][tidx];
+                        // NEW RUN without a look-back: a single hit and -- going through the ring nearest first, as the
+                        // general step would -- only runs of another record or strand until a ring position is empty or
+                        // a run lies beyond the 2500-base band (older runs and the summaries lie further back still), or
+                        // until the ring ends with nothing evicted so far.  No predecessor exists, and the runs left
+                        // in the ring cannot beat the new one: out of the band, or another key.
+#define RUN_END(E) (!(E).cnt || qp - (int32_t)(E).q_last > ANI_BP_BAND)
+#define RUN_OTHER(E) ((((E).rr_last ^ hw) & HIT_KEY_MASK) != 0u)
+                        const bool fresh = !(hw & 0x40000000u) &&
+                                           (RUN_END(r0) || (RUN_OTHER(r0) && (RUN_END(r1) || (RUN_OTHER(r1) && (RUN_END(r2) || (RUN_OTHER(r2) &&
+                                            (RUN_END(r3) || (RUN_OTHER(r3) && !nevict))))))));
+#undef RUN_END
+#undef RUN_OTHER
+                        if (fresh) {
+                            const uint32_t rp = hw & HIT_POS_MASK;
+                            EVICT(r3);
+                            if (!cplx) {
+                                r3 = r2; r2 = r1; r1 = r0;
+                                r0.q_last = (uint32_t)qp; r0.rr_last = hw; r0.f = ANI_ANCHOR_SCORE;
+                                r0.cnt = 1; r0.first_qi = s; r0.q_first = (uint32_t)qp; r0.rmin = r0.rmax = rp;
+                                r0.qi_last = s; r0.idx_last = ia; r0.pmax = NEG; r0.r_first = rp; r0.seg = ia;
+                                ia++;
+                                runmax = ANI_ANCHOR_SCORE > runmax ? ANI_ANCHOR_SCORE : runmax;
+                                dom = true;
+                                if (nevict) {       // the summaries of evicted runs, as at the end of the general step
+                                    const uint32_t k0 = hw & HIT_KEY_MASK;
+                                    const int32_t d0 = (hw >> 31) ? (int32_t)rp + qp : (int32_t)rp - qp;
+                                    if (s0_seg != 0xFFFFFFFFu)
+                                        dom = s0_key != k0 || s0_f <= r0.f || qp - (int32_t)s0_q > ANI_BP_BAND || d0 < s0_dlo - ANI_MAX_GAP || d0 > s0_dhi + ANI_MAX_GAP;
+                                    if (dom && lost_f != NEG)
+                                        dom = lost_f <= r0.f || qp - (int32_t)lost_q > ANI_BP_BAND || d0 < lost_dlo - ANI_MAX_GAP || d0 > lost_dhi + ANI_MAX_GAP;
+                                }
+                                s++;
+                            }
+                            park = false;
+                        }
+                    }
                 }
             }
-            if (ext) {
-                // k plain extensions at once: scores rise by 20 per anchor, positions move monotonically along
-                // the run's diagonal, so the aggregates follow from the last anchor alone
-                const int32_t f_prev = r0.f + ANI_ANCHOR_SCORE * (int32_t)(ext - 1u);
-                r0.pmax = f_prev > r0.pmax ? f_prev : r0.pmax;
-                r0.f = f_prev + ANI_ANCHOR_SCORE;
-                runmax = r0.f > runmax ? r0.f : runmax;
-                r0.cnt += ext;
-                r0.idx_last = ia + ext - 1u; ia += ext;
-                r0.qi_last = last_s;
-                const uint32_t rl = r0.rr_last & HIT_POS_MASK;
-                r0.rmin = rl < r0.rmin ? rl : r0.rmin;
-                r0.rmax = rl > r0.rmax ? rl : r0.rmax;
-            }
+            // the general step is long and every parked lane drags the whole wave through its branches: it
+            // runs when enough lanes wait for it, or when nobody is left who could advance without it
+            const uint32_t npark = (uint32_t)__popcll(__ballot(park));
+            const bool go = npark >= PASS_THRESH || !__any(!cplx && s < s1 && !park);
 #ifdef SKDER_PROFILE_COUNTERS
-            if (park) atomicAdd(slow_count + 10, 1u);                                               // parks (per lane)
-            if (__any(park) && (threadIdx.x & 63u) == __ffsll(__ballot(1)) - 1) atomicAdd(slow_count + 11, 1u);   // general passes (per wave)
+            if (park && go) atomicAdd(slow_count + 10, 1u);                                         // parks (per lane)
+            if (__any(park && go) && (threadIdx.x & 63u) == __ffsll(__ballot(1)) - 1) atomicAdd(slow_count + 11, 1u);   // general passes (per wave)
 #endif
-            if (park) do {
+            if (park && go) do {
+                park = false;
                 // ---- general step for seed s (all of its hits)
                 if (hw == HIT_MANY) { cplx = true; cause = 2; break; }
                 uint32_t m = 1, g0 = hw, g1 = HIT_NONE, g2 = HIT_NONE, g3 = HIT_NONE;
