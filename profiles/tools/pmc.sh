@@ -1,5 +1,5 @@
 #!/bin/bash
-# exp/pmc.sh KERNEL_SUBSTR  -- SQ counters for one kernel (separate passes, kernel-trace only)
+# profiles/tools/pmc.sh KERNEL_SUBSTR  -- SQ counters for one kernel (separate passes, kernel-trace only)
 export TMPDIR=/tmp
 K=${1:-chain_fast_kernel}
 OUT=gpurun_out/pmc_$K

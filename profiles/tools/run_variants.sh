@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: exp/run_variants.sh lib1.so lib2.so ...   (bench each library variant, print kernel times)
+# usage: profiles/tools/run_variants.sh lib1.so lib2.so ...   (bench each library variant, print kernel times)
 cp skder_amd/libskder_amd.so /tmp/lib_orig.so
 for L in "$@"; do
   cp exp/$L skder_amd/libskder_amd.so

@@ -25,7 +25,7 @@ struct SetView {
     const GenomeMeta *meta;
     const uint32_t *pkmer, *pgpos, *pchunk;   // position order
     const uint32_t *skmer, *sgpos, *sctg;     // bucket order
-    const uint32_t *stag;                     // bucket order: sgpos | (sctg & 63) << 24
+    const uint32_t *stag;                     // bucket order: sgpos | (sctg & 63) << 24 | strand of the k-mer << 31
     const uint32_t *boff;
     const uint32_t *chunk_start;
     const uint32_t *rec_goff;
@@ -63,6 +63,9 @@ struct PairOut {
 #define FIN_LDS_CHAINS 2048
 #define FIN_BINS 1024
 #define FAST_SLOTS 3
+#ifndef CF_OCC
+#define CF_OCC 3           // wavefronts per SIMD chain_fast_kernel is compiled for
+#endif
 #ifndef PASS_THRESH
 #define PASS_THRESH 8u       // parked lanes of a wavefront that start a general pass of chain_fast_kernel
 #endif
@@ -83,29 +86,39 @@ __device__ __forceinline__ uint32_t find_pair(const PairDesc *__restrict__ pairs
 // ---------------------------------------------------------------------------------------------
 // JOIN: hit words for every (pair, seed of the chunked genome), R-stationary.
 // Pairs are sorted by the probed genome R.  One 1024-thread workgroup takes a group of pairs that
-// share R, loads R's bucket offsets and bucket-ordered k-mers into LDS once (132 KB for a 3 Mb genome),
+// share R, loads R's bucket offsets and, per bucket-ordered seed, the REMAINDER of its k-mer (the
+// 30 - bits bits of the mixed k-mer that the bucket number does not fix: 16 bits for genomes of
+// 16 k seeds and more) into LDS once -- 80 KB for a 3 Mb genome, so two workgroups share a CU --
 // and then streams the position-ordered k-mers of every chunked genome of the group past it: one
-// coalesced 4-byte read per seed, a probe of the LDS-resident bucket (about 5 LDS reads), a gather of
-// the matched position (with its record tag) from R's stag array (L2-resident), and one coalesced 4-byte hit word written
-// per seed -- in position order, so nothing is scattered into HBM and no memset is needed.
-// Genomes whose index does not fit in LDS are probed in several passes over bucket ranges.
+// coalesced 4-byte read per seed, a probe of the LDS-resident bucket (about 4 LDS reads), a gather of
+// the matched position (with its record tag and strand) from R's stag array (L2-resident), and one
+// coalesced 4-byte hit word written per seed -- in position order, so nothing is scattered into HBM
+// and no memset is needed.  Genomes whose index does not fit in LDS are probed in several passes over
+// bucket ranges.
 struct JoinGroup { uint32_t pair_begin, pair_end; };
 #define JOIN_THREADS 1024
 #define JOIN_U 4             // seeds per thread and trip
-#define JOIN_BCAP 16400      // bucket offsets (16-bit, relative to the pass) held in LDS per pass
-#define JOIN_KCAP 30720      // k-mers held in LDS per pass
-#define JOIN_SMEM_BYTES (JOIN_BCAP * 2 + (JOIN_KCAP + 8) * 4)
+#define JOIN_SMEM_MAX (155u * 1024u)   // dynamic LDS of a workgroup at most
+#define JOIN_SMEM_TWO (80u * 1024u)    // up to here two workgroups fit a CU
 
-// the probe loop of one staged bucket range for all pairs of a group.  FITS: the range's k-mers are in
-// LDS (false only for a single bucket with more than JOIN_KCAP seeds); WHOLE: the range is the whole
-// table, so every seed belongs to this pass (the normal case: both true, no per-seed tests for either)
-template <bool FITS, bool WHOLE>
+// LDS bytes wanted for a whole-table pass over a genome with 2^bits buckets and n seeds
+static inline size_t join_need(uint32_t bits, uint32_t n)
+{
+    return (((size_t)(1u << bits) + 1u) * 2u + 15u) / 16u * 16u + 64u + ((size_t)n + 8u) * (bits >= 14u ? 2u : 4u);
+}
+
+// the probe loop of one staged bucket range for all pairs of a group.  FP: remainder type (16 bits once
+// the genome has 2^14 buckets, else 32); FITS: the range's remainders are in LDS (false only for a
+// single bucket with more seeds than LDS holds); WHOLE: the range is the whole table, so every seed
+// belongs to this pass (the normal case: both true, no per-seed tests for either)
+template <typename FP, bool FITS, bool WHOLE>
 __device__ __forceinline__ void join_pass(const SetView &A, const SetView &B, const PairDesc *__restrict__ pairs, const JoinGroup g,
                                           uint32_t *__restrict__ hits, uint4 *__restrict__ multi, uint32_t *__restrict__ pair_nmulti,
-                                          const uint32_t *s_rk, const uint16_t *s_boff, const uint32_t *__restrict__ rk,
+                                          const FP *s_fp, const uint16_t *s_boff, const uint32_t *__restrict__ rk,
                                           const uint32_t *__restrict__ rg, uint32_t base, uint32_t bits, uint32_t bb0, uint32_t bb1,
                                           uint32_t rrep, uint32_t tid)
 {
+    const uint32_t bsh = 30u - bits, rmask = (1u << bsh) - 1u;
     for (uint32_t p = g.pair_begin; p < g.pair_end; p++) {
         const PairDesc pd = pairs[p];
         const SetView &QS = (pd.flags & 2u) ? B : A;
@@ -119,7 +132,7 @@ __device__ __forceinline__ void join_pass(const SetView &A, const SetView &B, co
         // FULL trips (every seed of every thread exists) carry no bounds tests; one guarded trip finishes the pair
         auto trip = [&](auto full_tag, const uint32_t s0) {
             constexpr bool FULL = decltype(full_tag)::value;
-            uint32_t kqv[JOIN_U], lov[JOIN_U], hiv[JOIN_U], firstv[JOIN_U], cntv[JOIN_U], hvv[JOIN_U];
+            uint32_t kqv[JOIN_U], remv[JOIN_U], lov[JOIN_U], hiv[JOIN_U], firstv[JOIN_U], cntv[JOIN_U], hvv[JOIN_U];
             bool mine[JOIN_U];
 #pragma unroll
             for (int u = 0; u < JOIN_U; u++) {
@@ -129,7 +142,9 @@ __device__ __forceinline__ void join_pass(const SetView &A, const SetView &B, co
 #pragma unroll
             for (int u = 0; u < JOIN_U; u++) {
                 const uint32_t s = s0 + u * JOIN_THREADS;
-                const uint32_t b = kmer_bucket(kqv[u] & SK_SEED_MASK, bits);
+                const uint32_t mx = kmer_mix(kqv[u] & SK_SEED_MASK);
+                const uint32_t b = mx >> bsh;
+                remv[u] = mx & rmask;
                 mine[u] = (FULL || s < nq) && (WHOLE || (b >= bb0 && b < bb1));      // else: this seed's bucket belongs to another pass
                 lov[u] = mine[u] ? s_boff[b - bb0] : 0u;
                 hiv[u] = mine[u] ? s_boff[b - bb0 + 1] : 0u;
@@ -137,24 +152,22 @@ __device__ __forceinline__ void join_pass(const SetView &A, const SetView &B, co
             bool any_multi = false;
 #pragma unroll
             for (int u = 0; u < JOIN_U; u++) {
-                const uint32_t kmer = kqv[u] & SK_SEED_MASK;
                 uint32_t cnt = 0, first = 0;
                 if (FITS) {
-                    // buckets hold 1-2 seeds on average, ordered by k-mer: the first two entries are
+                    // buckets hold 1-2 seeds on average, equal k-mers side by side: the first two entries are
                     // compared without a loop (reads clamped into the table), longer buckets continue
-                    const uint32_t lo = lov[u], ne = hiv[u] - lo;
-                    const uint32_t k0 = s_rk[lo] & SK_SEED_MASK, k1 = s_rk[lo + 1] & SK_SEED_MASK;   // s_rk has slack behind nk
-                    const bool m0 = ne > 0 && k0 == kmer, m1 = ne > 1 && k1 == kmer;
+                    const uint32_t lo = lov[u], ne = hiv[u] - lo, rem = remv[u];
+                    const uint32_t f0 = s_fp[lo], f1 = s_fp[lo + 1];   // s_fp has slack behind the last seed
+                    const bool m0 = ne > 0 && f0 == rem, m1 = ne > 1 && f1 == rem;
                     cnt = (uint32_t)m0 + (uint32_t)m1;
                     first = m0 ? lo : lo + 1;
-                    if (ne > 2 && !(k1 > kmer)) {
+                    if (ne > 2) {
                         for (uint32_t e = lo + 2; e < hiv[u]; e++) {
-                            const uint32_t k2 = s_rk[e] & SK_SEED_MASK;
-                            if (k2 == kmer) { if (!cnt) first = e; cnt++; }
-                            else if (k2 > kmer) break;
+                            if (s_fp[e] == rem) { if (!cnt) first = e; cnt++; }
                         }
                     }
                 } else {
+                    const uint32_t kmer = kqv[u] & SK_SEED_MASK;
                     for (uint32_t e = lov[u]; e < hiv[u]; e++) {
                         const uint32_t k2 = rk[base + e] & SK_SEED_MASK;
                         if (k2 == kmer) { if (!cnt) first = e; cnt++; }
@@ -167,17 +180,16 @@ __device__ __forceinline__ void join_pass(const SetView &A, const SetView &B, co
             }
             // all position gathers in flight together: unconditional loads (seeds without a single hit read
             // the genome's first entry, one broadcast address), combined only after the last one is issued
-            uint32_t gv[JOIN_U], rkmv[JOIN_U];
+            uint32_t gv[JOIN_U];
 #pragma unroll
             for (int u = 0; u < JOIN_U; u++) {
                 const uint32_t e = cntv[u] == 1 ? firstv[u] : 0u;
                 gv[u] = rg[base + e];
-                rkmv[u] = FITS ? s_rk[e] : rk[base + e];
             }
 #pragma unroll
             for (int u = 0; u < JOIN_U; u++) {
-                hvv[u] = cntv[u] == 1 ? (gv[u] | (((kqv[u] >> 31) != (rkmv[u] >> 31)) ? USED_BIT : 0u))
-                                      : (cntv[u] > 4 ? HIT_MANY : HIT_NONE);
+                // bit 31 of a stag entry is the strand of the indexed k-mer: the hit is reversed when the two differ
+                hvv[u] = cntv[u] == 1 ? (gv[u] ^ (kqv[u] & USED_BIT)) : (cntv[u] > 4 ? HIT_MANY : HIT_NONE);
             }
             if (any_multi) {
 #pragma unroll
@@ -187,10 +199,7 @@ __device__ __forceinline__ void join_pass(const SetView &A, const SetView &B, co
                     const uint32_t slot = atomicAdd(&pair_nmulti[p], 1u);
                     if (slot < pd.multi_cap) {
                         uint32_t v[4] = {HIT_NONE, HIT_NONE, HIT_NONE, HIT_NONE};
-                        for (uint32_t w = 0; w < cnt; w++) {
-                            const uint32_t rkm = FITS ? s_rk[first + w] : rk[base + first + w];
-                            v[w] = rg[base + first + w] | (((kqv[u] >> 31) != (rkm >> 31)) ? USED_BIT : 0u);
-                        }
+                        for (uint32_t w = 0; w < cnt; w++) v[w] = rg[base + first + w] ^ (kqv[u] & USED_BIT);
                         multi[pd.multi_base + slot] = make_uint4(v[0], v[1], v[2], v[3]);
                         hvv[u] = HIT_MULTI | slot;
                     } else {
@@ -209,33 +218,37 @@ __device__ __forceinline__ void join_pass(const SetView &A, const SetView &B, co
     }
 }
 
-__global__ __launch_bounds__(JOIN_THREADS) void join_probe_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs,
-                                                                  const JoinGroup *__restrict__ groups,
-                                                                  uint32_t *__restrict__ hits, uint4 *__restrict__ multi,
-                                                                  uint32_t *__restrict__ pair_nmulti)
+// one bucket range of R after the other: stage, probe
+template <typename FP>
+__device__ __forceinline__ void join_group(const SetView &A, const SetView &B, const PairDesc *__restrict__ pairs, const JoinGroup g,
+                                           uint32_t *__restrict__ hits, uint4 *__restrict__ multi, uint32_t *__restrict__ pair_nmulti,
+                                           unsigned char *smem, uint32_t smem_bytes, const SetView &RS, const GenomeMeta *Rm, uint32_t tid)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char join_smem[];
-    uint32_t *s_rk = reinterpret_cast<uint32_t *>(join_smem);      // JOIN_KCAP
-    uint32_t *s_ctl = s_rk + JOIN_KCAP;                            // [0] = end bucket of the pass
-    uint16_t *s_boff = reinterpret_cast<uint16_t *>(s_ctl + 8);    // JOIN_BCAP, relative to the pass's first seed (< 65536)
-    const uint32_t tid = threadIdx.x;
-    const JoinGroup g = groups[blockIdx.x];
-    const PairDesc pd0 = pairs[g.pair_begin];
-    const SetView &RS = (pd0.flags & 4u) ? B : A;
-    const GenomeMeta *Rm = RS.meta + pd0.r;
     const uint32_t bits = Rm->bucket_bits, nbk = 1u << bits, rrep = Rm->rep_cut;
-    const uint32_t *rk = RS.skmer + Rm->seed_off, *rg = RS.stag + Rm->seed_off, *rb = RS.boff + Rm->bucket_off;   // rg: position | record tag
+    const uint32_t *rk = RS.skmer + Rm->seed_off, *rg = RS.stag + Rm->seed_off, *rb = RS.boff + Rm->bucket_off;   // rg: position | record tag | strand
+    // LDS: [control words | bucket offsets (16-bit, relative to the pass's first seed) | remainders]
+    uint32_t *s_ctl = reinterpret_cast<uint32_t *>(smem);           // [0] = end bucket of the pass
+    uint16_t *s_boff = reinterpret_cast<uint16_t *>(smem + 64);
+    // whole table in one pass if it fits; else as many buckets as half of the space takes, at most 65535 seeds per pass
+    const uint32_t whole_off = (uint32_t)((((size_t)nbk + 1u) * 2u + 15u) / 16u * 16u) + 64u;
+    const bool one = whole_off + ((size_t)Rm->n_seeds + 8u) * sizeof(FP) <= smem_bytes;
+    const uint32_t bcap = one ? nbk + 1u : (smem_bytes / 2u - 64u) / 2u;                 // bucket offsets held per pass
+    const uint32_t fp_off = one ? whole_off : smem_bytes / 2u;
+    FP *s_fp = reinterpret_cast<FP *>(smem + fp_off);
+    uint32_t kcap = (smem_bytes - fp_off) / (uint32_t)sizeof(FP) - 8u;                   // remainders held per pass
+    kcap = kcap < 65535u ? kcap : 65535u;
+    const uint32_t bsh = 30u - bits, rmask = (1u << bsh) - 1u;
 
     for (uint32_t bb0 = 0; bb0 < nbk;) {
         __syncthreads();
         if (tid == 0) {
-            // the largest bucket range [bb0, bb1) whose offsets and k-mers fit
-            uint32_t hi = bb0 + (JOIN_BCAP - 1) < nbk ? bb0 + (JOIN_BCAP - 1) : nbk, lo = bb0 + 1;
+            // the largest bucket range [bb0, bb1) whose offsets and remainders fit
+            uint32_t hi = bb0 + (bcap - 1) < nbk ? bb0 + (bcap - 1) : nbk, lo = bb0 + 1;
             const uint32_t base = rb[bb0];
-            if (rb[hi] - base > JOIN_KCAP) {
-                while (lo < hi) {   // largest bb1 in [bb0+1, hi] with rb[bb1] - base <= KCAP
+            if (rb[hi] - base > kcap) {
+                while (lo < hi) {   // largest bb1 in [bb0+1, hi] with rb[bb1] - base <= kcap
                     const uint32_t mid = (lo + hi + 1) >> 1;
-                    if (rb[mid] - base <= JOIN_KCAP) lo = mid; else hi = mid - 1;
+                    if (rb[mid] - base <= kcap) lo = mid; else hi = mid - 1;
                 }
                 hi = lo;
             }
@@ -244,17 +257,35 @@ __global__ __launch_bounds__(JOIN_THREADS) void join_probe_kernel(SetView A, Set
         __syncthreads();
         const uint32_t bb1 = s_ctl[0];
         const uint32_t base = rb[bb0], nk = rb[bb1] - base;
-        const bool fits = nk <= JOIN_KCAP;   // false only for one bucket with more than KCAP seeds
+        const bool fits = nk <= kcap;   // false only for one bucket with more than kcap seeds
         for (uint32_t i = tid; i <= bb1 - bb0; i += JOIN_THREADS) s_boff[i] = (uint16_t)(rb[bb0 + i] - base);
-        if (fits)
-            for (uint32_t i = tid; i < nk; i += JOIN_THREADS) s_rk[i] = rk[base + i];
+        if (fits) {
+            for (uint32_t i = tid; i < nk; i += JOIN_THREADS) s_fp[i] = (FP)(kmer_mix(rk[base + i] & SK_SEED_MASK) & rmask);
+            if (tid < 8) s_fp[nk + tid] = (FP)0;
+        }
         __syncthreads();
         const bool whole = bb0 == 0 && bb1 == nbk;
-        if (fits && whole) join_pass<true, true>(A, B, pairs, g, hits, multi, pair_nmulti, s_rk, s_boff, rk, rg, base, bits, bb0, bb1, rrep, tid);
-        else if (fits) join_pass<true, false>(A, B, pairs, g, hits, multi, pair_nmulti, s_rk, s_boff, rk, rg, base, bits, bb0, bb1, rrep, tid);
-        else join_pass<false, false>(A, B, pairs, g, hits, multi, pair_nmulti, s_rk, s_boff, rk, rg, base, bits, bb0, bb1, rrep, tid);
+        if (fits && whole) join_pass<FP, true, true>(A, B, pairs, g, hits, multi, pair_nmulti, s_fp, s_boff, rk, rg, base, bits, bb0, bb1, rrep, tid);
+        else if (fits) join_pass<FP, true, false>(A, B, pairs, g, hits, multi, pair_nmulti, s_fp, s_boff, rk, rg, base, bits, bb0, bb1, rrep, tid);
+        else join_pass<FP, false, false>(A, B, pairs, g, hits, multi, pair_nmulti, s_fp, s_boff, rk, rg, base, bits, bb0, bb1, rrep, tid);
         bb0 = bb1;
     }
+}
+
+__global__ __launch_bounds__(JOIN_THREADS) void join_probe_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs,
+                                                                  const JoinGroup *__restrict__ groups,
+                                                                  uint32_t *__restrict__ hits, uint4 *__restrict__ multi,
+                                                                  uint32_t *__restrict__ pair_nmulti, uint32_t smem_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char join_smem[];
+    const uint32_t tid = threadIdx.x;
+    const JoinGroup g = groups[blockIdx.x];
+    const PairDesc pd0 = pairs[g.pair_begin];
+    const SetView &RS = (pd0.flags & 4u) ? B : A;
+    const GenomeMeta *Rm = RS.meta + pd0.r;
+    // 16-bit remainders identify a k-mer inside its bucket once there are 2^14 buckets (30 - bits <= 16)
+    if (Rm->bucket_bits >= 14u) join_group<uint16_t>(A, B, pairs, g, hits, multi, pair_nmulti, join_smem, smem_bytes, RS, Rm, tid);
+    else join_group<uint32_t>(A, B, pairs, g, hits, multi, pair_nmulti, join_smem, smem_bytes, RS, Rm, tid);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -284,7 +315,7 @@ struct Run {
     uint32_t seg;                     // summary key: changes along a path only at score-lowering indels
 };
 
-__global__ __launch_bounds__(256, 3) void chain_fast_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs, uint32_t npairs,
+__global__ __launch_bounds__(256, CF_OCC) void chain_fast_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs, uint32_t npairs,
                                                          uint32_t total_chunks, const uint32_t *__restrict__ hits,
                                                          const uint4 *__restrict__ multi, ChainRec *__restrict__ fast_chains,
                                                          uint32_t *__restrict__ chunk_state, uint32_t *__restrict__ slow_list,
@@ -1634,13 +1665,24 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
             static bool join_attr_set = false;
             if (!join_attr_set) {
                 HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(join_probe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             JOIN_SMEM_BYTES));
+                                             JOIN_SMEM_MAX + 64));
                 HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(finalize_kernel_t<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              4096 * 35));
                 join_attr_set = true;
             }
-            hipLaunchKernelGGL(join_probe_kernel, dim3((unsigned)hg.size()), dim3(JOIN_THREADS), JOIN_SMEM_BYTES, st, VA, VB, S.d_pairs.p,
-                               reinterpret_cast<const JoinGroup *>(S.groups.p), S.hits.p, S.multi.p, S.pair_nmulti.p);
+            // LDS per workgroup: what the largest probed genome of the batch wants for a single pass; two
+            // workgroups share a CU when that is at most half of it
+            size_t want = 16384;
+            for (uint32_t i = 0; i < nb; i++) {
+                const GenomeMeta &R = (hp[i].flags & 4u) ? SB->h_meta[hp[i].r] : SA->h_meta[hp[i].r];
+                const size_t w = join_need(R.bucket_bits, R.n_seeds);
+                want = w > want ? w : want;
+            }
+            uint32_t join_smem = (uint32_t)(want < JOIN_SMEM_MAX ? want : JOIN_SMEM_MAX) / 64u * 64u + 64u;
+            if (want <= JOIN_SMEM_TWO && join_smem > JOIN_SMEM_TWO) join_smem = JOIN_SMEM_TWO;
+            hipLaunchKernelGGL(join_probe_kernel, dim3((unsigned)hg.size()), dim3(JOIN_THREADS), join_smem, st, VA, VB, S.d_pairs.p,
+                               reinterpret_cast<const JoinGroup *>(S.groups.p), S.hits.p, S.multi.p, S.pair_nmulti.p, join_smem);
+            HIPCHECK(hipGetLastError());
         }
         chain_stage(S);
         return p;

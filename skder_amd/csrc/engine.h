@@ -61,7 +61,9 @@ void rectangle_impl(skder_sketches *refs, skder_sketches *queries, double screen
 void synth_fill_impl(skder_ctx *ctx, uint8_t *d_bases, const skder_batch_t *b, const uint64_t *lineage,
                      const uint32_t *params);
 
-__host__ __device__ inline uint32_t kmer_bucket(uint32_t kmer, uint32_t bits)
-{
-    return (kmer * 0x9E3779B1u) >> (32u - bits);
-}
+// Multiplication by an odd constant is a bijection of the 30-bit k-mers: the bucket is the top `bits` bits
+// of the 30-bit product and the remaining 30 - bits bits (kmer_rem) identify the k-mer inside its bucket,
+// so an index can keep 16-bit remainders instead of k-mers once bits >= 14.
+__host__ __device__ inline uint32_t kmer_mix(uint32_t kmer) { return (kmer * 0x9E3779B1u) & 0x3FFFFFFFu; }
+__host__ __device__ inline uint32_t kmer_bucket(uint32_t kmer, uint32_t bits) { return kmer_mix(kmer) >> (30u - bits); }
+__host__ __device__ inline uint32_t kmer_rem(uint32_t kmer, uint32_t bits) { return kmer_mix(kmer) & ((1u << (30u - bits)) - 1u); }

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(IDX_THREADS) void index_genome_kernel(
     }
     atomicAdd(&s_distinct, my_distinct);
     __syncthreads();
-    for (uint32_t e = tid; e < n; e += IDX_THREADS) ot[e] = og[e] | ((oc[e] & 63u) << HIT_POS_BITS);
+    for (uint32_t e = tid; e < n; e += IDX_THREADS) ot[e] = og[e] | ((oc[e] & 63u) << HIT_POS_BITS) | (ok[e] & 0x80000000u);
     if (tid == 0) {
         // multiplicity of ascending rank D - D/1000 - 1 == the (D/1000 + 1)-th largest
         uint32_t D = s_distinct, cut = 0xFFFFFFFFu;
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(IDXF_THREADS) void index_genome_lds_kernel(
     for (uint32_t pos = tid; pos < n; pos += IDXF_THREADS) {
         const uint32_t s = perm[pos];
         const uint32_t gp = pg[s], ct = pc[s];
-        ok[pos] = pk[s]; og[pos] = gp; oc[pos] = ct; ot[pos] = gp | ((ct & 63u) << HIT_POS_BITS);
+        ok[pos] = pk[s]; og[pos] = gp; oc[pos] = ct; ot[pos] = gp | ((ct & 63u) << HIT_POS_BITS) | (pk[s] & 0x80000000u);
     }
     __syncthreads();   // the permutation is dead from here on
     // F. chunk ids in position order.  Seed s starts a chunk when its (record, 20 kb window) differs
