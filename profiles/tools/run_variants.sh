@@ -4,6 +4,6 @@ cp skder_amd/libskder_amd.so /tmp/lib_orig.so
 for L in "$@"; do
   cp exp/$L skder_amd/libskder_amd.so
   echo -n "$L: "
-  python bench.py --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],2), {k:round(v,2) for k,v in d['roofline']['kernel_ms'].items()}, d['config']['slow_path_chunks'], d['config']['edges'])"
+  timeout 120 python bench.py --no-cpu-baseline --steps 2 --warmup 1 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],2), {k:round(v,2) for k,v in d['roofline']['kernel_ms'].items()}, d['config']['slow_path_chunks'], d['config']['edges'])"
 done
 cp /tmp/lib_orig.so skder_amd/libskder_amd.so
