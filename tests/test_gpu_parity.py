@@ -369,6 +369,32 @@ def test_mixed_genome_sizes_multi_pass_join(gpu, oracle):
     assert len(self_hits) == len(big) and all(abs(float(e["ani"]) - 1.0) < 1e-6 and float(e["af_ref"]) > 0.99 for e in self_hits)
 
 
+def test_benchmark_size_genomes(gpu, oracle):
+    """genomes of the benchmark's size: 2^14 buckets, 16-bit k-mer remainders in the join's LDS index.  Below
+    3.07 Mb the index takes half a CU's LDS (two workgroups per CU), above it one workgroup per CU; both
+    against the oracle, bit for bit"""
+    engine, ctx, torch = gpu
+    from skder_amd import synth
+    p = oracle.default_params()
+    for glen, seed in ((2_850_000, 5), (3_500_000, 6)):
+        rec = synth.make_recipe(8, genome_len=glen, n_species=2, strains_per_species=2, seed=seed)
+        layout = engine.BatchLayout(rec.rec_lens)
+        d = torch.zeros(layout.total_bytes, dtype=torch.uint8, device="cuda")
+        ctx.synth_fill(d.data_ptr(), layout, rec.lineage, rec.params)
+        s = engine.Sketches(ctx)
+        s.sketch_batch(d.data_ptr(), layout)
+        og = [oracle.Genome.from_bases(synth.bases_numpy(rec, g), rec.rec_lens[g], p) for g in range(rec.n)]
+        assert all(16384 < o.n_seeds <= 32768 for o in og)
+        if glen < 3_000_000:
+            assert max(o.n_seeds for o in og) < 24500      # the whole index in 80 KB
+        _compare_sketch(engine, s, oracle, og)
+        edges = s.triangle_rows(0, 1, 80.0)
+        want = _oracle_edges(oracle, og, p, 80.0)
+        assert len(want) == 12
+        _check_edges(edges, want)
+        s.close()
+
+
 def test_degenerate_inputs(gpu, oracle, tmp_path):
     """a genome whose records are all shorter than 500 bp (no seeds), a one-genome listing (header-only
     table), identical genomes, a missing file (error, no output), search with a query outside the database"""
