@@ -147,6 +147,10 @@ int skder_amd_copy_d2d(skder_ctx_t *ctx, void *dst, const void *src, size_t byte
  * context's stream: [0] sketch kernel, [1] sketch post-processing + index, [2] screen,
  * [3] chaining fast path, [4] chaining slow path, [5] finalize; counts: [6] pairs screened in, [7] anchors */
 int skder_amd_last_timing(skder_ctx_t *ctx, double *out8);
+/* device milliseconds of the last seed-index build (skder_amd_sketches_index, or the build that
+ * triangle_rows / rectangle start themselves for a set that is not indexed yet: it then runs beside
+ * the marker screen on a second stream) */
+double skder_amd_last_index_ms(skder_ctx_t *ctx);
 /* counters of the last triangle_rows/rectangle call: [0] chunks processed, [1] chunks that needed the
  * unabridged (slow) chaining path */
 int skder_amd_last_counters(skder_ctx_t *ctx, uint64_t *out4);

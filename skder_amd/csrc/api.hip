@@ -36,6 +36,7 @@ extern "C" skder_ctx_t *skder_amd_ctx_create(int device, char *err, size_t errle
         ctx = new skder_ctx();
         ctx->device = device;
         HIPCHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        HIPCHECK(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
         for (auto &e : ctx->ev) HIPCHECK(hipEventCreate(&e));
         HIPCHECK(hipMalloc(&ctx->d_flags, 64));
         HIPCHECK(hipMemset(ctx->d_flags, 0, 64));
@@ -52,10 +53,12 @@ extern "C" void skder_amd_ctx_destroy(skder_ctx_t *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     if (ctx->chain_work && ctx->chain_work_free) ctx->chain_work_free(ctx->chain_work);
     for (auto &e : ctx->ev) (void)hipEventDestroy(e);
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     delete ctx;
 }
 
@@ -77,6 +80,8 @@ extern "C" int skder_amd_copy_d2d(skder_ctx_t *ctx, void *dst, const void *src, 
     return 0;
     API_CATCH_CTX(ctx, 2)
 }
+
+extern "C" double skder_amd_last_index_ms(skder_ctx_t *ctx) { return ctx ? ctx->timing_index : 0.0; }
 
 extern "C" int skder_amd_last_counters(skder_ctx_t *ctx, uint64_t *out4)
 {
@@ -166,7 +171,7 @@ extern "C" int skder_amd_sketches_append_raw(skder_sketches_t *s, const skder_ra
 {
     if (!s || !raw) return 1;
     API_TRY
-    if (s->indexed) throw SkError("sketch set already indexed; cannot append");
+    if (s->indexed || s->index_pending) throw SkError("sketch set already indexed; cannot append");
     HIPCHECK(hipSetDevice(s->ctx->device));
     hipStream_t st = s->ctx->stream;
     const uint64_t sb = s->seed_kmer.n, mb = s->markers.n;

@@ -1850,7 +1850,9 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
 void triangle_rows_impl(skder_sketches *s, uint32_t row_begin, uint32_t row_stride, double screen_pct)
 {
     skder_ctx *ctx = s->ctx;
-    if (!s->indexed) index_impl(s);
+    // a set that is not indexed yet: the seed index (stream2) is built while the marker screen runs -- the two
+    // touch different arrays, and both are bound by latency rather than by any one unit of the GPU
+    if (!s->indexed) index_begin(s, ctx->stream2);
     ctx->edges.clear();
     std::vector<uint32_t> rows;
     for (uint32_t i = row_begin; i < s->n_genomes; i += (row_stride ? row_stride : 1)) rows.push_back(i);
@@ -1862,6 +1864,7 @@ void triangle_rows_impl(skder_sketches *s, uint32_t row_begin, uint32_t row_stri
     float ms;
     HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[9], ctx->ev[10]));
     ctx->timing[2] = ms;
+    index_impl(s);
     // triangle row (i, j): Ref = i, Query = j
     const auto t0 = std::chrono::steady_clock::now();
     chain_pairs(s, s, prow, ppart, ctx->edges);
@@ -1873,8 +1876,8 @@ void triangle_rows_impl(skder_sketches *s, uint32_t row_begin, uint32_t row_stri
 void rectangle_impl(skder_sketches *refs, skder_sketches *queries, double screen_pct)
 {
     skder_ctx *ctx = refs->ctx;
-    if (!refs->indexed) index_impl(refs);
     if (!queries->indexed) index_impl(queries);
+    if (!refs->indexed) index_begin(refs, ctx->stream2);      // overlaps the screen, as in triangle_rows_impl
     ctx->edges.clear();
     std::vector<uint32_t> rows(queries->n_genomes);
     for (uint32_t i = 0; i < queries->n_genomes; i++) rows[i] = i;
@@ -1886,6 +1889,7 @@ void rectangle_impl(skder_sketches *refs, skder_sketches *queries, double screen
     float ms;
     HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[9], ctx->ev[10]));
     ctx->timing[2] = ms;
+    index_impl(refs);
     // rows are queries, partners are references
     chain_pairs(refs, queries, ppart, prow, ctx->edges);
 }

@@ -84,10 +84,12 @@ struct DevBuf {
 struct skder_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // second queue: the seed index is built here while the marker screen runs on `stream`
     std::string last_error;
     hipEvent_t ev[16];
     double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     double timing_join = 0;
+    double timing_index = 0;         // ms of the last index build (device)
     std::vector<skder_edge_t> edges;
     uint32_t *d_flags = nullptr;   // [0] overflow / error flags from kernels
     uint64_t counters[4] = {0, 0, 0, 0};   // [0] chunks processed, [1] chunks sent to the slow path

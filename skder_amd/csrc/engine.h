@@ -37,6 +37,10 @@ struct skder_sketches {
     skder_ctx *ctx = nullptr;
     uint32_t n_genomes = 0;
     bool indexed = false;
+    bool index_pending = false;            // index kernels enqueued (index_begin), results not fetched yet
+    DevBuf<uint32_t> idx_list;             // genome lists of the index kernels, alive until index_finish
+    std::vector<uint32_t> idx_small, idx_big;
+    hipStream_t idx_stream = nullptr;
     // raw sketches
     DevBuf<uint32_t> seed_kmer, seed_gpos, seed_ctg;   // position order
     DevBuf<uint64_t> markers;                          // sorted unique per genome
@@ -55,7 +59,9 @@ struct skder_sketches {
 };
 
 void sketch_batch_impl(skder_sketches *s, const uint8_t *d_bases, const skder_batch_t *b);
-void index_impl(skder_sketches *s);
+void index_impl(skder_sketches *s);                       // build the index and wait for it
+void index_begin(skder_sketches *s, hipStream_t st);     // enqueue the index build on st (after what ctx->stream holds now)
+void index_finish(skder_sketches *s);                    // wait for it, fetch the per-genome results
 void triangle_rows_impl(skder_sketches *s, uint32_t row_begin, uint32_t row_stride, double screen_pct);
 void rectangle_impl(skder_sketches *refs, skder_sketches *queries, double screen_pct);
 void synth_fill_impl(skder_ctx *ctx, uint8_t *d_bases, const skder_batch_t *b, const uint64_t *lineage,

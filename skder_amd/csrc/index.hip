@@ -321,8 +321,15 @@ __global__ __launch_bounds__(IDXF_THREADS) void index_genome_lds_kernel(
 void index_impl(skder_sketches *s)
 {
     if (s->indexed) return;
+    if (!s->index_pending) index_begin(s, s->ctx->stream);
+    index_finish(s);
+}
+
+void index_begin(skder_sketches *s, hipStream_t st)
+{
+    if (s->indexed || s->index_pending) return;
     skder_ctx *ctx = s->ctx;
-    hipStream_t st = ctx->stream;
+    s->idx_stream = st;
     const uint32_t G = s->n_genomes;
     s->h_meta.resize(G);
     uint64_t boff_total = 0, rg = 0, chunk_total = 0;
@@ -354,12 +361,19 @@ void index_impl(skder_sketches *s)
     s->boff.resize(boff_total + 1, st);
     s->chunk_start.resize(chunk_total + 1, st);
     if (G) {
-        HIPCHECK(hipMemcpyAsync(s->d_meta.p, s->h_meta.data(), G * sizeof(GenomeMeta), hipMemcpyHostToDevice, st));
-        HIPCHECK(hipMemcpyAsync(s->d_rec_goff.p, s->h_rec_goff.data(), s->h_rec_goff.size() * 4, hipMemcpyHostToDevice, st));
+        // the genome table goes through ctx->stream: the marker screen, which runs there beside the index build,
+        // reads it as well, and the sketches were produced there
+        HIPCHECK(hipMemcpyAsync(s->d_meta.p, s->h_meta.data(), G * sizeof(GenomeMeta), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHECK(hipMemcpyAsync(s->d_rec_goff.p, s->h_rec_goff.data(), s->h_rec_goff.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        if (st != ctx->stream) {
+            HIPCHECK(hipEventRecord(ctx->ev[11], ctx->stream));
+            HIPCHECK(hipStreamWaitEvent(st, ctx->ev[11], 0));
+        }
         HIPCHECK(hipEventRecord(ctx->ev[3], st));
         // genomes whose tables fit in LDS take the LDS-resident kernel, the others the general one
         const size_t lds_limit = 150 * 1024;
-        std::vector<uint32_t> small, big;
+        std::vector<uint32_t> &small = s->idx_small, &big = s->idx_big;
+        small.clear(); big.clear();
         size_t small_bytes = 0;
         uint32_t max_bits = 12;   // the general kernel's multiplicity histogram needs 4096 counters
         for (uint32_t g = 0; g < G; g++) {
@@ -373,7 +387,7 @@ void index_impl(skder_sketches *s)
                 max_bits = m.bucket_bits > max_bits ? m.bucket_bits : max_bits;
             }
         }
-        DevBuf<uint32_t> d_list;
+        DevBuf<uint32_t> &d_list = s->idx_list;
         d_list.resize(G + 1, st);
         if (!small.empty()) HIPCHECK(hipMemcpyAsync(d_list.p, small.data(), small.size() * 4, hipMemcpyHostToDevice, st));
         if (!big.empty()) HIPCHECK(hipMemcpyAsync(d_list.p + small.size(), big.data(), big.size() * 4, hipMemcpyHostToDevice, st));
@@ -392,13 +406,24 @@ void index_impl(skder_sketches *s)
                                s->sctg.p, s->stag.p, s->boff.p, s->pchunk.p, s->chunk_start.p);
         }
         HIPCHECK(hipGetLastError());
-        HIPCHECK(hipStreamSynchronize(st));   // d_list and the host vectors go out of scope
         HIPCHECK(hipEventRecord(ctx->ev[4], st));
-        HIPCHECK(hipMemcpyAsync(s->h_meta.data(), s->d_meta.p, G * sizeof(GenomeMeta), hipMemcpyDeviceToHost, st));
-        HIPCHECK(hipStreamSynchronize(st));
+    }
+    s->index_pending = true;
+}
+
+void index_finish(skder_sketches *s)
+{
+    if (s->indexed || !s->index_pending) return;
+    skder_ctx *ctx = s->ctx;
+    if (s->n_genomes) {
+        // (a copy into pageable memory would hold the host until the kernels are done: it is issued here, not in index_begin)
+        HIPCHECK(hipMemcpyAsync(s->h_meta.data(), s->d_meta.p, s->n_genomes * sizeof(GenomeMeta), hipMemcpyDeviceToHost, s->idx_stream));
+        HIPCHECK(hipStreamSynchronize(s->idx_stream));
         float ms = 0;
         HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]));
-        ctx->timing[1] += ms;
+        ctx->timing_index = ms;
     }
+    s->idx_list.release();
+    s->index_pending = false;
     s->indexed = true;
 }

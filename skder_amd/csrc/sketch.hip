@@ -360,7 +360,7 @@ void sketch_batch_impl(skder_sketches *s, const uint8_t *d_bases, const skder_ba
 {
     skder_ctx *ctx = s->ctx;
     hipStream_t st = ctx->stream;
-    if (s->indexed) throw SkError("sketch set already indexed; cannot append");
+    if (s->indexed || s->index_pending) throw SkError("sketch set already indexed; cannot append");
     if (b->n_genomes == 0) return;
     std::vector<RecDesc> recs;
     std::vector<uint32_t> gtb, rec_goff;

@@ -96,6 +96,10 @@ class Context:
         _lib.lib().skder_amd_last_timing(self.h, out)
         return np.array(out[:])
 
+    def index_ms(self) -> float:
+        """device milliseconds of the last seed-index build"""
+        return float(_lib.lib().skder_amd_last_index_ms(self.h))
+
     def counters(self) -> np.ndarray:
         out = (C.c_uint64 * 4)()
         _lib.lib().skder_amd_last_counters(self.h, out)
