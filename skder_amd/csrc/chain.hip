@@ -1012,7 +1012,9 @@ __global__ __launch_bounds__(64 * SLOWW_WAVES) void slow_wave_kernel(SetView A, 
     // marked "too many" -- or all seeds, when the chunked genome's own multiplicity filter is active --
     // are looked up again through the bucket index.  Records are compared by their 6-bit tags, exact
     // under the DP's distance limits like in the fast path.
-    const bool qfilter = Q.rep_cut != 0xFFFFFFFFu;
+    // (positions of a genome beyond 2^24 bases do not fit a hit word either: every hit is looked up again)
+    const bool qfilter = Q.rep_cut != 0xFFFFFFFFu || R.total_len > (uint64_t)HIT_POS_MASK;
+    const bool qrep = Q.rep_cut != 0xFFFFFFFFu;
     const uint32_t *hw_of = hits + pd.hit_base;
     uint32_t n = 0;
     bool over = false;
@@ -1040,7 +1042,7 @@ __global__ __launch_bounds__(64 * SLOWW_WAVES) void slow_wave_kernel(SetView A, 
                 else if (k2 > kmer) break;
             }
             if (cnt > R.rep_cut) cnt = 0;
-            if (cnt && qfilter) {   // multiplicity inside the chunked genome itself
+            if (cnt && qrep) {   // multiplicity inside the chunked genome itself
                 const uint32_t b2 = kmer_bucket(kmer, Q.bucket_bits);
                 uint32_t m2 = 0;
                 for (uint32_t e = qb[b2]; e < qb[b2 + 1]; e++) m2 += ((qsk[e] & SK_SEED_MASK) == kmer);

@@ -241,10 +241,7 @@ __global__ __launch_bounds__(256) void marker_sort_kernel(uint64_t *__restrict__
     __shared__ uint32_t wsum[4];
     const uint32_t g = blockIdx.x;
     const uint32_t lo = g_off[g], n = g_off[g + 1] - lo;
-    if (n > MARK_SORT_CAP) {
-        if (threadIdx.x == 0) { atomicOr(&flags[0], 2u); n_unique[g] = 0; }
-        return;
-    }
+    if (n > MARK_SORT_CAP) return;     // genomes beyond ~16 Mb: sorted in global memory (sort_big_genome_markers)
     uint32_t m = 1;
     while (m < n) m <<= 1;
     for (uint32_t i = threadIdx.x; i < m; i += 256) key[i] = i < n ? raw[lo + i] : ~0ULL;
@@ -272,6 +269,58 @@ __global__ __launch_bounds__(256) void marker_sort_kernel(uint64_t *__restrict__
         __syncthreads();
     }
     if (threadIdx.x == 0) n_unique[g] = running;
+}
+
+// Genomes with more raw markers than marker_sort_kernel's LDS holds (> ~16 Mb): the same bitonic network,
+// one launch per compare-exchange step over a padded copy in global memory, then the ordered dedup through
+// a device scan.  Rare (large eukaryotic genomes), so launch count is not a concern.
+__global__ __launch_bounds__(256) void marks_pad_copy_kernel(const uint64_t *__restrict__ raw, uint32_t lo, uint32_t n, uint32_t m,
+                                                             uint64_t *__restrict__ key)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < m) key[i] = i < n ? raw[lo + i] : ~0ULL;
+}
+
+__global__ __launch_bounds__(256) void bitonic_step_kernel(uint64_t *__restrict__ key, uint32_t m, uint32_t k, uint32_t j)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= m / 2) return;
+    const uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), ixj = i | j;
+    const uint64_t a = key[i], b = key[ixj];
+    const bool up = (i & k) == 0;
+    if ((a > b) == up) { key[i] = b; key[ixj] = a; }
+}
+
+__global__ __launch_bounds__(256) void marks_keep_kernel(const uint64_t *__restrict__ key, uint32_t n, uint32_t *__restrict__ keep)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i <= n) keep[i] = (i < n) && (i == 0 || key[i] != key[i - 1]);
+}
+
+__global__ __launch_bounds__(256) void marks_scatter_kernel(const uint64_t *__restrict__ key, const uint32_t *__restrict__ excl, uint32_t n,
+                                                            uint64_t *__restrict__ raw, uint32_t lo, uint32_t *__restrict__ n_unique_g)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n && excl[i + 1] != excl[i]) raw[lo + excl[i]] = key[i];
+    if (i == 0) *n_unique_g = excl[n];
+}
+
+static void sort_big_genome_markers(uint64_t *raw, uint32_t lo, uint32_t n, uint32_t *n_unique_g, ScanWorkspace &ws, hipStream_t st)
+{
+    uint32_t m = 1;
+    while (m < n) m <<= 1;
+    DevBuf<uint64_t> key;
+    DevBuf<uint32_t> keep, excl;
+    key.resize(m, st); keep.resize(n + 1, st); excl.resize(n + 1, st);
+    hipLaunchKernelGGL(marks_pad_copy_kernel, dim3((m + 255) / 256), dim3(256), 0, st, raw, lo, n, m, key.p);
+    for (uint32_t k = 2; k <= m; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1)
+            hipLaunchKernelGGL(bitonic_step_kernel, dim3((m / 2 + 255) / 256), dim3(256), 0, st, key.p, m, k, j);
+    hipLaunchKernelGGL(marks_keep_kernel, dim3((n + 256) / 256), dim3(256), 0, st, key.p, n, keep.p);
+    exclusive_scan_u32(keep.p, excl.p, n + 1, ws, st);
+    hipLaunchKernelGGL(marks_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, st, key.p, excl.p, n, raw, lo, n_unique_g);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(st));     // the temporaries go back to the pool
 }
 
 // compact sorted-unique marker runs (still at their raw offsets) to their final offsets
@@ -478,13 +527,15 @@ void sketch_batch_impl(skder_sketches *s, const uint8_t *d_bases, const skder_ba
     }
     hipLaunchKernelGGL(marker_sort_kernel, dim3(b->n_genomes), dim3(256), sort_cap * 8, st, raw_marks.p, d_goff.p,
                        d_nuniq.p, ctx->d_flags);
+    for (uint32_t g = 0; g < b->n_genomes; g++)
+        if (h_goff[g + 1] - h_goff[g] > MARK_SORT_CAP)
+            sort_big_genome_markers(raw_marks.p, h_goff[g], h_goff[g + 1] - h_goff[g], d_nuniq.p + g, ws, st);
     exclusive_scan_u32(d_nuniq.p, d_uoff.p, b->n_genomes + 1, ws, st);
     std::vector<uint32_t> h_uoff(b->n_genomes + 1);
     uint32_t h_flags = 0;
     HIPCHECK(hipMemcpyAsync(h_uoff.data(), d_uoff.p, (b->n_genomes + 1) * 4, hipMemcpyDeviceToHost, st));
     HIPCHECK(hipMemcpyAsync(&h_flags, ctx->d_flags, 4, hipMemcpyDeviceToHost, st));
     HIPCHECK(hipStreamSynchronize(st));
-    if (h_flags & 2u) throw SkError("genome with more than 16384 raw markers (> ~16 Mb) is not supported");
     const uint64_t mark_base = s->markers.n;
     s->markers.resize(mark_base + h_uoff[b->n_genomes], st);
     hipLaunchKernelGGL(marker_compact_kernel, dim3(b->n_genomes), dim3(256), 0, st, raw_marks.p, d_goff.p, d_nuniq.p,

@@ -395,6 +395,31 @@ def test_benchmark_size_genomes(gpu, oracle):
         s.close()
 
 
+def test_genomes_beyond_16_mb(gpu, oracle):
+    """20 Mb genomes (eukaryotic microbes): more raw markers than the LDS sort holds (sorted in global memory),
+    positions beyond the 24 bits of a hit word (every chunk chains on the slow path), ~160k seeds per genome
+    (general index kernel, several join passes); plus a small genome in the same set"""
+    engine, ctx, torch = gpu
+    from skder_amd import synth
+    p = oracle.default_params()
+    rec = _custom_recipe([20_000_000, 1_200_000], 2, seed=21)
+    layout = engine.BatchLayout(rec.rec_lens)
+    d = torch.zeros(layout.total_bytes, dtype=torch.uint8, device="cuda")
+    ctx.synth_fill(d.data_ptr(), layout, rec.lineage, rec.params)
+    s = engine.Sketches(ctx)
+    s.sketch_batch(d.data_ptr(), layout)
+    og = [oracle.Genome.from_bases(synth.bases_numpy(rec, g), rec.rec_lens[g], p) for g in range(rec.n)]
+    assert max(o.n_seeds for o in og) > 150000 and max(o.n_markers for o in og) > 16384
+    _compare_sketch(engine, s, oracle, og)
+    edges = s.triangle_rows(0, 1, 80.0)
+    want = _oracle_edges(oracle, og, p, 80.0)
+    assert len(want) == 2
+    _check_edges(edges, want)
+    c = ctx.counters()
+    assert c[1] >= 900                     # the 20 Mb pair's chunks all went through the slow path
+    s.close()
+
+
 def test_degenerate_inputs(gpu, oracle, tmp_path):
     """a genome whose records are all shorter than 500 bp (no seeds), a one-genome listing (header-only
     table), identical genomes, a missing file (error, no output), search with a query outside the database"""
