@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--genomes", type=int, default=5000)
     ap.add_argument("--genome-len", type=int, default=3_000_000)
     ap.add_argument("--screen", type=float, default=80.0)
-    ap.add_argument("--batch-genomes", type=int, default=500)
+    ap.add_argument("--batch-genomes", type=int, default=2500, help="genomes per resident input batch (one sketch call each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--e2e-genomes", type=int, default=256, help="genomes in the file-based end-to-end sample (0: skip)")
     args = ap.parse_args()
