@@ -39,6 +39,7 @@ struct skder_sketches {
     bool indexed = false;
     bool index_pending = false;            // index kernels enqueued (index_begin), results not fetched yet
     DevBuf<uint32_t> idx_list;             // genome lists of the index kernels, alive until index_finish
+    DevBuf<uint4> idx_packed;              // (k-mer, position, record, -) per seed: one gather instead of three, index build only
     std::vector<uint32_t> idx_small, idx_big;
     hipStream_t idx_stream = nullptr;
     // raw sketches

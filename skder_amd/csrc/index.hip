@@ -127,6 +127,7 @@ __global__ __launch_bounds__(IDX_THREADS) void index_genome_kernel(
 // the multiplicity histogram all live in LDS; global memory sees only coalesced reads of the
 // position-ordered arrays, gathers through the finished permutation and coalesced writes.
 #define IDXF_THREADS 1024
+#define IDXF_U 8                // independent loads per thread and trip
 #define IDXF_FIXED_BYTES (IDX_REP_HIST * 4)
 __host__ __device__ inline size_t idxf_smem_bytes(uint32_t nb, uint32_t n)
 {
@@ -140,7 +141,8 @@ __global__ __launch_bounds__(IDXF_THREADS) void index_genome_lds_kernel(
     GenomeMeta *__restrict__ meta, const uint32_t *__restrict__ list, const uint32_t *__restrict__ rec_goff,
     const uint32_t *__restrict__ seed_kmer, const uint32_t *__restrict__ seed_gpos, const uint32_t *__restrict__ seed_ctg,
     uint32_t *__restrict__ skmer, uint32_t *__restrict__ sgpos, uint32_t *__restrict__ sctg, uint32_t *__restrict__ stag,
-    uint32_t *__restrict__ boff_all, uint32_t *__restrict__ pchunk, uint32_t *__restrict__ chunk_start_all)
+    uint32_t *__restrict__ boff_all, uint32_t *__restrict__ pchunk, uint32_t *__restrict__ chunk_start_all,
+    uint4 *__restrict__ packed_all)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ uint32_t wsum[IDXF_THREADS / 64];
@@ -156,15 +158,30 @@ __global__ __launch_bounds__(IDXF_THREADS) void index_genome_lds_kernel(
     uint32_t *ok = skmer + m.seed_off, *og = sgpos + m.seed_off, *oc = sctg + m.seed_off, *ot = stag + m.seed_off;
     uint32_t *boff = boff_all + m.bucket_off;
     const uint32_t *rg = rec_goff + m.rec_goff_off;
+    uint4 *packed = packed_all + m.seed_off;      // written in A, gathered in E: one 16-byte request per seed instead of three
 
     for (uint32_t b = tid; b < nb / 2; b += IDXF_THREADS) cntp[b] = 0;
     for (uint32_t b = tid; b < IDX_REP_HIST; b += IDXF_THREADS) hist[b] = 0;
     if (tid == 0) s_distinct = 0;
     __syncthreads();
-    // A. bucket sizes
-    for (uint32_t s = tid; s < n; s += IDXF_THREADS) {
-        const uint32_t b = kmer_bucket(pk[s] & SK_SEED_MASK, bits);
-        atomicAdd(&cntp[b >> 1], 1u << ((b & 1u) * 16u));
+    // A. bucket sizes.  (Here and below: IDXF_U loads in flight per thread before anything depends on them --
+    // the kernel is a chain of short phases whose cost is the memory latency they expose.)
+    for (uint32_t s0 = tid; s0 < n; s0 += IDXF_U * IDXF_THREADS) {
+        uint32_t kv[IDXF_U], gv[IDXF_U], cv[IDXF_U];
+#pragma unroll
+        for (int u = 0; u < IDXF_U; u++) {
+            const uint32_t s = s0 + u * IDXF_THREADS;
+            kv[u] = s < n ? pk[s] : 0u; gv[u] = s < n ? pg[s] : 0u; cv[u] = s < n ? pc[s] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < IDXF_U; u++) {
+            const uint32_t s = s0 + u * IDXF_THREADS;
+            if (s < n) {
+                packed[s] = make_uint4(kv[u], gv[u], cv[u], 0u);
+                const uint32_t b = kmer_bucket(kv[u] & SK_SEED_MASK, bits);
+                atomicAdd(&cntp[b >> 1], 1u << ((b & 1u) * 16u));
+            }
+        }
     }
     __syncthreads();
     // B. exclusive scan: every thread owns nb/1024 consecutive 16-bit fields, handled as whole words
@@ -207,10 +224,19 @@ __global__ __launch_bounds__(IDXF_THREADS) void index_genome_lds_kernel(
     __syncthreads();
     // C. permutation: seed indices grouped by bucket (order inside a bucket fixed in D).  A cursor ends
     // at the start of the next bucket (<= n < 65536), so a field never carries into its neighbour
-    for (uint32_t s = tid; s < n; s += IDXF_THREADS) {
-        const uint32_t b = kmer_bucket(pk[s] & SK_SEED_MASK, bits), sh = (b & 1u) * 16u;
-        const uint32_t pos = (atomicAdd(&cntp[b >> 1], 1u << sh) >> sh) & 0xFFFFu;
-        perm[pos] = (uint16_t)s;
+    for (uint32_t s0 = tid; s0 < n; s0 += IDXF_U * IDXF_THREADS) {
+        uint32_t kv[IDXF_U];
+#pragma unroll
+        for (int u = 0; u < IDXF_U; u++) { const uint32_t s = s0 + u * IDXF_THREADS; kv[u] = s < n ? pk[s] : 0u; }
+#pragma unroll
+        for (int u = 0; u < IDXF_U; u++) {
+            const uint32_t s = s0 + u * IDXF_THREADS;
+            if (s < n) {
+                const uint32_t b = kmer_bucket(kv[u] & SK_SEED_MASK, bits), sh = (b & 1u) * 16u;
+                const uint32_t pos = (atomicAdd(&cntp[b >> 1], 1u << sh) >> sh) & 0xFFFFu;
+                perm[pos] = (uint16_t)s;
+            }
+        }
     }
     __syncthreads();
     // D. order inside every bucket by (k-mer, gpos); multiplicity histogram.  Buckets are independent:
@@ -219,18 +245,46 @@ __global__ __launch_bounds__(IDXF_THREADS) void index_genome_lds_kernel(
     for (uint32_t b = tid; b < nb; b += IDXF_THREADS) {
         const uint32_t lo = b ? cur16[b - 1] : 0u, hi = cur16[b], k = hi - lo;
         if (k == 1) { ones++; }
-        else if (k == 2) {
-            const uint32_t sa = perm[lo], sb = perm[lo + 1];
-            const uint32_t ka = pk[sa] & SK_SEED_MASK, kb = pk[sb] & SK_SEED_MASK;
-            if (ka == kb) {
-                if (pg[sb] < pg[sa]) { perm[lo] = (uint16_t)sb; perm[lo + 1] = (uint16_t)sa; }
-                atomicAdd(&hist[2], 1u);
-                my_distinct++;
-            } else {
-                if (kb < ka) { perm[lo] = (uint16_t)sb; perm[lo + 1] = (uint16_t)sa; }
-                ones += 2;
+        else if (k >= 2 && k <= 8) {
+            // buckets of 2..8 seeds: all k-mers fetched at once (a wavefront always has some lane here, and
+            // an insertion sort through dependent gathers made every lane wait for the longest bucket),
+            // sorted in registers by (k-mer, seed index) -- seeds are in position order, so the seed index
+            // orders equal k-mers by position
+            uint64_t key[9];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const bool in = (uint32_t)i < k;
+                const uint32_t si = in ? perm[lo + i] : 0u;
+                const uint32_t kk = packed[si].x & SK_SEED_MASK;
+                key[i] = in ? (((uint64_t)kk << 16) | si) : ~0ull;
             }
-        } else if (k > 2) {
+            key[8] = ~0ull;
+#define CE(A_, B_) { const uint64_t x_ = key[A_], y_ = key[B_]; const bool sw_ = y_ < x_; key[A_] = sw_ ? y_ : x_; key[B_] = sw_ ? x_ : y_; }
+            CE(0, 1) CE(2, 3) CE(4, 5) CE(6, 7)
+            CE(0, 2) CE(1, 3) CE(4, 6) CE(5, 7)
+            CE(1, 2) CE(5, 6)
+            CE(0, 4) CE(1, 5) CE(2, 6) CE(3, 7)
+            CE(2, 4) CE(3, 5)
+            CE(1, 2) CE(3, 4) CE(5, 6)
+#undef CE
+            uint32_t mult = 1;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                if ((uint32_t)i < k) perm[lo + i] = (uint16_t)(key[i] & 0xFFFFu);
+                // run of equal k-mers ending at entry i?
+                const bool last = (uint32_t)i + 1u == k;
+                const bool same = (uint32_t)i + 1u < k && (uint32_t)(key[i + 1] >> 16) == (uint32_t)(key[i] >> 16);
+                if ((uint32_t)i < k) {
+                    if (same) mult++;
+                    else {
+                        if (mult == 1) ones++;
+                        else { atomicAdd(&hist[mult], 1u); my_distinct++; }
+                        mult = 1;
+                    }
+                }
+                (void)last;
+            }
+        } else if (k > 8) {
             for (uint32_t i = lo + 1; i < hi; i++) {
                 const uint32_t si = perm[i], kk = pk[si] & SK_SEED_MASK, gp = pg[si];
                 uint32_t j = i;
@@ -278,10 +332,21 @@ __global__ __launch_bounds__(IDXF_THREADS) void index_genome_lds_kernel(
         if (tid == 0) meta[g].rep_cut = (D && s_cut >= ANI_REP_FLOOR) ? s_cut : 0xFFFFFFFFu;
     }
     // E. bucket-ordered arrays: gathers through the permutation, coalesced writes
-    for (uint32_t pos = tid; pos < n; pos += IDXF_THREADS) {
-        const uint32_t s = perm[pos];
-        const uint32_t gp = pg[s], ct = pc[s];
-        ok[pos] = pk[s]; og[pos] = gp; oc[pos] = ct; ot[pos] = gp | ((ct & 63u) << HIT_POS_BITS) | (pk[s] & 0x80000000u);
+    for (uint32_t p0 = tid; p0 < n; p0 += IDXF_U * IDXF_THREADS) {
+        uint4 pv[IDXF_U];
+#pragma unroll
+        for (int u = 0; u < IDXF_U; u++) {
+            const uint32_t pos = p0 + u * IDXF_THREADS;
+            pv[u] = packed[pos < n ? perm[pos] : 0u];
+        }
+#pragma unroll
+        for (int u = 0; u < IDXF_U; u++) {
+            const uint32_t pos = p0 + u * IDXF_THREADS;
+            if (pos < n) {
+                ok[pos] = pv[u].x; og[pos] = pv[u].y; oc[pos] = pv[u].z;
+                ot[pos] = pv[u].y | ((pv[u].z & 63u) << HIT_POS_BITS) | (pv[u].x & 0x80000000u);
+            }
+        }
     }
     __syncthreads();   // the permutation is dead from here on
     // F. chunk ids in position order.  Seed s starts a chunk when its (record, 20 kb window) differs
@@ -291,15 +356,25 @@ __global__ __launch_bounds__(IDXF_THREADS) void index_genome_lds_kernel(
         unsigned long long *ballots = reinterpret_cast<unsigned long long *>(cntp);     // <= 1024 (n < 65536)
         uint32_t *blk_off = reinterpret_cast<uint32_t *>(ballots + IDXF_THREADS);      // 1024
         const uint32_t nblk = (n + 63u) / 64u, lane = tid & 63u;
-        auto start_flag = [&](uint32_t s) -> bool {
-            if (s >= n) return false;
-            if (s == 0) return true;
-            const uint32_t c = pc[s], c2 = pc[s - 1];
-            return c != c2 || (pg[s] - rg[c]) / ANI_CHUNK_LEN != (pg[s - 1] - rg[c2]) / ANI_CHUNK_LEN;
-        };
-        for (uint32_t base = 0; base < nblk * 64u; base += IDXF_THREADS) {
-            const unsigned long long bal = __ballot(start_flag(base + tid));
-            if (lane == 0 && (base + tid) / 64u < nblk) ballots[(base + tid) / 64u] = bal;
+        for (uint32_t base = 0; base < nblk * 64u; base += IDXF_U * IDXF_THREADS) {
+            // the loads of IDXF_U trips first (record, position, the record's start), then the ballots
+            uint32_t c1[IDXF_U], c2[IDXF_U], g1[IDXF_U], g2[IDXF_U], r1[IDXF_U], r2[IDXF_U];
+#pragma unroll
+            for (int u = 0; u < IDXF_U; u++) {
+                const uint32_t sx = base + u * IDXF_THREADS + tid;
+                const bool in = sx < n && sx > 0;
+                c1[u] = in ? pc[sx] : 0u; c2[u] = in ? pc[sx - 1] : 0u;
+                g1[u] = in ? pg[sx] : 0u; g2[u] = in ? pg[sx - 1] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < IDXF_U; u++) { r1[u] = rg[c1[u]]; r2[u] = rg[c2[u]]; }
+#pragma unroll
+            for (int u = 0; u < IDXF_U; u++) {
+                const uint32_t sx = base + u * IDXF_THREADS + tid;
+                const bool flag = sx < n && (sx == 0 || c1[u] != c2[u] || (g1[u] - r1[u]) / ANI_CHUNK_LEN != (g2[u] - r2[u]) / ANI_CHUNK_LEN);
+                const unsigned long long bal = __ballot(flag);
+                if (lane == 0 && sx / 64u < nblk) ballots[sx / 64u] = bal;
+            }
         }
         __syncthreads();
         uint32_t total;
@@ -388,6 +463,7 @@ void index_begin(skder_sketches *s, hipStream_t st)
             }
         }
         DevBuf<uint32_t> &d_list = s->idx_list;
+        s->idx_packed.resize(ns + 1, st);
         d_list.resize(G + 1, st);
         if (!small.empty()) HIPCHECK(hipMemcpyAsync(d_list.p, small.data(), small.size() * 4, hipMemcpyHostToDevice, st));
         if (!big.empty()) HIPCHECK(hipMemcpyAsync(d_list.p + small.size(), big.data(), big.size() * 4, hipMemcpyHostToDevice, st));
@@ -396,7 +472,7 @@ void index_begin(skder_sketches *s, hipStream_t st)
                                          (int)lds_limit));
             hipLaunchKernelGGL(index_genome_lds_kernel, dim3((unsigned)small.size()), dim3(IDXF_THREADS), small_bytes, st, s->d_meta.p, d_list.p,
                                s->d_rec_goff.p, s->seed_kmer.p, s->seed_gpos.p, s->seed_ctg.p, s->skmer.p, s->sgpos.p, s->sctg.p, s->stag.p, s->boff.p,
-                               s->pchunk.p, s->chunk_start.p);
+                               s->pchunk.p, s->chunk_start.p, s->idx_packed.p);
         }
         if (!big.empty()) {
             HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(index_genome_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -424,6 +500,7 @@ void index_finish(skder_sketches *s)
         ctx->timing_index = ms;
     }
     s->idx_list.release();
+    s->idx_packed.release();
     s->index_pending = false;
     s->indexed = true;
 }
