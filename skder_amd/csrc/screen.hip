@@ -11,6 +11,7 @@
 
 #define MK_EMPTY 0xFFFFFFFFFFFFFFFFULL
 #define SCREEN_JTILE 8192
+#define SCREEN_U 4             // markers per wave and trip of screen_rows_kernel
 
 __device__ __forceinline__ uint64_t mix64(uint64_t x)
 {
@@ -77,13 +78,36 @@ __global__ __launch_bounds__(256) void screen_rows_kernel(
         for (uint32_t j = tid; j < SCREEN_JTILE; j += 256) cnt[j] = 0;
         __syncthreads();
         if (!(triangle && j1 <= row + 1)) {
-            for (uint32_t e = wave; e < q.n_markers; e += 4) {   // one wave per marker
-                const uint32_t slot = q_slot_of[q.marker_off + e];
-                if (slot == 0xFFFFFFFFu) continue;
-                const uint32_t lo = loff[slot], hi = loff[slot + 1];
-                for (uint32_t k = lo + lane; k < hi; k += 64) {
-                    const uint32_t j = list[k];
+            // one wave per marker, SCREEN_U markers per trip: their slots, then their list bounds, then the first
+            // 128 entries of every list are requested together (three dependent loads per marker otherwise)
+            for (uint32_t e0 = wave; e0 < q.n_markers; e0 += 4 * SCREEN_U) {
+                uint32_t slot[SCREEN_U], lo[SCREEN_U], hi[SCREEN_U], ja[SCREEN_U], jb[SCREEN_U];
+#pragma unroll
+                for (int u = 0; u < SCREEN_U; u++) {
+                    const uint32_t e = e0 + 4u * u;
+                    slot[u] = e < q.n_markers ? q_slot_of[q.marker_off + e] : 0xFFFFFFFFu;
+                }
+#pragma unroll
+                for (int u = 0; u < SCREEN_U; u++) {
+                    const bool ok = slot[u] != 0xFFFFFFFFu;
+                    lo[u] = ok ? loff[slot[u]] : 0u;
+                    hi[u] = ok ? loff[slot[u] + 1] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < SCREEN_U; u++) {
+                    const uint32_t k = lo[u] + lane;
+                    ja[u] = k < hi[u] ? list[k] : 0xFFFFFFFFu;
+                    jb[u] = k + 64u < hi[u] ? list[k + 64u] : 0xFFFFFFFFu;
+                }
+#pragma unroll
+                for (int u = 0; u < SCREEN_U; u++) {
+                    const uint32_t j = ja[u], j2 = jb[u];
                     if (j >= j0 && j < j1 && (!triangle || j > row)) atomicAdd(&cnt[j - j0], 1u);
+                    if (j2 >= j0 && j2 < j1 && (!triangle || j2 > row)) atomicAdd(&cnt[j2 - j0], 1u);
+                    for (uint32_t k = lo[u] + 128u + lane; k < hi[u]; k += 64) {
+                        const uint32_t j3 = list[k];
+                        if (j3 >= j0 && j3 < j1 && (!triangle || j3 > row)) atomicAdd(&cnt[j3 - j0], 1u);
+                    }
                 }
             }
         }
