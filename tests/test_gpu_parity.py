@@ -754,6 +754,87 @@ def test_repeats_indels_and_inversions(gpu, oracle):
     s.close()
 
 
+def _structural_variant(rng, anc, realistic):
+    """a descendant of `anc`: substitutions, indels (realistic: short, geometric lengths, one per ~12 substitutions;
+    else 1-60 bases every few hundred bases), then inversions / translocations / duplications / deletions of
+    1-20 kb, cut into 1-80 records"""
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    comp = np.zeros(256, np.uint8)
+    comp[ord("A")], comp[ord("C")], comp[ord("G")], comp[ord("T")] = ord("T"), ord("G"), ord("C"), ord("A")
+    seq = anc.copy()
+    sub = 10 ** rng.uniform(-3.3, -1.4)
+    k = rng.binomial(len(seq), sub)
+    if k:
+        idx = rng.choice(len(seq), k, replace=False)
+        seq[idx] = alpha[(np.searchsorted(alpha, seq[idx]) + 1 + rng.randint(0, 3, k)) % 4]
+    every = max(150, int(12.0 / sub)) if realistic else int(10 ** rng.uniform(2.3, 3.9))
+    out, pos = [], 0
+    while pos < len(seq):
+        step = rng.randint(every // 2, every * 2)
+        out.append(seq[pos:pos + step])
+        pos += step
+        n = rng.geometric(0.4) if realistic else rng.randint(1, 60)
+        if rng.rand() < 0.5:
+            out.append(alpha[rng.randint(0, 4, n)])
+        else:
+            pos += n
+    seq = np.concatenate(out)
+    for _ in range(rng.randint(0, 4 if realistic else 12)):
+        a, n, ev = rng.randint(0, len(seq) - 25000), rng.randint(1000, 20000), rng.randint(0, 4)
+        seg = seq[a:a + n]
+        if ev == 0:
+            seq = np.concatenate([seq[:a], comp[seg[::-1]], seq[a + n:]])
+        elif ev == 1:
+            rest = np.concatenate([seq[:a], seq[a + n:]])
+            b = rng.randint(0, len(rest))
+            seq = np.concatenate([rest[:b], seg, rest[b:]])
+        elif ev == 2:
+            d = seq[a:a + rng.randint(1000, 5000)]
+            for _ in range(rng.randint(1, 6)):
+                b = rng.randint(0, len(seq))
+                seq = np.concatenate([seq[:b], d, seq[b:]])
+        else:
+            seq = np.concatenate([seq[:a], seq[a + n:]])
+    nrec = int(10 ** rng.uniform(0, 1.9))
+    cuts = np.sort(rng.choice(np.arange(600, len(seq) - 600), size=min(nrec - 1, 80), replace=False)) if nrec > 1 else np.array([], int)
+    lens = np.diff(np.concatenate([[0], cuts, [len(seq)]]))
+    keep = [lens[0]]
+    for l in lens[1:]:
+        if l < 500 or keep[-1] < 500:
+            keep[-1] += l
+        else:
+            keep.append(l)
+    return seq, np.array(keep, np.uint32)
+
+
+@pytest.mark.parametrize("realistic", [True, False])
+def test_structural_variants_randomized(gpu, oracle, realistic):
+    """families of five 0.3-0.9 Mb genomes derived from one ancestor by substitutions, indels and structural
+    events, every pair against the oracle.  realistic=True keeps most chunks on the fast chaining path (short
+    indels: a new run on the same path each), realistic=False sends most of them down the slow path (long
+    indels make the DP skip short runs: branching chains)."""
+    engine, ctx, torch = gpu
+    p = oracle.default_params()
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    chunks = slow = 0
+    for seed in range(4):
+        rng = np.random.RandomState(1000 * int(realistic) + seed)
+        anc = alpha[rng.randint(0, 4, rng.randint(300000, 900000))]
+        fam = [_structural_variant(rng, anc, realistic) for _ in range(5)]
+        bases, lens = [g[0] for g in fam], [g[1] for g in fam]
+        s, _ = _sketch(gpu, lens, bases)
+        og = [oracle.Genome.from_bases(b, l, p) for b, l in zip(bases, lens)]
+        edges = s.triangle_rows(0, 1, 0.0)
+        want = _oracle_edges(oracle, og, p, 0.0)
+        assert len(want) == 10
+        _check_edges(edges, want)
+        c = ctx.counters()
+        chunks += int(c[0])
+        slow += int(c[1])
+        s.close()
+    assert (slow < 0.15 * chunks) if realistic else (slow > 0.3 * chunks)
+
+
 def test_repetitive_cutoff_and_large_genome(gpu, oracle):
     """(a) genomes in which one 4 kb segment occurs 32 times: the repetitive cut-off becomes active (own
     multiplicity filter, every chunk on the slow path, look-ups through the bucket index); (b) a 15 Mb
