@@ -344,7 +344,8 @@ __global__ __launch_bounds__(256, CF_OCC) void chain_fast_kernel(SetView A, SetV
     const uint32_t s0 = QS.chunk_start[Qm->chunk_off + c], s1 = QS.chunk_start[Qm->chunk_off + c + 1];
     // own-multiplicity filter active, or positions of the probed genome do not fit a hit word's 24 bits:
     // leave the chunk to the slow path
-    bool cplx = Qm->rep_cut != 0xFFFFFFFFu || Rm->total_len > (uint64_t)HIT_POS_MASK;
+    bool cplx = Qm->rep_cut != 0xFFFFFFFFu || Rm->total_len > (uint64_t)HIT_POS_MASK || (xcd_remap & 2) ||
+                ((xcd_remap >> 2) && (uint32_t)(xcd_remap >> 2) != t + 1u);
     uint32_t cause = cplx ? 6u : 0u;
 
     const int32_t NEG = -0x40000000;
@@ -362,6 +363,9 @@ __global__ __launch_bounds__(256, CF_OCC) void chain_fast_kernel(SetView A, SetV
     // summaries of runs that left the ring: the most recent segment, plus one conservative scalar
     uint32_t s0_seg = 0xFFFFFFFFu, s0_key = 0, s0_q = 0, lost_q = 0;
     int32_t s0_f = NEG, lost_f = NEG, s0_dlo = 0, s0_dhi = 0, lost_dlo = 0, lost_dhi = 0;
+    // the keyless summary keeps TWO diagonal intervals (empty: lo > hi): the remnants of the main path and a
+    // stray single hit far off its diagonal would otherwise merge into one interval that covers everything in between
+    int32_t lost2_dlo = 1, lost2_dhi = 0;
     ChainRec *slots = fast_chains + (uint64_t)t * FAST_SLOTS;
 
 #define EMIT_PATH(E)                                                                         \
@@ -393,7 +397,18 @@ __global__ __launch_bounds__(256, CF_OCC) void chain_fast_kernel(SetView A, SetV
             } else {                                                                         \
                 if (s0_seg != 0xFFFFFFFFu) {                                                 \
                     if (lost_f == NEG) { lost_dlo = s0_dlo; lost_dhi = s0_dhi; }             \
-                    else { lost_dlo = s0_dlo < lost_dlo ? s0_dlo : lost_dlo; lost_dhi = s0_dhi > lost_dhi ? s0_dhi : lost_dhi; } \
+                    else {                                                                   \
+                        const int32_t g1a = s0_dlo - lost_dhi, g1b = lost_dlo - s0_dhi;      \
+                        const int32_t g1 = g1a > g1b ? (g1a > 0 ? g1a : 0) : (g1b > 0 ? g1b : 0); /* distance to interval 1 */ \
+                        bool into1 = g1 <= 2 * ANI_MAX_GAP;                                  \
+                        if (!into1 && lost2_dlo <= lost2_dhi) {                              \
+                            const int32_t g2a = s0_dlo - lost2_dhi, g2b = lost2_dlo - s0_dhi; \
+                            const int32_t g2 = g2a > g2b ? (g2a > 0 ? g2a : 0) : (g2b > 0 ? g2b : 0); \
+                            into1 = g1 <= g2;                                                \
+                            if (!into1) { lost2_dlo = s0_dlo < lost2_dlo ? s0_dlo : lost2_dlo; lost2_dhi = s0_dhi > lost2_dhi ? s0_dhi : lost2_dhi; } \
+                        } else if (!into1) { lost2_dlo = s0_dlo; lost2_dhi = s0_dhi; }        \
+                        if (into1) { lost_dlo = s0_dlo < lost_dlo ? s0_dlo : lost_dlo; lost_dhi = s0_dhi > lost_dhi ? s0_dhi : lost_dhi; } \
+                    }                                                                        \
                     lost_f = s0_f > lost_f ? s0_f : lost_f; lost_q = s0_q > lost_q ? s0_q : lost_q; \
                 }                                                                            \
                 s0_seg = (E).seg; s0_key = k3; s0_f = (E).f; s0_q = (E).q_last; s0_dlo = d3; s0_dhi = d3; \
@@ -542,7 +557,9 @@ __global__ __launch_bounds__(256, CF_OCC) void chain_fast_kernel(SetView A, SetV
                                     if (s0_seg != 0xFFFFFFFFu)
                                         dom = s0_key != k0 || s0_f <= r0.f || qp - (int32_t)s0_q > ANI_BP_BAND || d0 < s0_dlo - ANI_MAX_GAP || d0 > s0_dhi + ANI_MAX_GAP;
                                     if (dom && lost_f != NEG)
-                                        dom = lost_f <= r0.f || qp - (int32_t)lost_q > ANI_BP_BAND || d0 < lost_dlo - ANI_MAX_GAP || d0 > lost_dhi + ANI_MAX_GAP;
+                                        dom = lost_f <= r0.f || qp - (int32_t)lost_q > ANI_BP_BAND ||
+                                              ((d0 < lost_dlo - ANI_MAX_GAP || d0 > lost_dhi + ANI_MAX_GAP) &&
+                                               (lost2_dlo > lost2_dhi || d0 < lost2_dlo - ANI_MAX_GAP || d0 > lost2_dhi + ANI_MAX_GAP));
                                 }
                                 s++;
                             }
@@ -625,11 +642,12 @@ __global__ __launch_bounds__(256, CF_OCC) void chain_fast_kernel(SetView A, SetV
                         }
                         SUMMARY_BLOCKS(s0_f, s0_q, s0_dlo, s0_dhi, s0_seg != 0xFFFFFFFFu && s0_key == key)
                         SUMMARY_BLOCKS(lost_f, lost_q, lost_dlo, lost_dhi, lost_f != NEG)
+                        SUMMARY_BLOCKS(lost_f, lost_q, lost2_dlo, lost2_dhi, lost_f != NEG && lost2_dlo <= lost2_dhi)
         #undef SUMMARY_BLOCKS
                         if (!ok) { cplx = true; cause = 3; break; }
                     }
                     if (bj >= 0) {
-                        // bring the predecessor run to the front (ring order = recency of the last anchor)
+                        // bring the predecessor run to the front (it gets the newest anchor, or goes back: see below)
                         if (bj == 1) { const Run tr = r1; r1 = r0; r0 = tr; }
                         else if (bj == 2) { const Run tr = r2; r2 = r1; r1 = r0; r0 = tr; }
                         else if (bj == 3) { const Run tr = r3; r3 = r2; r2 = r1; r1 = r0; r0 = tr; }
@@ -652,6 +670,12 @@ __global__ __launch_bounds__(256, CF_OCC) void chain_fast_kernel(SetView A, SetV
                             e.qi_last = s; e.idx_last = ia; e.pmax = r0.f > r0.pmax ? r0.f : r0.pmax;
                             e.r_first = (uint32_t)rp; e.seg = pgap >= ANI_ANCHOR_SCORE ? ia : r0.seg;
                             r0.cnt |= SUCC_BIT;
+                            // the predecessor run goes back to where it was: the ring is ordered by the LAST ANCHOR of
+                            // its runs (the look-back stops at the first run beyond a band and trusts that older ones,
+                            // in the ring and in the summaries, lie further back), and this run's last anchor did not move
+                            if (bj == 1) { const Run tr = r0; r0 = r1; r1 = tr; }
+                            else if (bj == 2) { const Run tr = r0; r0 = r1; r1 = r2; r2 = tr; }
+                            else if (bj == 3) { const Run tr = r0; r0 = r1; r1 = r2; r2 = r3; r3 = tr; }
                             EVICT(r3);
                             r3 = r2; r2 = r1; r1 = r0; r0 = e;
                         }
@@ -684,7 +708,9 @@ __global__ __launch_bounds__(256, CF_OCC) void chain_fast_kernel(SetView A, SetV
                     if (dom && s0_seg != 0xFFFFFFFFu)
                         dom = s0_key != k0 || s0_f <= r0.f || q0l - (int32_t)s0_q > ANI_BP_BAND || d0 < s0_dlo - ANI_MAX_GAP || d0 > s0_dhi + ANI_MAX_GAP;
                     if (dom && lost_f != NEG)
-                        dom = lost_f <= r0.f || q0l - (int32_t)lost_q > ANI_BP_BAND || d0 < lost_dlo - ANI_MAX_GAP || d0 > lost_dhi + ANI_MAX_GAP;
+                        dom = lost_f <= r0.f || q0l - (int32_t)lost_q > ANI_BP_BAND ||
+                              ((d0 < lost_dlo - ANI_MAX_GAP || d0 > lost_dhi + ANI_MAX_GAP) &&
+                               (lost2_dlo > lost2_dhi || d0 < lost2_dlo - ANI_MAX_GAP || d0 > lost2_dhi + ANI_MAX_GAP));
                         }
             } while (0);
         }
@@ -1498,7 +1524,10 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         hipLaunchKernelGGL(root_lut_kernel, dim3(ROOT_LUT * ROOT_LUT / 256), dim3(256), 0, st, W.root_lut.p);
     }
     const SetView VA = view_of(SA), VB = view_of(SB);
-    const int xcd_remap = getenv("SKDER_AMD_NO_XCD") ? 0 : 1;
+    // debugging switches: SKDER_AMD_NO_XCD keeps the launch order; SKDER_AMD_FORCE_SLOW sends every chunk down the slow path;
+    // SKDER_AMD_FAST_ONLY_CHUNK=k lets only chunk k of a batch take the fast path (to find the chunk behind a parity failure)
+    int xcd_remap = (getenv("SKDER_AMD_NO_XCD") ? 0 : 1) | (getenv("SKDER_AMD_FORCE_SLOW") ? 2 : 0);
+    if (const char *e = getenv("SKDER_AMD_FAST_ONLY_CHUNK")) xcd_remap |= (atoi(e) + 1) << 2;
     double t_fast = 0, t_slow = 0, t_fin = 0, t_join = 0;
     uint64_t tot_anchors = 0, tot_slow = 0, tot_chunks = 0, tot_over = 0;
     // orientation of every pair, then order the work by the probed genome (R): consecutive

@@ -817,8 +817,10 @@ def test_structural_variants_randomized(gpu, oracle, realistic):
     p = oracle.default_params()
     alpha = np.frombuffer(b"ACGT", np.uint8)
     chunks = slow = 0
-    for seed in range(4):
-        rng = np.random.RandomState(1000 * int(realistic) + seed)
+    # (309: a run that got a successor through an indel used to move in front of a younger run in the ring, and a
+    # look-back that stopped at it beyond the 2500-base band missed an evicted single anchor inside the band)
+    for seed in ((1000, 1001, 1002, 1003) if realistic else (0, 1, 2, 309)):
+        rng = np.random.RandomState(seed)
         anc = alpha[rng.randint(0, 4, rng.randint(300000, 900000))]
         fam = [_structural_variant(rng, anc, realistic) for _ in range(5)]
         bases, lens = [g[0] for g in fam], [g[1] for g in fam]
