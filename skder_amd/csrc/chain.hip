@@ -1245,7 +1245,10 @@ __device__ __forceinline__ bool better(const int32_t *sc, const uint32_t *q0, co
     if (sc[j] != sc[i]) return sc[j] > sc[i];
     if (q0[j] != q0[i]) return q0[j] < q0[i];
     if (r0[j] != r0[i]) return r0[j] < r0[i];
-    return q1[j] < q1[i];
+    if (q1[j] != q1[i]) return q1[j] < q1[i];
+    // chains equal in every key (repeats can yield two chains with the same ends and score): the sort of the oracle
+    // puts one of them first, and that one drops the other; which one cannot matter, so the array order decides
+    return j < i;
 }
 
 // GLOBAL = false: the chain arrays of the pair live in dynamic LDS (`cap_arg` chains, sized per batch by the
