@@ -12,9 +12,11 @@ for a, b in zip(b"ACGTacgtN", b"TGCAtgcaN"): comp[a] = b
 MODE = sys.argv[3] if len(sys.argv) > 3 else ''
 def ancestor(rng):
     L = int(10 ** rng.uniform(4.7, 6.2)) if MODE != 'big' else int(rng.uniform(2.0e6, 5.2e6))
+    if MODE == 'tiny': L = int(10 ** rng.uniform(3.1, 4.7))
     seq = alpha[rng.randint(0, 4, L)]
     # repeats: a few segment families copied around, tandem repeats, low-complexity stretches
     for _ in range(rng.randint(0, 6)):
+        if L < 13000: break
         m = rng.randint(300, 6000); a = rng.randint(0, L - m); d = seq[a:a + m].copy()
         for _ in range(rng.randint(1, 10)):
             b = rng.randint(0, L - m); seq[b:b + m] = d if rng.rand() < 0.7 else comp[d[::-1]]
@@ -24,7 +26,7 @@ def ancestor(rng):
             b = rng.randint(0, L - m); seq[b:b + m] = d if rng.rand() < 0.8 else comp[d[::-1]]
     for _ in range(rng.randint(0, 4)):
         unit = alpha[rng.randint(0, 4, rng.randint(1, 40))]; reps = rng.randint(5, 400)
-        t = np.tile(unit, reps)[:20000]; b = rng.randint(0, L - len(t)); seq[b:b + len(t)] = t
+        t = np.tile(unit, reps)[:min(20000, L // 2)]; b = rng.randint(0, L - len(t)); seq[b:b + len(t)] = t
     return seq
 
 def descend(rng, anc, level):
@@ -59,12 +61,12 @@ def descend(rng, anc, level):
     # non-ACGT: N runs and lower case
     seq = seq.copy()
     for _ in range(rng.randint(0, 5)):
-        a = rng.randint(0, len(seq) - 100); n = rng.randint(1, 3000); seq[a:a + n] = ord("N")
+        a = rng.randint(0, max(1, len(seq) - 100)); n = rng.randint(1, 3000); seq[a:a + n] = ord("N")
     if rng.rand() < 0.3:
-        a = rng.randint(0, len(seq) - 100); n = rng.randint(1, len(seq) // 3); seq[a:a + n] |= 0x20
+        a = rng.randint(0, max(1, len(seq) - 100)); n = rng.randint(1, max(2, len(seq) // 3)); seq[a:a + n] |= 0x20
     nrec = int(10 ** rng.uniform(0, 2.2))
     lo = 600
-    cuts = np.sort(rng.choice(np.arange(lo, len(seq) - lo), size=min(nrec - 1, 150), replace=False)) if nrec > 1 and len(seq) > 2 * lo + 10 else np.array([], int)
+    cuts = np.sort(rng.choice(np.arange(lo, len(seq) - lo), size=min(nrec - 1, 150, len(seq) - 2 * lo), replace=False)) if nrec > 1 and len(seq) > 2 * lo + 10 else np.array([], int)
     lens = np.diff(np.concatenate([[0], cuts, [len(seq)]]))
     keep = [lens[0]]
     for l in lens[1:]:
@@ -83,7 +85,14 @@ def main():
         gl = [descend(rng, anc, i) for i in range(n)]
         bases, lens = [g[0] for g in gl], [g[1] for g in gl]
         try:
-            s, _ = T._sketch(gpu, lens, bases)
+            if MODE == 'append':      # several sketch calls (random split into batches) instead of one
+                s = engine.Sketches(ctx); pos = 0
+                while pos < n:
+                    k = rng.randint(1, n - pos + 1)
+                    lay = engine.BatchLayout(lens[pos:pos + k]); d = torch.from_numpy(lay.pack_host(bases[pos:pos + k])).cuda()
+                    s.sketch_batch(d.data_ptr(), lay); torch.cuda.synchronize(); pos += k
+            else:
+                s, _ = T._sketch(gpu, lens, bases)
             og = [oracle.Genome.from_bases(b, l, p) for b, l in zip(bases, lens)]
             T._compare_sketch(engine, s, oracle, og)
             screen = 0.0 if rng.rand() < 0.7 else 80.0
