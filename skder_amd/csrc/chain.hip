@@ -1325,7 +1325,6 @@ __global__ __launch_bounds__(256) void finalize_kernel_t(SetView A, SetView B, c
     __shared__ uint32_t bin_start[FIN_BINS + 2], bin_fill[FIN_BINS + 1];
     __shared__ uint32_t wsum[4];
     if (tid == 0) { s_maxlen = 0; s_maxr = 0; }
-    for (uint32_t b = tid; b <= FIN_BINS; b += 256) bin_fill[b] = 0;
     __syncthreads();
     {
         uint32_t ml = 0, mr = 0;
@@ -1337,21 +1336,25 @@ __global__ __launch_bounds__(256) void finalize_kernel_t(SetView A, SetView B, c
     uint32_t shift = 1;
     while ((1u << shift) <= s_maxlen) shift++;
     while ((s_maxr >> shift) >= FIN_BINS) shift++;
+    const uint32_t nb_used = (s_maxr >> shift) + 1u;     // bins that can hold a chain (a 3 Mb genome with 20 kb chunks: ~90 of 1024)
+    for (uint32_t b = tid; b <= nb_used; b += 256) bin_fill[b] = 0;
+    __syncthreads();
     for (uint32_t i = tid; i < n; i += 256) atomicAdd(&bin_fill[r0[i] >> shift], 1u);
     __syncthreads();
     {
         uint32_t running = 0;
-        for (uint32_t base = 0; base < FIN_BINS; base += 256) {
-            const uint32_t v = bin_fill[base + tid];
+        for (uint32_t base = 0; base < nb_used; base += 256) {
+            const uint32_t v = base + tid < nb_used ? bin_fill[base + tid] : 0u;
             uint32_t total;
             const uint32_t ex = block_excl_scan_256(v, wsum, total);
             bin_start[base + tid] = running + ex;
             running += total;
         }
-        if (tid == 0) { bin_start[FIN_BINS] = n; bin_start[FIN_BINS + 1] = n; }
+        __syncthreads();
+        if (tid == 0) { bin_start[nb_used] = n; bin_start[nb_used + 1] = n; }
     }
     __syncthreads();
-    for (uint32_t b = tid; b <= FIN_BINS; b += 256) bin_fill[b] = 0;
+    for (uint32_t b = tid; b <= nb_used; b += 256) bin_fill[b] = 0;
     __syncthreads();
     for (uint32_t i = tid; i < n; i += 256) {
         const uint32_t b = r0[i] >> shift;
@@ -1368,7 +1371,7 @@ __global__ __launch_bounds__(256) void finalize_kernel_t(SetView A, SetView B, c
             const uint32_t li = r1[i] - r0[i];
             bool dropped = false, pending = false;
             const uint32_t b = r0[i] >> shift;
-            const uint32_t k0 = bin_start[b ? b - 1 : 0], k1 = bin_start[b + 2 <= FIN_BINS ? b + 2 : FIN_BINS];
+            const uint32_t k0 = bin_start[b ? b - 1 : 0], k1 = bin_start[b + 2];    // bin_start[nb_used], [nb_used + 1] = n
             for (uint32_t k = k0; k < k1; k++) {
                 const uint32_t j = order[k];
                 if (j == i) continue;     // chains lie inside one record and positions are genome-linear: overlap implies the same record
