@@ -540,18 +540,55 @@ __global__ __launch_bounds__(256, CF_OCC) void chain_fast_kernel(SetView A, SetV
                                             (RUN_END(r3) || (RUN_OTHER(r3) && !nevict))))))));
 #undef RUN_END
 #undef RUN_OTHER
-                        if (fresh) {
-                            const uint32_t rp = hw & HIT_POS_MASK;
+                        // INDEL on the current path, also without a look-back: a single hit of r0's record and strand, 1..2500
+                        // bases after r0's last anchor and ahead of it on the other genome, 1..300 off r0's diagonal, r0
+                        // without a successor -- and nothing else able to offer as much as r0 does: every other run and
+                        // summary is empty, of another key, beyond the 2500-base band, or scores at most r0.f - off (so
+                        // that even at zero gap cost it stays at or below r0's offer; r0's last anchor is the nearest of
+                        // all, and the look-back keeps the first of equal offers).  Interior anchors of those runs score
+                        // no more than their last ones, so the "inside a run's extent" case cannot matter here either.
+                        const uint32_t rp = hw & HIT_POS_MASK;
+                        bool take = fresh, dom_after = true;
+                        int32_t best = ANI_ANCHOR_SCORE;
+                        Run e;
+                        e.q_last = (uint32_t)qp; e.rr_last = hw; e.f = ANI_ANCHOR_SCORE;
+                        e.cnt = 1; e.first_qi = s; e.q_first = (uint32_t)qp; e.rmin = e.rmax = rp;
+                        e.qi_last = s; e.idx_last = ia; e.pmax = NEG; e.r_first = rp; e.seg = ia;
+                        if (!fresh && !(hw & 0x40000000u) && r0.cnt && !(r0.cnt & SUCC_BIT) && !((r0.rr_last ^ hw) & HIT_KEY_MASK)) {
+                            const bool rev = (hw >> 31) != 0u;
+                            const int32_t rp0 = (int32_t)(r0.rr_last & HIT_POS_MASK), q0l = (int32_t)r0.q_last;
+                            const int32_t dgx = rev ? (int32_t)rp + qp : (int32_t)rp - qp, d0 = rev ? rp0 + q0l : rp0 - q0l;
+                            const int32_t off = dgx > d0 ? dgx - d0 : d0 - dgx;
+                            const int32_t dq = qp - q0l, dr = rev ? rp0 - (int32_t)rp : (int32_t)rp - rp0;
+                            const int32_t lim = r0.f - off;
+                            bool ok = off >= 1 && off <= ANI_MAX_GAP && (uint32_t)(dq - 1) < (uint32_t)ANI_BP_BAND && dr > 0 && lim > 0;
+#define HARMLESS(E) (!(E).cnt || ((((E).rr_last ^ hw) & HIT_KEY_MASK) != 0u) || (E).f <= lim || qp - (int32_t)(E).q_last > ANI_BP_BAND)
+                            ok = ok && HARMLESS(r1) && HARMLESS(r2) && HARMLESS(r3);
+#undef HARMLESS
+                            if (ok && nevict) {
+                                ok = (s0_seg == 0xFFFFFFFFu || s0_key != (hw & HIT_KEY_MASK) || s0_f <= lim || qp - (int32_t)s0_q > ANI_BP_BAND) &&
+                                     (lost_f == NEG || lost_f <= lim || qp - (int32_t)lost_q > ANI_BP_BAND);
+                            }
+                            if (ok) {
+                                take = true;
+                                best = r0.f + ANI_ANCHOR_SCORE - off;
+                                e.f = best;
+                                e.cnt = r0.cnt + 1u; e.first_qi = r0.first_qi; e.q_first = r0.q_first;
+                                e.rmin = rp < r0.rmin ? rp : r0.rmin; e.rmax = rp > r0.rmax ? rp : r0.rmax;
+                                e.pmax = r0.f > r0.pmax ? r0.f : r0.pmax;
+                                e.seg = off >= ANI_ANCHOR_SCORE ? ia : r0.seg;
+                                r0.cnt |= SUCC_BIT;
+                                dom_after = off <= ANI_ANCHOR_SCORE;      // the old run (now second) must not score above the new one
+                            }
+                        }
+                        if (take) {
                             EVICT(r3);
                             if (!cplx) {
-                                r3 = r2; r2 = r1; r1 = r0;
-                                r0.q_last = (uint32_t)qp; r0.rr_last = hw; r0.f = ANI_ANCHOR_SCORE;
-                                r0.cnt = 1; r0.first_qi = s; r0.q_first = (uint32_t)qp; r0.rmin = r0.rmax = rp;
-                                r0.qi_last = s; r0.idx_last = ia; r0.pmax = NEG; r0.r_first = rp; r0.seg = ia;
+                                r3 = r2; r2 = r1; r1 = r0; r0 = e;
                                 ia++;
-                                runmax = ANI_ANCHOR_SCORE > runmax ? ANI_ANCHOR_SCORE : runmax;
-                                dom = true;
-                                if (nevict) {       // the summaries of evicted runs, as at the end of the general step
+                                runmax = best > runmax ? best : runmax;
+                                dom = dom_after;
+                                if (dom && nevict) {       // the summaries of evicted runs, as at the end of the general step
                                     const uint32_t k0 = hw & HIT_KEY_MASK;
                                     const int32_t d0 = (hw >> 31) ? (int32_t)rp + qp : (int32_t)rp - qp;
                                     if (s0_seg != 0xFFFFFFFFu)
