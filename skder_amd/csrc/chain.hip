@@ -464,9 +464,9 @@ __global__ __launch_bounds__(256, CF_OCC) void chain_fast_kernel(SetView A, SetV
                 lb_hit[K][tidx] = w_; lb_qp[K][tidx] = q_;                                               \
                 const bool none_ = w_ == HIT_NONE;                                                       \
                 const uint32_t sg_ = (uint32_t)((int32_t)w_ >> 31);                                      \
-                const uint32_t dg_ = (w_ & HIT_POS_MASK) - ((q_ ^ sg_) - sg_);   /* pos - q, or pos + q */ \
+                const uint32_t dg_ = ((w_ & HIT_POS_MASK) ^ sg_) - q_;   /* pos - q, or -(pos + q) - 1: one value per diagonal */ \
                 const uint32_t x_ = ((w_ ^ pw) & (HIT_KEY_MASK | 0x40000000u)) | (dg_ ^ pdiag) | (w_ & 0x40000000u); \
-                const bool cont_ = (x_ == 0u) & ((q_ - pq - 1u) < (uint32_t)ANI_BP_BAND);                \
+                const bool cont_ = (x_ == 0u) & ((q_ - pq) <= (uint32_t)ANI_BP_BAND);   /* positions rise strictly: q - pq >= 1 */ \
                 cw |= (none_ ? 1u : (cont_ ? 0u : 2u)) << (2 * (K));                                     \
                 pw = none_ ? pw : w_; pq = none_ ? pq : q_; pdiag = none_ ? pdiag : dg_;                 \
             }
