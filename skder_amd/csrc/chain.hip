@@ -307,7 +307,7 @@ struct Run {
     uint32_t q_last, rr_last;         // last anchor: query pos; hit word (ref pos | record tag << 24 | rev << 31)
     int32_t f;                        // score of the last anchor
     uint32_t cnt;                     // anchors on the PATH ending at the last anchor | SUCC_BIT
-    uint32_t first_qi, q_first, rmin, rmax;   // path aggregates: first seed index and its position (kept so that emitting a
+    uint32_t first_qi, q_first, r_pfirst;     // path aggregates: first seed index and its position (kept so that emitting a
                                       // chain needs no load: a wait on one would also drain the input prefetch), ref extent
     uint32_t qi_last, idx_last;       // seed index / anchor ordinal of the last anchor
     int32_t pmax;                     // highest score among the earlier anchors of the path
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256, CF_OCC) void chain_fast_kernel(SetView A, SetV
     r0.f = r1.f = r2.f = r3.f = NEG;
     r0.q_last = r1.q_last = r2.q_last = r3.q_last = 0; r0.rr_last = r1.rr_last = r2.rr_last = r3.rr_last = 0;
     r0.first_qi = r1.first_qi = r2.first_qi = r3.first_qi = 0; r0.q_first = r1.q_first = r2.q_first = r3.q_first = 0;
-    r0.rmin = r1.rmin = r2.rmin = r3.rmin = 0; r0.rmax = r1.rmax = r2.rmax = r3.rmax = 0;
+    r0.r_pfirst = r1.r_pfirst = r2.r_pfirst = r3.r_pfirst = 0;
     r0.qi_last = r1.qi_last = r2.qi_last = r3.qi_last = 0; r0.idx_last = r1.idx_last = r2.idx_last = r3.idx_last = 0;
     r0.pmax = r1.pmax = r2.pmax = r3.pmax = NEG; r0.r_first = r1.r_first = r2.r_first = r3.r_first = 0;
     r0.seg = r1.seg = r2.seg = r3.seg = 0;
@@ -376,7 +376,11 @@ __global__ __launch_bounds__(256, CF_OCC) void chain_fast_kernel(SetView A, SetV
             else {                                                                           \
                 ChainRec cr;                                                                 \
                 cr.score = (E).f; cr.n = (E).cnt; cr.n_seeds = (E).qi_last - (E).first_qi + 1; \
-                cr.q0 = (E).q_first; cr.q1 = (E).q_last; cr.r0 = (E).rmin; cr.r1 = (E).rmax; cr.rctg = ((E).rr_last >> HIT_POS_BITS) & 63u; \
+                cr.q0 = (E).q_first; cr.q1 = (E).q_last;                                       \
+                { /* a predecessor lies strictly behind on the other genome too: the path's extent there is spanned by its two ends */ \
+                  const uint32_t rl_ = (E).rr_last & HIT_POS_MASK;                            \
+                  cr.r0 = rl_ < (E).r_pfirst ? rl_ : (E).r_pfirst; cr.r1 = rl_ > (E).r_pfirst ? rl_ : (E).r_pfirst; } \
+                cr.rctg = ((E).rr_last >> HIT_POS_BITS) & 63u; \
                 slots[nfin++] = cr;                                                          \
             }                                                                                \
         }                                                                                    \
@@ -518,9 +522,6 @@ __global__ __launch_bounds__(256, CF_OCC) void chain_fast_kernel(SetView A, SetV
                         r0.cnt += ext;
                         r0.idx_last = ia + ext - 1u; ia += ext;
                         r0.qi_last = last_s;
-                        const uint32_t rl = r0.rr_last & HIT_POS_MASK;
-                        r0.rmin = rl < r0.rmin ? rl : r0.rmin;
-                        r0.rmax = rl > r0.rmax ? rl : r0.rmax;
                     }
                     s += first;
                     park = first < nv;
@@ -552,7 +553,7 @@ __global__ __launch_bounds__(256, CF_OCC) void chain_fast_kernel(SetView A, SetV
                         int32_t best = ANI_ANCHOR_SCORE;
                         Run e;
                         e.q_last = (uint32_t)qp; e.rr_last = hw; e.f = ANI_ANCHOR_SCORE;
-                        e.cnt = 1; e.first_qi = s; e.q_first = (uint32_t)qp; e.rmin = e.rmax = rp;
+                        e.cnt = 1; e.first_qi = s; e.q_first = (uint32_t)qp; e.r_pfirst = rp;
                         e.qi_last = s; e.idx_last = ia; e.pmax = NEG; e.r_first = rp; e.seg = ia;
                         if (!fresh && !(hw & 0x40000000u) && r0.cnt && !(r0.cnt & SUCC_BIT) && !((r0.rr_last ^ hw) & HIT_KEY_MASK)) {
                             const bool rev = (hw >> 31) != 0u;
@@ -574,7 +575,7 @@ __global__ __launch_bounds__(256, CF_OCC) void chain_fast_kernel(SetView A, SetV
                                 best = r0.f + ANI_ANCHOR_SCORE - off;
                                 e.f = best;
                                 e.cnt = r0.cnt + 1u; e.first_qi = r0.first_qi; e.q_first = r0.q_first;
-                                e.rmin = rp < r0.rmin ? rp : r0.rmin; e.rmax = rp > r0.rmax ? rp : r0.rmax;
+                                e.r_pfirst = r0.r_pfirst;
                                 e.pmax = r0.f > r0.pmax ? r0.f : r0.pmax;
                                 e.seg = off >= ANI_ANCHOR_SCORE ? ia : r0.seg;
                                 r0.cnt |= SUCC_BIT;
@@ -694,16 +695,13 @@ __global__ __launch_bounds__(256, CF_OCC) void chain_fast_kernel(SetView A, SetV
                             r0.pmax = r0.f > r0.pmax ? r0.f : r0.pmax;
                             r0.f = best;
                             r0.q_last = (uint32_t)qp; r0.rr_last = rr; r0.cnt += 1u;
-                            r0.rmin = (uint32_t)rp < r0.rmin ? (uint32_t)rp : r0.rmin;
-                            r0.rmax = (uint32_t)rp > r0.rmax ? (uint32_t)rp : r0.rmax;
                             r0.qi_last = s; r0.idx_last = ia;
                         } else {
                             // an indel: new run on the same path; the old run's last anchor now has a successor
                             Run e;
                             e.q_last = (uint32_t)qp; e.rr_last = rr; e.f = best;
                             e.cnt = (r0.cnt & ~SUCC_BIT) + 1u; e.first_qi = r0.first_qi; e.q_first = r0.q_first;
-                            e.rmin = (uint32_t)rp < r0.rmin ? (uint32_t)rp : r0.rmin;
-                            e.rmax = (uint32_t)rp > r0.rmax ? (uint32_t)rp : r0.rmax;
+                            e.r_pfirst = r0.r_pfirst;
                             e.qi_last = s; e.idx_last = ia; e.pmax = r0.f > r0.pmax ? r0.f : r0.pmax;
                             e.r_first = (uint32_t)rp; e.seg = pgap >= ANI_ANCHOR_SCORE ? ia : r0.seg;
                             r0.cnt |= SUCC_BIT;
@@ -719,7 +717,7 @@ __global__ __launch_bounds__(256, CF_OCC) void chain_fast_kernel(SetView A, SetV
                     } else {
                         Run e;
                         e.q_last = (uint32_t)qp; e.rr_last = rr; e.f = best;
-                        e.cnt = 1; e.first_qi = s; e.q_first = (uint32_t)qp; e.rmin = e.rmax = (uint32_t)rp;
+                        e.cnt = 1; e.first_qi = s; e.q_first = (uint32_t)qp; e.r_pfirst = (uint32_t)rp;
                         e.qi_last = s; e.idx_last = ia; e.pmax = NEG; e.r_first = (uint32_t)rp; e.seg = ia;
                         EVICT(r3);
                         r3 = r2; r2 = r1; r1 = r0; r0 = e;
