@@ -13,11 +13,11 @@ import torch.multiprocessing as mp
 from conftest import ROOT
 
 
-def _fake_raw(rank):
+def _fake_raw(rank, empty=-1):
     rng = np.random.RandomState(100 + rank)
-    ng = 3 + rank
-    ns = rng.randint(5, 40, ng)
-    nm = rng.randint(1, 9, ng)
+    ng = 0 if rank == empty else 3 + rank
+    ns = rng.randint(5, 40, ng).astype(np.int64)
+    nm = rng.randint(1, 9, ng).astype(np.int64)
     nrec = rng.randint(1, 4, ng).astype(np.uint32)
     return dict(
         n_genomes=ng,
@@ -29,18 +29,18 @@ def _fake_raw(rank):
         marker_off=np.concatenate([[0], np.cumsum(nm)]).astype(np.uint64),
         genome_len=rng.randint(1000, 9000, ng).astype(np.uint64),
         genome_nrec=nrec,
-        rec_goff=np.concatenate([np.arange(k + 1, dtype=np.uint32) * 500 for k in nrec]))
+        rec_goff=np.concatenate([np.zeros(0, np.uint32)] + [np.arange(k + 1, dtype=np.uint32) * 500 for k in nrec]))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, empty=-1):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from skder_amd import engine, multigpu
-    raw = _fake_raw(rank)
+    raw = _fake_raw(rank, empty)
     merged = multigpu.exchange_raw(raw)
-    edges = np.zeros(2 + rank, engine.EDGE_DTYPE)
+    edges = np.zeros(0 if rank == empty else 2 + rank, engine.EDGE_DTYPE)
     edges["ref"] = rank
     edges["query"] = np.arange(len(edges)) + 10 * rank
     allv = multigpu.gather_edges(edges)
@@ -90,3 +90,33 @@ def test_exchange_and_gather_world2():
         assert np.array_equal(m["rec_goff"], np.concatenate([x["rec_goff"] for x in raws]))
     assert len(res[0][1]) == 2 + 3 and len(res[1][1]) == 0          # edges land on rank 0 only
     assert sorted(res[0][1]["ref"].tolist()) == [0, 0, 1, 1, 1]
+
+
+def test_exchange_with_an_empty_rank():
+    """three ranks, the middle one without genomes and without edges (fewer genomes than ranks): empty tensors in
+    the padded all-gathers and in the edge gather"""
+    world, empty = 3, 1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, empty)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, merged, allv = q.get(timeout=120)
+        res[r] = (merged, allv)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    raws = [_fake_raw(r, empty) for r in range(world)]
+    for r in range(world):
+        m = res[r][0]
+        assert m["n_genomes"] == sum(x["n_genomes"] for x in raws) == 3 + 5
+        for k in ("seed_kmer", "seed_gpos", "markers"):
+            assert np.array_equal(m[k], np.concatenate([x[k].numpy() for x in raws])), k
+        assert len(m["seed_off"]) == m["n_genomes"] + 1 and m["seed_off"][-1] == len(m["seed_kmer"])
+        assert np.array_equal(m["genome_len"], np.concatenate([x["genome_len"] for x in raws]))
+        assert np.array_equal(m["rec_goff"], np.concatenate([x["rec_goff"] for x in raws]))
+    assert len(res[0][1]) == 2 + 4 and len(res[1][1]) == 0 and len(res[2][1]) == 0
+    assert sorted(res[0][1]["ref"].tolist()) == [0, 0, 2, 2, 2, 2]
