@@ -236,6 +236,14 @@ def main():
         dom = max(cand, key=lambda k: cand[k][0])
         dms, dbytes = cand[dom]
         achieved = dbytes / (dms * 1e-3) / 1e9 if dms > 0 else 0.0
+        # the same step priced with SURVEY.md 8(d)'s layout-independent figures (16-byte seed records): sketch
+        # 1.136 B per base over the sketch stage, chain 16 B x (both genomes' seeds) per chained pair over
+        # join + chaining + finalize; the per-kernel figure above uses this build's smaller records instead
+        def gbs(nbytes, ms):
+            return {"bytes": float(nbytes), "ms": float(ms), "GB/s": float(nbytes / (ms * 1e-3) / 1e9) if ms > 0 else 0.0}
+        s8_sketch = gbs(total_bases * (1.0 + 16.0 / 125 + 8.0 / 1000), tm[0] + tm[1])
+        s8_chain = gbs(n_chained * 16.0 * 2.0 * seeds_per_genome, join_ms + tm[3] + tm[4] + tm[5])
+        s8_all = gbs(s8_sketch["bytes"] + s8_chain["bytes"], ms_per_step)          # over the whole step's wall time
         # measured HBM traffic of the dominant kernel per step (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
         # separate passes, profiles/round1_pmc_traffic.json; only valid for the default workload on 1 GPU)
         traffic = None
@@ -258,6 +266,7 @@ def main():
                        "parallelism": "rows%d" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": dbytes,
+                         "survey_8d": {"sketch": s8_sketch, "chain": s8_chain, "step": s8_all},
                          "kernel_ms": {k: float(v[0]) for k, v in cand.items()},
                          "host_wall_ms": {k: 1e3 * v / (args.steps + args.warmup) for k, v in wall.items()},
                          "other_ms": {"sketch_post": float(tm[1]), "index_beside_screen": float(step.index_ms), "screen": float(tm[2]), "chain_slow_path": float(tm[4]),
