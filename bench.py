@@ -117,6 +117,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--genomes", type=int, default=5000)
     ap.add_argument("--genome-len", type=int, default=3_000_000)
+    ap.add_argument("--len-range", type=int, nargs=2, default=None, metavar=("LO", "HI"),
+                    help="species lengths uniform in [LO, HI] (BASELINE config 5: 1000000 8000000) instead of --genome-len +-5 %%")
     ap.add_argument("--screen", type=float, default=80.0)
     ap.add_argument("--batch-genomes", type=int, default=2500, help="genomes per resident input batch (one sketch call each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -148,7 +150,7 @@ def main():
     ctx = engine.Context(dev)
 
     N = args.genomes
-    recipe = synth.make_recipe(N, genome_len=args.genome_len)
+    recipe = synth.make_recipe(N, genome_len=args.genome_len, len_range=args.len_range)
     mine = multigpu.partition(N, world)[rank]
     # inputs: generated on the device, resident in HBM before the timed region
     batches = []
@@ -224,6 +226,12 @@ def main():
         n_chained, n_anchors = tm[6], tm[7]
         sketch_bytes = total_bases * (1.0 + 8.0 / 125 + 8.0 / 1000)        # this rank's sketch kernel launches
         seeds_per_genome = args.genome_len / 125.0
+        if args.len_range is not None:
+            # mixed lengths: the chained pairs are the within-species pairs, so weight each species' length by its pair count
+            ns = np.bincount(recipe.species)
+            sl = np.array([recipe.total_len(int(np.argmax(recipe.species == s))) for s in range(len(ns))], np.float64)
+            w = ns * (ns - 1) / 2.0
+            seeds_per_genome = float((w * sl).sum() / max(w.sum(), 1.0)) / 125.0
         # join_probe_kernel: per chained pair the chunked genome's position-ordered k-mers are read once
         # (4 B per seed), one hit word per seed is written (4 B) and the matched position is gathered for
         # about 70 % of the seeds (4 B); the probed genome's index is staged in LDS once per <= 16 pairs;
@@ -248,7 +256,7 @@ def main():
         # separate passes, profiles/round1_pmc_traffic.json; only valid for the default workload on 1 GPU)
         traffic = None
         try:
-            if N == 5000 and world == 1:
+            if N == 5000 and world == 1 and args.len_range is None and args.genome_len == 3_000_000:
                 pm = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")))[dom]
                 # counter values corrected by the calibration of profiles/calib (profiles/summarise.py)
                 traffic = sum(pm[c].get("corrected_bytes", pm[c]["sum_counter_kb"] * 1024.0) for c in ("FETCH_SIZE", "WRITE_SIZE"))
@@ -259,8 +267,9 @@ def main():
             "unit": "genome-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u64 hash / i32 chaining / f64 ANI", "data": "synthetic",
-            "config": {"workload": "%d synthetic genomes x %.1f Mb (50 species x 10 strains x 10 isolates), triangle, screen %.0f"
-                       % (N, args.genome_len / 1e6, args.screen), "genomes": N, "pairs": pairs,
+            "config": {"workload": "%d synthetic genomes x %s Mb (%d species x 10 strains x 10 isolates), triangle, screen %.0f"
+                       % (N, "%.1f" % (args.genome_len / 1e6) if args.len_range is None else
+                          "%.1f-%.1f" % (args.len_range[0] / 1e6, args.len_range[1] / 1e6), max(1, N // 100), args.screen), "genomes": N, "pairs": pairs,
                        "chained_pairs": int(n_chained_all), "edges": int(len(edges)),
                        "chunks": int(step.counters[0]), "slow_path_chunks": int(step.counters[1]),
                        "parallelism": "rows%d" % world},

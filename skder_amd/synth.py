@@ -54,9 +54,10 @@ class Recipe:
 
 
 def make_recipe(n: int, genome_len: int = 3_000_000, n_species: int = None, strains_per_species: int = 10,
-                seed: int = SEED) -> Recipe:
+                seed: int = SEED, len_range=None) -> Recipe:
     """n genomes: species roots (iid, genome_len +-5 %) x strain ancestors (1-3 % substitutions, 5-10 %
-    accessory segments) x isolates (0.01-0.5 % substitutions); log-normal record lengths."""
+    accessory segments) x isolates (0.01-0.5 % substitutions); log-normal record lengths.
+    len_range = (lo, hi): species lengths uniform in [lo, hi] instead (BASELINE.json's mixed 1-8 Mb set)."""
     if n_species is None:
         n_species = max(1, n // 100)
     rng = np.random.RandomState(seed & 0x7FFFFFFF)
@@ -66,6 +67,8 @@ def make_recipe(n: int, genome_len: int = 3_000_000, n_species: int = None, stra
     species = np.zeros(n, np.int64)
     rec_lens = []
     sp_len = (genome_len * (0.95 + 0.10 * rng.rand(n_species))).astype(np.int64)
+    if len_range is not None:
+        sp_len = (len_range[0] + (len_range[1] - len_range[0]) * rng.rand(n_species)).astype(np.int64)
     for g in range(n):
         s = g // per_species
         within = g % per_species
