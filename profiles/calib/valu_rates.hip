@@ -80,6 +80,39 @@ KERNEL32(k_xor_e64, "v_xor_b32_e64 %0, %0, %1")
 KERNEL32(k_bfrev, "v_bfrev_b32 %0, %0")
 KERNEL32(k_pk_add, "v_pk_add_u16 %0, %0, %1")
 
+// scalar ALU, and a 1:1 mix of scalar and vector instructions of one wave
+__global__ void k_salu(uint32_t *out, uint32_t seed)
+{
+    uint32_t r[8];
+    for (int i = 0; i < 8; i++) r[i] = __builtin_amdgcn_readfirstlane(seed * (i + 1));
+    uint32_t c = __builtin_amdgcn_readfirstlane(seed | 3u);
+    for (int it = 0; it < ITERS; it++) {
+        _Pragma("unroll") for (int k = 0; k < ROUNDS; k++) {
+            _Pragma("unroll") for (int i = 0; i < 8; i++) asm volatile("s_add_u32 %0, %0, %1" : "+s"(r[i]) : "s"(c) : "scc");
+        }
+    }
+    uint32_t s = 0;
+    for (int i = 0; i < 8; i++) s ^= r[i];
+    if (s == 0x12345678u) out[threadIdx.x] = s;
+}
+__global__ void k_mix(uint32_t *out, uint32_t seed)     // ROUNDS x 8 pairs (one scalar + one vector instruction)
+{
+    uint32_t r[8], v[8];
+    for (int i = 0; i < 8; i++) { r[i] = __builtin_amdgcn_readfirstlane(seed * (i + 1)); v[i] = seed * (threadIdx.x + i + 1); }
+    uint32_t c = __builtin_amdgcn_readfirstlane(seed | 3u), cv = seed | 5u;
+    for (int it = 0; it < ITERS; it++) {
+        _Pragma("unroll") for (int k = 0; k < ROUNDS; k++) {
+            _Pragma("unroll") for (int i = 0; i < 8; i++) {
+                asm volatile("s_add_u32 %0, %0, %1" : "+s"(r[i]) : "s"(c) : "scc");
+                asm volatile("v_xor_b32 %0, %0, %1" : "+v"(v[i]) : "v"(cv));
+            }
+        }
+    }
+    uint32_t s = 0;
+    for (int i = 0; i < 8; i++) s ^= r[i] ^ v[i];
+    if (s == 0x12345678u) out[threadIdx.x] = s;
+}
+
 typedef void (*kern_t)(uint32_t *, uint32_t);
 
 static double run(kern_t k, uint32_t *d, int blocks, int threads = 512)
@@ -126,6 +159,21 @@ int main()
         // one wave per SIMD: the 8 chains of that single wave are all the independence there is
         double lat = run(ks[i].k, d, cus, 256) * 1e6 / ((double)ITERS * ROUNDS * 8);
         printf("%s\"%s\": {\"ns_per_wave_instr\": %.3f, \"vs_xor\": %.2f, \"one_wave_ns\": %.3f}", i ? ", " : "", ks[i].name, per, per / base, lat);
+    }
+    // how the issue rate grows with the number of resident waves per SIMD (256-thread workgroups: one wave per SIMD each)
+    struct { const char *name; kern_t k; double per_round; } ws[] = {
+        {"v_xor_b32", k_xor, 1}, {"v_lshlrev_b32", k_lshl, 1}, {"v_mad_u64_u32", k_mad64, 1}, {"s_add_u32", k_salu, 1}, {"s_add_u32+v_xor_b32", k_mix, 2},
+    };
+    printf("}, \"instr_per_cycle_per_simd_by_waves\": {");
+    const int nw[] = {1, 2, 3, 4, 6, 8};
+    for (size_t i = 0; i < sizeof(ws) / sizeof(ws[0]); i++) {
+        printf("%s\"%s\": {", i ? ", " : "", ws[i].name);
+        for (size_t j = 0; j < sizeof(nw) / sizeof(nw[0]); j++) {
+            double ms = run(ws[i].k, d, cus * nw[j], 256);
+            double instr = (double)nw[j] * ITERS * ROUNDS * 8 * ws[i].per_round;      // wave-instructions per SIMD
+            printf("%s\"%d\": %.3f", j ? ", " : "", nw[j], instr / (ms * 1e-3 * 2.4e9));
+        }
+        printf("}");
     }
     printf("}}\n");
     return 0;
