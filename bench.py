@@ -72,6 +72,49 @@ def end_to_end_sample(tmp, paths, nbytes, device):
     return {"genomes": len(paths), "fasta_bytes": nbytes, "seconds": dt, "rows": rows, "ingest_MB_per_s": nbytes / dt / 1e6}
 
 
+def golden_parity(device):
+    """BASELINE.json's second figure, "max |dANI| vs skani": the drop-in triangle on the 34 genomes of the
+    reference's own test run against the skani table that run holds (tests/golden/G5, two decimals).
+    Outside the timed region; skani itself is not available on this box."""
+    import ctypes as C
+    import tempfile
+    from skder_amd import _lib
+    gold = os.path.join(ROOT, "tests", "golden")
+    want = {}
+    with open(os.path.join(gold, "G5_triangle_minaf10_s89.5.tsv")) as f:
+        next(f)
+        for line in f:
+            c = line.rstrip("\n").split("\t")
+            want[frozenset((os.path.basename(c[0]), os.path.basename(c[1])))] = (float(c[2]), float(c[3]), float(c[4]), os.path.basename(c[0]))
+    names = sorted(os.listdir(os.path.join(gold, "genomes")))
+    with tempfile.TemporaryDirectory(prefix="skder_amd_gold_") as tmp:
+        listing = os.path.join(tmp, "listing.txt")
+        open(listing, "w").write("".join(os.path.join(gold, "genomes", n) + "\n" for n in names))
+        out = os.path.join(tmp, "tri.tsv")
+        err = C.create_string_buffer(_lib.ERRLEN)
+        if _lib.lib().skder_amd_triangle(listing.encode(), 10.0, 89.5, device, out.encode(), err, _lib.ERRLEN) != 0:
+            raise RuntimeError(err.value.decode())
+        d_ani, d_af, seen = [], [], 0
+        with open(out) as f:
+            next(f)
+            for line in f:
+                c = line.rstrip("\n").split("\t")
+                k = frozenset((os.path.basename(c[0]), os.path.basename(c[1])))
+                if k not in want:
+                    continue
+                seen += 1
+                g = want[k]
+                afr, afq = (float(c[3]), float(c[4])) if os.path.basename(c[0]) == g[3] else (float(c[4]), float(c[3]))
+                d_ani.append(float(c[2]) - g[0])
+                d_af += [afr - g[1], afq - g[2]]
+    d_ani, d_af = np.array(d_ani), np.array(d_af)
+    return {"max_abs_dANI": float(np.abs(d_ani).max()), "rms_dANI": float(np.sqrt((d_ani ** 2).mean())),
+            "max_abs_dAF": float(np.abs(d_af).max()), "rms_dAF": float(np.sqrt((d_af ** 2).mean())),
+            "pairs": seen, "golden_pairs": len(want), "unit": "percentage points",
+            "against": "skani table of the reference's own test run (tests/golden/G5: 34 C. granulosum genomes, ANI 96.4-100, two decimals); "
+                       "skani's version is unpinned and its learned-ANI model is replaced by a fitted map (DESIGN.md 2)"}
+
+
 def cpu_baseline_files(tmp, paths, threads):
     """oracle (CPU restatement, OpenMP) on the sample files, wall clock on `threads` host threads:
       per genome   : read + sketch, from a triangle whose 101 % screen lets no pair through;
@@ -281,6 +324,8 @@ def main():
                          "other_ms": {"sketch_post": float(tm[1]), "index_beside_screen": float(step.index_ms), "screen": float(tm[2]), "chain_slow_path": float(tm[4]),
                                       "finalize": float(tm[5])}},
         }
+        if world == 1 and not args.no_cpu_baseline:
+            out["parity_vs_skani"] = golden_parity(dev)
         if world == 1 and not args.no_cpu_baseline and args.e2e_genomes > 0:
             import shutil
             tmp, paths, nbytes = write_sample_files(batches, args.e2e_genomes)
