@@ -101,3 +101,17 @@ def test_synthetic_recipe_is_deterministic_and_structured():
     ident_species = (g0[:m] == g20[:m]).mean()        # different species: ~0.25
     assert ident_isolate > ident_strain > 0.6 and ident_species < 0.3
     assert ident_isolate > 0.99
+
+
+def test_synthetic_recipe_mixed_lengths():
+    """len_range (BASELINE config 5's 1-8 Mb shape): species lengths fall in the range, genomes of one species
+    share their length, and the default recipe's random stream is untouched by the option"""
+    from skder_amd import synth
+    r = synth.make_recipe(300, n_species=6, len_range=(100_000, 800_000))
+    lens = np.array([r.total_len(g) for g in range(r.n)])
+    assert lens.min() >= 100_000 and lens.max() <= 800_000
+    for s in range(6):
+        assert len(set(lens[r.species == s])) == 1
+    assert len(set(lens)) == 6
+    a, b = synth.make_recipe(60, genome_len=50000, n_species=3), synth.make_recipe(60, genome_len=50000, n_species=3, len_range=None)
+    assert all(np.array_equal(x, y) for x, y in zip(a.rec_lens, b.rec_lens))
