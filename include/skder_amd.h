@@ -119,14 +119,17 @@ int skder_amd_sketches_index(skder_sketches_t *s);
 typedef struct {
     uint32_t ref;            /* genome index on the reference side */
     uint32_t query;          /* genome index on the query side */
-    double ani;              /* fraction, after calibration */
+    double ani;              /* fraction, after the ANI model of skder_amd_spec.h (what the TSV prints) */
     double af_ref;
     double af_query;
-    uint32_t n_chains;
+    uint32_t n_chains;       /* kept chains */
     uint32_t n_anchors;
     uint64_t aligned_bases;
-    int64_t ani_fx_sum;
-    uint64_t sum_seeds;
+    uint64_t sum_anchors;    /* A: anchors in the kept chains */
+    uint64_t sum_seeds;      /* S: seeds of the chunked genome inside the kept chains' spans */
+    uint64_t cell_seeds;     /* N: all seeds of the chunked genome in the 20 kb cells that hold a kept chain */
+    double ani_raw;          /* (A/N)^(1/15): the chunk-level k-mer estimate BEFORE the model, for callers with a
+                              * model of their own ((A/S)^(1/15), the span estimate, follows from the counts) */
 } skder_edge_t;
 
 /* Upper triangle rows i = row_begin, row_begin+row_stride, ... of `s` against all j > i:

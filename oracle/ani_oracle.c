@@ -57,11 +57,11 @@ void oracle_default_params(oracle_params_t *p)
 /* ------------------------------------------------------------------ hashing */
 
 /* minimap2's invertible 64-bit mix (Thomas Wang), which skani uses for FracMinHash sampling
- * (SURVEY R1).  The first step is `~key + (key << 21)`: with this form eight near-identical
- * golden pairs of G5 land within 0.03 AF points, with `~(key + (key << 21))` none do. */
+ * (SURVEY R1), with the first step as skani's Rust source spells it:
+ * `key = !key.wrapping_add(key << 21)` == ~(key + (key << 21)) -- see include/skder_amd_spec.h. */
 uint64_t oracle_mm_hash64(uint64_t key)
 {
-    key = ~key + (key << 21);
+    key = ~(key + (key << 21));
     key = key ^ (key >> 24);
     key = (key + (key << 3)) + (key << 8);
     key = key ^ (key >> 14);
@@ -366,14 +366,15 @@ int oracle_screen(const oracle_genome_t *a, const oracle_genome_t *b, double scr
     return (double)shared > cutoff * (double)mn;
 }
 
-/* ------------------------------------------------------------------ fixed-point root */
+/* ------------------------------------------------------------------ k-th root, ANI model */
 
-/* round(2^32 * (num/den)^(1/k)) by Newton iterations on doubles using only + - * / in a fixed
- * order (compile with -ffp-contract=off): bit-identical on host and device. */
-uint32_t oracle_root_fx(uint32_t num, uint32_t den, int k)
+/* (num/den)^(1/k) by Newton iterations on doubles using only + - * / in a fixed order (compile
+ * with -ffp-contract=off): bit-identical on host and device.  0 for an empty ratio, 1 when
+ * num >= den. */
+double oracle_root(uint64_t num, uint64_t den, int k)
 {
-    if (den == 0 || num == 0) return 0;
-    if (num >= den) return 0xFFFFFFFFu;
+    if (den == 0 || num == 0) return 0.0;
+    if (num >= den) return 1.0;
     double x = (double)num / (double)den;
     double y = 1.0;
     double km1 = (double)(k - 1), kk = (double)k;
@@ -382,32 +383,16 @@ uint32_t oracle_root_fx(uint32_t num, uint32_t den, int k)
         for (int i = 0; i < k - 1; i++) yp = yp * y;      /* y^(k-1) */
         y = (km1 * y + x / yp) / kk;
     }
-    double s = y * ANI_FX_ONE + 0.5;
-    if (s >= 4294967295.0) return 0xFFFFFFFFu;
-    return (uint32_t)s;
+    return y;
 }
 
-/* ------------------------------------------------------------------ calibration ("learned ANI") */
-
-/* skani's default output passes the chained k-mer ANI through a gradient-boosted regression
- * ("learned ANI") whose model is not reproducible here.  Stand-in: the piecewise-
- * linear map of include/skder_amd_spec.h on d = 100*(1 - ani_raw); slope 1 past the last knot. */
-double oracle_calibrate_ani(double ani_raw)
+/* skani's default output passes its chunk-level k-mer ANI through a gradient-boosted regression
+ * ("learned ANI") whose model is not reproducible here.  Stand-in: the two-parameter
+ * line of include/skder_amd_spec.h in the divergences of the cell and the span estimate. */
+double oracle_model_ani(double ani_cell, double ani_span)
 {
-    static const double cx[ANI_CAL_N] = ANI_CAL_X;
-    static const double cy[ANI_CAL_N] = ANI_CAL_Y;
-    double d = 100.0 * (1.0 - ani_raw);
-    if (d < 0.0) d = 0.0;
-    double out;
-    if (d >= cx[ANI_CAL_N - 1]) {
-        out = cy[ANI_CAL_N - 1] + (d - cx[ANI_CAL_N - 1]);
-    } else {
-        int i = 0;
-        while (i + 2 < ANI_CAL_N && d >= cx[i + 1]) i++;
-        double t = (d - cx[i]) / (cx[i + 1] - cx[i]);
-        out = cy[i] + t * (cy[i + 1] - cy[i]);
-    }
-    double a = 1.0 - out / 100.0;
+    double d = ANI_CAL_CELL * (100.0 * (1.0 - ani_cell)) + ANI_CAL_SPAN * (100.0 * (1.0 - ani_span));
+    double a = 1.0 - d / 100.0;
     if (a < 0.0) a = 0.0;
     if (a > 1.0) a = 1.0;
     return a;
@@ -511,6 +496,8 @@ int oracle_pair(const oracle_genome_t *ref, const oracle_genome_t *query, const 
     size_t nch = 0, chcap = 1024;
     oracle_chain_t *C = (oracle_chain_t *)malloc(chcap * sizeof(oracle_chain_t));
     uint32_t n_chunks = 0;
+    size_t ckcap = 1024;
+    uint32_t *cell_seeds = (uint32_t *)malloc(ckcap * sizeof(uint32_t));   /* per chunk with anchors: ALL seeds of its 20 kb cell */
 
     /* 2. chunks: (record, (gpos - record_off) / chunk_len) of the chunked genome */
     size_t s = 0;
@@ -571,7 +558,19 @@ int oracle_pair(const oracle_genome_t *ref, const oracle_genome_t *query, const 
             C[nch].r0 = rmin; C[nch].r1 = rmax;
             C[nch].rctg = A[endi].rctg;
             C[nch].kept = 1;
+            C[nch].chunk = n_chunks;
             nch++;
+        }
+        /* seeds of the chunked genome in this cell: gpos in [cell start, cell end) of record qc */
+        {
+            uint32_t g0 = Q->ctg_off[qc] + ck * (uint32_t)p->chunk_len;
+            uint64_t g1 = (uint64_t)g0 + (uint64_t)p->chunk_len;
+            if (g1 > Q->ctg_off[qc + 1]) g1 = Q->ctg_off[qc + 1];
+            uint32_t lo = A[s].qi, hi = A[e - 1].qi + 1;
+            while (lo > 0 && Q->s_ctg[lo - 1] == qc && Q->s_gpos[lo - 1] >= g0) lo--;
+            while (hi < Q->n_seeds && Q->s_ctg[hi] == qc && (uint64_t)Q->s_gpos[hi] < g1) hi++;
+            if (n_chunks == ckcap) { ckcap *= 2; cell_seeds = (uint32_t *)realloc(cell_seeds, ckcap * sizeof(uint32_t)); }
+            cell_seeds[n_chunks] = hi - lo;
         }
         n_chunks++;
         s = e;
@@ -595,20 +594,25 @@ int oracle_pair(const oracle_genome_t *ref, const oracle_genome_t *query, const 
         }
     }
 
-    /* 6. per-chain containment ANI in fixed point, weighted by seeds in span; aligned bases */
-    for (size_t i = 0; i < nch; i++) {
-        if (!C[i].kept) continue;
-        uint32_t fx = oracle_root_fx(C[i].n_anchors, C[i].n_seeds, p->k);
-        out->ani_fx_sum += (int64_t)C[i].n_seeds * (int64_t)fx;
-        out->sum_seeds += C[i].n_seeds;
-        out->sum_anchors += C[i].n_anchors;
-        out->sum_span += (uint64_t)(C[i].q1 - C[i].q0);
-        out->n_chains++;
+    /* 6. sums over the kept chains; N = all seeds of the cells that hold a kept chain; the two
+     *    k-mer estimates and the model (include/skder_amd_spec.h) */
+    {
+        uint8_t *cell_used = (uint8_t *)calloc(n_chunks + 1, 1);
+        for (size_t i = 0; i < nch; i++) {
+            if (!C[i].kept) continue;
+            out->sum_seeds += C[i].n_seeds;
+            out->sum_anchors += C[i].n_anchors;
+            out->sum_span += (uint64_t)(C[i].q1 - C[i].q0);
+            out->n_chains++;
+            if (!cell_used[C[i].chunk]) { cell_used[C[i].chunk] = 1; out->cell_seeds += cell_seeds[C[i].chunk]; }
+        }
+        free(cell_used);
     }
     out->aligned_bases = out->sum_span + (uint64_t)p->pad * out->n_chains;
     if (out->sum_seeds) {
-        out->ani_raw = ((double)out->ani_fx_sum / (double)out->sum_seeds) / ANI_FX_ONE;
-        out->ani = p->learned ? oracle_calibrate_ani(out->ani_raw) : out->ani_raw;
+        out->ani_raw = oracle_root(out->sum_anchors, out->cell_seeds, p->k);
+        out->ani_span = oracle_root(out->sum_anchors, out->sum_seeds, p->k);
+        out->ani = p->learned ? oracle_model_ani(out->ani_raw, out->ani_span) : out->ani_raw;
     }
     double B = (double)out->aligned_bases;
     double afq = Q->total_len ? B / (double)Q->total_len : 0.0;
@@ -620,7 +624,7 @@ int oracle_pair(const oracle_genome_t *ref, const oracle_genome_t *query, const 
 
     if (chains_out)
         memcpy(chains_out, C, (nch < chain_cap ? nch : chain_cap) * sizeof(oracle_chain_t));
-    free(A); free(f); free(bp); free(used); free(order); free(C);
+    free(A); free(f); free(bp); free(used); free(order); free(C); free(cell_seeds);
     return 0;
 }
 

@@ -10,7 +10,8 @@
  * file restates skani's published algorithm (Shaw & Yu, Nat. Methods 2023; cited at
  * /root/reference/bin/skder:83-84) and is pinned ONLY against the five golden edge tables the
  * reference's own test run holds (tests/golden/G1..G5: 2-decimal ANI/AF, one species).  Measured
- * residual on G5 (561 pairs): AF rms 0.44 / max 1.4 points, ANI rms 0.16 / max 0.60 points; the
+ * residual on G5 (561 pairs): AF rms 0.37 / max 1.1 points, ANI rms 0.14 / max 0.43 points
+ * (held out: rms 0.15, oracle/fit_calibration.py); the
  * representative listings derived from G1/G5 are reproduced where the goldens are not knife-edge
  * (tests/test_oracle_golden.py).  Beyond those tables: **parity unpinned**.
  *
@@ -32,7 +33,7 @@ typedef struct {
     int32_t band, bp_band;              /* 50 anchors, 2500 bases */
     int32_t max_gap, max_lin;           /* 300, 5000 */
     int32_t anchor_score, min_anchors;  /* 20, 3 */
-    int32_t pad;                        /* 250 */
+    int32_t pad;                        /* 230 */
     int32_t small_pass, rep_floor;      /* 20, 30 */
     int32_t learned;                    /* 1: apply the calibration map (default) */
 } oracle_params_t;
@@ -71,6 +72,7 @@ typedef struct {
     uint32_t r0, r1;          /* min/max gpos on the other genome */
     uint32_t rctg;            /* kept-record index on the other genome */
     uint32_t kept;            /* 1 if it survived the overlap filter */
+    uint32_t chunk;           /* ordinal of its chunk among the chunks that hold anchors */
 } oracle_chain_t;
 
 typedef struct {
@@ -80,12 +82,13 @@ typedef struct {
     uint32_t n_chains_all;    /* chains before the overlap filter */
     uint32_t n_chains;        /* kept chains */
     uint64_t sum_anchors;     /* anchors in kept chains */
-    uint64_t sum_seeds;       /* = w_sum: chunked-genome seeds inside kept chain spans */
+    uint64_t sum_seeds;       /* S: chunked-genome seeds inside kept chain spans */
     uint64_t sum_span;        /* sum of (q1 - q0) over kept chains */
     uint64_t aligned_bases;   /* B = sum_span + pad * n_chains */
-    int64_t  ani_fx_sum;      /* sum over kept chains of n_seeds * round(2^32 * (n_anchors/n_seeds)^(1/k)) */
-    double   ani_raw;         /* (ani_fx_sum / sum_seeds) / 2^32 */
-    double   ani;             /* after calibration; fraction */
+    uint64_t cell_seeds;      /* N: ALL chunked-genome seeds of the 20 kb cells that hold a kept chain */
+    double   ani_raw;         /* cell estimate (sum_anchors / cell_seeds)^(1/k) */
+    double   ani_span;        /* span estimate (sum_anchors / sum_seeds)^(1/k) */
+    double   ani;             /* after the two-estimate model; fraction */
     double   af_ref;          /* min(1, B / T_ref) */
     double   af_query;        /* min(1, B / T_query) */
 } oracle_pair_t;
@@ -98,8 +101,8 @@ int oracle_screen(const oracle_genome_t *a, const oracle_genome_t *b, double scr
 int oracle_pair(const oracle_genome_t *ref, const oracle_genome_t *query, const oracle_params_t *p,
                 oracle_pair_t *out, oracle_chain_t *chains, uint32_t chain_cap);
 
-uint32_t oracle_root_fx(uint32_t num, uint32_t den, int k);   /* round(2^32*(num/den)^(1/k)), capped */
-double   oracle_calibrate_ani(double ani_raw);
+double   oracle_root(uint64_t num, uint64_t den, int k);        /* (num/den)^(1/k), + - * / only */
+double   oracle_model_ani(double ani_cell, double ani_span);    /* include/skder_amd_spec.h ANI model */
 uint64_t oracle_mm_hash64(uint64_t key);
 
 /* drop-in drivers (listing in, TSV out), mirroring the skani sub-commands skDER spawns */

@@ -18,15 +18,15 @@ class Params(C.Structure):
 class Chain(C.Structure):
     _fields_ = [("score", C.c_int32), ("n_anchors", C.c_uint32), ("n_seeds", C.c_uint32),
                 ("q0", C.c_uint32), ("q1", C.c_uint32), ("r0", C.c_uint32), ("r1", C.c_uint32),
-                ("rctg", C.c_uint32), ("kept", C.c_uint32)]
+                ("rctg", C.c_uint32), ("kept", C.c_uint32), ("chunk", C.c_uint32)]
 
 
 class Pair(C.Structure):
     _fields_ = [("chunked_query", C.c_int32), ("n_anchors", C.c_uint32), ("n_chunks", C.c_uint32),
                 ("n_chains_all", C.c_uint32), ("n_chains", C.c_uint32),
                 ("sum_anchors", C.c_uint64), ("sum_seeds", C.c_uint64), ("sum_span", C.c_uint64),
-                ("aligned_bases", C.c_uint64), ("ani_fx_sum", C.c_int64),
-                ("ani_raw", C.c_double), ("ani", C.c_double),
+                ("aligned_bases", C.c_uint64), ("cell_seeds", C.c_uint64),
+                ("ani_raw", C.c_double), ("ani_span", C.c_double), ("ani", C.c_double),
                 ("af_ref", C.c_double), ("af_query", C.c_double)]
 
 
@@ -60,10 +60,10 @@ def lib():
         L.oracle_pair.restype = C.c_int
         L.oracle_pair.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Params), C.POINTER(Pair),
                                   C.c_void_p, C.c_uint32]
-        L.oracle_root_fx.restype = C.c_uint32
-        L.oracle_root_fx.argtypes = [C.c_uint32, C.c_uint32, C.c_int]
-        L.oracle_calibrate_ani.restype = C.c_double
-        L.oracle_calibrate_ani.argtypes = [C.c_double]
+        L.oracle_root.restype = C.c_double
+        L.oracle_root.argtypes = [C.c_uint64, C.c_uint64, C.c_int]
+        L.oracle_model_ani.restype = C.c_double
+        L.oracle_model_ani.argtypes = [C.c_double, C.c_double]
         L.oracle_mm_hash64.restype = C.c_uint64
         L.oracle_mm_hash64.argtypes = [C.c_uint64]
         for fn, nstr in (("oracle_triangle", 1), ("oracle_dist", 2), ("oracle_search", 2)):
@@ -150,7 +150,7 @@ def pair(ref: Genome, query: Genome, p: Params, chains: bool = False):
     buf = (Chain * cap)()
     lib().oracle_pair(ref.h, query.h, C.byref(p), C.byref(out), buf, cap)
     n = min(out.n_chains_all, cap)
-    arr = np.frombuffer(buf, dtype=np.uint32, count=9 * n).reshape(n, 9).copy()
+    arr = np.frombuffer(buf, dtype=np.uint32, count=10 * n).reshape(n, 10).copy()
     return out, arr
 
 

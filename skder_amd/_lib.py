@@ -28,7 +28,8 @@ class RawView(C.Structure):
 class Edge(C.Structure):
     _fields_ = [("ref", C.c_uint32), ("query", C.c_uint32), ("ani", C.c_double), ("af_ref", C.c_double),
                 ("af_query", C.c_double), ("n_chains", C.c_uint32), ("n_anchors", C.c_uint32),
-                ("aligned_bases", C.c_uint64), ("ani_fx_sum", C.c_int64), ("sum_seeds", C.c_uint64)]
+                ("aligned_bases", C.c_uint64), ("sum_anchors", C.c_uint64), ("sum_seeds", C.c_uint64),
+                ("cell_seeds", C.c_uint64), ("ani_raw", C.c_double)]
 
 
 # every symbol include/skder_amd.h declares: name -> (restype, argtypes)

@@ -49,14 +49,14 @@ struct PairDesc {
 
 struct ChainRec {
     int32_t score;
-    uint32_t n, n_seeds, q0, q1, r0, r1, rctg;
+    uint32_t n, n_seeds, q0, q1, r0, r1, chunk;   // chunk: index of the chain's 20 kb cell inside its pair
 };
 
 struct PairOut {
-    int64_t fx_sum;
+    uint64_t cell_seeds;               // all seeds of the chunked genome in the cells that hold a kept chain
     uint64_t sum_seeds, sum_anchors, sum_span;
     uint32_t n_chains, n_chains_all, n_anchors, pad;
-    double ani_raw, ani, af_q, af_r;   // q = chunked genome
+    double ani_raw, ani_span, ani, af_q, af_r;   // q = chunked genome
 };
 
 #define USED_BIT 0x80000000u
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256, CF_OCC) void chain_fast_kernel(SetView A, SetV
                 { /* a predecessor lies strictly behind on the other genome too: the path's extent there is spanned by its two ends */ \
                   const uint32_t rl_ = (E).rr_last & HIT_POS_MASK;                            \
                   cr.r0 = rl_ < (E).r_pfirst ? rl_ : (E).r_pfirst; cr.r1 = rl_ > (E).r_pfirst ? rl_ : (E).r_pfirst; } \
-                cr.rctg = ((E).rr_last >> HIT_POS_BITS) & 63u; \
+                cr.chunk = c; \
                 slots[nfin++] = cr;                                                          \
             }                                                                                \
         }                                                                                    \
@@ -1004,7 +1004,7 @@ __global__ __launch_bounds__(256) void slow_chain_kernel(SetView A, SetView B, c
             c.q0 = qg[qi[first]];
             c.q1 = qg[qi[besti]];
             c.r0 = rmin; c.r1 = rmax;
-            c.rctg = ac[besti];
+            c.chunk = t - pd.chunk_base;
             chains[pd.c_base + slot] = c;
         } else {
             atomicOr(&flags[0], 8u);
@@ -1213,7 +1213,7 @@ __global__ __launch_bounds__(64 * SLOWW_WAVES) void slow_wave_kernel(SetView A, 
                 if (slot < pd.c_cap) {
                     ChainRec cr;
                     cr.score = bestv; cr.n = cnt; cr.n_seeds = qi[besti] - qi[first] + 1;
-                    cr.q0 = qp[first]; cr.q1 = qp[besti]; cr.r0 = rmin; cr.r1 = rmax; cr.rctg = ac[besti];
+                    cr.q0 = qp[first]; cr.q1 = qp[besti]; cr.r0 = rmin; cr.r1 = rmax; cr.chunk = c;
                     chains[pd.c_base + slot] = cr;
                 } else {
                     atomicOr(&flags[0], 8u);
@@ -1225,11 +1225,11 @@ __global__ __launch_bounds__(64 * SLOWW_WAVES) void slow_wave_kernel(SetView A, 
     }   // declined chunks of this wave
 }
 
-// round(2^32 * (num/den)^(1/15)): Newton on doubles, + - * / only (oracle_root_fx)
-__device__ __forceinline__ uint32_t root_fx(uint32_t num, uint32_t den)
+// (num/den)^(1/15): Newton on doubles, + - * / only (ani_oracle.c oracle_root)
+__device__ __forceinline__ double root_k(uint64_t num, uint64_t den)
 {
-    if (den == 0 || num == 0) return 0;
-    if (num >= den) return 0xFFFFFFFFu;
+    if (den == 0 || num == 0) return 0.0;
+    if (num >= den) return 1.0;
     const double x = (double)num / (double)den;
     double y = 1.0;
     const double km1 = (double)(ANI_K - 1), kk = (double)ANI_K;
@@ -1239,36 +1239,14 @@ __device__ __forceinline__ uint32_t root_fx(uint32_t num, uint32_t den)
         for (int i = 0; i < ANI_K - 1; i++) yp = yp * y;
         y = (km1 * y + x / yp) / kk;
     }
-    const double s = y * ANI_FX_ONE + 0.5;
-    if (s >= 4294967295.0) return 0xFFFFFFFFu;
-    return (uint32_t)s;
+    return y;
 }
 
-// root_fx for every (num, den) below ROOT_LUT: filled once per context by the same device function, so
-// a table hit is bit-identical with the direct computation
-#define ROOT_LUT 256
-__global__ __launch_bounds__(256) void root_lut_kernel(uint32_t *__restrict__ lut)
+// the two-estimate ANI model of include/skder_amd_spec.h (ani_oracle.c oracle_model_ani)
+__device__ __forceinline__ double model_ani(double ani_cell, double ani_span)
 {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < ROOT_LUT * ROOT_LUT) lut[i] = root_fx(i / ROOT_LUT, i % ROOT_LUT);
-}
-
-__device__ __forceinline__ double calibrate_ani(double ani_raw)
-{
-    const double cx[ANI_CAL_N] = ANI_CAL_X;
-    const double cy[ANI_CAL_N] = ANI_CAL_Y;
-    double d = 100.0 * (1.0 - ani_raw);
-    if (d < 0.0) d = 0.0;
-    double out;
-    if (d >= cx[ANI_CAL_N - 1]) {
-        out = cy[ANI_CAL_N - 1] + (d - cx[ANI_CAL_N - 1]);
-    } else {
-        int i = 0;
-        while (i + 2 < ANI_CAL_N && d >= cx[i + 1]) i++;
-        const double t = (d - cx[i]) / (cx[i + 1] - cx[i]);
-        out = cy[i] + t * (cy[i + 1] - cy[i]);
-    }
-    double a = 1.0 - out / 100.0;
+    const double d = ANI_CAL_CELL * (100.0 * (1.0 - ani_cell)) + ANI_CAL_SPAN * (100.0 * (1.0 - ani_span));
+    double a = 1.0 - d / 100.0;
     if (a < 0.0) a = 0.0;
     if (a > 1.0) a = 1.0;
     return a;
@@ -1295,7 +1273,7 @@ __global__ __launch_bounds__(256) void finalize_kernel_t(SetView A, SetView B, c
                                                          const ChainRec *__restrict__ fast_chains, const uint32_t *__restrict__ chunk_state,
                                                          const ChainRec *__restrict__ chains, const uint32_t *__restrict__ pair_nch,
                                                          const uint32_t *__restrict__ pair_na, PairOut *__restrict__ out,
-                                                         uint32_t *__restrict__ flags, const uint32_t *__restrict__ root_lut, uint32_t cap_arg,
+                                                         uint32_t *__restrict__ flags, uint32_t *__restrict__ chunk_mark, uint32_t cap_arg,
                                                          unsigned char *__restrict__ gws, const uint64_t *__restrict__ goff,
                                                          const uint32_t *__restrict__ glist, const uint32_t *__restrict__ gcap)
 {
@@ -1306,15 +1284,15 @@ __global__ __launch_bounds__(256) void finalize_kernel_t(SetView A, SetView B, c
     unsigned char *const arrays = GLOBAL ? gws + goff[blockIdx.x] : fin_smem;
     int32_t *sc = reinterpret_cast<int32_t *>(arrays);
     uint32_t *q0 = reinterpret_cast<uint32_t *>(arrays) + lds_cap, *q1 = q0 + lds_cap, *r0 = q1 + lds_cap, *r1 = r0 + lds_cap;
-    uint32_t *rc = r1 + lds_cap, *na = rc + lds_cap, *nsd = na + lds_cap;
+    uint32_t *ckc = r1 + lds_cap, *na = ckc + lds_cap, *nsd = na + lds_cap;   // ckc: the chain's chunk inside the pair
     uint8_t *state = reinterpret_cast<uint8_t *>(nsd + lds_cap);   // 0 unknown, 1 kept, 2 dropped
     uint16_t *order = reinterpret_cast<uint16_t *>(state + lds_cap);  // chain indices grouped by bin
-    __shared__ unsigned long long s_fx, s_seeds, s_anch, s_span;
+    __shared__ unsigned long long s_cells, s_seeds, s_anch, s_span;
     __shared__ uint32_t s_kept, s_unknown, s_n;
 
     const PairDesc pd = pairs[pidx];
     const uint32_t tid = threadIdx.x;
-    if (tid == 0) { s_fx = 0; s_seeds = 0; s_anch = 0; s_span = 0; s_kept = 0; s_unknown = 0; s_n = 0; }
+    if (tid == 0) { s_cells = 0; s_seeds = 0; s_anch = 0; s_span = 0; s_kept = 0; s_unknown = 0; s_n = 0; }
     __syncthreads();
     // gather: chains of the fast path (per-chunk slots) and of the slow path (per-pair list)
     uint32_t nslow = pair_nch[pidx];
@@ -1332,7 +1310,7 @@ __global__ __launch_bounds__(256) void finalize_kernel_t(SetView A, SetView B, c
         }
         const uint32_t d = atomicAdd(&s_n, 1u);
         if (d < lds_cap) {
-            sc[d] = c.score; q0[d] = c.q0; q1[d] = c.q1; r0[d] = c.r0; r1[d] = c.r1; rc[d] = c.rctg;
+            sc[d] = c.score; q0[d] = c.q0; q1[d] = c.q1; r0[d] = c.r0; r1[d] = c.r1; ckc[d] = c.chunk;
             na[d] = c.n; nsd[d] = c.n_seeds;
             state[d] = 0;
         }
@@ -1431,26 +1409,37 @@ __global__ __launch_bounds__(256) void finalize_kernel_t(SetView A, SetView B, c
         __syncthreads();
         if (!u) break;
     }
-    unsigned long long fx = 0, sd = 0, an = 0, sp = 0;
+    // sums over the kept chains; the cells (chunks) that hold one are marked in global memory -- a pair
+    // can have any number of chunks -- and their seed counts summed from the chunk table afterwards
+    uint32_t *mark = chunk_mark + pd.chunk_base;
+    for (uint32_t i = tid; i < pd.n_chunks; i += 256) mark[i] = 0u;
+    __syncthreads();
+    unsigned long long sd = 0, an = 0, sp = 0, cs = 0;
     uint32_t kept = 0;
     for (uint32_t i = tid; i < n; i += 256) {
         if (state[i] != 1) continue;
-        const uint32_t rf = (na[i] < ROOT_LUT && nsd[i] < ROOT_LUT) ? root_lut[na[i] * ROOT_LUT + nsd[i]] : root_fx(na[i], nsd[i]);
-        fx += (unsigned long long)nsd[i] * (unsigned long long)rf;
         sd += nsd[i];
         an += na[i];
         sp += q1[i] - q0[i];
         kept++;
+        mark[ckc[i]] = 1u;
+    }
+    __syncthreads();
+    {
+        const SetView &QS = (pd.flags & 2u) ? B : A;
+        const uint32_t *cst = QS.chunk_start + QS.meta[pd.q].chunk_off;
+        for (uint32_t i = tid; i < pd.n_chunks; i += 256)
+            if (mark[i]) cs += cst[i + 1] - cst[i];
     }
     // wave-level reduction first: 4 LDS atomics per sum and workgroup instead of 256
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-        fx += __shfl_down(fx, o, 64); sd += __shfl_down(sd, o, 64);
+        cs += __shfl_down(cs, o, 64); sd += __shfl_down(sd, o, 64);
         an += __shfl_down(an, o, 64); sp += __shfl_down(sp, o, 64);
         kept += __shfl_down(kept, o, 64);
     }
-    if ((tid & 63u) == 0 && kept) {
-        atomicAdd(&s_fx, fx); atomicAdd(&s_seeds, sd); atomicAdd(&s_anch, an); atomicAdd(&s_span, sp);
+    if ((tid & 63u) == 0 && (kept || cs)) {
+        atomicAdd(&s_cells, cs); atomicAdd(&s_seeds, sd); atomicAdd(&s_anch, an); atomicAdd(&s_span, sp);
         atomicAdd(&s_kept, kept);
     }
     __syncthreads();
@@ -1458,12 +1447,13 @@ __global__ __launch_bounds__(256) void finalize_kernel_t(SetView A, SetView B, c
         const SetView &QS = (pd.flags & 2u) ? B : A;
         const SetView &RS = (pd.flags & 4u) ? B : A;
         PairOut o;
-        o.fx_sum = (int64_t)s_fx; o.sum_seeds = s_seeds; o.sum_anchors = s_anch; o.sum_span = s_span;
+        o.cell_seeds = s_cells; o.sum_seeds = s_seeds; o.sum_anchors = s_anch; o.sum_span = s_span;
         o.n_chains = s_kept; o.n_chains_all = n; o.n_anchors = pair_na[pidx]; o.pad = 0;
-        o.ani_raw = 0.0; o.ani = 0.0;
+        o.ani_raw = 0.0; o.ani_span = 0.0; o.ani = 0.0;
         if (s_seeds) {
-            o.ani_raw = ((double)o.fx_sum / (double)s_seeds) / ANI_FX_ONE;
-            o.ani = calibrate_ani(o.ani_raw);
+            o.ani_raw = root_k(s_anch, s_cells);
+            o.ani_span = root_k(s_anch, s_seeds);
+            o.ani = model_ani(o.ani_raw, o.ani_span);
         }
         const double Bv = (double)(s_span + (unsigned long long)ANI_PAD * s_kept);
         const uint64_t tq = QS.meta[pd.q].total_len, tr = RS.meta[pd.r].total_len;
@@ -1506,7 +1496,7 @@ static bool chunk_the_query(const GenomeMeta &ref, const GenomeMeta &query)
 // post-processes the other slot's results and prepares the descriptors of the next batch.
 struct ChainSlot {
     DevBuf<PairDesc> d_pairs;
-    DevBuf<uint32_t> chunk_state, slow_list, counters, pair_na, pair_nch;
+    DevBuf<uint32_t> chunk_state, chunk_mark, slow_list, counters, pair_na, pair_nch;
     DevBuf<uint32_t> hits, pair_nmulti, groups, over_list, flags;
     DevBuf<uint4> multi;
     DevBuf<ChainRec> fast_chains, chains;
@@ -1538,7 +1528,6 @@ struct ChainWork {
     DevBuf<uint32_t> cap, abase, slow_n, a_qi, a_r, a_rctg, BP;
     DevBuf<int32_t> F;
     DevBuf<uint64_t> ORD;
-    DevBuf<uint32_t> root_lut;
     ScanWorkspace ws;
 };
 static ChainWork *chain_work(skder_ctx *ctx)
@@ -1560,10 +1549,6 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
     size_t budget = 6u << 20;   // chunks (work items) per batch
     if (const char *e = getenv("SKDER_AMD_CHUNK_BUDGET")) budget = strtoull(e, nullptr, 10);
     ChainWork &W = *chain_work(ctx);
-    if (!W.root_lut.p) {
-        W.root_lut.resize(ROOT_LUT * ROOT_LUT, st);
-        hipLaunchKernelGGL(root_lut_kernel, dim3(ROOT_LUT * ROOT_LUT / 256), dim3(256), 0, st, W.root_lut.p);
-    }
     const SetView VA = view_of(SA), VB = view_of(SB);
     // debugging switches: SKDER_AMD_NO_XCD keeps the launch order; SKDER_AMD_FORCE_SLOW sends every chunk down the slow path;
     // SKDER_AMD_FAST_ONLY_CHUNK=k lets only chunk k of a batch take the fast path (to find the chunk behind a parity failure)
@@ -1661,7 +1646,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         S.lds_cap = lds_cap;
         if (nb)
             hipLaunchKernelGGL(finalize_kernel_t<false>, dim3(nb), dim3(256), lds_cap * 35u, st, VA, VB, S.d_pairs.p, S.fast_chains.p, S.chunk_state.p,
-                               S.chains.p, S.pair_nch.p, S.pair_na.p, S.d_out.p, S.flags.p, W.root_lut.p, lds_cap, nullptr, nullptr, nullptr, nullptr);
+                               S.chains.p, S.pair_nch.p, S.pair_na.p, S.d_out.p, S.flags.p, S.chunk_mark.p, lds_cap, nullptr, nullptr, nullptr, nullptr);
         HIPCHECK(hipGetLastError());     // a rejected launch (resources) must not pass as an empty result
         HIPCHECK(hipEventRecord(S.ev[4], st));
         HIPCHECK(hipMemcpyAsync(S.h_out, S.d_out.p, nb * sizeof(PairOut), hipMemcpyDeviceToHost, st));
@@ -1707,7 +1692,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         }
         const auto t_al0 = std::chrono::steady_clock::now();
         S.d_pairs.resize(nb, st);
-        S.chunk_state.resize(nchunks + 1, st); S.slow_list.resize(nchunks + 1, st); S.over_list.resize(nchunks + 1, st);
+        S.chunk_state.resize(nchunks + 1, st); S.chunk_mark.resize(nchunks + 1, st); S.slow_list.resize(nchunks + 1, st); S.over_list.resize(nchunks + 1, st);
         S.fast_chains.resize(nchunks * FAST_SLOTS + 1, st);
         S.counters.resize(16, st); S.flags.resize(16, st);
         S.pair_na.resize(nb, st); S.pair_nch.resize(nb, st); S.pair_nmulti.resize(nb, st);
@@ -1787,7 +1772,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         //  * flag 16: a pair has more chains than the LDS capacity chosen for finalize: again at 4096.
         auto finalize_and_fetch = [&]() {
             hipLaunchKernelGGL(finalize_kernel_t<false>, dim3(nb), dim3(256), S.lds_cap * 35u, st, VA, VB, S.d_pairs.p, S.fast_chains.p, S.chunk_state.p,
-                               S.chains.p, S.pair_nch.p, S.pair_na.p, S.d_out.p, S.flags.p, W.root_lut.p, S.lds_cap, nullptr, nullptr, nullptr, nullptr);
+                               S.chains.p, S.pair_nch.p, S.pair_na.p, S.d_out.p, S.flags.p, S.chunk_mark.p, S.lds_cap, nullptr, nullptr, nullptr, nullptr);
             HIPCHECK(hipGetLastError());
             HIPCHECK(hipMemcpyAsync(S.h_out, S.d_out.p, nb * sizeof(PairOut), hipMemcpyDeviceToHost, st));
             HIPCHECK(hipMemcpyAsync(S.h_cnt + 16, S.flags.p, 4, hipMemcpyDeviceToHost, st));
@@ -1863,7 +1848,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
                     HIPCHECK(hipMemcpyAsync(d_off.p, goff.data(), ng * 8, hipMemcpyHostToDevice, st));
                     HIPCHECK(hipMemsetAsync(S.flags.p, 0, 64, st));
                     hipLaunchKernelGGL(finalize_kernel_t<true>, dim3((unsigned)ng), dim3(256), 0, st, VA, VB, S.d_pairs.p, S.fast_chains.p,
-                                       S.chunk_state.p, S.chains.p, S.pair_nch.p, S.pair_na.p, S.d_out.p, S.flags.p, W.root_lut.p, 0u, gws.p,
+                                       S.chunk_state.p, S.chains.p, S.pair_nch.p, S.pair_na.p, S.d_out.p, S.flags.p, S.chunk_mark.p, 0u, gws.p,
                                        d_off.p, d_list.p, d_cap.p);
                     HIPCHECK(hipGetLastError());
                     HIPCHECK(hipMemcpyAsync(S.h_out, S.d_out.p, nb * sizeof(PairOut), hipMemcpyDeviceToHost, st));
@@ -1889,7 +1874,8 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
             e.af_ref = cq ? o.af_r : o.af_q;
             e.n_chains = o.n_chains; e.n_anchors = o.n_anchors;
             e.aligned_bases = o.sum_span + (uint64_t)ANI_PAD * o.n_chains;
-            e.ani_fx_sum = o.fx_sum; e.sum_seeds = o.sum_seeds;
+            e.sum_anchors = o.sum_anchors; e.sum_seeds = o.sum_seeds; e.cell_seeds = o.cell_seeds;
+            e.ani_raw = o.ani_raw;
             edges.push_back(e);
         }
     };

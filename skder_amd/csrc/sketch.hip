@@ -25,7 +25,7 @@
 
 __device__ __forceinline__ uint64_t mm_hash64(uint64_t key)
 {
-    key = ~key + (key << 21);
+    key = ~(key + (key << 21));      // skani's Rust spelling of the first step: include/skder_amd_spec.h
     key = key ^ (key >> 24);
     key = (key + (key << 3)) + (key << 8);
     key = key ^ (key >> 14);

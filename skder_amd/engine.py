@@ -12,7 +12,7 @@ from ._lib import Batch, Edge, RawView, SKDER_TILE
 
 EDGE_DTYPE = np.dtype([("ref", "<u4"), ("query", "<u4"), ("ani", "<f8"), ("af_ref", "<f8"), ("af_query", "<f8"),
                        ("n_chains", "<u4"), ("n_anchors", "<u4"), ("aligned_bases", "<u8"),
-                       ("ani_fx_sum", "<i8"), ("sum_seeds", "<u8")])
+                       ("sum_anchors", "<u8"), ("sum_seeds", "<u8"), ("cell_seeds", "<u8"), ("ani_raw", "<f8")])
 assert EDGE_DTYPE.itemsize == C.sizeof(Edge)
 
 

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     from skder_amd import _lib, engine
-    assert C.sizeof(_lib.Edge) == 64 and engine.EDGE_DTYPE.itemsize == 64
+    assert C.sizeof(_lib.Edge) == 80 and engine.EDGE_DTYPE.itemsize == 80
     assert C.sizeof(_lib.Batch) == 32
     assert C.sizeof(_lib.RawView) == 8 + 3 * 8 + 9 * 8
 

@@ -143,7 +143,8 @@ def _check_edges(edges, want):
         assert int(e["n_anchors"]) == r.n_anchors, (k, "anchors", int(e["n_anchors"]), r.n_anchors)
         assert int(e["n_chains"]) == r.n_chains, (k, "chains", int(e["n_chains"]), r.n_chains)
         assert int(e["sum_seeds"]) == r.sum_seeds, (k, "seeds")
-        assert int(e["ani_fx_sum"]) == r.ani_fx_sum, (k, "fx")
+        assert int(e["sum_anchors"]) == r.sum_anchors and int(e["cell_seeds"]) == r.cell_seeds, (k, "A/N")
+        assert float(e["ani_raw"]) == r.ani_raw, (k, "raw")
         assert int(e["aligned_bases"]) == r.aligned_bases, (k, "B")
         # doubles: bit-equal
         assert float(e["ani"]) == r.ani, (k, float(e["ani"]), r.ani)
@@ -360,7 +361,7 @@ def test_mixed_genome_sizes_multi_pass_join(gpu, oracle):
             pr = oracle.pair(og[r], og[g], p) if ok else None
             if pr is not None and pr.n_chains and pr.ani > 0:
                 e = got[(r, qi)]
-                assert int(e["ani_fx_sum"]) == pr.ani_fx_sum and float(e["ani"]) == pr.ani
+                assert int(e["cell_seeds"]) == pr.cell_seeds and float(e["ani"]) == pr.ani
                 assert float(e["af_ref"]) == pr.af_ref and float(e["af_query"]) == pr.af_query
             else:
                 assert (r, qi) not in got
@@ -942,7 +943,7 @@ def test_repeat_rich_randomized(gpu, oracle):
                 pr = oracle.pair(og[r], og[n - 2 + qi], p) if ok else None
                 if pr is not None and pr.n_chains and pr.ani > 0:
                     e = got[(r, qi)]
-                    assert int(e["ani_fx_sum"]) == pr.ani_fx_sum and float(e["ani"]) == pr.ani and int(e["sum_seeds"]) == pr.sum_seeds
+                    assert int(e["cell_seeds"]) == pr.cell_seeds and float(e["ani"]) == pr.ani and int(e["sum_seeds"]) == pr.sum_seeds
                     assert float(e["af_ref"]) == pr.af_ref and float(e["af_query"]) == pr.af_query
                 else:
                     assert (r, qi) not in got

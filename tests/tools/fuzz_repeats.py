@@ -111,7 +111,7 @@ def main():
                     pr = oracle.pair(og[r], og[g], p) if ok else None
                     if pr is not None and pr.n_chains and pr.ani > 0:
                         e = got[(r, qi)]
-                        assert int(e["ani_fx_sum"]) == pr.ani_fx_sum and float(e["ani"]) == pr.ani and int(e["sum_seeds"]) == pr.sum_seeds, ("rect", r, qi)
+                        assert int(e["cell_seeds"]) == pr.cell_seeds and float(e["ani"]) == pr.ani and int(e["sum_seeds"]) == pr.sum_seeds, ("rect", r, qi)
                         assert float(e["af_ref"]) == pr.af_ref and float(e["af_query"]) == pr.af_query, ("rect af", r, qi)
                     else:
                         assert (r, qi) not in got, ("rect extra", r, qi)
