@@ -154,6 +154,8 @@ int skder_amd_last_timing(skder_ctx_t *ctx, double *out8);
  * triangle_rows / rectangle start themselves for a set that is not indexed yet: it then runs beside
  * the marker screen on a second stream) */
 double skder_amd_last_index_ms(skder_ctx_t *ctx);
+/* device milliseconds of the run-extraction kernel (hit words -> run records) in the last triangle_rows / rectangle call */
+double skder_amd_last_runs_ms(skder_ctx_t *ctx);
 /* counters of the last triangle_rows/rectangle call: [0] chunks processed, [1] chunks that needed the
  * unabridged (slow) chaining path */
 int skder_amd_last_counters(skder_ctx_t *ctx, uint64_t *out4);

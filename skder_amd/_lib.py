@@ -59,6 +59,7 @@ SYMBOLS = {
     "skder_amd_last_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "skder_amd_last_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "skder_amd_last_index_ms": (C.c_double, [C.c_void_p]),
+    "skder_amd_last_runs_ms": (C.c_double, [C.c_void_p]),
     "skder_amd_synth_fill": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p]),
     "skder_amd_triangle_n50": (C.c_int, [C.c_char_p, C.c_double, C.c_double, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p,
                                          C.c_size_t]),

@@ -82,6 +82,7 @@ extern "C" int skder_amd_copy_d2d(skder_ctx_t *ctx, void *dst, const void *src, 
 }
 
 extern "C" double skder_amd_last_index_ms(skder_ctx_t *ctx) { return ctx ? ctx->timing_index : 0.0; }
+extern "C" double skder_amd_last_runs_ms(skder_ctx_t *ctx) { return ctx ? ctx->timing_runs : 0.0; }
 
 extern "C" int skder_amd_last_counters(skder_ctx_t *ctx, uint64_t *out4)
 {

@@ -4,9 +4,11 @@
 // bit-identical by construction, the few double operations are + - * / in the oracle's order
 // (this file is compiled with -ffp-contract=off).
 //
-//   chain_fast_kernel  one LANE per (pair, 20 kb chunk): seeds streamed, hash-table probes, banded DP
-//                      against a 4-anchor register ring; exact for "simple" chunks, which it proves
-//                      as it goes; everything else is handed to the slow path.
+//   join_probe_kernel  hit word of every (pair, seed of the chunked genome), the probed genome's index in LDS
+//   run_extract_kernel seed-parallel: runs of seeds that continue the previous hit -> run records per 256-seed segment
+//   chain_runs_kernel  one LANE per (pair, 20 kb chunk): banded DP over the chunk's run records against a
+//                      4-run register ring; exact for "simple" chunks, which it proves as it goes;
+//                      everything else is handed to the slow path.
 //   slow_*_kernel      unabridged algorithm for the declined chunks: ordered anchors via the bucket
 //                      index (one wave per chunk), full band-50 DP and best-first chain extraction
 //                      with back-tracking (one lane per chunk).
@@ -24,6 +26,7 @@
 struct SetView {
     const GenomeMeta *meta;
     const uint32_t *pkmer, *pgpos, *pchunk;   // position order
+    const uint8_t *pcs;                       // position order: 1 = first seed of its chunk
     const uint32_t *skmer, *sgpos, *sctg;     // bucket order
     const uint32_t *stag;                     // bucket order: sgpos | (sctg & 63) << 24 | strand of the k-mer << 31
     const uint32_t *boff;
@@ -36,10 +39,12 @@ struct PairDesc {
     uint32_t chunk_base;    // first work item (chunk) of this pair in the batch
     uint32_t n_chunks;
     uint32_t c_base, c_cap; // chain-record region of the slow path
-    uint32_t flags;         // bit0: chunked genome is the pair's Query; bit1: q in set B; bit2: r in set B
+    uint32_t flags;         // bit0: chunked genome is the pair's Query; bit1: q in set B; bit2: r in set B; bit3: every chunk takes the slow path
     uint32_t hit_base;      // first entry of this pair in the hit array (one u32 per seed of the chunked genome)
     uint32_t multi_base, multi_cap;   // region of 4-hit records for seeds with several hits
-    uint32_t pad[2];
+    uint32_t rec_base, rec_cap;   // region of the pair's run records
+    uint32_t q_chunk_off;         // offset of the chunked genome's chunk table (GenomeMeta::chunk_off)
+    uint32_t pad[3];              // 64 bytes: one cache line per descriptor
 };
 
 // hit[s] for seed s of the chunked genome: gpos on the other genome | rev<<31, or one of
@@ -289,38 +294,223 @@ __global__ __launch_bounds__(JOIN_THREADS) void join_probe_kernel(SetView A, Set
 }
 
 // ---------------------------------------------------------------------------------------------
-// FAST PATH: one lane per (pair, 20 kb chunk).
+// RUN EXTRACTION: seed-parallel, coalesced.  Most classified seeds of related genomes merely continue the
+// previous hit -- same record and strand, 1..2500 bases on, ahead on the other genome, and on the same
+// diagonal or at most RUN_GAP bases off it (real genomes carry a short indel every few hundred bases) --
+// so the chaining kernel is fed RUNS, maximal stretches of such seeds, instead of one word per seed.
+// Why RUN_GAP = 10 = anchor score / 2: along a run every link scores 20 - gap >= 10, and the offer of any
+// other anchor (constant score + 20 - diagonal distance) moves by at most the link's gap <= 10, so (1) inside
+// a run the previous anchor is always the best predecessor of the next one (nearest on ties) and (2) a
+// competitor that cannot beat the run at its second anchor never can (chain_runs_kernel checks that once).
+// One workgroup per pair; a wavefront takes a SEGMENT of 256 consecutive seeds (4 per lane: one 16-byte
+// load per input stream and lane) and classifies every seed against the previous hit (inside the lane in
+// registers, across lanes by ballots and shuffles, across waves through LDS).  A record is written where a
+// run STARTS and carries, besides its first seed, the hit in front of it and the pair's running counts of
+// hits and diagonal steps up to there: the end, the length and the step sum of a run are then read off the
+// NEXT record (a terminator closes the pair), so no reduction over a run is needed.  The four waves advance
+// in step through the pair's segments: the records of a pair are contiguous and in seed order (one LDS
+// exchange per round).  A run never crosses a segment or a chunk boundary; the chaining kernel joins the
+// pieces again through its ordinary look-back.  A seed with 2..4 occurrences, or too many, is a record of
+// its own.  The first record of every chunk is registered in chunk_rec0.  A pair with more records than its
+// region holds is marked: all its chunks take the slow path.
+struct __attribute__((aligned(16))) RunRec {
+    uint32_t qi, q0, hw, cn;      // first seed: index in the chunked genome, position, hit word (or HIT_MULTI | slot, HIT_MANY); hits of the pair in front of it
+    uint32_t pq, pw, pqi, cg;     // the hit in front of it: position, hit word, seed index; diagonal steps of the pair in front of it
+};
+#define SEG_SEEDS 256u
+#define RUN_GAP 10
+#define REC_OVER 0xFFFFFFFFu
+static_assert(2 * RUN_GAP <= ANI_ANCHOR_SCORE, "run links must keep at least half of the anchor score");
+
+__global__ __launch_bounds__(256) void run_extract_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs,
+                                                          const uint32_t *__restrict__ hits, RunRec *__restrict__ recs,
+                                                          uint32_t *__restrict__ pair_nrec, uint32_t *__restrict__ chunk_rec0)
+{
+    __shared__ uint32_t s_x[2][4][4];      // per round parity and wave: packed counts, last hit (position, word, seed) or ~0
+    const PairDesc pd = pairs[blockIdx.x];
+    const SetView &QS = (pd.flags & 2u) ? B : A;
+    const GenomeMeta *Qm = QS.meta + pd.q;
+    const uint32_t nq = Qm->n_seeds, a = (uint32_t)(Qm->seed_off & 3u), nv = nq + a;
+    // virtual seed index v = s + a: v = 0 sits on a 16-byte boundary of all three streams (the hit words of a pair
+    // start at an entry congruent to the genome's seed offset)
+    const uint32_t *qg_al = QS.pgpos + (Qm->seed_off - a);
+    const uint8_t *cs_al = QS.pcs + (Qm->seed_off - a);
+    const uint32_t *ck_of = QS.pchunk + Qm->seed_off;
+    const uint32_t *hit_al = hits + (pd.hit_base - a);
+    RunRec *out_base = recs + pd.rec_base;
+    uint32_t *rec0 = chunk_rec0 + pd.chunk_base;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t nseg = (nv + SEG_SEEDS - 1u) / SEG_SEEDS;
+    uint32_t run_rec = 0, run_nm = 0, run_g = 0;                     // totals of the rounds so far (uniform over the workgroup)
+    uint32_t car_q = 0, car_w = HIT_NONE, car_v = 0xFFFFFFFFu;       // last hit of the rounds so far
+    bool overflow = false;
+    for (uint32_t sg0 = 0; sg0 < nseg; sg0 += 4u) {
+        const uint32_t sg = sg0 + wv;
+        const uint32_t v0 = sg * SEG_SEEDS + lane * 4u;
+        uint32_t hv[4], qv[4], csw = 0;
+        if (v0 >= a && v0 + 4u <= nv) {
+            const uint4 h4 = *reinterpret_cast<const uint4 *>(hit_al + v0);
+            const uint4 q4 = *reinterpret_cast<const uint4 *>(qg_al + v0);
+            csw = *reinterpret_cast<const uint32_t *>(cs_al + v0);
+            hv[0] = h4.x; hv[1] = h4.y; hv[2] = h4.z; hv[3] = h4.w;
+            qv[0] = q4.x; qv[1] = q4.y; qv[2] = q4.z; qv[3] = q4.w;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t v = v0 + u;
+                const bool in = v >= a && v < nv;
+                hv[u] = in ? hit_al[v] : HIT_NONE;
+                qv[u] = in ? qg_al[v] : 0u;
+                csw |= in ? (uint32_t)cs_al[v] << (8 * u) : 0u;
+            }
+        }
+#define SEL4(X, I) ((I) == 0 ? X[0] : ((I) == 1 ? X[1] : ((I) == 2 ? X[2] : X[3])))
+        // A. the lane's own four seeds
+        uint32_t nmmask = 0, csmask = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            nmmask |= (hv[u] != HIT_NONE ? 1u : 0u) << u;
+            csmask |= ((csw >> (8 * u)) & 1u) << u;
+        }
+        const bool has_nm = nmmask != 0u;
+        const uint32_t ul = has_nm ? 31u - (uint32_t)__clz((int)nmmask) : 0u;
+        const uint32_t w_l = SEL4(hv, ul), q_l = SEL4(qv, ul);
+        // a chunk starts behind the lane's last hit (anywhere, if the lane has none): the next hit cannot continue
+        const bool tail_cs = has_nm ? (csmask >> (ul + 1u)) != 0u : csmask != 0u;
+        const unsigned long long M = __ballot(has_nm), T = __ballot(tail_cs);
+        // B. the previous hit, from the nearest lane below that has one
+        const unsigned long long below = M & ((1ull << lane) - 1ull);
+        const bool pin = below != 0ull;                       // the hit in front of the lane's seeds lies in this segment
+        const uint32_t P = pin ? 63u - (uint32_t)__clzll((long long)below) : 0u;
+        uint32_t pw = (uint32_t)__shfl((int)w_l, (int)P, 64), pq = (uint32_t)__shfl((int)q_l, (int)P, 64);
+        const uint32_t pv_in = (uint32_t)__shfl((int)(v0 + ul), (int)P, 64);
+        const uint32_t pw_in = pw, pq_in = pq;
+        const bool pv = pin && ((T >> P) & ((1ull << (lane - P)) - 1ull)) == 0ull;
+        // C. run starts among the lane's seeds; diagonal step of every continuing seed.  firstmask: starts that may be
+        // the first record of their chunk (a chunk began since the previous hit, or the previous hit is in another segment)
+        uint32_t startmask = 0, firstmask = 0, gl[4] = {0, 0, 0, 0};
+        bool pending = !pv;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if ((csmask >> u) & 1u) pending = true;
+            if ((nmmask >> u) & 1u) {
+                const uint32_t w = hv[u], q = qv[u];
+                const uint32_t sgw = (uint32_t)((int32_t)w >> 31), sgp = (uint32_t)((int32_t)pw >> 31);
+                const int32_t dgw = (int32_t)(((w & HIT_POS_MASK) ^ sgw) - q), dgp = (int32_t)(((pw & HIT_POS_MASK) ^ sgp) - pq);   // one value per diagonal
+                const int32_t dd = dgw - dgp, g = dd < 0 ? -dd : dd;
+                const int32_t drs = (int32_t)(w & HIT_POS_MASK) - (int32_t)(pw & HIT_POS_MASK);       // ahead on the other genome
+                const bool cont = !pending && !((w | pw) & 0x40000000u) && !((w ^ pw) & HIT_KEY_MASK) && g <= RUN_GAP &&
+                                  (q - pq) <= (uint32_t)ANI_BP_BAND && (sgw ? drs < 0 : drs > 0);
+                startmask |= (cont ? 0u : 1u) << u;
+                firstmask |= (pending ? 1u : 0u) << u;
+                gl[u] = cont ? (uint32_t)g : 0u;
+                pw = w; pq = q; pending = false;
+            }
+        }
+        // D. running counts in front of the lane: hits, records, diagonal steps (one packed scan)
+        const uint32_t cnt_l = (uint32_t)__popc(nmmask), nrec_l = (uint32_t)__popc(startmask);
+        const uint32_t g_l = gl[0] + gl[1] + gl[2] + gl[3];
+        uint32_t tot;
+        const uint32_t ex = wave_excl_scan(cnt_l | (nrec_l << 10) | (g_l << 20), tot);
+        // E. the four waves' records go behind one another: counts and last hits through LDS (one barrier per round)
+        const uint32_t par = (sg0 >> 2) & 1u;
+        const uint32_t topl = M ? 63u - (uint32_t)__clzll((long long)M) : 0u;
+        const uint32_t lq = (uint32_t)__shfl((int)q_l, (int)topl, 64), lw = (uint32_t)__shfl((int)w_l, (int)topl, 64);
+        const uint32_t lv = (uint32_t)__shfl((int)(v0 + ul), (int)topl, 64);
+        if (lane == 0) {
+            s_x[par][wv][0] = sg < nseg ? tot : 0u;
+            s_x[par][wv][1] = lq; s_x[par][wv][2] = lw; s_x[par][wv][3] = (M && sg < nseg) ? lv : 0xFFFFFFFFu;
+        }
+        __syncthreads();
+        uint32_t base_rec = run_rec, base_nm = run_nm, base_g = run_g;
+        uint32_t cq = car_q, cw = car_w, cv = car_v;            // the last hit in front of MY segment
+#pragma unroll
+        for (uint32_t w2 = 0; w2 < 4u; w2++) {
+            const uint32_t t0 = s_x[par][w2][0], tv = s_x[par][w2][3];
+            const uint32_t tq = s_x[par][w2][1], tw = s_x[par][w2][2];
+            if (w2 < wv) {
+                base_nm += t0 & 1023u; base_rec += (t0 >> 10) & 1023u; base_g += t0 >> 20;
+                if (tv != 0xFFFFFFFFu) { cq = tq; cw = tw; cv = tv; }
+            }
+            run_nm += t0 & 1023u; run_rec += (t0 >> 10) & 1023u; run_g += t0 >> 20;
+            if (tv != 0xFFFFFFFFu) { car_q = tq; car_w = tw; car_v = tv; }
+        }
+        if (run_rec + 1u > pd.rec_cap) { overflow = true; break; }      // + the terminator; uniform over the workgroup
+        if (!overflow && startmask) {
+            const uint32_t pex = ex & 1023u, rex = (ex >> 10) & 1023u, gex = ex >> 20;
+            uint32_t sm = startmask, j = 0;
+            while (sm) {
+                const uint32_t u = (uint32_t)__ffs((int)sm) - 1u;
+                sm &= sm - 1u;
+                RunRec r;
+                r.qi = v0 + u - a; r.q0 = SEL4(qv, u); r.hw = SEL4(hv, u);
+                const uint32_t lowm = nmmask & ((1u << u) - 1u);          // the lane's hits in front of this one
+                r.cn = base_nm + pex + (uint32_t)__popc(lowm);
+                uint32_t gs = 0;
+#pragma unroll
+                for (int x = 0; x < 4; x++) gs += ((uint32_t)x < u) ? gl[x] : 0u;
+                r.cg = base_g + gex + gs;
+                if (lowm) {
+                    const uint32_t lu = 31u - (uint32_t)__clz((int)lowm);
+                    r.pq = SEL4(qv, lu); r.pw = SEL4(hv, lu); r.pqi = v0 + lu - a;
+                } else if (pin) { r.pq = pq_in; r.pw = pw_in; r.pqi = pv_in - a; }
+                else { r.pq = cq; r.pw = cw; r.pqi = cv == 0xFFFFFFFFu ? 0xFFFFFFFFu : cv - a; }
+                out_base[base_rec + rex + j] = r;
+                if ((firstmask >> u) & 1u) atomicMin(&rec0[ck_of[r.qi]], base_rec + rex + j);
+                j++;
+            }
+        }
+#undef SEL4
+    }
+    if (threadIdx.x == 0) {
+        if (!overflow) {
+            RunRec r;       // terminator: closes the last run of the pair
+            r.qi = 0xFFFFFFFFu; r.q0 = 0; r.hw = HIT_NONE; r.cn = run_nm;
+            r.pq = car_q; r.pw = car_w; r.pqi = car_v == 0xFFFFFFFFu ? 0xFFFFFFFFu : car_v - a; r.cg = run_g;
+            out_base[run_rec] = r;
+        }
+        pair_nrec[blockIdx.x] = overflow ? REC_OVER : run_rec;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// FAST PATH on runs: one lane per (pair, 20 kb chunk).
 //
-// The lane streams the chunk's hit words (from the join) and seed positions and runs the banded
-// chaining DP of ani_oracle.c on a compressed state: a register ring of the 4 most recently touched
-// RUNS.  A run is a maximal stretch of anchors chained with zero gap cost (same record, strand and
-// diagonal); its scores rise by 20 per anchor, so among the anchors of a run only the last one can be
-// the best predecessor of a later anchor (it is nearer and scores higher) -- unless the later anchor
-// lies inside the run's own extent, which is detected and declined.  Extending a run is an in-place
-// update of a few registers; anything else walks the ring exactly like the oracle's look-back loop
-// (nearest first, strict '>', early exits on the running maximum / 2500-base band / 50-anchor band).
-// Runs that fall out of the ring are kept as summaries (best score, last position, diagonal range);
-// a look-back that would have to continue into them is accepted only if no summarised anchor can
-// reach the current best.  The lane proves as it goes that its result is the oracle's; a chunk where
-// the proof fails (branching chains, best end not last, too many hits or chains) goes to the slow path.
+// The lane reads the run records of its chunk (contiguous, in seed order, from chunk_rec0 on) and runs the
+// banded chaining DP of ani_oracle.c on a compressed
+// state: a register ring of the 4 most recently touched RUNS.  A run is a stretch of anchors each chained to
+// the one before at a gap cost of at most RUN_GAP (same record and strand, diagonal steps <= 10); its scores
+// rise by at least 10 per anchor while its diagonal moves by at most 10, so among the anchors of a run only
+// the last one can be the best predecessor of a later anchor (it is nearer and offers at least as much) --
+// unless the later anchor lies inside the run's own extent, which is detected and declined.
+// Every record is ONE step: its first anchor walks the ring exactly like the oracle's look-back loop
+// (nearest first, strict '>', early exits on the running maximum / 2500-base band / 50-anchor band); its
+// other n - 1 anchors follow at once when no other run or summary can offer any of them more than the run
+// itself does -- per anchor the run's own offer rises by 20 - gap >= 10 and an offer from elsewhere (score +
+// 20 - diagonal distance) by at most the gap <= 10, so the test at the second anchor covers all of them
+// (equal offers go to the nearest anchor, the run's own previous one).  Runs that fall out of the ring are kept as summaries (best
+// score, last position, diagonal range); a look-back that would have to continue into them is accepted only
+// if no summarised anchor can reach the current best.  The lane proves as it goes that its result is the
+// oracle's; a chunk where the proof fails (branching chains, best end not last, too many hits or chains)
+// goes to the slow path.  Rounds are uniform across the wavefront: every live lane takes one record per round.
 struct Run {
     uint32_t q_last, rr_last;         // last anchor: query pos; hit word (ref pos | record tag << 24 | rev << 31)
     int32_t f;                        // score of the last anchor
     uint32_t cnt;                     // anchors on the PATH ending at the last anchor | SUCC_BIT
-    uint32_t first_qi, q_first, r_pfirst;     // path aggregates: first seed index and its position (kept so that emitting a
-                                      // chain needs no load: a wait on one would also drain the input prefetch), ref extent
+    uint32_t first_qi, q_first, r_pfirst;     // path aggregates: first seed index and its position, ref extent
     uint32_t qi_last, idx_last;       // seed index / anchor ordinal of the last anchor
     int32_t pmax;                     // highest score among the earlier anchors of the path
     uint32_t r_first;                 // ref pos of the run's first anchor
     uint32_t seg;                     // summary key: changes along a path only at score-lowering indels
 };
 
-__global__ __launch_bounds__(256, CF_OCC) void chain_fast_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs, uint32_t npairs,
-                                                         uint32_t total_chunks, const uint32_t *__restrict__ hits,
-                                                         const uint4 *__restrict__ multi, ChainRec *__restrict__ fast_chains,
-                                                         uint32_t *__restrict__ chunk_state, uint32_t *__restrict__ slow_list,
-                                                         uint32_t *__restrict__ slow_count, uint32_t *__restrict__ pair_na,
-                                                         int xcd_remap)
+__global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs, uint32_t npairs,
+                                                         uint32_t total_chunks, const RunRec *__restrict__ recs,
+                                                         const uint32_t *__restrict__ pair_nrec, const uint32_t *__restrict__ chunk_rec0,
+                                                         const uint32_t *__restrict__ wg_pair, const uint4 *__restrict__ multi,
+                                                         ChainRec *__restrict__ fast_chains, uint32_t *__restrict__ chunk_state,
+                                                         uint32_t *__restrict__ slow_list, uint32_t *__restrict__ slow_count,
+                                                         uint32_t *__restrict__ pair_na, int xcd_remap)
 {
     // XCD-aware work mapping: workgroups are dealt round-robin to the 8 XCDs, so give every XCD one
     // contiguous eighth of the (R-sorted) work list
@@ -330,22 +520,21 @@ __global__ __launch_bounds__(256, CF_OCC) void chain_fast_kernel(SetView A, SetV
         wg = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + idx;
     }
     const uint32_t t = wg * 256u + threadIdx.x;
-    // lane-private LDS rings: two 64-byte lines of each stream (see the staging below)
-    __shared__ uint32_t lb_hit[16][256];
-    __shared__ uint32_t lb_qp[16][256];
     if (t >= total_chunks) return;
-    const uint32_t pi = find_pair(pairs, npairs, t);
+    // the pair of this chunk: the workgroup's first pair comes from a host-built table, a workgroup's 256 chunks span two
+    // or three pairs (no dependent binary search); everything the lane needs of its genomes sits in the descriptor
+    const uint32_t idx0 = chunk_rec0[t];                 // independent of the descriptor: in flight beside it
+    uint32_t pi = wg_pair[wg];
+    while (pi + 1u < npairs && pairs[pi + 1u].chunk_base <= t) pi++;
     const PairDesc pd = pairs[pi];
+    const uint32_t nrec = pair_nrec[pi];
     const uint32_t c = t - pd.chunk_base;
     const SetView &QS = (pd.flags & 2u) ? B : A;
-    const SetView &RS = (pd.flags & 4u) ? B : A;
-    const GenomeMeta *Qm = QS.meta + pd.q, *Rm = RS.meta + pd.r;
-    const uint64_t qoff = Qm->seed_off;
-    const uint32_t s0 = QS.chunk_start[Qm->chunk_off + c], s1 = QS.chunk_start[Qm->chunk_off + c + 1];
-    // own-multiplicity filter active, or positions of the probed genome do not fit a hit word's 24 bits:
-    // leave the chunk to the slow path
-    bool cplx = Qm->rep_cut != 0xFFFFFFFFu || Rm->total_len > (uint64_t)HIT_POS_MASK || (xcd_remap & 2) ||
-                ((xcd_remap >> 2) && (uint32_t)(xcd_remap >> 2) != t + 1u);
+    const uint2 cs2 = make_uint2(QS.chunk_start[pd.q_chunk_off + c], QS.chunk_start[pd.q_chunk_off + c + 1]);
+    const uint32_t s0 = cs2.x, s1 = cs2.y;
+    // own-multiplicity filter active, or positions of the probed genome do not fit a hit word's 24 bits (descriptor
+    // bit 3): leave the chunk to the slow path
+    bool cplx = (pd.flags & 8u) || (xcd_remap & 2) || ((xcd_remap >> 2) && (uint32_t)(xcd_remap >> 2) != t + 1u);
     uint32_t cause = cplx ? 6u : 0u;
 
     const int32_t NEG = -0x40000000;
@@ -420,336 +609,187 @@ __global__ __launch_bounds__(256, CF_OCC) void chain_fast_kernel(SetView A, SetV
         }                                                                                    \
     } while (0)
 
-    const uint32_t tidx = threadIdx.x;
-    const uint64_t hbase = pd.hit_base;          // absolute entry index of seed 0 in the hit array
-    const uint32_t *qg_abs = QS.pgpos;           // absolute base of the position array
-    const uint32_t qphase = (uint32_t)(qoff & 15u);
-    uint32_t s = s0;
-    bool dom = false;   // "r0 dominates": no other run or summary can out-score an extension of r0
-    // Control structure against wave divergence.  Work proceeds in ROUNDS that are uniform across the
-    // wave: (1) every lane disposes of the rest of its current 16-seed line -- misses and plain
-    // extensions of its current run, found by bit operations on the line's class word -- and parks at
-    // the first seed that is anything else; (2) the general step runs once for the lanes that parked.
-    // All loop exits are votes, so the wave stays converged.
-    // Input staging: the hit words of a pair start at an entry congruent (mod 16) to the genome's seed
-    // offset, so 64-byte line k of both streams covers the same 16 seeds.  Each lane keeps its current
-    // line in a private LDS column (16 entries per stream, for the dynamic look-ups at a park) and the
-    // following line in registers: the loads for line k+1 are issued when line k is moved into LDS, a
-    // whole round before they are needed.
-    uint32_t rfa = (s0 + qphase) & ~15u;            // aligned index (seed + qphase) of the line held in registers
-    const uint32_t *hline = hits + (hbase - qphase);  // line k of the hit stream starts at hline + 16 k
-    const uint32_t *qline = qg_abs + (qoff - qphase);
-    uint4 h0, h1, h2, h3, q0, q1, q2, q3;
-    {
-        const uint4 *srh = reinterpret_cast<const uint4 *>(hline + rfa);
-        const uint4 *srq = reinterpret_cast<const uint4 *>(qline + rfa);
-        h0 = srh[0]; h1 = srh[1]; h2 = srh[2]; h3 = srh[3];
-        q0 = srq[0]; q1 = srq[1]; q2 = srq[2]; q3 = srq[3];
-    }
-    // Seed classes of the staged line, two bits per seed: 0 = CONTINUES the previous hit (single position
-    // word with the previous non-miss seed's record, strand and diagonal, 1..2500 bases behind it),
-    // 1 = miss, 2 = anything else.  The classes depend on the data alone, so they are computed for the
-    // 16 seeds of a line in straight-line code when the line is staged; a class-0 seed is a plain
-    // extension of the current run exactly when that run dominates (`dom`), because the hit processed
-    // last is always the last anchor of the front run.  The walk over a line is then a few bit
-    // operations on the class word instead of a loop over the seeds.
-    uint32_t cw = 0;
-    uint32_t pw = 0x40000000u, pq = 0, pdiag = 0;   // previous non-miss seed: hit word, position, diagonal
-    bool park = false;                              // waiting at seed s for the general step
-    uint32_t hw = HIT_NONE;
-    int32_t qp = 0;
+    // record cursor: the chunk's records are contiguous in the pair's region, from chunk_rec0 on, in seed order; the
+    // record BEHIND a run closes it (the pair's last one is a terminator), so two records are held and the third is
+    // on its way while the first is worked on
+    const uint4 *prec = reinterpret_cast<const uint4 *>(recs + pd.rec_base);
+    uint32_t idx = idx0;
+    if (!cplx && nrec == REC_OVER) { cplx = true; cause = 8; }
+    bool done = cplx || idx == 0xFFFFFFFFu || s1 <= s0;
+    uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0, b0 = a0, b1 = a0;
+    if (!done) { a0 = prec[2u * idx]; a1 = prec[2u * idx + 1u]; b0 = prec[2u * idx + 2u]; b1 = prec[2u * idx + 3u]; }   // idx < nrec: idx + 1 exists
     for (;;) {
-        const bool live = !cplx && s < s1;
-        if (live && s + qphase >= rfa) {           // s has entered the line held in registers
-            cw = 0;
-#define STAGE(K, W, Q)                                                                                   \
-            {                                                                                            \
-                const uint32_t w_ = (W), q_ = (Q);                                                       \
-                lb_hit[K][tidx] = w_; lb_qp[K][tidx] = q_;                                               \
-                const bool none_ = w_ == HIT_NONE;                                                       \
-                const uint32_t sg_ = (uint32_t)((int32_t)w_ >> 31);                                      \
-                const uint32_t dg_ = ((w_ & HIT_POS_MASK) ^ sg_) - q_;   /* pos - q, or -(pos + q) - 1: one value per diagonal */ \
-                const uint32_t x_ = ((w_ ^ pw) & (HIT_KEY_MASK | 0x40000000u)) | (dg_ ^ pdiag) | (w_ & 0x40000000u); \
-                const bool cont_ = (x_ == 0u) & ((q_ - pq) <= (uint32_t)ANI_BP_BAND);   /* positions rise strictly: q - pq >= 1 */ \
-                cw |= (none_ ? 1u : (cont_ ? 0u : 2u)) << (2 * (K));                                     \
-                pw = none_ ? pw : w_; pq = none_ ? pq : q_; pdiag = none_ ? pdiag : dg_;                 \
-            }
-            STAGE(0, h0.x, q0.x) STAGE(1, h0.y, q0.y) STAGE(2, h0.z, q0.z) STAGE(3, h0.w, q0.w)
-            STAGE(4, h1.x, q1.x) STAGE(5, h1.y, q1.y) STAGE(6, h1.z, q1.z) STAGE(7, h1.w, q1.w)
-            STAGE(8, h2.x, q2.x) STAGE(9, h2.y, q2.y) STAGE(10, h2.z, q2.z) STAGE(11, h2.w, q2.w)
-            STAGE(12, h3.x, q3.x) STAGE(13, h3.y, q3.y) STAGE(14, h3.z, q3.z) STAGE(15, h3.w, q3.w)
-#undef STAGE
-            rfa += 16u;
-            if (rfa < s1 + qphase) {             // the next line still holds seeds of this chunk
-                const uint4 *srh = reinterpret_cast<const uint4 *>(hline + rfa);
-                const uint4 *srq = reinterpret_cast<const uint4 *>(qline + rfa);
-                h0 = srh[0]; h1 = srh[1]; h2 = srh[2]; h3 = srh[3];
-                q0 = srq[0]; q1 = srq[1]; q2 = srq[2]; q3 = srq[3];
+        // one record per round
+        bool have = false;
+        struct { uint32_t qi, q0, hw, q1, qi1, hw1, n, gsum; } rc;
+        rc.qi = 0; rc.q0 = 0; rc.hw = HIT_NONE; rc.hw1 = HIT_NONE; rc.q1 = 0; rc.qi1 = 0; rc.n = 0; rc.gsum = 0;
+        if (!done) {
+            if (a0.x >= s1) done = true;                  // records are in seed order (terminator: ~0): the chunk is finished
+            else {
+                have = true;
+                rc.qi = a0.x; rc.q0 = a0.y; rc.hw = a0.z;
+                rc.n = b0.w - a0.w; rc.gsum = b1.w - a1.w;                 // running counts: this run's share
+                rc.q1 = b1.x; rc.hw1 = b1.y; rc.qi1 = b1.z;               // the hit in front of the next record ends this run
+                a0 = b0; a1 = b1;
+                idx++;
+                if (idx < nrec) { b0 = prec[2u * idx + 2u]; b1 = prec[2u * idx + 3u]; }   // record idx + 1 (<= nrec: the terminator)
+                else a0.x = 0xFFFFFFFFu;                                   // that was the pair's last record
             }
         }
-#ifdef SKDER_PROFILE_COUNTERS
-        if ((threadIdx.x & 63u) == __ffsll(__ballot(1)) - 1) atomicAdd(slow_count + 13, 1u);      // rounds (per wave)
-#endif
-        {
-            // the rest of the staged line: skip misses and (while r0 dominates) continuing seeds, stop at the
-            // first seed that needs a decision.  The most common decision -- the hit starts a new run because no
-            // run of the ring can precede it -- is taken here as well; everything else parks for the general step.
-            for (;;) {
-                const bool actv = !cplx && !park && s < s1 && s + qphase < rfa;
-                if (!__any(actv)) break;
-                if (actv) {
-                    const uint32_t k = (s + qphase) & 15u;
-                    uint32_t nv = 16u - k;
-                    nv = nv < s1 - s ? nv : s1 - s;
-                    const uint32_t rem = cw >> (2u * k);
-                    const uint32_t hi = (rem >> 1) & 0x55555555u, lo = rem & 0x55555555u;
-                    const uint32_t vmask = nv >= 16u ? 0xFFFFFFFFu : (1u << (2u * nv)) - 1u;
-                    const uint32_t stop = (dom ? hi : (~lo & 0x55555555u)) & vmask;
-                    const uint32_t first = stop ? (uint32_t)(__ffs((int)stop) - 1) >> 1 : nv;
-                    const uint32_t rmask = first >= 16u ? 0xFFFFFFFFu : (1u << (2u * first)) - 1u;
-                    const uint32_t contm = ~(hi | lo) & 0x55555555u & rmask;      // plain extensions of r0 among the skipped seeds
-                    if (contm) {
-                        // k plain extensions at once: scores rise by 20 per anchor, positions move monotonically along
-                        // the run's diagonal, so the aggregates follow from the last anchor alone
-                        const uint32_t ext = (uint32_t)__popc(contm);
-                        const uint32_t last_s = s + ((31u - (uint32_t)__clz((int)contm)) >> 1);
-                        const uint32_t lrow = (qphase + last_s) & 15u;
-                        r0.q_last = lb_qp[lrow][tidx]; r0.rr_last = lb_hit[lrow][tidx];
-                        const int32_t f_prev = r0.f + ANI_ANCHOR_SCORE * (int32_t)(ext - 1u);
-                        r0.pmax = f_prev > r0.pmax ? f_prev : r0.pmax;
-                        r0.f = f_prev + ANI_ANCHOR_SCORE;
-                        runmax = r0.f > runmax ? r0.f : runmax;
-                        r0.cnt += ext;
-                        r0.idx_last = ia + ext - 1u; ia += ext;
-                        r0.qi_last = last_s;
-                    }
-                    s += first;
-                    park = first < nv;
-                    if (park) {
-                        const uint32_t row = (qphase + s) & 15u;
-                        hw = lb_hit[row][tidx];
-                        qp = (int32_t)lb_qp[row][tidx];
-                        // NEW RUN without a look-back: a single hit and -- going through the ring nearest first, as the
-                        // general step would -- only runs of another record or strand until a ring position is empty or
-                        // a run lies beyond the 2500-base band (older runs and the summaries lie further back still), or
-                        // until the ring ends with nothing evicted so far.  No predecessor exists, and the runs left
-                        // in the ring cannot beat the new one: out of the band, or another key.
-#define RUN_END(E) (!(E).cnt || qp - (int32_t)(E).q_last > ANI_BP_BAND)
-#define RUN_OTHER(E) ((((E).rr_last ^ hw) & HIT_KEY_MASK) != 0u)
-                        const bool fresh = !(hw & 0x40000000u) &&
-                                           (RUN_END(r0) || (RUN_OTHER(r0) && (RUN_END(r1) || (RUN_OTHER(r1) && (RUN_END(r2) || (RUN_OTHER(r2) &&
-                                            (RUN_END(r3) || (RUN_OTHER(r3) && !nevict))))))));
-#undef RUN_END
-#undef RUN_OTHER
-                        // INDEL on the current path, also without a look-back: a single hit of r0's record and strand, 1..2500
-                        // bases after r0's last anchor and ahead of it on the other genome, 1..300 off r0's diagonal, r0
-                        // without a successor -- and nothing else able to offer as much as r0 does: every other run and
-                        // summary is empty, of another key, beyond the 2500-base band, or scores at most r0.f - off (so
-                        // that even at zero gap cost it stays at or below r0's offer; r0's last anchor is the nearest of
-                        // all, and the look-back keeps the first of equal offers).  Interior anchors of those runs score
-                        // no more than their last ones, so the "inside a run's extent" case cannot matter here either.
-                        const uint32_t rp = hw & HIT_POS_MASK;
-                        bool take = fresh, dom_after = true;
-                        int32_t best = ANI_ANCHOR_SCORE;
-                        Run e;
-                        e.q_last = (uint32_t)qp; e.rr_last = hw; e.f = ANI_ANCHOR_SCORE;
-                        e.cnt = 1; e.first_qi = s; e.q_first = (uint32_t)qp; e.r_pfirst = rp;
-                        e.qi_last = s; e.idx_last = ia; e.pmax = NEG; e.r_first = rp; e.seg = ia;
-                        if (!fresh && !(hw & 0x40000000u) && r0.cnt && !(r0.cnt & SUCC_BIT) && !((r0.rr_last ^ hw) & HIT_KEY_MASK)) {
-                            const bool rev = (hw >> 31) != 0u;
-                            const int32_t rp0 = (int32_t)(r0.rr_last & HIT_POS_MASK), q0l = (int32_t)r0.q_last;
-                            const int32_t dgx = rev ? (int32_t)rp + qp : (int32_t)rp - qp, d0 = rev ? rp0 + q0l : rp0 - q0l;
-                            const int32_t off = dgx > d0 ? dgx - d0 : d0 - dgx;
-                            const int32_t dq = qp - q0l, dr = rev ? rp0 - (int32_t)rp : (int32_t)rp - rp0;
-                            const int32_t lim = r0.f - off;
-                            bool ok = off >= 1 && off <= ANI_MAX_GAP && (uint32_t)(dq - 1) < (uint32_t)ANI_BP_BAND && dr > 0 && lim > 0;
-#define HARMLESS(E) (!(E).cnt || ((((E).rr_last ^ hw) & HIT_KEY_MASK) != 0u) || (E).f <= lim || qp - (int32_t)(E).q_last > ANI_BP_BAND)
-                            ok = ok && HARMLESS(r1) && HARMLESS(r2) && HARMLESS(r3);
-#undef HARMLESS
-                            if (ok && nevict) {
-                                ok = (s0_seg == 0xFFFFFFFFu || s0_key != (hw & HIT_KEY_MASK) || s0_f <= lim || qp - (int32_t)s0_q > ANI_BP_BAND) &&
-                                     (lost_f == NEG || lost_f <= lim || qp - (int32_t)lost_q > ANI_BP_BAND);
-                            }
-                            if (ok) {
-                                take = true;
-                                best = r0.f + ANI_ANCHOR_SCORE - off;
-                                e.f = best;
-                                e.cnt = r0.cnt + 1u; e.first_qi = r0.first_qi; e.q_first = r0.q_first;
-                                e.r_pfirst = r0.r_pfirst;
-                                e.pmax = r0.f > r0.pmax ? r0.f : r0.pmax;
-                                e.seg = off >= ANI_ANCHOR_SCORE ? ia : r0.seg;
-                                r0.cnt |= SUCC_BIT;
-                                dom_after = off <= ANI_ANCHOR_SCORE;      // the old run (now second) must not score above the new one
-                            }
-                        }
-                        if (take) {
-                            EVICT(r3);
-                            if (!cplx) {
-                                r3 = r2; r2 = r1; r1 = r0; r0 = e;
-                                ia++;
-                                runmax = best > runmax ? best : runmax;
-                                dom = dom_after;
-                                if (dom && nevict) {       // the summaries of evicted runs, as at the end of the general step
-                                    const uint32_t k0 = hw & HIT_KEY_MASK;
-                                    const int32_t d0 = (hw >> 31) ? (int32_t)rp + qp : (int32_t)rp - qp;
-                                    if (s0_seg != 0xFFFFFFFFu)
-                                        dom = s0_key != k0 || s0_f <= r0.f || qp - (int32_t)s0_q > ANI_BP_BAND || d0 < s0_dlo - ANI_MAX_GAP || d0 > s0_dhi + ANI_MAX_GAP;
-                                    if (dom && lost_f != NEG)
-                                        dom = lost_f <= r0.f || qp - (int32_t)lost_q > ANI_BP_BAND ||
-                                              ((d0 < lost_dlo - ANI_MAX_GAP || d0 > lost_dhi + ANI_MAX_GAP) &&
-                                               (lost2_dlo > lost2_dhi || d0 < lost2_dlo - ANI_MAX_GAP || d0 > lost2_dhi + ANI_MAX_GAP));
-                                }
-                                s++;
-                            }
-                            park = false;
-                        }
-                    }
-                }
+        if (have) do {
+            // ---- one record: its first anchor (all hits of a multi-occurrence seed) through the look-back
+            const uint32_t s = rc.qi;
+            const int32_t qp = (int32_t)rc.q0;
+            const uint32_t hw = rc.hw;
+            if (hw == HIT_MANY) { cplx = true; cause = 2; break; }
+            uint32_t m = 1, g0 = hw, g1 = HIT_NONE, g2 = HIT_NONE, g3 = HIT_NONE;
+            if ((hw & 0xFF000000u) == HIT_MULTI) {   // 2..4 occurrences, ascending gpos
+                const uint4 mv = multi[pd.multi_base + (hw & 0x00FFFFFFu)];
+                g0 = mv.x; g1 = mv.y; g2 = mv.z; g3 = mv.w;
+                m = 2u + (g2 != HIT_NONE) + (g3 != HIT_NONE);
             }
-            // the general step is long and every parked lane drags the whole wave through its branches: it
-            // runs when enough lanes wait for it, or when nobody is left who could advance without it
-            const uint32_t npark = (uint32_t)__popcll(__ballot(park));
-            const bool go = npark >= PASS_THRESH || !__any(!cplx && s < s1 && !park);
-#ifdef SKDER_PROFILE_COUNTERS
-            if (park && go) atomicAdd(slow_count + 10, 1u);                                         // parks (per lane)
-            if (__any(park && go) && (threadIdx.x & 63u) == __ffsll(__ballot(1)) - 1) atomicAdd(slow_count + 11, 1u);   // general passes (per wave)
-#endif
-            if (park && go) do {
-                park = false;
-                // ---- general step for seed s (all of its hits)
-                if (hw == HIT_MANY) { cplx = true; cause = 2; break; }
-                uint32_t m = 1, g0 = hw, g1 = HIT_NONE, g2 = HIT_NONE, g3 = HIT_NONE;
-                if ((hw & 0xFF000000u) == HIT_MULTI) {   // 2..4 occurrences, ascending gpos
-                    const uint4 mv = multi[pd.multi_base + (hw & 0x00FFFFFFu)];
-                    g0 = mv.x; g1 = mv.y; g2 = mv.z; g3 = mv.w;
-                    m = 2u + (g2 != HIT_NONE) + (g3 != HIT_NONE);
+            for (uint32_t u = 0; u < m && !cplx; u++) {
+                const uint32_t rr = g0;
+                g0 = g1; g1 = g2; g2 = g3;
+                const int32_t rp = (int32_t)(rr & HIT_POS_MASK);
+                const uint32_t rev = rr >> 31;
+                const uint32_t key = rr & HIT_KEY_MASK;     // strand + record tag
+                const int32_t dg = rev ? rp + qp : rp - qp;
+                // ---- the oracle's look-back over the last anchors of the ring's runs
+                int32_t best = ANI_ANCHOR_SCORE, pgap = 0;
+                int bj = -1;
+                bool exact = false;
+    #define TRY(K, E)                                                                                   \
+                if (!exact && !cplx) {                                                                  \
+                    if (!(E).cnt) exact = true;                       /* no older anchors at all */     \
+                    else if (best >= runmax + ANI_ANCHOR_SCORE) exact = true;                           \
+                    else if (ia - (E).idx_last > ANI_BAND) exact = true;                                \
+                    else {                                                                              \
+                        const int32_t dq = qp - (int32_t)(E).q_last;                                    \
+                        if (dq > ANI_BP_BAND) exact = true;                                             \
+                        else if (((E).rr_last & HIT_KEY_MASK) == key) {                                 \
+                            const int32_t rpj = (int32_t)((E).rr_last & HIT_POS_MASK);                   \
+                            const int32_t dr = rev ? rpj - rp : rp - rpj;                               \
+                            const int32_t ed = rev ? rpj + (int32_t)(E).q_last : rpj - (int32_t)(E).q_last; /* run diagonal */ \
+                            const int32_t off = dg > ed ? dg - ed : ed - dg;                            \
+                            if (off <= ANI_MAX_GAP) {                                                   \
+                                /* an INTERIOR anchor of the run could be a valid predecessor where the last one is not */ \
+                                const int32_t rf = (int32_t)(E).r_first;                                \
+                                const bool inside = rev ? (rp < rf && dr <= 0) : (rp > rf && dr <= 0);  \
+                                if (dq <= 0 || inside) { cplx = true; cause = 7; }                      \
+                                else if (dr > 0 && dq <= ANI_MAX_LIN && dr <= ANI_MAX_LIN) {            \
+                                    const int32_t sc = (E).f + ANI_ANCHOR_SCORE - off;                  \
+                                    if (sc > best) { best = sc; bj = (K); pgap = off; }                 \
+                                }                                                                       \
+                            }                                                                           \
+                        }                                                                               \
+                    }                                                                                   \
                 }
-                dom = false;
-                for (uint32_t u = 0; u < m && !cplx; u++) {
-                    const uint32_t rr = g0;
-                    g0 = g1; g1 = g2; g2 = g3;
-                    const int32_t rp = (int32_t)(rr & HIT_POS_MASK);
-#ifdef SKDER_PROFILE_COUNTERS
-                    if (!r0.cnt) atomicAdd(slow_count + 14, 1u);                                   // parks with an empty ring
-                    else if ((rr ^ r0.rr_last) & HIT_KEY_MASK) atomicAdd(slow_count + 9, 1u);                    // strand or record change
-#endif
-                    const uint32_t rev = rr >> 31;
-                    const uint32_t key = rr & HIT_KEY_MASK;     // strand + record tag
-                    const int32_t dg = rev ? rp + qp : rp - qp;
-
-                    // ---- general case: the oracle's look-back over the last anchors of the ring's runs
-                    int32_t best = ANI_ANCHOR_SCORE, pgap = 0;
-                    int bj = -1;
-                    bool exact = false;
-        #define TRY(K, E)                                                                                   \
-                    if (!exact && !cplx) {                                                                  \
-                        if (!(E).cnt) exact = true;                       /* no older anchors at all */     \
-                        else if (best >= runmax + ANI_ANCHOR_SCORE) exact = true;                           \
-                        else if (ia - (E).idx_last > ANI_BAND) exact = true;                                \
-                        else {                                                                              \
-                            const int32_t dq = qp - (int32_t)(E).q_last;                                    \
-                            if (dq > ANI_BP_BAND) exact = true;                                             \
-                            else if (((E).rr_last & HIT_KEY_MASK) == key) {                                 \
-                                const int32_t rpj = (int32_t)((E).rr_last & HIT_POS_MASK);                   \
-                                const int32_t dr = rev ? rpj - rp : rp - rpj;                               \
-                                const int32_t ed = rev ? rpj + (int32_t)(E).q_last : rpj - (int32_t)(E).q_last; /* run diagonal */ \
-                                const int32_t off = dg > ed ? dg - ed : ed - dg;                            \
-                                if (off <= ANI_MAX_GAP) {                                                   \
-                                    /* an INTERIOR anchor of the run could be a valid predecessor where the last one is not */ \
-                                    const int32_t rf = (int32_t)(E).r_first;                                \
-                                    const bool inside = rev ? (rp < rf && dr <= 0) : (rp > rf && dr <= 0);  \
-                                    if (dq <= 0 || inside) { cplx = true; cause = 7; }                      \
-                                    else if (dr > 0 && dq <= ANI_MAX_LIN && dr <= ANI_MAX_LIN) {            \
-                                        const int32_t sc = (E).f + ANI_ANCHOR_SCORE - off;                  \
-                                        if (sc > best) { best = sc; bj = (K); pgap = off; }                 \
-                                    }                                                                       \
-                                }                                                                           \
-                            }                                                                               \
-                        }                                                                                   \
+                TRY(0, r0) TRY(1, r1) TRY(2, r2) TRY(3, r3)
+    #undef TRY
+                if (cplx) break;
+                if (!exact && nevict) {
+                    // the look-back would continue into evicted runs: accept only if none of them can matter
+                    bool ok = true;
+    #define SUMMARY_BLOCKS(SF, SQ, DLO, DHI, KEYOK)                                                                  \
+                    if ((KEYOK) && qp - (int32_t)(SQ) <= ANI_BP_BAND) {                                              \
+                        const int32_t off = dg < (DLO) ? (DLO) - dg : (dg > (DHI) ? dg - (DHI) : 0);                  \
+                        if (off <= ANI_MAX_GAP && !(best >= (SF) + ANI_ANCHOR_SCORE - off)) ok = false;               \
                     }
-                    TRY(0, r0) TRY(1, r1) TRY(2, r2) TRY(3, r3)
-        #undef TRY
-                    if (cplx) break;
-                    if (!exact && nevict) {
-                        // the look-back would continue into evicted runs: accept only if none of them can matter
-                        bool ok = true;
-        #define SUMMARY_BLOCKS(SF, SQ, DLO, DHI, KEYOK)                                                                  \
-                        if ((KEYOK) && qp - (int32_t)(SQ) <= ANI_BP_BAND) {                                              \
-                            const int32_t off = dg < (DLO) ? (DLO) - dg : (dg > (DHI) ? dg - (DHI) : 0);                  \
-                            if (off <= ANI_MAX_GAP && !(best >= (SF) + ANI_ANCHOR_SCORE - off)) ok = false;               \
-                        }
-                        SUMMARY_BLOCKS(s0_f, s0_q, s0_dlo, s0_dhi, s0_seg != 0xFFFFFFFFu && s0_key == key)
-                        SUMMARY_BLOCKS(lost_f, lost_q, lost_dlo, lost_dhi, lost_f != NEG)
-                        SUMMARY_BLOCKS(lost_f, lost_q, lost2_dlo, lost2_dhi, lost_f != NEG && lost2_dlo <= lost2_dhi)
-        #undef SUMMARY_BLOCKS
-                        if (!ok) { cplx = true; cause = 3; break; }
-                    }
-                    if (bj >= 0) {
-                        // bring the predecessor run to the front (it gets the newest anchor, or goes back: see below)
-                        if (bj == 1) { const Run tr = r1; r1 = r0; r0 = tr; }
-                        else if (bj == 2) { const Run tr = r2; r2 = r1; r1 = r0; r0 = tr; }
-                        else if (bj == 3) { const Run tr = r3; r3 = r2; r2 = r1; r1 = r0; r0 = tr; }
-                        if (r0.cnt & SUCC_BIT) { cplx = true; cause = 4; break; }   // two anchors chain to one predecessor
-                        if (pgap == 0) {
-                            // same diagonal: the run simply grows
-                            r0.pmax = r0.f > r0.pmax ? r0.f : r0.pmax;
-                            r0.f = best;
-                            r0.q_last = (uint32_t)qp; r0.rr_last = rr; r0.cnt += 1u;
-                            r0.qi_last = s; r0.idx_last = ia;
-                        } else {
-                            // an indel: new run on the same path; the old run's last anchor now has a successor
-                            Run e;
-                            e.q_last = (uint32_t)qp; e.rr_last = rr; e.f = best;
-                            e.cnt = (r0.cnt & ~SUCC_BIT) + 1u; e.first_qi = r0.first_qi; e.q_first = r0.q_first;
-                            e.r_pfirst = r0.r_pfirst;
-                            e.qi_last = s; e.idx_last = ia; e.pmax = r0.f > r0.pmax ? r0.f : r0.pmax;
-                            e.r_first = (uint32_t)rp; e.seg = pgap >= ANI_ANCHOR_SCORE ? ia : r0.seg;
-                            r0.cnt |= SUCC_BIT;
-                            // the predecessor run goes back to where it was: the ring is ordered by the LAST ANCHOR of
-                            // its runs (the look-back stops at the first run beyond a band and trusts that older ones,
-                            // in the ring and in the summaries, lie further back), and this run's last anchor did not move
-                            if (bj == 1) { const Run tr = r0; r0 = r1; r1 = tr; }
-                            else if (bj == 2) { const Run tr = r0; r0 = r1; r1 = r2; r2 = tr; }
-                            else if (bj == 3) { const Run tr = r0; r0 = r1; r1 = r2; r2 = r3; r3 = tr; }
-                            EVICT(r3);
-                            r3 = r2; r2 = r1; r1 = r0; r0 = e;
-                        }
+                    SUMMARY_BLOCKS(s0_f, s0_q, s0_dlo, s0_dhi, s0_seg != 0xFFFFFFFFu && s0_key == key)
+                    SUMMARY_BLOCKS(lost_f, lost_q, lost_dlo, lost_dhi, lost_f != NEG)
+                    SUMMARY_BLOCKS(lost_f, lost_q, lost2_dlo, lost2_dhi, lost_f != NEG && lost2_dlo <= lost2_dhi)
+    #undef SUMMARY_BLOCKS
+                    if (!ok) { cplx = true; cause = 3; break; }
+                }
+                if (bj >= 0) {
+                    // bring the predecessor run to the front (it gets the newest anchor, or goes back: see below)
+                    if (bj == 1) { const Run tr = r1; r1 = r0; r0 = tr; }
+                    else if (bj == 2) { const Run tr = r2; r2 = r1; r1 = r0; r0 = tr; }
+                    else if (bj == 3) { const Run tr = r3; r3 = r2; r2 = r1; r1 = r0; r0 = tr; }
+                    if (r0.cnt & SUCC_BIT) { cplx = true; cause = 4; break; }   // two anchors chain to one predecessor
+                    if (pgap == 0) {
+                        // same diagonal: the run simply grows
+                        r0.pmax = r0.f > r0.pmax ? r0.f : r0.pmax;
+                        r0.f = best;
+                        r0.q_last = (uint32_t)qp; r0.rr_last = rr; r0.cnt += 1u;
+                        r0.qi_last = s; r0.idx_last = ia;
                     } else {
+                        // an indel: new run on the same path; the old run's last anchor now has a successor
                         Run e;
                         e.q_last = (uint32_t)qp; e.rr_last = rr; e.f = best;
-                        e.cnt = 1; e.first_qi = s; e.q_first = (uint32_t)qp; e.r_pfirst = (uint32_t)rp;
-                        e.qi_last = s; e.idx_last = ia; e.pmax = NEG; e.r_first = (uint32_t)rp; e.seg = ia;
+                        e.cnt = (r0.cnt & ~SUCC_BIT) + 1u; e.first_qi = r0.first_qi; e.q_first = r0.q_first;
+                        e.r_pfirst = r0.r_pfirst;
+                        e.qi_last = s; e.idx_last = ia; e.pmax = r0.f > r0.pmax ? r0.f : r0.pmax;
+                        e.r_first = (uint32_t)rp; e.seg = pgap >= ANI_ANCHOR_SCORE ? ia : r0.seg;
+                        r0.cnt |= SUCC_BIT;
+                        // the predecessor run goes back to where it was: the ring is ordered by the LAST ANCHOR of
+                        // its runs (the look-back stops at the first run beyond a band and trusts that older ones,
+                        // in the ring and in the summaries, lie further back), and this run's last anchor did not move
+                        if (bj == 1) { const Run tr = r0; r0 = r1; r1 = tr; }
+                        else if (bj == 2) { const Run tr = r0; r0 = r1; r1 = r2; r2 = tr; }
+                        else if (bj == 3) { const Run tr = r0; r0 = r1; r1 = r2; r2 = r3; r3 = tr; }
                         EVICT(r3);
                         r3 = r2; r2 = r1; r1 = r0; r0 = e;
                     }
-                    ia++;
-                    runmax = best > runmax ? best : runmax;
+                } else {
+                    Run e;
+                    e.q_last = (uint32_t)qp; e.rr_last = rr; e.f = best;
+                    e.cnt = 1; e.first_qi = s; e.q_first = (uint32_t)qp; e.r_pfirst = (uint32_t)rp;
+                    e.qi_last = s; e.idx_last = ia; e.pmax = NEG; e.r_first = (uint32_t)rp; e.seg = ia;
+                    EVICT(r3);
+                    r3 = r2; r2 = r1; r1 = r0; r0 = e;
                 }
-                if (cplx) break;
-                s++;
-                // does r0 now dominate?  every other run / summary must be unable to offer more than r0.f + 20
-                // to an anchor that extends r0: other record or strand, more than max_gap off r0's diagonal,
-                // out of the 2500-base band for good, or simply not scoring higher than r0
-                if (r0.cnt && !(r0.cnt & SUCC_BIT)) {
-                    const uint32_t k0 = r0.rr_last & HIT_KEY_MASK;
-                    const int32_t q0l = (int32_t)r0.q_last;
-                    const int32_t d0 = (r0.rr_last >> 31) ? (int32_t)(r0.rr_last & HIT_POS_MASK) + q0l : (int32_t)(r0.rr_last & HIT_POS_MASK) - q0l;
-        #define CANNOT_BEAT(E)                                                                              \
-                    (!(E).cnt || ((E).rr_last & HIT_KEY_MASK) != k0 || (E).f <= r0.f || q0l - (int32_t)(E).q_last > ANI_BP_BAND || \
-                     abs((((E).rr_last >> 31) ? (int32_t)((E).rr_last & HIT_POS_MASK) + (int32_t)(E).q_last                                       \
-                                              : (int32_t)((E).rr_last & HIT_POS_MASK) - (int32_t)(E).q_last) - d0) > ANI_MAX_GAP)
-                    dom = CANNOT_BEAT(r1) && CANNOT_BEAT(r2) && CANNOT_BEAT(r3);
-        #undef CANNOT_BEAT
-                    if (dom && s0_seg != 0xFFFFFFFFu)
-                        dom = s0_key != k0 || s0_f <= r0.f || q0l - (int32_t)s0_q > ANI_BP_BAND || d0 < s0_dlo - ANI_MAX_GAP || d0 > s0_dhi + ANI_MAX_GAP;
-                    if (dom && lost_f != NEG)
-                        dom = lost_f <= r0.f || q0l - (int32_t)lost_q > ANI_BP_BAND ||
-                              ((d0 < lost_dlo - ANI_MAX_GAP || d0 > lost_dhi + ANI_MAX_GAP) &&
-                               (lost2_dlo > lost2_dhi || d0 < lost2_dlo - ANI_MAX_GAP || d0 > lost2_dhi + ANI_MAX_GAP));
-                        }
-            } while (0);
-        }
-        if (!__any(!cplx && s < s1)) break;     // the whole wave is finished
+                ia++;
+                runmax = best > runmax ? best : runmax;
+            }
+            if (cplx) break;
+            if (rc.n > 1u) {
+                // ---- the run's other anchors: extensions of r0 (which holds the anchor just placed) along the run,
+                // provided nothing else can offer its second anchor more than r0 does (header comment): every other
+                // run / summary is empty, of another record or strand, beyond the 2500-base band already at the first
+                // anchor, further off than max_gap plus all the diagonal steps of the run, or scores no more than
+                // r0.f + its diagonal distance (- 20 when the run has steps)
+                const uint32_t k0 = hw & HIT_KEY_MASK;
+                const int32_t rp0 = (int32_t)(hw & HIT_POS_MASK);
+                const int32_t d0 = (hw >> 31) ? rp0 + qp : rp0 - qp;
+                const int32_t G = (int32_t)rc.gsum, slack = G ? 2 * RUN_GAP : 0;
+                const int32_t f0 = r0.f - slack;
+    #define DIAG_OFF(E) abs((((E).rr_last >> 31) ? (int32_t)((E).rr_last & HIT_POS_MASK) + (int32_t)(E).q_last               \
+                                                 : (int32_t)((E).rr_last & HIT_POS_MASK) - (int32_t)(E).q_last) - d0)
+    #define HARMLESS(E)                                                                                   \
+                (!(E).cnt || ((E).rr_last & HIT_KEY_MASK) != k0 || qp - (int32_t)(E).q_last > ANI_BP_BAND ||    \
+                 DIAG_OFF(E) - G > ANI_MAX_GAP || (E).f - DIAG_OFF(E) <= f0)
+                bool domr = !(r0.cnt & SUCC_BIT) && HARMLESS(r1) && HARMLESS(r2) && HARMLESS(r3);
+    #undef HARMLESS
+    #undef DIAG_OFF
+                if (domr && s0_seg != 0xFFFFFFFFu && s0_key == k0 && qp - (int32_t)s0_q <= ANI_BP_BAND) {
+                    const int32_t off = d0 < s0_dlo ? s0_dlo - d0 : (d0 > s0_dhi ? d0 - s0_dhi : 0);
+                    if (off - G <= ANI_MAX_GAP && s0_f - off > f0) domr = false;
+                }
+                if (domr && lost_f != NEG && qp - (int32_t)lost_q <= ANI_BP_BAND) {
+                    const int32_t off1 = d0 < lost_dlo ? lost_dlo - d0 : (d0 > lost_dhi ? d0 - lost_dhi : 0);
+                    if (off1 - G <= ANI_MAX_GAP && lost_f - off1 > f0) domr = false;
+                    if (lost2_dlo <= lost2_dhi) {
+                        const int32_t off2 = d0 < lost2_dlo ? lost2_dlo - d0 : (d0 > lost2_dhi ? d0 - lost2_dhi : 0);
+                        if (off2 - G <= ANI_MAX_GAP && lost_f - off2 > f0) domr = false;
+                    }
+                }
+                if (!domr) { cplx = true; cause = 9; break; }
+                const uint32_t ext = rc.n - 1u;
+                r0.q_last = rc.q1;
+                r0.rr_last = rc.hw1;
+                r0.f = r0.f + ANI_ANCHOR_SCORE * (int32_t)ext - G;
+                // the second-to-last anchor of the run scores at most r0.f - (20 - RUN_GAP): an upper bound serves pmax
+                r0.pmax = r0.f - (ANI_ANCHOR_SCORE - RUN_GAP) > r0.pmax ? r0.f - (ANI_ANCHOR_SCORE - RUN_GAP) : r0.pmax;
+                runmax = r0.f > runmax ? r0.f : runmax;
+                r0.cnt += ext;
+                r0.idx_last = ia + ext - 1u; ia += ext;
+                r0.qi_last = rc.qi1;
+            }
+        } while (0);
+        if (cplx) done = true;
+        if (!__any(!done)) break;     // the whole wave is finished
     }
     if (!cplx) EMIT_PATH(r3);
     if (!cplx) EMIT_PATH(r2);
@@ -1472,7 +1512,7 @@ static SetView view_of(skder_sketches *s)
 {
     SetView v;
     v.meta = s->d_meta.p;
-    v.pkmer = s->seed_kmer.p; v.pgpos = s->seed_gpos.p; v.pchunk = s->pchunk.p;
+    v.pkmer = s->seed_kmer.p; v.pgpos = s->seed_gpos.p; v.pchunk = s->pchunk.p; v.pcs = s->pcs.p;
     v.skmer = s->skmer.p; v.sgpos = s->sgpos.p; v.sctg = s->sctg.p; v.stag = s->stag.p; v.boff = s->boff.p;
     v.chunk_start = s->chunk_start.p; v.rec_goff = s->d_rec_goff.p;
     return v;
@@ -1499,6 +1539,9 @@ struct ChainSlot {
     DevBuf<uint32_t> chunk_state, chunk_mark, slow_list, counters, pair_na, pair_nch;
     DevBuf<uint32_t> hits, pair_nmulti, groups, over_list, flags;
     DevBuf<uint4> multi;
+    DevBuf<RunRec> recs;
+    DevBuf<uint32_t> pair_nrec, chunk_rec0, wg_pair;
+    std::vector<uint32_t> h_wg_pair;
     DevBuf<ChainRec> fast_chains, chains;
     DevBuf<PairOut> d_out;
     std::vector<PairDesc> hp;
@@ -1507,10 +1550,10 @@ struct ChainSlot {
     PairOut *h_out = nullptr;
     size_t h_out_cap = 0;
     uint32_t *h_cnt = nullptr;      // [0..15] counters, [16] flags
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // start, join, fast, slow, finalize, results on host
+    hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // start, join, fast, slow, finalize, results on host; [6] run records
     size_t p0 = 0;
     uint32_t nb = 0, lds_cap = 0;
-    uint64_t nchunks = 0;
+    uint64_t nchunks = 0, nrecs = 0;
     bool busy = false;
     ~ChainSlot()
     {
@@ -1554,7 +1597,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
     // SKDER_AMD_FAST_ONLY_CHUNK=k lets only chunk k of a batch take the fast path (to find the chunk behind a parity failure)
     int xcd_remap = (getenv("SKDER_AMD_NO_XCD") ? 0 : 1) | (getenv("SKDER_AMD_FORCE_SLOW") ? 2 : 0);
     if (const char *e = getenv("SKDER_AMD_FAST_ONLY_CHUNK")) xcd_remap |= (atoi(e) + 1) << 2;
-    double t_fast = 0, t_slow = 0, t_fin = 0, t_join = 0;
+    double t_fast = 0, t_slow = 0, t_fin = 0, t_join = 0, t_runs = 0;
     uint64_t tot_anchors = 0, tot_slow = 0, tot_chunks = 0, tot_over = 0;
     // orientation of every pair, then order the work by the probed genome (R): consecutive
     // workgroups probe the same hash table, which keeps it in the XCD's L2
@@ -1622,10 +1665,16 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         HIPCHECK(hipMemsetAsync(S.counters.p, 0, 64, st));
         HIPCHECK(hipMemsetAsync(S.flags.p, 0, 64, st));
         HIPCHECK(hipEventRecord(S.ev[1], st));
-        if (S.nchunks)
-            hipLaunchKernelGGL(chain_fast_kernel, dim3((unsigned)((S.nchunks + 255) / 256)), dim3(256), 0, st, VA, VB, S.d_pairs.p, nb,
-                               (uint32_t)S.nchunks, S.hits.p, S.multi.p, S.fast_chains.p, S.chunk_state.p, S.slow_list.p, S.counters.p, S.pair_na.p,
-                               xcd_remap);
+        if (S.nchunks) {
+            HIPCHECK(hipMemsetAsync(S.chunk_rec0.p, 0xFF, S.nchunks * 4, st));
+            hipLaunchKernelGGL(run_extract_kernel, dim3(nb), dim3(256), 0, st, VA, VB, S.d_pairs.p, S.hits.p, S.recs.p, S.pair_nrec.p, S.chunk_rec0.p);
+            HIPCHECK(hipEventRecord(S.ev[6], st));
+            hipLaunchKernelGGL(chain_runs_kernel, dim3((unsigned)((S.nchunks + 255) / 256)), dim3(256), 0, st, VA, VB, S.d_pairs.p, nb,
+                               (uint32_t)S.nchunks, S.recs.p, S.pair_nrec.p, S.chunk_rec0.p, S.wg_pair.p, S.multi.p, S.fast_chains.p, S.chunk_state.p, S.slow_list.p, S.counters.p,
+                               S.pair_na.p, xcd_remap);
+        } else {
+            HIPCHECK(hipEventRecord(S.ev[6], st));
+        }
         HIPCHECK(hipEventRecord(S.ev[2], st));
         // declined chunks: one wavefront each, in LDS (count read on the device); the rare chunk with more
         // than 1024 anchors is put on over_list and dealt with after the batch's results are back
@@ -1658,7 +1707,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
     auto enqueue = [&](ChainSlot &S, size_t p0) -> size_t {
         std::vector<PairDesc> &hp = S.hp;
         hp.clear();
-        uint64_t nchunks = 0, ccap = 0, nhits = 0, nmulti = 0;
+        uint64_t nchunks = 0, ccap = 0, nhits = 0, nmulti = 0, nrecs = 0;
         size_t p = p0;
         for (; p < np; p++) {
             const PairJob &jb = jobs[p];
@@ -1666,22 +1715,30 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
             PairDesc d;
             memset(&d, 0, sizeof d);
             d.q = jb.q; d.r = jb.r; d.flags = jb.flags;
+            {
+                const GenomeMeta &R = (jb.flags & 4u) ? SB->h_meta[jb.r] : SA->h_meta[jb.r];
+                if (Q.rep_cut != 0xFFFFFFFFu || R.total_len > (uint64_t)HIT_POS_MASK) d.flags |= 8u;
+            }
+            if (Q.chunk_off + Q.n_chunks + 1u > 0xFFFFFFFFull) throw SkError("chunk tables of the sketch set exceed 2^32 entries");
+            d.q_chunk_off = (uint32_t)Q.chunk_off;
             d.n_chunks = Q.n_chunks;
             d.c_cap = 4u * Q.n_chunks + 64u;       // slow-path chains of the pair; made exact and retried when a pair needs more
             d.multi_cap = 256u + Q.n_seeds / 8u;
             if (d.multi_cap > 0x00FFFFF0u) d.multi_cap = 0x00FFFFF0u;
             if (!hp.empty() && nchunks + d.n_chunks > budget) break;
             if (nchunks + d.n_chunks > 0x7FFF0000ull || ccap + d.c_cap > 0xFFFF0000ull || nhits + Q.n_seeds + 32u > 0xFFFF0000ull ||
-                nmulti + d.multi_cap > 0xFFFF0000ull) break;
+                nmulti + d.multi_cap > 0xFFFF0000ull || nrecs + Q.n_seeds / 8u + 64u > 0xFFFF0000ull) break;
             // hit words of the pair start at an entry congruent (mod 16) to the genome's seed offset:
             // chain_fast_kernel's two input streams then change their 64-byte line at the same seeds
             const uint64_t hb = nhits + ((Q.seed_off - nhits) & 15u);
             d.chunk_base = (uint32_t)nchunks; d.c_base = (uint32_t)ccap; d.hit_base = (uint32_t)hb; d.multi_base = (uint32_t)nmulti;
+            d.rec_base = (uint32_t)nrecs; d.rec_cap = Q.n_seeds / 8u + 64u;     // more runs than that: the pair takes the slow path
+            nrecs += d.rec_cap;
             nchunks += d.n_chunks; ccap += d.c_cap; nhits = (hb + Q.n_seeds + 15u) & ~(uint64_t)15u; nmulti += d.multi_cap;
             hp.push_back(d);
         }
         const uint32_t nb = (uint32_t)hp.size();
-        S.p0 = p0; S.nb = nb; S.nchunks = nchunks; S.busy = true;
+        S.p0 = p0; S.nb = nb; S.nchunks = nchunks; S.nrecs = nrecs; S.busy = true;
         for (auto &e : S.ev) if (!e) HIPCHECK(hipEventCreate(&e));
         if (!S.h_cnt) HIPCHECK(hipHostMalloc(&S.h_cnt, 32 * sizeof(uint32_t)));
         if (S.h_out_cap < nb) {
@@ -1697,12 +1754,27 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         S.counters.resize(16, st); S.flags.resize(16, st);
         S.pair_na.resize(nb, st); S.pair_nch.resize(nb, st); S.pair_nmulti.resize(nb, st);
         S.hits.resize(nhits + 64, st); S.multi.resize(nmulti + 1, st);
+        S.recs.resize(nrecs + 1, st); S.pair_nrec.resize(nb + 1, st); S.chunk_rec0.resize(nchunks + 1, st);
         S.chains.resize(ccap + 1, st);
         S.d_out.resize(nb, st);
         if (getenv("SKDER_AMD_DEBUG"))
             fprintf(stderr, "[skder_amd] host: work buffers of the batch ready after %.2f ms\n",
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_al0).count());
         HIPCHECK(hipMemcpyAsync(S.d_pairs.p, hp.data(), nb * sizeof(PairDesc), hipMemcpyHostToDevice, st));
+        {
+            // first pair of every 256-chunk workgroup of the chaining kernel
+            std::vector<uint32_t> &wp = S.h_wg_pair;
+            const size_t nwg = (size_t)((nchunks + 255) / 256);
+            wp.resize(nwg + 1);
+            uint32_t pi = 0;
+            for (size_t w = 0; w < nwg; w++) {
+                const uint64_t t0 = (uint64_t)w * 256u;
+                while (pi + 1u < nb && hp[pi + 1u].chunk_base <= t0) pi++;
+                wp[w] = pi;
+            }
+            S.wg_pair.resize(nwg + 1, st);
+            if (nwg) HIPCHECK(hipMemcpyAsync(S.wg_pair.p, wp.data(), nwg * 4, hipMemcpyHostToDevice, st));
+        }
         HIPCHECK(hipMemsetAsync(S.pair_nmulti.p, 0, nb * 4, st));
         HIPCHECK(hipEventRecord(S.ev[0], st));
         {
@@ -1756,13 +1828,14 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         const uint32_t nb = S.nb, nslow = S.h_cnt[0], nover = S.h_cnt[15];
         float ms;
         HIPCHECK(hipEventElapsedTime(&ms, S.ev[0], S.ev[1])); t_join += ms;
-        HIPCHECK(hipEventElapsedTime(&ms, S.ev[1], S.ev[2])); t_fast += ms;
+        HIPCHECK(hipEventElapsedTime(&ms, S.ev[1], S.ev[6])); t_runs += ms;
+        HIPCHECK(hipEventElapsedTime(&ms, S.ev[6], S.ev[2])); t_fast += ms;
         HIPCHECK(hipEventElapsedTime(&ms, S.ev[2], S.ev[3])); t_slow += ms;
         HIPCHECK(hipEventElapsedTime(&ms, S.ev[3], S.ev[4])); t_fin += ms;
         if (getenv("SKDER_AMD_DEBUG")) {
             const uint32_t *hcnt = S.h_cnt;
-            fprintf(stderr, "[skder_amd] batch: over %u; %u pairs %llu chunks, slow %u (none %u, slots %u, hits %u, ring %u, branch %u, score %u, qrep %u, inside %u) parks %u passes %u walk-trips %u rounds %u empty-ring %u rec-change %u\n",
-                    nover, nb, (unsigned long long)S.nchunks, nslow, hcnt[1], hcnt[2], hcnt[3], hcnt[4], hcnt[5], hcnt[6], hcnt[7], hcnt[8], hcnt[10], hcnt[11], hcnt[12], hcnt[13], hcnt[14], hcnt[9]);
+            fprintf(stderr, "[skder_amd] batch: over %u; %u pairs %llu chunks, room for %llu run records, slow %u (none %u, slots %u, hits %u, ring %u, branch %u, score %u, qrep %u, inside %u, records-full %u, run-not-dominant %u)\n",
+                    nover, nb, (unsigned long long)S.nchunks, (unsigned long long)S.nrecs, nslow, hcnt[1], hcnt[2], hcnt[3], hcnt[4], hcnt[5], hcnt[6], hcnt[7], hcnt[8], hcnt[9], hcnt[10]);
         }
         // Rare-path fix-ups; the slot's buffers are untouched since (the batch in flight uses the other slot).
         //  * nover: chunks the wave kernel could not hold go through the global-memory kernels;
@@ -1897,12 +1970,32 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         throw;
     }
     if (getenv("SKDER_AMD_DEBUG"))
-        fprintf(stderr, "[skder_amd] host: batch loop %.2f ms wall (kernels: join %.2f fast %.2f slow %.2f finalize %.2f)\n",
-                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop0).count(), t_join, t_fast, t_slow, t_fin);
-    ctx->timing[3] = t_fast; ctx->timing[4] = t_slow; ctx->timing[5] = t_fin;
-    ctx->timing[6] = (double)np; ctx->timing[7] = (double)tot_anchors;
-    ctx->counters[0] = tot_chunks; ctx->counters[1] = tot_slow; ctx->counters[3] = tot_over;
-    ctx->timing_join = t_join;
+        fprintf(stderr, "[skder_amd] host: batch loop %.2f ms wall (kernels: join %.2f runs %.2f fast %.2f slow %.2f finalize %.2f)\n",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop0).count(), t_join, t_runs, t_fast, t_slow, t_fin);
+    // accumulated: a caller that works through its rows in blocks clears them once (chain_timing_reset)
+    ctx->timing[3] += t_fast; ctx->timing[4] += t_slow; ctx->timing[5] += t_fin;
+    ctx->timing[6] += (double)np; ctx->timing[7] += (double)tot_anchors;
+    ctx->counters[0] += tot_chunks; ctx->counters[1] += tot_slow; ctx->counters[3] += tot_over;
+    ctx->timing_join += t_join;
+    ctx->timing_runs += t_runs;
+}
+
+static void chain_timing_reset(skder_ctx *ctx)
+{
+    ctx->timing[2] = ctx->timing[3] = ctx->timing[4] = ctx->timing[5] = ctx->timing[6] = ctx->timing[7] = 0.0;
+    ctx->counters[0] = ctx->counters[1] = ctx->counters[3] = 0;
+    ctx->timing_join = ctx->timing_runs = 0.0;
+}
+
+// Rows are screened and chained in BLOCKS whose worst case (every partner passes the screen) stays below
+// 2^31 pairs: the screen counts and offsets pairs in 32 bits, and the host holds a few words per pair
+// (92,700 genomes of one species screen to more than 2^32 pairs in one go).  5,000 genomes are one block.
+static size_t rows_per_block(uint32_t n_partners)
+{
+    uint64_t budget = 1ull << 31;
+    if (const char *e = getenv("SKDER_AMD_PAIR_BUDGET")) budget = strtoull(e, nullptr, 10);
+    const uint64_t r = budget / (n_partners ? n_partners : 1u);
+    return (size_t)(r ? r : 1u);
 }
 
 void triangle_rows_impl(skder_sketches *s, uint32_t row_begin, uint32_t row_stride, double screen_pct)
@@ -1912,23 +2005,30 @@ void triangle_rows_impl(skder_sketches *s, uint32_t row_begin, uint32_t row_stri
     // touch different arrays, and both are bound by latency rather than by any one unit of the GPU
     if (!s->indexed) index_begin(s, ctx->stream2);
     ctx->edges.clear();
+    chain_timing_reset(ctx);
     std::vector<uint32_t> rows;
     for (uint32_t i = row_begin; i < s->n_genomes; i += (row_stride ? row_stride : 1)) rows.push_back(i);
-    std::vector<uint32_t> prow, ppart;
-    HIPCHECK(hipEventRecord(ctx->ev[9], ctx->stream));
-    screen_pairs(s, s, rows, true, screen_pct, prow, ppart);
-    HIPCHECK(hipEventRecord(ctx->ev[10], ctx->stream));
-    HIPCHECK(hipStreamSynchronize(ctx->stream));
-    float ms;
-    HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[9], ctx->ev[10]));
-    ctx->timing[2] = ms;
-    index_impl(s);
-    // triangle row (i, j): Ref = i, Query = j
-    const auto t0 = std::chrono::steady_clock::now();
-    chain_pairs(s, s, prow, ppart, ctx->edges);
-    if (getenv("SKDER_AMD_DEBUG"))
-        fprintf(stderr, "[skder_amd] host: screen %.2f ms (device), chain_pairs %.2f ms wall, %zu edges\n", ms,
-                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), ctx->edges.size());
+    const size_t rpb = rows_per_block(s->n_genomes);
+    std::vector<uint32_t> prow, ppart, sub;
+    for (size_t b0 = 0; b0 < rows.size() || b0 == 0; b0 += rpb) {
+        const size_t b1 = b0 + rpb < rows.size() ? b0 + rpb : rows.size();
+        const std::vector<uint32_t> &blk = (b0 == 0 && b1 == rows.size()) ? rows : (sub.assign(rows.begin() + b0, rows.begin() + b1), sub);
+        HIPCHECK(hipEventRecord(ctx->ev[9], ctx->stream));
+        screen_pairs(s, s, blk, true, screen_pct, prow, ppart);
+        HIPCHECK(hipEventRecord(ctx->ev[10], ctx->stream));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        float ms;
+        HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[9], ctx->ev[10]));
+        ctx->timing[2] += ms;
+        index_impl(s);
+        // triangle row (i, j): Ref = i, Query = j
+        const auto t0 = std::chrono::steady_clock::now();
+        chain_pairs(s, s, prow, ppart, ctx->edges);
+        if (getenv("SKDER_AMD_DEBUG"))
+            fprintf(stderr, "[skder_amd] host: rows %zu..%zu: screen %.2f ms (device), chain_pairs %.2f ms wall, %zu edges so far\n", b0, b1, ms,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), ctx->edges.size());
+        if (b1 >= rows.size()) break;
+    }
 }
 
 void rectangle_impl(skder_sketches *refs, skder_sketches *queries, double screen_pct)
@@ -1937,17 +2037,24 @@ void rectangle_impl(skder_sketches *refs, skder_sketches *queries, double screen
     if (!queries->indexed) index_impl(queries);
     if (!refs->indexed) index_begin(refs, ctx->stream2);      // overlaps the screen, as in triangle_rows_impl
     ctx->edges.clear();
+    chain_timing_reset(ctx);
     std::vector<uint32_t> rows(queries->n_genomes);
     for (uint32_t i = 0; i < queries->n_genomes; i++) rows[i] = i;
-    std::vector<uint32_t> prow, ppart;
-    HIPCHECK(hipEventRecord(ctx->ev[9], ctx->stream));
-    screen_pairs(refs, queries, rows, false, screen_pct, prow, ppart);
-    HIPCHECK(hipEventRecord(ctx->ev[10], ctx->stream));
-    HIPCHECK(hipStreamSynchronize(ctx->stream));
-    float ms;
-    HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[9], ctx->ev[10]));
-    ctx->timing[2] = ms;
-    index_impl(refs);
-    // rows are queries, partners are references
-    chain_pairs(refs, queries, ppart, prow, ctx->edges);
+    const size_t rpb = rows_per_block(refs->n_genomes);
+    std::vector<uint32_t> prow, ppart, sub;
+    for (size_t b0 = 0; b0 < rows.size() || b0 == 0; b0 += rpb) {
+        const size_t b1 = b0 + rpb < rows.size() ? b0 + rpb : rows.size();
+        const std::vector<uint32_t> &blk = (b0 == 0 && b1 == rows.size()) ? rows : (sub.assign(rows.begin() + b0, rows.begin() + b1), sub);
+        HIPCHECK(hipEventRecord(ctx->ev[9], ctx->stream));
+        screen_pairs(refs, queries, blk, false, screen_pct, prow, ppart);
+        HIPCHECK(hipEventRecord(ctx->ev[10], ctx->stream));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        float ms;
+        HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[9], ctx->ev[10]));
+        ctx->timing[2] += ms;
+        index_impl(refs);
+        // rows are queries, partners are references
+        chain_pairs(refs, queries, ppart, prow, ctx->edges);
+        if (b1 >= rows.size()) break;
+    }
 }

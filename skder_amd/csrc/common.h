@@ -89,6 +89,7 @@ struct skder_ctx {
     hipEvent_t ev[16];
     double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     double timing_join = 0;
+    double timing_runs = 0;          // ms of the run-extraction kernel in the last call
     double timing_index = 0;         // ms of the last index build (device)
     std::vector<skder_edge_t> edges;
     uint32_t *d_flags = nullptr;   // [0] overflow / error flags from kernels

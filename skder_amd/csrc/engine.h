@@ -55,6 +55,7 @@ struct skder_sketches {
     DevBuf<uint32_t> stag;                 // sgpos | (sctg & 63) << 24: the word the join hands to the chaining kernel
     DevBuf<uint32_t> boff;                 // bucket offset tables
     DevBuf<uint32_t> pchunk;               // chunk id of every seed (position order)
+    DevBuf<uint8_t> pcs;                   // 1 where a seed is the first of its chunk (position order): the run extraction reads 4 flags per lane
     DevBuf<uint32_t> chunk_start;          // first seed of every chunk (+ end sentinel), per genome
     ScreenIndex screen;
 };

@@ -14,7 +14,7 @@ __global__ __launch_bounds__(IDX_THREADS) void index_genome_kernel(
     GenomeMeta *__restrict__ meta, const uint32_t *__restrict__ list, const uint32_t *__restrict__ rec_goff,
     const uint32_t *__restrict__ seed_kmer, const uint32_t *__restrict__ seed_gpos, const uint32_t *__restrict__ seed_ctg,
     uint32_t *__restrict__ skmer, uint32_t *__restrict__ sgpos, uint32_t *__restrict__ sctg, uint32_t *__restrict__ stag,
-    uint32_t *__restrict__ boff_all, uint32_t *__restrict__ pchunk, uint32_t *__restrict__ chunk_start_all)
+    uint32_t *__restrict__ boff_all, uint32_t *__restrict__ pchunk, uint32_t *__restrict__ chunk_start_all, uint8_t *__restrict__ pcs)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t *cnt = reinterpret_cast<uint32_t *>(smem_raw);   // 2^bits counters, later cursor, later histogram
@@ -114,6 +114,7 @@ __global__ __launch_bounds__(IDX_THREADS) void index_genome_kernel(
         uint32_t ex = block_excl_scan<IDX_THREADS / 64>(flag, wsum, total);
         if (s < n) {
             pchunk[m.seed_off + s] = crun + ex + flag - 1u;
+            pcs[m.seed_off + s] = (uint8_t)flag;
             if (flag) chunk_start_all[m.chunk_off + crun + ex] = s;
         }
         crun += total;
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(IDXF_THREADS) void index_genome_lds_kernel(
     const uint32_t *__restrict__ seed_kmer, const uint32_t *__restrict__ seed_gpos, const uint32_t *__restrict__ seed_ctg,
     uint32_t *__restrict__ skmer, uint32_t *__restrict__ sgpos, uint32_t *__restrict__ sctg, uint32_t *__restrict__ stag,
     uint32_t *__restrict__ boff_all, uint32_t *__restrict__ pchunk, uint32_t *__restrict__ chunk_start_all,
-    uint4 *__restrict__ packed_all)
+    uint4 *__restrict__ packed_all, uint8_t *__restrict__ pcs)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ uint32_t wsum[IDXF_THREADS / 64];
@@ -387,6 +388,7 @@ __global__ __launch_bounds__(IDXF_THREADS) void index_genome_lds_kernel(
             const uint32_t upto = (uint32_t)__popcll(bal & (~0ull >> (63u - lane)));   // flags at lanes <= mine
             const uint32_t id = blk_off[s / 64u] + upto;                                // chunks started up to and including s
             pchunk[m.seed_off + s] = id - 1u;
+            pcs[m.seed_off + s] = (uint8_t)((bal >> lane) & 1ull);
             if ((bal >> lane) & 1ull) chunk_start_all[m.chunk_off + id - 1u] = s;
         }
         if (tid == 0) { meta[g].n_chunks = total; chunk_start_all[m.chunk_off + total] = n; }
@@ -433,6 +435,7 @@ void index_begin(skder_sketches *s, hipStream_t st)
     s->d_rec_goff.resize(s->h_rec_goff.size() + 1, st);
     s->skmer.resize(ns + 1, st); s->sgpos.resize(ns + 1, st); s->sctg.resize(ns + 1, st); s->stag.resize(ns + 1, st);
     s->pchunk.resize(ns + 1, st);
+    s->pcs.resize(ns + 16, st);
     s->boff.resize(boff_total + 1, st);
     s->chunk_start.resize(chunk_total + 1, st);
     if (G) {
@@ -472,14 +475,14 @@ void index_begin(skder_sketches *s, hipStream_t st)
                                          (int)lds_limit));
             hipLaunchKernelGGL(index_genome_lds_kernel, dim3((unsigned)small.size()), dim3(IDXF_THREADS), small_bytes, st, s->d_meta.p, d_list.p,
                                s->d_rec_goff.p, s->seed_kmer.p, s->seed_gpos.p, s->seed_ctg.p, s->skmer.p, s->sgpos.p, s->sctg.p, s->stag.p, s->boff.p,
-                               s->pchunk.p, s->chunk_start.p, s->idx_packed.p);
+                               s->pchunk.p, s->chunk_start.p, s->idx_packed.p, s->pcs.p);
         }
         if (!big.empty()) {
             HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(index_genome_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)((1u << max_bits) * 4)));
             hipLaunchKernelGGL(index_genome_kernel, dim3((unsigned)big.size()), dim3(IDX_THREADS), (1u << max_bits) * 4, st, s->d_meta.p,
                                d_list.p + small.size(), s->d_rec_goff.p, s->seed_kmer.p, s->seed_gpos.p, s->seed_ctg.p, s->skmer.p, s->sgpos.p,
-                               s->sctg.p, s->stag.p, s->boff.p, s->pchunk.p, s->chunk_start.p);
+                               s->sctg.p, s->stag.p, s->boff.p, s->pchunk.p, s->chunk_start.p, s->pcs.p);
         }
         HIPCHECK(hipGetLastError());
         HIPCHECK(hipEventRecord(ctx->ev[4], st));

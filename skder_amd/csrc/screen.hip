@@ -195,6 +195,9 @@ void screen_pairs(skder_sketches *refs, skder_sketches *queries, const std::vect
     pair_q.clear(); pair_r.clear();
     const uint32_t nrows = (uint32_t)rows.size(), nref = refs->n_genomes;
     if (!nrows || !nref) return;
+    // pairs are counted and placed with 32-bit offsets: the callers (chain.hip rows_per_block) keep a call's worst case below 2^32
+    if ((uint64_t)nrows * (uint64_t)nref >= (1ull << 32))
+        throw SkError("screen: " + std::to_string(nrows) + " rows x " + std::to_string(nref) + " genomes exceed the 2^32 pairs of one screening call");
     const uint64_t total_marks = refs->h_marker_off[nref];
     ScreenIndex &X = refs->screen;
     ScanWorkspace ws;

@@ -100,6 +100,10 @@ class Context:
         """device milliseconds of the last seed-index build"""
         return float(_lib.lib().skder_amd_last_index_ms(self.h))
 
+    def runs_ms(self) -> float:
+        """device milliseconds of the run-extraction kernel in the last triangle_rows / rectangle call"""
+        return float(_lib.lib().skder_amd_last_runs_ms(self.h))
+
     def counters(self) -> np.ndarray:
         out = (C.c_uint64 * 4)()
         _lib.lib().skder_amd_last_counters(self.h, out)
