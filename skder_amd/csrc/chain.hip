@@ -297,36 +297,37 @@ __global__ __launch_bounds__(JOIN_THREADS) void join_probe_kernel(SetView A, Set
 // RUN EXTRACTION: seed-parallel, coalesced.  Most classified seeds of related genomes merely continue the
 // previous hit -- same record and strand, 1..2500 bases on, ahead on the other genome, and on the same
 // diagonal or at most RUN_GAP bases off it (real genomes carry a short indel every few hundred bases) --
-// so the chaining kernel is fed RUNS, maximal stretches of such seeds, instead of one word per seed.
+// so the chaining kernels are fed RUNS, maximal stretches of such seeds, instead of one word per seed.
 // Why RUN_GAP = 10 = anchor score / 2: along a run every link scores 20 - gap >= 10, and the offer of any
 // other anchor (constant score + 20 - diagonal distance) moves by at most the link's gap <= 10, so (1) inside
 // a run the previous anchor is always the best predecessor of the next one (nearest on ties) and (2) a
 // competitor that cannot beat the run at its second anchor never can (chain_runs_kernel checks that once).
-// One workgroup per pair; a wavefront takes a SEGMENT of 256 consecutive seeds (4 per lane: one 16-byte
-// load per input stream and lane) and classifies every seed against the previous hit (inside the lane in
-// registers, across lanes by ballots and shuffles, across waves through LDS).  A record is written where a
-// run STARTS and carries, besides its first seed, the hit in front of it and the pair's running counts of
-// hits and diagonal steps up to there: the end, the length and the step sum of a run are then read off the
-// NEXT record (a terminator closes the pair), so no reduction over a run is needed.  The four waves advance
-// in step through the pair's segments: the records of a pair are contiguous and in seed order (one LDS
-// exchange per round).  A run never crosses a segment or a chunk boundary; the chaining kernel joins the
-// pieces again through its ordinary look-back.  A seed with 2..4 occurrences, or too many, is a record of
-// its own.  The first record of every chunk is registered in chunk_rec0.  A pair with more records than its
-// region holds is marked: all its chunks take the slow path.
+// One workgroup per pair, its four wavefronts independent of one another: wave w takes the w-th quarter of
+// the pair's seeds, a SEGMENT of 256 consecutive seeds at a time (4 per lane: one 16-byte load per input
+// stream and lane), and classifies every seed against the previous hit (inside the lane in registers,
+// across lanes by ballots and shuffles, across segments in wave-uniform registers).  A record is written
+// where a run STARTS and carries, besides its first seed, the hit in front of it and the wave's running
+// counts of hits and diagonal steps up to there: the end, the length and the step sum of a run are read
+// off the NEXT record, so no reduction over a run is needed.  Wave w writes into the w-th quarter of the
+// pair's record region and closes it with a LINK record (next: the following quarter) or, the last one, a
+// TERMINATOR; both close the run in front of them.  A run never crosses a chunk boundary or a quarter; the
+// chaining kernel joins such pieces again through its ordinary look-back.  A seed with 2..4 occurrences, or
+// too many, is a record of its own.  The first record of every chunk is registered in chunk_rec0.  A quarter
+// with more records than it holds marks the pair: all its chunks take the slow path.
 struct __attribute__((aligned(16))) RunRec {
-    uint32_t qi, q0, hw, cn;      // first seed: index in the chunked genome, position, hit word (or HIT_MULTI | slot, HIT_MANY); hits of the pair in front of it
-    uint32_t pq, pw, pqi, cg;     // the hit in front of it: position, hit word, seed index; diagonal steps of the pair in front of it
+    uint32_t qi, q0, hw, cn;      // first seed: index in the chunked genome, position, hit word (or HIT_MULTI | slot, HIT_MANY); hits of the quarter in front of it
+    uint32_t pq, pw, pqi, cg;     // the hit in front of it: position, hit word, seed index; diagonal steps of the quarter in front of it
 };
 #define SEG_SEEDS 256u
 #define RUN_GAP 10
-#define REC_OVER 0xFFFFFFFFu
+#define REC_LINK 0xFFFFFFFEu      // qi of a link record; its q0 is the index of the next record
+#define REC_END 0xFFFFFFFFu       // qi of the terminator
 static_assert(2 * RUN_GAP <= ANI_ANCHOR_SCORE, "run links must keep at least half of the anchor score");
 
 __global__ __launch_bounds__(256) void run_extract_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs,
                                                           const uint32_t *__restrict__ hits, RunRec *__restrict__ recs,
-                                                          uint32_t *__restrict__ pair_nrec, uint32_t *__restrict__ chunk_rec0)
+                                                          uint32_t *__restrict__ pair_over, uint32_t *__restrict__ chunk_rec0)
 {
-    __shared__ uint32_t s_x[2][4][4];      // per round parity and wave: packed counts, last hit (position, word, seed) or ~0
     const PairDesc pd = pairs[blockIdx.x];
     const SetView &QS = (pd.flags & 2u) ? B : A;
     const GenomeMeta *Qm = QS.meta + pd.q;
@@ -337,15 +338,17 @@ __global__ __launch_bounds__(256) void run_extract_kernel(SetView A, SetView B, 
     const uint8_t *cs_al = QS.pcs + (Qm->seed_off - a);
     const uint32_t *ck_of = QS.pchunk + Qm->seed_off;
     const uint32_t *hit_al = hits + (pd.hit_base - a);
-    RunRec *out_base = recs + pd.rec_base;
     uint32_t *rec0 = chunk_rec0 + pd.chunk_base;
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const uint32_t nseg = (nv + SEG_SEEDS - 1u) / SEG_SEEDS;
-    uint32_t run_rec = 0, run_nm = 0, run_g = 0;                     // totals of the rounds so far (uniform over the workgroup)
-    uint32_t car_q = 0, car_w = HIT_NONE, car_v = 0xFFFFFFFFu;       // last hit of the rounds so far
+    const uint32_t nseg = (nv + SEG_SEEDS - 1u) / SEG_SEEDS, per = (nseg + 3u) / 4u;
+    const uint32_t sg_lo = wv * per < nseg ? wv * per : nseg, sg_hi = (wv + 1u) * per < nseg ? (wv + 1u) * per : nseg;
+    const uint32_t cap4 = pd.rec_cap / 4u, reg0 = wv * cap4;           // this wave's quarter of the pair's record region
+    RunRec *out_base = recs + pd.rec_base;
+    uint32_t run_rec = 0, run_nm = 0, run_g = 0;                     // totals of the segments so far (wave-uniform)
+    uint32_t car_q = 0, car_w = HIT_NONE, car_v = 0xFFFFFFFFu;       // last hit of the segments so far
+    bool car_cs = true;                                              // a chunk began since (or there is no hit yet)
     bool overflow = false;
-    for (uint32_t sg0 = 0; sg0 < nseg; sg0 += 4u) {
-        const uint32_t sg = sg0 + wv;
+    for (uint32_t sg = sg_lo; sg < sg_hi; sg++) {
         const uint32_t v0 = sg * SEG_SEEDS + lane * 4u;
         uint32_t hv[4], qv[4], csw = 0;
         if (v0 >= a && v0 + 4u <= nv) {
@@ -378,33 +381,37 @@ __global__ __launch_bounds__(256) void run_extract_kernel(SetView A, SetView B, 
         // a chunk starts behind the lane's last hit (anywhere, if the lane has none): the next hit cannot continue
         const bool tail_cs = has_nm ? (csmask >> (ul + 1u)) != 0u : csmask != 0u;
         const unsigned long long M = __ballot(has_nm), T = __ballot(tail_cs);
-        // B. the previous hit, from the nearest lane below that has one
-        const unsigned long long below = M & ((1ull << lane) - 1ull);
-        const bool pin = below != 0ull;                       // the hit in front of the lane's seeds lies in this segment
+        // B. the previous hit: from the nearest lane below that has one, else the last hit of the segments before
+        const unsigned long long lowbits = (1ull << lane) - 1ull, below = M & lowbits;
+        const bool pin = below != 0ull;
         const uint32_t P = pin ? 63u - (uint32_t)__clzll((long long)below) : 0u;
-        uint32_t pw = (uint32_t)__shfl((int)w_l, (int)P, 64), pq = (uint32_t)__shfl((int)q_l, (int)P, 64);
-        const uint32_t pv_in = (uint32_t)__shfl((int)(v0 + ul), (int)P, 64);
-        const uint32_t pw_in = pw, pq_in = pq;
-        const bool pv = pin && ((T >> P) & ((1ull << (lane - P)) - 1ull)) == 0ull;
+        const uint32_t sw = (uint32_t)__shfl((int)w_l, (int)P, 64), sq = (uint32_t)__shfl((int)q_l, (int)P, 64);
+        const uint32_t sv = (uint32_t)__shfl((int)(v0 + ul), (int)P, 64);
+        const uint32_t pw_in = pin ? sw : car_w, pq_in = pin ? sq : car_q, pv_in = pin ? sv : car_v;
+        const bool pv = pin ? ((T >> P) & ((1ull << (lane - P)) - 1ull)) == 0ull
+                            : (car_v != 0xFFFFFFFFu && !car_cs && (T & lowbits) == 0ull);
         // C. run starts among the lane's seeds; diagonal step of every continuing seed.  firstmask: starts that may be
-        // the first record of their chunk (a chunk began since the previous hit, or the previous hit is in another segment)
+        // the first record of their chunk (a chunk began since the previous hit, or there is none)
         uint32_t startmask = 0, firstmask = 0, gl[4] = {0, 0, 0, 0};
-        bool pending = !pv;
+        {
+            uint32_t pw = pw_in, pq = pq_in;
+            bool pending = !pv;
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if ((csmask >> u) & 1u) pending = true;
-            if ((nmmask >> u) & 1u) {
-                const uint32_t w = hv[u], q = qv[u];
-                const uint32_t sgw = (uint32_t)((int32_t)w >> 31), sgp = (uint32_t)((int32_t)pw >> 31);
-                const int32_t dgw = (int32_t)(((w & HIT_POS_MASK) ^ sgw) - q), dgp = (int32_t)(((pw & HIT_POS_MASK) ^ sgp) - pq);   // one value per diagonal
-                const int32_t dd = dgw - dgp, g = dd < 0 ? -dd : dd;
-                const int32_t drs = (int32_t)(w & HIT_POS_MASK) - (int32_t)(pw & HIT_POS_MASK);       // ahead on the other genome
-                const bool cont = !pending && !((w | pw) & 0x40000000u) && !((w ^ pw) & HIT_KEY_MASK) && g <= RUN_GAP &&
-                                  (q - pq) <= (uint32_t)ANI_BP_BAND && (sgw ? drs < 0 : drs > 0);
-                startmask |= (cont ? 0u : 1u) << u;
-                firstmask |= (pending ? 1u : 0u) << u;
-                gl[u] = cont ? (uint32_t)g : 0u;
-                pw = w; pq = q; pending = false;
+            for (int u = 0; u < 4; u++) {
+                if ((csmask >> u) & 1u) pending = true;
+                if ((nmmask >> u) & 1u) {
+                    const uint32_t w = hv[u], q = qv[u];
+                    const uint32_t sgw = (uint32_t)((int32_t)w >> 31), sgp = (uint32_t)((int32_t)pw >> 31);
+                    const int32_t dgw = (int32_t)(((w & HIT_POS_MASK) ^ sgw) - q), dgp = (int32_t)(((pw & HIT_POS_MASK) ^ sgp) - pq);   // one value per diagonal
+                    const int32_t dd = dgw - dgp, g = dd < 0 ? -dd : dd;
+                    const int32_t drs = (int32_t)(w & HIT_POS_MASK) - (int32_t)(pw & HIT_POS_MASK);       // ahead on the other genome
+                    const bool cont = !pending && !((w | pw) & 0x40000000u) && !((w ^ pw) & HIT_KEY_MASK) && g <= RUN_GAP &&
+                                      (q - pq) <= (uint32_t)ANI_BP_BAND && (sgw ? drs < 0 : drs > 0);
+                    startmask |= (cont ? 0u : 1u) << u;
+                    firstmask |= (pending ? 1u : 0u) << u;
+                    gl[u] = cont ? (uint32_t)g : 0u;
+                    pw = w; pq = q; pending = false;
+                }
             }
         }
         // D. running counts in front of the lane: hits, records, diagonal steps (one packed scan)
@@ -412,31 +419,9 @@ __global__ __launch_bounds__(256) void run_extract_kernel(SetView A, SetView B, 
         const uint32_t g_l = gl[0] + gl[1] + gl[2] + gl[3];
         uint32_t tot;
         const uint32_t ex = wave_excl_scan(cnt_l | (nrec_l << 10) | (g_l << 20), tot);
-        // E. the four waves' records go behind one another: counts and last hits through LDS (one barrier per round)
-        const uint32_t par = (sg0 >> 2) & 1u;
-        const uint32_t topl = M ? 63u - (uint32_t)__clzll((long long)M) : 0u;
-        const uint32_t lq = (uint32_t)__shfl((int)q_l, (int)topl, 64), lw = (uint32_t)__shfl((int)w_l, (int)topl, 64);
-        const uint32_t lv = (uint32_t)__shfl((int)(v0 + ul), (int)topl, 64);
-        if (lane == 0) {
-            s_x[par][wv][0] = sg < nseg ? tot : 0u;
-            s_x[par][wv][1] = lq; s_x[par][wv][2] = lw; s_x[par][wv][3] = (M && sg < nseg) ? lv : 0xFFFFFFFFu;
-        }
-        __syncthreads();
-        uint32_t base_rec = run_rec, base_nm = run_nm, base_g = run_g;
-        uint32_t cq = car_q, cw = car_w, cv = car_v;            // the last hit in front of MY segment
-#pragma unroll
-        for (uint32_t w2 = 0; w2 < 4u; w2++) {
-            const uint32_t t0 = s_x[par][w2][0], tv = s_x[par][w2][3];
-            const uint32_t tq = s_x[par][w2][1], tw = s_x[par][w2][2];
-            if (w2 < wv) {
-                base_nm += t0 & 1023u; base_rec += (t0 >> 10) & 1023u; base_g += t0 >> 20;
-                if (tv != 0xFFFFFFFFu) { cq = tq; cw = tw; cv = tv; }
-            }
-            run_nm += t0 & 1023u; run_rec += (t0 >> 10) & 1023u; run_g += t0 >> 20;
-            if (tv != 0xFFFFFFFFu) { car_q = tq; car_w = tw; car_v = tv; }
-        }
-        if (run_rec + 1u > pd.rec_cap) { overflow = true; break; }      // + the terminator; uniform over the workgroup
-        if (!overflow && startmask) {
+        const uint32_t seg_rec = (tot >> 10) & 1023u;
+        if (run_rec + seg_rec + 1u > cap4) { overflow = true; break; }       // + the closing record; wave-uniform
+        if (startmask) {
             const uint32_t pex = ex & 1023u, rex = (ex >> 10) & 1023u, gex = ex >> 20;
             uint32_t sm = startmask, j = 0;
             while (sm) {
@@ -445,31 +430,213 @@ __global__ __launch_bounds__(256) void run_extract_kernel(SetView A, SetView B, 
                 RunRec r;
                 r.qi = v0 + u - a; r.q0 = SEL4(qv, u); r.hw = SEL4(hv, u);
                 const uint32_t lowm = nmmask & ((1u << u) - 1u);          // the lane's hits in front of this one
-                r.cn = base_nm + pex + (uint32_t)__popc(lowm);
+                r.cn = run_nm + pex + (uint32_t)__popc(lowm);
                 uint32_t gs = 0;
 #pragma unroll
                 for (int x = 0; x < 4; x++) gs += ((uint32_t)x < u) ? gl[x] : 0u;
-                r.cg = base_g + gex + gs;
+                r.cg = run_g + gex + gs;
                 if (lowm) {
                     const uint32_t lu = 31u - (uint32_t)__clz((int)lowm);
                     r.pq = SEL4(qv, lu); r.pw = SEL4(hv, lu); r.pqi = v0 + lu - a;
-                } else if (pin) { r.pq = pq_in; r.pw = pw_in; r.pqi = pv_in - a; }
-                else { r.pq = cq; r.pw = cw; r.pqi = cv == 0xFFFFFFFFu ? 0xFFFFFFFFu : cv - a; }
-                out_base[base_rec + rex + j] = r;
-                if ((firstmask >> u) & 1u) atomicMin(&rec0[ck_of[r.qi]], base_rec + rex + j);
+                } else { r.pq = pq_in; r.pw = pw_in; r.pqi = pv_in == 0xFFFFFFFFu ? 0xFFFFFFFFu : pv_in - a; }
+                const uint32_t at = reg0 + run_rec + rex + j;
+                out_base[at] = r;
+                if ((firstmask >> u) & 1u) atomicMin(&rec0[ck_of[r.qi]], at);
                 j++;
             }
         }
+        // E. carry into the next segment
+        run_nm += tot & 1023u; run_rec += seg_rec; run_g += tot >> 20;
+        if (M) {
+            const uint32_t topl = 63u - (uint32_t)__clzll((long long)M);
+            car_q = (uint32_t)__shfl((int)q_l, (int)topl, 64); car_w = (uint32_t)__shfl((int)w_l, (int)topl, 64);
+            car_v = (uint32_t)__shfl((int)(v0 + ul), (int)topl, 64);
+            car_cs = (T >> topl) != 0ull;
+        } else {
+            car_cs = car_cs || T != 0ull;
+        }
 #undef SEL4
     }
-    if (threadIdx.x == 0) {
-        if (!overflow) {
-            RunRec r;       // terminator: closes the last run of the pair
-            r.qi = 0xFFFFFFFFu; r.q0 = 0; r.hw = HIT_NONE; r.cn = run_nm;
-            r.pq = car_q; r.pw = car_w; r.pqi = car_v == 0xFFFFFFFFu ? 0xFFFFFFFFu : car_v - a; r.cg = run_g;
-            out_base[run_rec] = r;
+    if (overflow) { if (lane == 0) pair_over[blockIdx.x] = 1u; return; }
+    if (lane == 0) {
+        RunRec r;       // closes the last run of the quarter; leads on to the next quarter, or ends the pair
+        r.qi = wv == 3u ? REC_END : REC_LINK; r.q0 = (wv + 1u) * cap4; r.hw = HIT_NONE; r.cn = run_nm;
+        r.pq = car_q; r.pw = car_w; r.pqi = car_v == 0xFFFFFFFFu ? 0xFFFFFFFFu : car_v - a; r.cg = run_g;
+        out_base[reg0 + run_rec] = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// FAST PATH, first sieve: one lane per (pair, 20 kb chunk), a short loop over the chunk's first records.
+// A chunk without a hit has no chain.  A chunk whose hits form ONE run of single-occurrence seeds IS its
+// chain: inside a run every anchor chains to the one before (run_extract_kernel, "Why RUN_GAP"), scores rise
+// along it, so the best end is the last anchor and the back-track takes all n of them -- score 20 n - steps,
+// a chain if n >= 3.  With k = 15 about one seed in 180 also hits an unrelated place of the other genome, so
+// the usual chunk is such a run cut into pieces by one or two STRAY hits; that is settled here as well:
+//   * a PATH: records that follow one another like the seeds of a run do (same record and strand,
+//     1..2500 bases on, ahead on the other genome, at most RUN_GAP off the diagonal of the hit in front) --
+//     all links cost <= 10, so each anchor chains to the main anchor before it, strays in between or not
+//     (they lie at most two anchors deep in the 50-anchor look-back); a chunk may hold up to three paths one
+//     after the other (the other genome's records end inside it, or a stretch without hits is longer than
+//     the 2500-base band), each of a record / strand of its own or out of reach of the others' anchors, so
+//     that nothing chains from one to the next;
+//   * at most TWO strays -- a seed that hits an unrelated place only, or the second occurrence of a seed whose
+//     other occurrence lies on the main path --, each of another record or strand than the main path or
+//     further from its diagonal than max_gap plus all the path's diagonal steps: they can neither give to nor
+//     take from a main anchor, and two anchors alone are not a chain (min_anchors = 3).
+// Everything else goes on a list for chain_runs_kernel (lanes packed with chunks that need its loop); pairs
+// whose records overflowed and pairs that need the unabridged algorithm go to the slow path.
+#define SIEVE_RECORDS 6
+#ifdef SKDER_SIEVE_STATS
+#define SIEVE_WHY(I) atomicAdd(counters + 16 + (I), 1u)
+#else
+#define SIEVE_WHY(I)
+#endif
+__global__ __launch_bounds__(256) void chain_single_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs, uint32_t npairs,
+                                                           uint32_t total_chunks, const RunRec *__restrict__ recs,
+                                                           const uint32_t *__restrict__ pair_over, const uint32_t *__restrict__ chunk_rec0,
+                                                           const uint32_t *__restrict__ wg_pair, const uint4 *__restrict__ multi,
+                                                           ChainRec *__restrict__ fast_chains,
+                                                           uint32_t *__restrict__ chunk_state, uint32_t *__restrict__ slow_list,
+                                                           uint32_t *__restrict__ counters, uint32_t *__restrict__ gen_list,
+                                                           uint32_t *__restrict__ pair_na, int xcd_remap)
+{
+    // XCD-aware work mapping: workgroups are dealt round-robin to the 8 XCDs, so give every XCD one
+    // contiguous eighth of the (R-sorted) work list
+    uint32_t wg = blockIdx.x;
+    if (xcd_remap & 1) {
+        const uint32_t nwg = gridDim.x, xcd = wg & 7u, idx = wg >> 3, q8 = nwg >> 3, r8 = nwg & 7u;
+        wg = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + idx;
+    }
+    const uint32_t t = wg * 256u + threadIdx.x;
+    const bool in = t < total_chunks;
+    uint32_t pi = 0, n_add = 0;
+    if (in) {
+        const uint32_t idx0 = chunk_rec0[t];                 // independent of the descriptor: in flight beside it
+        pi = wg_pair[wg];
+        while (pi + 1u < npairs && pairs[pi + 1u].chunk_base <= t) pi++;
+        const PairDesc pd = pairs[pi];
+        const uint32_t c = t - pd.chunk_base;
+        if ((pd.flags & 8u) || pair_over[pi] || (xcd_remap & 2)) {
+            chunk_state[t] = CHUNK_SLOW;
+            slow_list[atomicAdd(counters, 1u)] = t;
+            atomicAdd(counters + 1 + ((pd.flags & 8u) || (xcd_remap & 2) ? 6 : 8), 1u);
+        } else if (idx0 == 0xFFFFFFFFu) {
+            chunk_state[t] = 0u;
+        } else {
+            const SetView &QS = (pd.flags & 2u) ? B : A;
+            const uint32_t s1 = QS.chunk_start[pd.q_chunk_off + c + 1];
+            const uint4 *rp = reinterpret_cast<const uint4 *>(recs + pd.rec_base) + 2u * idx0;
+            uint4 a0 = rp[0], a1 = rp[1];
+            bool fail = false, main_on = false;
+            uint32_t n = 0, G = 0, nstray = 0, anchors = 0, nfin = 0, npath = 0;
+            uint32_t m_qi = 0, m_q0 = 0, m_hw = 0, l_q = 0, l_hw = 0, l_qi = 0;     // current path: first anchor; last anchor
+            uint32_t st_hw0 = 0, st_q0 = 0, st_hw1 = 0, st_q1 = 0;                  // the strays
+            uint32_t p_hw[FAST_SLOTS] = {0, 0, 0}, p_G[FAST_SLOTS] = {0, 0, 0};     // closed and current paths: key, first diagonal, steps
+            int32_t p_D[FAST_SLOTS] = {0, 0, 0};
+            uint32_t p_lq[FAST_SLOTS] = {0, 0, 0};                                   // ... and the position of their last anchor
+            ChainRec *slots = fast_chains + (uint64_t)t * FAST_SLOTS;
+            // the current path ends: its chain, and what the strays have to be checked against
+#define CLOSE_PATH()                                                                                                  \
+            do {                                                                                                      \
+                p_hw[npath] = m_hw; p_G[npath] = G; p_lq[npath] = l_q;                                                \
+                p_D[npath] = (m_hw >> 31) ? (int32_t)(m_hw & HIT_POS_MASK) + (int32_t)m_q0 : (int32_t)(m_hw & HIT_POS_MASK) - (int32_t)m_q0; \
+                npath++;                                                                                              \
+                if (n >= ANI_MIN_ANCHORS) {                                                                           \
+                    ChainRec cr;                                                                                      \
+                    cr.score = ANI_ANCHOR_SCORE * (int32_t)n - (int32_t)G; cr.n = n; cr.n_seeds = l_qi - m_qi + 1u;   \
+                    cr.q0 = m_q0; cr.q1 = l_q;                                                                        \
+                    const uint32_t ra = m_hw & HIT_POS_MASK, rb = l_hw & HIT_POS_MASK;                                \
+                    cr.r0 = ra < rb ? ra : rb; cr.r1 = ra > rb ? ra : rb;                                             \
+                    cr.chunk = c;                                                                                     \
+                    slots[nfin++] = cr;                                                                               \
+                }                                                                                                     \
+            } while (0)
+            for (int k = 0; k < SIEVE_RECORDS + 1; k++) {
+                if (a0.x >= s1) { if (a0.x == REC_LINK) { fail = true; SIEVE_WHY(8); } break; }      // (a link: the chunk goes on in another quarter)
+                if (k == SIEVE_RECORDS || a0.z == HIT_MANY) { fail = true; SIEVE_WHY(k == SIEVE_RECORDS ? 12 : 13); break; }
+                rp += 2;
+                const uint4 b0 = rp[0], b1 = rp[1];          // the record behind closes this one
+                const uint32_t rn = b0.w - a0.w, rg = b1.w - a1.w;
+                // does a hit continue the current path behind its last anchor?
+#define JOINS(W, GOUT)                                                                                               \
+                [&]() -> bool {                                                                                       \
+                    const uint32_t sgw = (uint32_t)((int32_t)(W) >> 31), sgp = (uint32_t)((int32_t)l_hw >> 31);       \
+                    const int32_t dd = (int32_t)((((W) & HIT_POS_MASK) ^ sgw) - a0.y) - (int32_t)(((l_hw & HIT_POS_MASK) ^ sgp) - l_q); \
+                    const int32_t gabs_ = dd < 0 ? -dd : dd;                                                          \
+                    const int32_t drs = (int32_t)((W) & HIT_POS_MASK) - (int32_t)(l_hw & HIT_POS_MASK);               \
+                    GOUT = (uint32_t)gabs_;                                                                           \
+                    return !(((W) ^ l_hw) & HIT_KEY_MASK) && gabs_ <= RUN_GAP && (a0.y - l_q) - 1u < (uint32_t)ANI_BP_BAND && \
+                           (sgw ? drs < 0 : drs > 0);                                                                 \
+                }()
+                if ((a0.z & 0xFF000000u) == HIT_MULTI) {
+                    // a seed with two occurrences: usually its place on the current path and a stray
+                    const uint4 mv = multi[pd.multi_base + (a0.z & 0x00FFFFFFu)];
+                    uint32_t gx = 0, gy = 0;
+                    const bool two = mv.z == HIT_NONE && main_on && nstray < 2u;
+                    const bool jx = two && JOINS(mv.x, gx), jy = two && JOINS(mv.y, gy);
+                    if (jx == jy) { fail = true; SIEVE_WHY(13); break; }
+                    const uint32_t wj = jx ? mv.x : mv.y, ws = jx ? mv.y : mv.x;
+                    anchors += 2u;
+                    n += 1u; G += jx ? gx : gy; l_q = a0.y; l_hw = wj; l_qi = a0.x;
+                    if (nstray == 0u) { st_hw0 = ws; st_q0 = a0.y; } else { st_hw1 = ws; st_q1 = a0.y; }
+                    nstray++;
+                } else {
+                    anchors += rn;
+                    bool joins = false;
+                    uint32_t g = 0;
+                    if (main_on) {
+                        joins = JOINS(a0.z, g);
+                        if (joins) { n += rn; G += rg + g; l_q = b1.x; l_hw = b1.y; l_qi = b1.z; }
+                    }
+                    if (!joins) {
+                        if (rn >= 2u) {
+                            // a new path: of a record / strand no path of the chunk had so far, or more than the 2500-base band
+                            // behind the last anchor of every path that had it (nothing can chain across)
+                            if (main_on) {
+                                if (npath + 1u >= FAST_SLOTS) { fail = true; SIEVE_WHY(10); break; }
+                                CLOSE_PATH();
+                                bool clash = false;
+                                for (uint32_t x = 0; x < npath; x++) clash |= !((p_hw[x] ^ a0.z) & HIT_KEY_MASK) && a0.y - p_lq[x] <= (uint32_t)ANI_BP_BAND;
+                                if (clash) { fail = true; SIEVE_WHY(10); break; }
+                            }
+                            main_on = true;
+                            m_qi = a0.x; m_q0 = a0.y; m_hw = a0.z; n = rn; G = rg; l_q = b1.x; l_hw = b1.y; l_qi = b1.z;
+                        } else if (nstray < 2u) {
+                            if (nstray == 0u) { st_hw0 = a0.z; st_q0 = a0.y; } else { st_hw1 = a0.z; st_q1 = a0.y; }
+                            nstray++;
+                        } else { fail = true; SIEVE_WHY(14); break; }
+                    }
+                }
+#undef JOINS
+                a0 = b0; a1 = b1;
+            }
+            if (!fail && main_on) CLOSE_PATH();
+#undef CLOSE_PATH
+            if (!fail && nstray) {
+                // the strays must be unable to chain with any path
+                const int32_t ds0 = (st_hw0 >> 31) ? (int32_t)(st_hw0 & HIT_POS_MASK) + (int32_t)st_q0 : (int32_t)(st_hw0 & HIT_POS_MASK) - (int32_t)st_q0;
+                const int32_t ds1 = (st_hw1 >> 31) ? (int32_t)(st_hw1 & HIT_POS_MASK) + (int32_t)st_q1 : (int32_t)(st_hw1 & HIT_POS_MASK) - (int32_t)st_q1;
+                for (uint32_t x = 0; x < npath; x++) {
+                    const int32_t lim = ANI_MAX_GAP + (int32_t)p_G[x];
+                    if (!((st_hw0 ^ p_hw[x]) & HIT_KEY_MASK) && abs(ds0 - p_D[x]) <= lim) fail = true;
+                    if (nstray > 1u && !((st_hw1 ^ p_hw[x]) & HIT_KEY_MASK) && abs(ds1 - p_D[x]) <= lim) fail = true;
+                }
+                if (fail) SIEVE_WHY(15);
+            }
+            if (!fail) { n_add = anchors; chunk_state[t] = nfin; }
+            else gen_list[atomicAdd(counters + 11, 1u)] = t;
         }
-        pair_nrec[blockIdx.x] = overflow ? REC_OVER : run_rec;
+    }
+    // anchors of the pair: one atomic per wavefront when all its chunks belong to one pair (nearly always)
+    const uint32_t pi0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)pi);
+    if (__all(!in || pi == pi0)) {
+        uint32_t v = n_add;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if ((threadIdx.x & 63u) == 0 && v) atomicAdd(&pair_na[pi0], v);
+    } else if (n_add) {
+        atomicAdd(&pair_na[pi], n_add);
     }
 }
 
@@ -505,37 +672,26 @@ struct Run {
 };
 
 __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs, uint32_t npairs,
-                                                         uint32_t total_chunks, const RunRec *__restrict__ recs,
-                                                         const uint32_t *__restrict__ pair_nrec, const uint32_t *__restrict__ chunk_rec0,
-                                                         const uint32_t *__restrict__ wg_pair, const uint4 *__restrict__ multi,
+                                                         const uint32_t *__restrict__ gen_list, const RunRec *__restrict__ recs,
+                                                         const uint32_t *__restrict__ chunk_rec0, const uint4 *__restrict__ multi,
                                                          ChainRec *__restrict__ fast_chains, uint32_t *__restrict__ chunk_state,
                                                          uint32_t *__restrict__ slow_list, uint32_t *__restrict__ slow_count,
-                                                         uint32_t *__restrict__ pair_na, int xcd_remap)
+                                                         uint32_t *__restrict__ pair_na)
 {
-    // XCD-aware work mapping: workgroups are dealt round-robin to the 8 XCDs, so give every XCD one
-    // contiguous eighth of the (R-sorted) work list
-    uint32_t wg = blockIdx.x;
-    if (xcd_remap & 1) {
-        const uint32_t nwg = gridDim.x, xcd = wg & 7u, idx = wg >> 3, q8 = nwg >> 3, r8 = nwg & 7u;
-        wg = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + idx;
-    }
-    const uint32_t t = wg * 256u + threadIdx.x;
-    if (t >= total_chunks) return;
-    // the pair of this chunk: the workgroup's first pair comes from a host-built table, a workgroup's 256 chunks span two
-    // or three pairs (no dependent binary search); everything the lane needs of its genomes sits in the descriptor
-    const uint32_t idx0 = chunk_rec0[t];                 // independent of the descriptor: in flight beside it
-    uint32_t pi = wg_pair[wg];
-    while (pi + 1u < npairs && pairs[pi + 1u].chunk_base <= t) pi++;
+    // the chunks chain_single_kernel could not settle, one per lane; their number is only known on the device: a fixed
+    // grid strides over the list
+    const uint32_t n_items = slow_count[11];
+    for (uint32_t w0 = blockIdx.x * 256u; w0 < n_items; w0 += gridDim.x * 256u) {
+    const bool live = w0 + threadIdx.x < n_items;
+    const uint32_t t = live ? gen_list[w0 + threadIdx.x] : 0u;
+    const uint32_t pi = find_pair(pairs, npairs, t);
     const PairDesc pd = pairs[pi];
-    const uint32_t nrec = pair_nrec[pi];
+    const uint32_t idx0 = chunk_rec0[t];
     const uint32_t c = t - pd.chunk_base;
     const SetView &QS = (pd.flags & 2u) ? B : A;
-    const uint2 cs2 = make_uint2(QS.chunk_start[pd.q_chunk_off + c], QS.chunk_start[pd.q_chunk_off + c + 1]);
-    const uint32_t s0 = cs2.x, s1 = cs2.y;
-    // own-multiplicity filter active, or positions of the probed genome do not fit a hit word's 24 bits (descriptor
-    // bit 3): leave the chunk to the slow path
-    bool cplx = (pd.flags & 8u) || (xcd_remap & 2) || ((xcd_remap >> 2) && (uint32_t)(xcd_remap >> 2) != t + 1u);
-    uint32_t cause = cplx ? 6u : 0u;
+    const uint32_t s0 = QS.chunk_start[pd.q_chunk_off + c], s1 = QS.chunk_start[pd.q_chunk_off + c + 1];
+    bool cplx = false;
+    uint32_t cause = 0u;
 
     const int32_t NEG = -0x40000000;
     Run r0, r1, r2, r3;
@@ -609,22 +765,25 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, c
         }                                                                                    \
     } while (0)
 
-    // record cursor: the chunk's records are contiguous in the pair's region, from chunk_rec0 on, in seed order; the
-    // record BEHIND a run closes it (the pair's last one is a terminator), so two records are held and the third is
-    // on its way while the first is worked on
+    // record cursor: the chunk's records follow one another in the pair's region, from chunk_rec0 on, in seed order; the
+    // record BEHIND a run closes it (a link or the terminator at the end of a quarter), so two records are held and
+    // the third is on its way while the first is worked on
     const uint4 *prec = reinterpret_cast<const uint4 *>(recs + pd.rec_base);
     uint32_t idx = idx0;
-    if (!cplx && nrec == REC_OVER) { cplx = true; cause = 8; }
-    bool done = cplx || idx == 0xFFFFFFFFu || s1 <= s0;
+    bool done = !live || idx == 0xFFFFFFFFu || s1 <= s0;
     uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0, b0 = a0, b1 = a0;
-    if (!done) { a0 = prec[2u * idx]; a1 = prec[2u * idx + 1u]; b0 = prec[2u * idx + 2u]; b1 = prec[2u * idx + 3u]; }   // idx < nrec: idx + 1 exists
+    if (!done) { a0 = prec[2u * idx]; a1 = prec[2u * idx + 1u]; b0 = prec[2u * idx + 2u]; b1 = prec[2u * idx + 3u]; }   // a run record is never the last of its quarter
     for (;;) {
         // one record per round
         bool have = false;
         struct { uint32_t qi, q0, hw, q1, qi1, hw1, n, gsum; } rc;
         rc.qi = 0; rc.q0 = 0; rc.hw = HIT_NONE; rc.hw1 = HIT_NONE; rc.q1 = 0; rc.qi1 = 0; rc.n = 0; rc.gsum = 0;
         if (!done) {
-            if (a0.x >= s1) done = true;                  // records are in seed order (terminator: ~0): the chunk is finished
+            if (a0.x == REC_LINK) {                       // the chunk goes on in the next quarter of the region
+                idx = a0.y;
+                a0 = prec[2u * idx]; a1 = prec[2u * idx + 1u];
+                if (a0.x < REC_LINK) { b0 = prec[2u * idx + 2u]; b1 = prec[2u * idx + 3u]; }
+            } else if (a0.x >= s1) done = true;           // records are in seed order (terminator: ~0): the chunk is finished
             else {
                 have = true;
                 rc.qi = a0.x; rc.q0 = a0.y; rc.hw = a0.z;
@@ -632,8 +791,7 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, c
                 rc.q1 = b1.x; rc.hw1 = b1.y; rc.qi1 = b1.z;               // the hit in front of the next record ends this run
                 a0 = b0; a1 = b1;
                 idx++;
-                if (idx < nrec) { b0 = prec[2u * idx + 2u]; b1 = prec[2u * idx + 3u]; }   // record idx + 1 (<= nrec: the terminator)
-                else a0.x = 0xFFFFFFFFu;                                   // that was the pair's last record
+                if (a0.x < REC_LINK) { b0 = prec[2u * idx + 2u]; b1 = prec[2u * idx + 3u]; }
             }
         }
         if (have) do {
@@ -797,14 +955,17 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, c
     if (!cplx) EMIT_PATH(r0);
 #undef EMIT_PATH
 #undef EVICT
-    if (cplx) {
-        chunk_state[t] = CHUNK_SLOW;
-        slow_list[atomicAdd(slow_count, 1u)] = t;
-        atomicAdd(slow_count + 1 + cause, 1u);
-    } else {
-        chunk_state[t] = nfin;
-        if (ia) atomicAdd(&pair_na[pi], ia);
+    if (live) {
+        if (cplx) {
+            chunk_state[t] = CHUNK_SLOW;
+            slow_list[atomicAdd(slow_count, 1u)] = t;
+            atomicAdd(slow_count + 1 + cause, 1u);
+        } else {
+            chunk_state[t] = nfin;
+            if (ia) atomicAdd(&pair_na[pi], ia);
+        }
     }
+    }   // items of this lane
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1540,7 +1701,7 @@ struct ChainSlot {
     DevBuf<uint32_t> hits, pair_nmulti, groups, over_list, flags;
     DevBuf<uint4> multi;
     DevBuf<RunRec> recs;
-    DevBuf<uint32_t> pair_nrec, chunk_rec0, wg_pair;
+    DevBuf<uint32_t> pair_over, chunk_rec0, wg_pair, gen_list;
     std::vector<uint32_t> h_wg_pair;
     DevBuf<ChainRec> fast_chains, chains;
     DevBuf<PairOut> d_out;
@@ -1662,16 +1823,20 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         const uint32_t nb = S.nb;
         HIPCHECK(hipMemsetAsync(S.pair_nch.p, 0, nb * 4, st));
         HIPCHECK(hipMemsetAsync(S.pair_na.p, 0, nb * 4, st));
-        HIPCHECK(hipMemsetAsync(S.counters.p, 0, 64, st));
+        HIPCHECK(hipMemsetAsync(S.counters.p, 0, 128, st));
         HIPCHECK(hipMemsetAsync(S.flags.p, 0, 64, st));
         HIPCHECK(hipEventRecord(S.ev[1], st));
         if (S.nchunks) {
             HIPCHECK(hipMemsetAsync(S.chunk_rec0.p, 0xFF, S.nchunks * 4, st));
-            hipLaunchKernelGGL(run_extract_kernel, dim3(nb), dim3(256), 0, st, VA, VB, S.d_pairs.p, S.hits.p, S.recs.p, S.pair_nrec.p, S.chunk_rec0.p);
+            HIPCHECK(hipMemsetAsync(S.pair_over.p, 0, nb * 4, st));
+            hipLaunchKernelGGL(run_extract_kernel, dim3(nb), dim3(256), 0, st, VA, VB, S.d_pairs.p, S.hits.p, S.recs.p, S.pair_over.p, S.chunk_rec0.p);
             HIPCHECK(hipEventRecord(S.ev[6], st));
-            hipLaunchKernelGGL(chain_runs_kernel, dim3((unsigned)((S.nchunks + 255) / 256)), dim3(256), 0, st, VA, VB, S.d_pairs.p, nb,
-                               (uint32_t)S.nchunks, S.recs.p, S.pair_nrec.p, S.chunk_rec0.p, S.wg_pair.p, S.multi.p, S.fast_chains.p, S.chunk_state.p, S.slow_list.p, S.counters.p,
-                               S.pair_na.p, xcd_remap);
+            const unsigned nwg = (unsigned)((S.nchunks + 255) / 256);
+            hipLaunchKernelGGL(chain_single_kernel, dim3(nwg), dim3(256), 0, st, VA, VB, S.d_pairs.p, nb, (uint32_t)S.nchunks, S.recs.p,
+                               S.pair_over.p, S.chunk_rec0.p, S.wg_pair.p, S.multi.p, S.fast_chains.p, S.chunk_state.p, S.slow_list.p, S.counters.p,
+                               S.gen_list.p, S.pair_na.p, xcd_remap);
+            hipLaunchKernelGGL(chain_runs_kernel, dim3(nwg < 4096u ? nwg : 4096u), dim3(256), 0, st, VA, VB, S.d_pairs.p, nb, S.gen_list.p,
+                               S.recs.p, S.chunk_rec0.p, S.multi.p, S.fast_chains.p, S.chunk_state.p, S.slow_list.p, S.counters.p, S.pair_na.p);
         } else {
             HIPCHECK(hipEventRecord(S.ev[6], st));
         }
@@ -1701,6 +1866,9 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         HIPCHECK(hipMemcpyAsync(S.h_out, S.d_out.p, nb * sizeof(PairOut), hipMemcpyDeviceToHost, st));
         HIPCHECK(hipMemcpyAsync(S.h_cnt, S.counters.p, 64, hipMemcpyDeviceToHost, st));
         HIPCHECK(hipMemcpyAsync(S.h_cnt + 16, S.flags.p, 4, hipMemcpyDeviceToHost, st));
+#ifdef SKDER_SIEVE_STATS
+        HIPCHECK(hipMemcpyAsync(S.h_cnt + 24, S.counters.p + 24, 32, hipMemcpyDeviceToHost, st));
+#endif
         HIPCHECK(hipEventRecord(S.ev[5], st));
     };
     // ---- one batch: descriptors (host), then everything on the stream without a host round trip
@@ -1732,7 +1900,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
             // chain_fast_kernel's two input streams then change their 64-byte line at the same seeds
             const uint64_t hb = nhits + ((Q.seed_off - nhits) & 15u);
             d.chunk_base = (uint32_t)nchunks; d.c_base = (uint32_t)ccap; d.hit_base = (uint32_t)hb; d.multi_base = (uint32_t)nmulti;
-            d.rec_base = (uint32_t)nrecs; d.rec_cap = Q.n_seeds / 8u + 64u;     // more runs than that: the pair takes the slow path
+            d.rec_base = (uint32_t)nrecs; d.rec_cap = (Q.n_seeds / 8u + 64u) & ~3u;     // four quarters; more runs than a quarter holds: the pair takes the slow path
             nrecs += d.rec_cap;
             nchunks += d.n_chunks; ccap += d.c_cap; nhits = (hb + Q.n_seeds + 15u) & ~(uint64_t)15u; nmulti += d.multi_cap;
             hp.push_back(d);
@@ -1751,10 +1919,10 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         S.d_pairs.resize(nb, st);
         S.chunk_state.resize(nchunks + 1, st); S.chunk_mark.resize(nchunks + 1, st); S.slow_list.resize(nchunks + 1, st); S.over_list.resize(nchunks + 1, st);
         S.fast_chains.resize(nchunks * FAST_SLOTS + 1, st);
-        S.counters.resize(16, st); S.flags.resize(16, st);
+        S.counters.resize(32, st); S.flags.resize(16, st);
         S.pair_na.resize(nb, st); S.pair_nch.resize(nb, st); S.pair_nmulti.resize(nb, st);
         S.hits.resize(nhits + 64, st); S.multi.resize(nmulti + 1, st);
-        S.recs.resize(nrecs + 1, st); S.pair_nrec.resize(nb + 1, st); S.chunk_rec0.resize(nchunks + 1, st);
+        S.recs.resize(nrecs + 4, st); S.pair_over.resize(nb + 1, st); S.chunk_rec0.resize(nchunks + 1, st); S.gen_list.resize(nchunks + 1, st);
         S.chains.resize(ccap + 1, st);
         S.d_out.resize(nb, st);
         if (getenv("SKDER_AMD_DEBUG"))
@@ -1832,10 +2000,13 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         HIPCHECK(hipEventElapsedTime(&ms, S.ev[6], S.ev[2])); t_fast += ms;
         HIPCHECK(hipEventElapsedTime(&ms, S.ev[2], S.ev[3])); t_slow += ms;
         HIPCHECK(hipEventElapsedTime(&ms, S.ev[3], S.ev[4])); t_fin += ms;
+#ifdef SKDER_SIEVE_STATS
+        fprintf(stderr, "[skder_amd] sieve: link %u, main-not-started-big %u, second-path %u, too-many-records %u, multi %u, third-stray %u, stray-near-main %u\n", S.h_cnt[24], S.h_cnt[25], S.h_cnt[26], S.h_cnt[28], S.h_cnt[29], S.h_cnt[30], S.h_cnt[31]);
+#endif
         if (getenv("SKDER_AMD_DEBUG")) {
             const uint32_t *hcnt = S.h_cnt;
-            fprintf(stderr, "[skder_amd] batch: over %u; %u pairs %llu chunks, room for %llu run records, slow %u (none %u, slots %u, hits %u, ring %u, branch %u, score %u, qrep %u, inside %u, records-full %u, run-not-dominant %u)\n",
-                    nover, nb, (unsigned long long)S.nchunks, (unsigned long long)S.nrecs, nslow, hcnt[1], hcnt[2], hcnt[3], hcnt[4], hcnt[5], hcnt[6], hcnt[7], hcnt[8], hcnt[9], hcnt[10]);
+            fprintf(stderr, "[skder_amd] batch: over %u; %u pairs %llu chunks, room for %llu run records, %u to the run loop, slow %u (none %u, slots %u, hits %u, ring %u, branch %u, score %u, qrep %u, inside %u, records-full %u, run-not-dominant %u)\n",
+                    nover, nb, (unsigned long long)S.nchunks, (unsigned long long)S.nrecs, hcnt[11], nslow, hcnt[1], hcnt[2], hcnt[3], hcnt[4], hcnt[5], hcnt[6], hcnt[7], hcnt[8], hcnt[9], hcnt[10]);
         }
         // Rare-path fix-ups; the slot's buffers are untouched since (the batch in flight uses the other slot).
         //  * nover: chunks the wave kernel could not hold go through the global-memory kernels;
