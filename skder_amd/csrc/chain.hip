@@ -487,6 +487,7 @@ __global__ __launch_bounds__(256) void run_extract_kernel(SetView A, SetView B, 
 // Everything else goes on a list for chain_runs_kernel (lanes packed with chunks that need its loop); pairs
 // whose records overflowed and pairs that need the unabridged algorithm go to the slow path.
 #define SIEVE_RECORDS 6
+#define GEN_LISTS 256u
 #ifdef SKDER_SIEVE_STATS
 #define SIEVE_WHY(I) atomicAdd(counters + 16 + (I), 1u)
 #else
@@ -499,6 +500,7 @@ __global__ __launch_bounds__(256) void chain_single_kernel(SetView A, SetView B,
                                                            ChainRec *__restrict__ fast_chains,
                                                            uint32_t *__restrict__ chunk_state, uint32_t *__restrict__ slow_list,
                                                            uint32_t *__restrict__ counters, uint32_t *__restrict__ gen_list,
+                                                           uint32_t *__restrict__ gen_cnt, uint32_t gen_cap,
                                                            uint32_t *__restrict__ pair_na, int xcd_remap)
 {
     // XCD-aware work mapping: workgroups are dealt round-robin to the 8 XCDs, so give every XCD one
@@ -511,13 +513,21 @@ __global__ __launch_bounds__(256) void chain_single_kernel(SetView A, SetView B,
     const uint32_t t = wg * 256u + threadIdx.x;
     const bool in = t < total_chunks;
     uint32_t pi = 0, n_add = 0;
+    bool to_gen = false;
     if (in) {
         const uint32_t idx0 = chunk_rec0[t];                 // independent of the descriptor: in flight beside it
         pi = wg_pair[wg];
-        while (pi + 1u < npairs && pairs[pi + 1u].chunk_base <= t) pi++;
+        {
+            // a workgroup's 256 chunks rarely span more than three pairs: their first chunks in one go, no dependent search
+            const uint32_t p1 = pi + 1u < npairs ? pi + 1u : pi, p2 = pi + 2u < npairs ? pi + 2u : p1;
+            const uint32_t cb1 = pairs[p1].chunk_base, cb2 = pairs[p2].chunk_base;
+            if (p2 != p1 && cb2 <= t) { pi = p2; while (pi + 1u < npairs && pairs[pi + 1u].chunk_base <= t) pi++; }
+            else if (p1 != pi && cb1 <= t) pi = p1;
+        }
         const PairDesc pd = pairs[pi];
+        const uint32_t over = pair_over[pi];
         const uint32_t c = t - pd.chunk_base;
-        if ((pd.flags & 8u) || pair_over[pi] || (xcd_remap & 2)) {
+        if ((pd.flags & 8u) || over || (xcd_remap & 2)) {
             chunk_state[t] = CHUNK_SLOW;
             slow_list[atomicAdd(counters, 1u)] = t;
             atomicAdd(counters + 1 + ((pd.flags & 8u) || (xcd_remap & 2) ? 6 : 8), 1u);
@@ -528,6 +538,9 @@ __global__ __launch_bounds__(256) void chain_single_kernel(SetView A, SetView B,
             const uint32_t s1 = QS.chunk_start[pd.q_chunk_off + c + 1];
             const uint4 *rp = reinterpret_cast<const uint4 *>(recs + pd.rec_base) + 2u * idx0;
             uint4 a0 = rp[0], a1 = rp[1];
+            // the next three records are requested at once (a chunk seldom has more; the region has room behind its last record)
+            uint4 f0 = rp[2], f1 = rp[3], f2 = a0, f3 = a0, f4 = a0, f5 = a0;
+            if (!(xcd_remap & 512)) { f2 = rp[4]; f3 = rp[5]; f4 = rp[6]; f5 = rp[7]; }
             bool fail = false, main_on = false;
             uint32_t n = 0, G = 0, nstray = 0, anchors = 0, nfin = 0, npath = 0;
             uint32_t m_qi = 0, m_q0 = 0, m_hw = 0, l_q = 0, l_hw = 0, l_qi = 0;     // current path: first anchor; last anchor
@@ -549,14 +562,17 @@ __global__ __launch_bounds__(256) void chain_single_kernel(SetView A, SetView B,
                     const uint32_t ra = m_hw & HIT_POS_MASK, rb = l_hw & HIT_POS_MASK;                                \
                     cr.r0 = ra < rb ? ra : rb; cr.r1 = ra > rb ? ra : rb;                                             \
                     cr.chunk = c;                                                                                     \
-                    slots[nfin++] = cr;                                                                               \
+                    if (!(xcd_remap & 256)) slots[nfin] = cr;                                                          \
+                    nfin++;                                                                                           \
                 }                                                                                                     \
             } while (0)
             for (int k = 0; k < SIEVE_RECORDS + 1; k++) {
                 if (a0.x >= s1) { if (a0.x == REC_LINK) { fail = true; SIEVE_WHY(8); } break; }      // (a link: the chunk goes on in another quarter)
                 if (k == SIEVE_RECORDS || a0.z == HIT_MANY) { fail = true; SIEVE_WHY(k == SIEVE_RECORDS ? 12 : 13); break; }
                 rp += 2;
-                const uint4 b0 = rp[0], b1 = rp[1];          // the record behind closes this one
+                uint4 b0, b1;                                // the record behind closes this one
+                if (k < ((xcd_remap & 512) ? 1 : 3)) { b0 = f0; b1 = f1; f0 = f2; f1 = f3; f2 = f4; f3 = f5; }
+                else { b0 = rp[0]; b1 = rp[1]; }
                 const uint32_t rn = b0.w - a0.w, rg = b1.w - a1.w;
                 // does a hit continue the current path behind its last anchor?
 #define JOINS(W, GOUT)                                                                                               \
@@ -625,7 +641,20 @@ __global__ __launch_bounds__(256) void chain_single_kernel(SetView A, SetView B,
                 if (fail) SIEVE_WHY(15);
             }
             if (!fail) { n_add = anchors; chunk_state[t] = nfin; }
-            else gen_list[atomicAdd(counters + 11, 1u)] = t;
+            else to_gen = true;
+        }
+    }
+    {
+        // the chunks left for chain_runs_kernel: one atomic per wavefront, the lanes take consecutive places.  Nearly every
+        // wavefront has some, and one counter for the whole device would serialise them: GEN_LISTS lists, picked by the
+        // workgroup number, each with room for all chunks of the workgroups that use it
+        const unsigned long long gm = __ballot(to_gen);
+        if (gm) {
+            const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__ffsll((long long)gm) - 1u, li = blockIdx.x & (GEN_LISTS - 1u);
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(gen_cnt + li, (uint32_t)__popcll(gm));
+            base = (uint32_t)__shfl((int)base, (int)leader, 64);
+            if (to_gen) gen_list[(uint64_t)li * gen_cap + base + (uint32_t)__popcll(gm & ((1ull << lane) - 1ull))] = t;
         }
     }
     // anchors of the pair: one atomic per wavefront when all its chunks belong to one pair (nearly always)
@@ -672,18 +701,33 @@ struct Run {
 };
 
 __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs, uint32_t npairs,
-                                                         const uint32_t *__restrict__ gen_list, const RunRec *__restrict__ recs,
+                                                         const uint32_t *__restrict__ gen_list, const uint32_t *__restrict__ gen_cnt,
+                                                         uint32_t gen_cap, const RunRec *__restrict__ recs,
                                                          const uint32_t *__restrict__ chunk_rec0, const uint4 *__restrict__ multi,
                                                          ChainRec *__restrict__ fast_chains, uint32_t *__restrict__ chunk_state,
                                                          uint32_t *__restrict__ slow_list, uint32_t *__restrict__ slow_count,
                                                          uint32_t *__restrict__ pair_na)
 {
     // the chunks chain_single_kernel could not settle, one per lane; their number is only known on the device: a fixed
-    // grid strides over the list
-    const uint32_t n_items = slow_count[11];
+    // grid strides over the GEN_LISTS lists laid end to end (offsets by a scan of the 256 counts, in LDS)
+    __shared__ uint32_t g_off[GEN_LISTS + 1], g_ws[4];
+    {
+        uint32_t total;
+        const uint32_t ex = block_excl_scan_256(gen_cnt[threadIdx.x], g_ws, total);
+        g_off[threadIdx.x] = ex;
+        if (threadIdx.x == 0) g_off[GEN_LISTS] = total;
+        __syncthreads();
+    }
+    const uint32_t n_items = g_off[GEN_LISTS];
     for (uint32_t w0 = blockIdx.x * 256u; w0 < n_items; w0 += gridDim.x * 256u) {
-    const bool live = w0 + threadIdx.x < n_items;
-    const uint32_t t = live ? gen_list[w0 + threadIdx.x] : 0u;
+    const uint32_t w = w0 + threadIdx.x;
+    const bool live = w < n_items;
+    uint32_t t = 0;
+    if (live) {
+        uint32_t lo = 0, hi = GEN_LISTS;              // the list that holds item w: last offset <= w
+        while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (g_off[mid] <= w) lo = mid; else hi = mid; }
+        t = gen_list[(uint64_t)lo * gen_cap + (w - g_off[lo])];
+    }
     const uint32_t pi = find_pair(pairs, npairs, t);
     const PairDesc pd = pairs[pi];
     const uint32_t idx0 = chunk_rec0[t];
@@ -1701,7 +1745,7 @@ struct ChainSlot {
     DevBuf<uint32_t> hits, pair_nmulti, groups, over_list, flags;
     DevBuf<uint4> multi;
     DevBuf<RunRec> recs;
-    DevBuf<uint32_t> pair_over, chunk_rec0, wg_pair, gen_list;
+    DevBuf<uint32_t> pair_over, chunk_rec0, wg_pair, gen_list, gen_cnt;
     std::vector<uint32_t> h_wg_pair;
     DevBuf<ChainRec> fast_chains, chains;
     DevBuf<PairOut> d_out;
@@ -1757,6 +1801,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
     // debugging switches: SKDER_AMD_NO_XCD keeps the launch order; SKDER_AMD_FORCE_SLOW sends every chunk down the slow path;
     // SKDER_AMD_FAST_ONLY_CHUNK=k lets only chunk k of a batch take the fast path (to find the chunk behind a parity failure)
     int xcd_remap = (getenv("SKDER_AMD_NO_XCD") ? 0 : 1) | (getenv("SKDER_AMD_FORCE_SLOW") ? 2 : 0);
+    if (const char *e = getenv("SKDER_AMD_EXPERIMENT")) xcd_remap |= atoi(e);
     if (const char *e = getenv("SKDER_AMD_FAST_ONLY_CHUNK")) xcd_remap |= (atoi(e) + 1) << 2;
     double t_fast = 0, t_slow = 0, t_fin = 0, t_join = 0, t_runs = 0;
     uint64_t tot_anchors = 0, tot_slow = 0, tot_chunks = 0, tot_over = 0;
@@ -1832,11 +1877,13 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
             hipLaunchKernelGGL(run_extract_kernel, dim3(nb), dim3(256), 0, st, VA, VB, S.d_pairs.p, S.hits.p, S.recs.p, S.pair_over.p, S.chunk_rec0.p);
             HIPCHECK(hipEventRecord(S.ev[6], st));
             const unsigned nwg = (unsigned)((S.nchunks + 255) / 256);
+            const uint32_t gen_cap = ((nwg + GEN_LISTS - 1u) / GEN_LISTS) * 256u;
+            HIPCHECK(hipMemsetAsync(S.gen_cnt.p, 0, GEN_LISTS * 4, st));
             hipLaunchKernelGGL(chain_single_kernel, dim3(nwg), dim3(256), 0, st, VA, VB, S.d_pairs.p, nb, (uint32_t)S.nchunks, S.recs.p,
                                S.pair_over.p, S.chunk_rec0.p, S.wg_pair.p, S.multi.p, S.fast_chains.p, S.chunk_state.p, S.slow_list.p, S.counters.p,
-                               S.gen_list.p, S.pair_na.p, xcd_remap);
+                               S.gen_list.p, S.gen_cnt.p, gen_cap, S.pair_na.p, xcd_remap);
             hipLaunchKernelGGL(chain_runs_kernel, dim3(nwg < 4096u ? nwg : 4096u), dim3(256), 0, st, VA, VB, S.d_pairs.p, nb, S.gen_list.p,
-                               S.recs.p, S.chunk_rec0.p, S.multi.p, S.fast_chains.p, S.chunk_state.p, S.slow_list.p, S.counters.p, S.pair_na.p);
+                               S.gen_cnt.p, gen_cap, S.recs.p, S.chunk_rec0.p, S.multi.p, S.fast_chains.p, S.chunk_state.p, S.slow_list.p, S.counters.p, S.pair_na.p);
         } else {
             HIPCHECK(hipEventRecord(S.ev[6], st));
         }
@@ -1872,6 +1919,8 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         HIPCHECK(hipEventRecord(S.ev[5], st));
     };
     // ---- one batch: descriptors (host), then everything on the stream without a host round trip
+    uint32_t rec_div = 8;
+    if (const char *e = getenv("SKDER_AMD_REC_DIV")) rec_div = (uint32_t)atoi(e);
     auto enqueue = [&](ChainSlot &S, size_t p0) -> size_t {
         std::vector<PairDesc> &hp = S.hp;
         hp.clear();
@@ -1895,12 +1944,12 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
             if (d.multi_cap > 0x00FFFFF0u) d.multi_cap = 0x00FFFFF0u;
             if (!hp.empty() && nchunks + d.n_chunks > budget) break;
             if (nchunks + d.n_chunks > 0x7FFF0000ull || ccap + d.c_cap > 0xFFFF0000ull || nhits + Q.n_seeds + 32u > 0xFFFF0000ull ||
-                nmulti + d.multi_cap > 0xFFFF0000ull || nrecs + Q.n_seeds / 8u + 64u > 0xFFFF0000ull) break;
+                nmulti + d.multi_cap > 0xFFFF0000ull || nrecs + Q.n_seeds / rec_div + 64u > 0xFFFF0000ull) break;
             // hit words of the pair start at an entry congruent (mod 16) to the genome's seed offset:
             // chain_fast_kernel's two input streams then change their 64-byte line at the same seeds
             const uint64_t hb = nhits + ((Q.seed_off - nhits) & 15u);
             d.chunk_base = (uint32_t)nchunks; d.c_base = (uint32_t)ccap; d.hit_base = (uint32_t)hb; d.multi_base = (uint32_t)nmulti;
-            d.rec_base = (uint32_t)nrecs; d.rec_cap = (Q.n_seeds / 8u + 64u) & ~3u;     // four quarters; more runs than a quarter holds: the pair takes the slow path
+            d.rec_base = (uint32_t)nrecs; d.rec_cap = (Q.n_seeds / rec_div + 64u) & ~3u;     // four quarters; more runs than a quarter holds: the pair takes the slow path
             nrecs += d.rec_cap;
             nchunks += d.n_chunks; ccap += d.c_cap; nhits = (hb + Q.n_seeds + 15u) & ~(uint64_t)15u; nmulti += d.multi_cap;
             hp.push_back(d);
@@ -1922,7 +1971,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         S.counters.resize(32, st); S.flags.resize(16, st);
         S.pair_na.resize(nb, st); S.pair_nch.resize(nb, st); S.pair_nmulti.resize(nb, st);
         S.hits.resize(nhits + 64, st); S.multi.resize(nmulti + 1, st);
-        S.recs.resize(nrecs + 4, st); S.pair_over.resize(nb + 1, st); S.chunk_rec0.resize(nchunks + 1, st); S.gen_list.resize(nchunks + 1, st);
+        S.recs.resize(nrecs + 8, st); S.pair_over.resize(nb + 1, st); S.chunk_rec0.resize(nchunks + 1, st); S.gen_list.resize(nchunks + 256ull * GEN_LISTS + 1, st); S.gen_cnt.resize(GEN_LISTS, st);
         S.chains.resize(ccap + 1, st);
         S.d_out.resize(nb, st);
         if (getenv("SKDER_AMD_DEBUG"))
