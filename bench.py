@@ -115,6 +115,140 @@ def golden_parity(device):
                        "skani's version is unpinned and its learned-ANI model is replaced by a fitted map (DESIGN.md 2)"}
 
 
+def _read_fasta_records(path):
+    """FASTA (plain or gz) -> (kept record lengths, concatenated kept bases), records >= 500 bp as the product's reader keeps them"""
+    import gzip
+    op = gzip.open if path.endswith(".gz") else open
+    recs, cur = [], None
+    with op(path, "rb") as f:
+        for line in f:
+            if line.startswith(b">"):
+                cur = []
+                recs.append(cur)
+            elif cur is not None:
+                cur.append(line.strip())
+    kept = [b"".join(r) for r in recs]
+    kept = [x for x in kept if len(x) >= 500]
+    return np.array([len(x) for x in kept], np.uint32), np.frombuffer(b"".join(kept), np.uint8)
+
+
+def _indel_descendant(rng, anc):
+    """a descendant with substitutions (0.05 - 4 %) and SHORT INDELS, one per ~12 substitutions, geometric lengths
+    (mean 2.5): the FUZZ_REAL model of tests/tools (the counter-based device generator has substitutions only)"""
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    seq = anc.copy()
+    sub = 10 ** rng.uniform(-3.3, -1.4)
+    k = rng.binomial(len(seq), sub)
+    if k:
+        idx = rng.randint(0, len(seq), k)
+        seq[idx] = alpha[(np.searchsorted(alpha, seq[idx]) + 1 + rng.randint(0, 3, k)) % 4]
+    every = max(150, int(12.0 / sub))
+    n_ev = max(1, len(seq) // every)
+    at = np.sort(rng.randint(1, len(seq) - 1, n_ev))
+    ln = rng.geometric(0.4, n_ev)
+    ins = rng.rand(n_ev) < 0.5
+    out, pos = [], 0
+    for a, n, i in zip(at, ln, ins):
+        if a < pos:
+            continue
+        out.append(seq[pos:a])
+        if i:
+            out.append(alpha[rng.randint(0, 4, n)])
+            pos = a
+        else:
+            pos = a + n
+    out.append(seq[pos:])
+    seq = np.concatenate(out)
+    nrec = int(10 ** rng.uniform(0, 1.5))
+    cuts = np.sort(rng.choice(np.arange(1000, len(seq) - 1000, 1000), size=nrec - 1, replace=False)) if nrec > 1 else np.array([], int)
+    lens = np.diff(np.concatenate([[0], cuts, [len(seq)]])).astype(np.uint32)
+    return seq, lens
+
+
+def _triangle_stats(engine, ctx, torch, rec_lens_list, bases_list, screen, steps=2):
+    """sketch + triangle of host genomes through the device API; per-step times of the chaining stage and path counters"""
+    layout = engine.BatchLayout(rec_lens_list)
+    d = torch.from_numpy(layout.pack_host(bases_list)).cuda()
+    sk = engine.Sketches(ctx)
+    sk.sketch_batch(d.data_ptr(), layout)
+    best = None
+    for _ in range(steps + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        edges = sk.triangle_rows(0, 1, screen, copy=False)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        t, c = ctx.timing(), ctx.counters()
+        cur = {"triangle_ms": dt * 1e3, "chained_pairs": int(t[6]), "edges": int(len(edges)), "chunks": int(c[0]), "slow_path_chunks": int(c[1]),
+               "join_ms": float(c[2]) / 1000.0, "run_extract_ms": ctx.runs_ms(), "chain_fast_ms": float(t[3]), "chain_slow_ms": float(t[4]),
+               "finalize_ms": float(t[5])}
+        if best is None or cur["triangle_ms"] < best["triangle_ms"]:
+            best = cur
+    sk.close()
+    del d
+    n = len(rec_lens_list)
+    stage = best["join_ms"] + best["run_extract_ms"] + best["chain_fast_ms"] + best["chain_slow_ms"] + best["finalize_ms"]
+    best.update({"genomes": n, "pairs": n * (n - 1) // 2, "slow_path_fraction": best["slow_path_chunks"] / max(best["chunks"], 1),
+                 "chain_stage_ms": stage, "us_per_chained_pair": 1e3 * stage / max(best["chained_pairs"], 1),
+                 "pairs_per_s": n * (n - 1) / 2 / (best["triangle_ms"] * 1e-3)})
+    return best
+
+
+def realistic_workloads(engine, ctx, torch, synth, args):
+    """Workloads next to the headline (never part of `value`): the headline's generator has substitutions only, which is the
+    engine's best case -- no indels, so nearly every chunk is one run."""
+    out = {}
+    gold = os.path.join(ROOT, "tests", "golden", "genomes")
+    if os.path.isdir(gold):
+        recs = [_read_fasta_records(os.path.join(gold, n)) for n in sorted(os.listdir(gold))]
+        r = _triangle_stats(engine, ctx, torch, [x[0] for x in recs], [x[1] for x in recs], 89.5)
+        r["workload"] = "the 34 real Cutibacterium granulosum assemblies of the reference's GTDB test run (1-391 contigs), all 561 pairs, screen 89.5"
+        out["real_34_genomes"] = r
+    rng = np.random.RandomState(11)
+    L = args.genome_len
+    anc = np.frombuffer(b"ACGT", np.uint8)[rng.randint(0, 4, L)]
+    fam = [_indel_descendant(rng, anc) for _ in range(args.indel_genomes)]
+    r = _triangle_stats(engine, ctx, torch, [g[1] for g in fam], [g[0] for g in fam], args.screen)
+    r["workload"] = ("%d host-generated descendants of one %.1f Mb ancestor: 0.05-4 %% substitutions and one short indel (geometric, mean 2.5 "
+                     "bases) per ~12 substitutions, 1-30 records; all pairs chained" % (args.indel_genomes, L / 1e6))
+    out["indel_%.0fMb" % (L / 1e6)] = r
+    del fam
+    # BASELINE.json config 5's shape on one GPU: species lengths uniform in 1-8 Mb
+    n = args.mixed_genomes
+    if n > 0:
+        recipe = synth.make_recipe(n, len_range=(1_000_000, 8_000_000))
+        batches, total = [], 0
+        for b0 in range(0, n, 1250):
+            gs = range(b0, min(b0 + 1250, n))
+            layout = engine.BatchLayout([recipe.rec_lens[g] for g in gs])
+            d = torch.empty(layout.total_bytes, dtype=torch.uint8, device="cuda")
+            ctx.synth_fill(d.data_ptr(), layout, recipe.lineage[gs.start:gs.stop], recipe.params[gs.start:gs.stop])
+            batches.append((layout, d))
+            total += layout.total_bases
+        best = None
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sk = engine.Sketches(ctx)
+            sk.reserve(total // 120, total // 900)
+            for layout, d in batches:
+                sk.sketch_batch(d.data_ptr(), layout)
+            edges = sk.triangle_rows(0, 1, args.screen, copy=False)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            c = ctx.counters()
+            cur = {"ms_per_step": dt * 1e3, "edges": int(len(edges)), "chunks": int(c[0]), "slow_path_chunks": int(c[1])}
+            sk.close()
+            if best is None or cur["ms_per_step"] < best["ms_per_step"]:
+                best = cur
+        best.update({"genomes": n, "pairs": n * (n - 1) // 2, "bases": int(total), "pairs_per_s": n * (n - 1) / 2 / (best["ms_per_step"] * 1e-3),
+                     "slow_path_fraction": best["slow_path_chunks"] / max(best["chunks"], 1),
+                     "workload": "%d synthetic genomes, species lengths uniform in 1-8 Mb (BASELINE.json config 5's shape), one full step incl. sketching" % n})
+        out["mixed_1_8Mb"] = best
+        del batches
+    return out
+
+
 def cpu_baseline_files(tmp, paths, threads):
     """oracle (CPU restatement, OpenMP) on the sample files, wall clock on `threads` host threads:
       per genome   : read + sketch, from a triangle whose 101 % screen lets no pair through;
@@ -166,6 +300,9 @@ def main():
     ap.add_argument("--batch-genomes", type=int, default=2500, help="genomes per resident input batch (one sketch call each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--e2e-genomes", type=int, default=256, help="genomes in the file-based end-to-end sample (0: skip)")
+    ap.add_argument("--no-realistic", action="store_true", help="skip the extra workloads (real genomes, indels, mixed sizes)")
+    ap.add_argument("--indel-genomes", type=int, default=48, help="genomes of the host-generated indel family")
+    ap.add_argument("--mixed-genomes", type=int, default=5000, help="genomes of the mixed 1-8 Mb extra workload (0: skip)")
     args = ap.parse_args()
 
     import torch
@@ -230,6 +367,7 @@ def main():
         t = ctx.timing()
         tm[2:] = t[2:]
         step.index_ms = ctx.index_ms()
+        step.runs_ms = ctx.runs_ms()
         step.counters = ctx.counters()
         if dist_on:
             edges = multigpu.gather_edges(edges)
@@ -278,12 +416,21 @@ def main():
         # join_probe_kernel: per chained pair the chunked genome's position-ordered k-mers are read once
         # (4 B per seed), one hit word per seed is written (4 B) and the matched position is gathered for
         # about 70 % of the seeds (4 B); the probed genome's index is staged in LDS once per <= 16 pairs;
-        # chain_fast_kernel: per chained pair the hit word and the position of every seed are read (8 B)
+        # run_extract_kernel: per chained pair the hit word, the position and the chunk-start flag of every seed are
+        # read (9 B), the run records written are two orders of magnitude fewer;
+        # chain_single_kernel (+ chain_runs_kernel for the 9 % of chunks it leaves): per chunk the first-record index (4 B),
+        # on average two 32-byte run records and their closing record, the chunk's state (4 B) and its chain (32 B)
         join_bytes = n_chained * (11.0 * seeds_per_genome)
-        chain_bytes = n_chained * (8.0 * seeds_per_genome)
+        runs_bytes = n_chained * (9.0 * seeds_per_genome)
+        chain_bytes = float(step.counters[0]) * (4.0 + 3 * 32.0 + 4.0 + 32.0)
         join_ms = float(step.counters[2]) / 1000.0
         cand = {"sketch_tiles_kernel": (tm[0], sketch_bytes), "join_probe_kernel": (join_ms, join_bytes),
-                "chain_fast_kernel": (tm[3], chain_bytes)}
+                "run_extract_kernel": (step.runs_ms, runs_bytes), "chain_single_kernel+chain_runs_kernel": (tm[3], chain_bytes)}
+        # what actually limits each kernel (SQ counters under profiles/): none of them is at the HBM roof
+        limiter = {"sketch_tiles_kernel": "VALU issue: 2 x mm_hash64 per position, 91 integer instructions per base",
+                   "join_probe_kernel": "latency chain k-mer load -> LDS probe -> position gather at 39 % VALU utilisation",
+                   "run_extract_kernel": "VALU issue: ~400 instructions per 256 seeds",
+                   "chain_single_kernel+chain_runs_kernel": "memory latency: a dozen dependent loads per wavefront"}
         dom = max(cand, key=lambda k: cand[k][0])
         dms, dbytes = cand[dom]
         achieved = dbytes / (dms * 1e-3) / 1e9 if dms > 0 else 0.0
@@ -293,16 +440,18 @@ def main():
         def gbs(nbytes, ms):
             return {"bytes": float(nbytes), "ms": float(ms), "GB/s": float(nbytes / (ms * 1e-3) / 1e9) if ms > 0 else 0.0}
         s8_sketch = gbs(total_bases * (1.0 + 16.0 / 125 + 8.0 / 1000), tm[0] + tm[1])
-        s8_chain = gbs(n_chained * 16.0 * 2.0 * seeds_per_genome, join_ms + tm[3] + tm[4] + tm[5])
+        s8_chain = gbs(n_chained * 16.0 * 2.0 * seeds_per_genome, join_ms + step.runs_ms + tm[3] + tm[4] + tm[5])
         s8_all = gbs(s8_sketch["bytes"] + s8_chain["bytes"], ms_per_step)          # over the whole step's wall time
         # measured HBM traffic of the dominant kernel per step (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
         # separate passes, profiles/round1_pmc_traffic.json; only valid for the default workload on 1 GPU)
-        traffic = None
+        traffic, traffic_source = None, None
         try:
             if N == 5000 and world == 1 and args.len_range is None and args.genome_len == 3_000_000:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")))[dom]
+                src = os.path.join("profiles", "round2_pmc_traffic.json")
+                pm = json.load(open(os.path.join(ROOT, src)))[dom.split("+")[0]]
                 # counter values corrected by the calibration of profiles/calib (profiles/summarise.py)
                 traffic = sum(pm[c].get("corrected_bytes", pm[c]["sum_counter_kb"] * 1024.0) for c in ("FETCH_SIZE", "WRITE_SIZE"))
+                traffic_source = src + " (static: rocprofv3 --pmc passes of this build, not measured in this run)"
         except Exception:
             traffic = None
         out = {
@@ -317,13 +466,16 @@ def main():
                        "chunks": int(step.counters[0]), "slow_path_chunks": int(step.counters[1]),
                        "parallelism": "rows%d" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": dbytes,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "limited_by": limiter[dom], "algorithmic_bytes": dbytes,
                          "survey_8d": {"sketch": s8_sketch, "chain": s8_chain, "step": s8_all},
                          "kernel_ms": {k: float(v[0]) for k, v in cand.items()},
                          "host_wall_ms": {k: 1e3 * v / (args.steps + args.warmup) for k, v in wall.items()},
+                         "kernel_GBs": {k: float(v[1] / (v[0] * 1e-3) / 1e9) if v[0] > 0 else 0.0 for k, v in cand.items()},
                          "other_ms": {"sketch_post": float(tm[1]), "index_beside_screen": float(step.index_ms), "screen": float(tm[2]), "chain_slow_path": float(tm[4]),
                                       "finalize": float(tm[5])}},
         }
+        out["config"]["us_per_chained_pair"] = 1e3 * (join_ms + step.runs_ms + tm[3] + tm[4] + tm[5]) / max(n_chained, 1.0)
         if world == 1 and not args.no_cpu_baseline:
             out["parity_vs_skani"] = golden_parity(dev)
         if world == 1 and not args.no_cpu_baseline and args.e2e_genomes > 0:
@@ -348,6 +500,10 @@ def main():
                                                  % (threads, len(paths), pg, pp, pc, chained, spent, N, pairs, int(n_chained))}
             finally:
                 shutil.rmtree(tmp, ignore_errors=True)
+        if world == 1 and not args.no_realistic and not args.no_cpu_baseline:
+            batches.clear()      # the headline's resident bases are not needed any more
+            torch.cuda.empty_cache()
+            out["realistic"] = realistic_workloads(engine, ctx, torch, synth, args)
         print(json.dumps(out))
     ctx.close()
     if dist_on:

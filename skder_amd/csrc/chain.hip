@@ -44,7 +44,8 @@ struct PairDesc {
     uint32_t multi_base, multi_cap;   // region of 4-hit records for seeds with several hits
     uint32_t rec_base, rec_cap;   // region of the pair's run records
     uint32_t q_chunk_off;         // offset of the chunked genome's chunk table (GenomeMeta::chunk_off)
-    uint32_t pad[3];              // 64 bytes: one cache line per descriptor
+    uint32_t seg_per, seg_a;      // run extraction: 256-seed segments per quarter of the pair; seed_off & 3 of the chunked genome
+    uint32_t pad;                 // 64 bytes: one cache line per descriptor
 };
 
 // hit[s] for seed s of the chunked genome: gpos on the other genome | rev<<31, or one of
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(JOIN_THREADS) void join_probe_kernel(SetView A, Set
 // TERMINATOR; both close the run in front of them.  A run never crosses a chunk boundary or a quarter; the
 // chaining kernel joins such pieces again through its ordinary look-back.  A seed with 2..4 occurrences, or
 // too many, is a record of its own.  The first record of every chunk is registered in chunk_rec0.  A quarter
-// with more records than it holds marks the pair: all its chunks take the slow path.
+// with more records than it holds is marked: the chunks with seeds in it take the slow path.
 struct __attribute__((aligned(16))) RunRec {
     uint32_t qi, q0, hw, cn;      // first seed: index in the chunked genome, position, hit word (or HIT_MULTI | slot, HIT_MANY); hits of the quarter in front of it
     uint32_t pq, pw, pqi, cg;     // the hit in front of it: position, hit word, seed index; diagonal steps of the quarter in front of it
@@ -457,7 +458,7 @@ __global__ __launch_bounds__(256) void run_extract_kernel(SetView A, SetView B, 
         }
 #undef SEL4
     }
-    if (overflow) { if (lane == 0) pair_over[blockIdx.x] = 1u; return; }
+    if (overflow) { if (lane == 0) atomicOr(&pair_over[blockIdx.x], 1u << wv); return; }      // the chunks of this quarter take the slow path
     if (lane == 0) {
         RunRec r;       // closes the last run of the quarter; leads on to the next quarter, or ends the pair
         r.qi = wv == 3u ? REC_END : REC_LINK; r.q0 = (wv + 1u) * cap4; r.hw = HIT_NONE; r.cn = run_nm;
@@ -525,8 +526,14 @@ __global__ __launch_bounds__(256) void chain_single_kernel(SetView A, SetView B,
             else if (p1 != pi && cb1 <= t) pi = p1;
         }
         const PairDesc pd = pairs[pi];
-        const uint32_t over = pair_over[pi];
+        uint32_t over = pair_over[pi];
         const uint32_t c = t - pd.chunk_base;
+        const SetView &QS = (pd.flags & 2u) ? B : A;
+        const uint32_t s0 = QS.chunk_start[pd.q_chunk_off + c], s1 = QS.chunk_start[pd.q_chunk_off + c + 1];
+        if (over) {      // quarters of the record region that overflowed: only the chunks with seeds in one of them are lost
+            const uint32_t qa = ((s0 + pd.seg_a) >> 8) / pd.seg_per, qb = ((s1 - 1u + pd.seg_a) >> 8) / pd.seg_per;
+            over &= (2u << qb) - (1u << qa);
+        }
         if ((pd.flags & 8u) || over || (xcd_remap & 2)) {
             chunk_state[t] = CHUNK_SLOW;
             slow_list[atomicAdd(counters, 1u)] = t;
@@ -534,8 +541,6 @@ __global__ __launch_bounds__(256) void chain_single_kernel(SetView A, SetView B,
         } else if (idx0 == 0xFFFFFFFFu) {
             chunk_state[t] = 0u;
         } else {
-            const SetView &QS = (pd.flags & 2u) ? B : A;
-            const uint32_t s1 = QS.chunk_start[pd.q_chunk_off + c + 1];
             const uint4 *rp = reinterpret_cast<const uint4 *>(recs + pd.rec_base) + 2u * idx0;
             uint4 a0 = rp[0], a1 = rp[1];
             // the next three records are requested at once (a chunk seldom has more; the region has room behind its last record)
@@ -1919,7 +1924,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         HIPCHECK(hipEventRecord(S.ev[5], st));
     };
     // ---- one batch: descriptors (host), then everything on the stream without a host round trip
-    uint32_t rec_div = 8;
+    uint32_t rec_div = 4;      // room for one run record per four seeds of the chunked genome (the 34 real C. granulosum genomes need one per six)
     if (const char *e = getenv("SKDER_AMD_REC_DIV")) rec_div = (uint32_t)atoi(e);
     auto enqueue = [&](ChainSlot &S, size_t p0) -> size_t {
         std::vector<PairDesc> &hp = S.hp;
@@ -1949,6 +1954,9 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
             // chain_fast_kernel's two input streams then change their 64-byte line at the same seeds
             const uint64_t hb = nhits + ((Q.seed_off - nhits) & 15u);
             d.chunk_base = (uint32_t)nchunks; d.c_base = (uint32_t)ccap; d.hit_base = (uint32_t)hb; d.multi_base = (uint32_t)nmulti;
+            d.seg_a = (uint32_t)(Q.seed_off & 3u);
+            d.seg_per = ((Q.n_seeds + d.seg_a + SEG_SEEDS - 1u) / SEG_SEEDS + 3u) / 4u;
+            if (!d.seg_per) d.seg_per = 1u;
             d.rec_base = (uint32_t)nrecs; d.rec_cap = (Q.n_seeds / rec_div + 64u) & ~3u;     // four quarters; more runs than a quarter holds: the pair takes the slow path
             nrecs += d.rec_cap;
             nchunks += d.n_chunks; ccap += d.c_cap; nhits = (hb + Q.n_seeds + 15u) & ~(uint64_t)15u; nmulti += d.multi_cap;

@@ -751,7 +751,7 @@ def test_repeats_indels_and_inversions(gpu, oracle):
     assert len(want) >= 15
     _check_edges(edges, want)
     c = ctx.counters()
-    assert c[1] > 0 and c[0] > c[1]                                           # both chaining paths were exercised
+    assert c[1] > 0      # the unabridged path was exercised (repeat-rich genomes: the run records of every quarter overflow)
     s.close()
 
 
