@@ -2016,13 +2016,12 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
             }
             S.groups.resize(hg.size() * 2, st);
             HIPCHECK(hipMemcpyAsync(S.groups.p, hg.data(), hg.size() * sizeof(JoinGroup), hipMemcpyHostToDevice, st));
-            static bool join_attr_set = false;
-            if (!join_attr_set) {
+            if (!ctx->chain_attr_set) {      // per context: the attribute belongs to the device, and a process may use several
                 HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(join_probe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              JOIN_SMEM_MAX + 64));
                 HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(finalize_kernel_t<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              4096 * 35));
-                join_attr_set = true;
+                ctx->chain_attr_set = true;
             }
             // LDS per workgroup: what the largest probed genome of the batch wants for a single pass; two
             // workgroups share a CU when that is at most half of it

@@ -94,6 +94,7 @@ struct skder_ctx {
     std::vector<skder_edge_t> edges;
     uint32_t *d_flags = nullptr;   // [0] overflow / error flags from kernels
     uint64_t counters[4] = {0, 0, 0, 0};   // [0] chunks processed, [1] chunks sent to the slow path
+    bool chain_attr_set = false;           // large-LDS opt-in of the join / finalize kernels done on this context's device
     void *chain_work = nullptr;            // grow-only work buffers of chain_pairs (chain.hip)
     void (*chain_work_free)(void *) = nullptr;
 };

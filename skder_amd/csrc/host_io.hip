@@ -97,7 +97,17 @@ void read_fasta(const std::string &path, HostGenome &g, uint8_t *region, size_t 
     for (;;) {
         long n = gz ? (long)gzread(fc.gz, buf.data(), (unsigned)buf.size()) : (long)read(fc.fd, buf.data(), buf.size());
         if (n < 0) throw SkError("read error in " + path);
-        if (n == 0) break;
+        if (n == 0) {
+            // zlib returns 0, not -1, when a gzip stream ends early and reports it through gzerror only: a truncated or
+            // corrupt file must fail as it does in the reference (gzip.open in util.n50_calc, and skani itself), not be
+            // taken for a shorter genome
+            if (gz) {
+                int zerr = Z_OK;
+                const char *msg = gzerror(fc.gz, &zerr);
+                if (zerr != Z_OK && zerr != Z_STREAM_END) throw SkError("truncated or corrupt gzip file " + path + ": " + (msg ? msg : "zlib error"));
+            }
+            break;
+        }
         const char *p = buf.data(), *end = p + n;
         // one pass over the buffer decides between the bulk path (no blank characters: lines are copied with
         // memcpy) and the careful path (CRLF files, blanks inside lines): is any byte below 0x21 not a '\n'?
@@ -412,7 +422,8 @@ struct TmpFile {
     }
     void commit()
     {
-        if (fclose(f) != 0) { f = nullptr; remove(tmp.c_str()); throw SkError("write error on " + final_name); }
+        const bool bad = ferror(f) != 0;
+        if (fclose(f) != 0 || bad) { f = nullptr; remove(tmp.c_str()); throw SkError("write error on " + final_name); }
         f = nullptr;
         if (rename(tmp.c_str(), final_name.c_str()) != 0) { remove(tmp.c_str()); throw SkError("cannot rename to " + final_name); }
     }

@@ -1,14 +1,20 @@
 // pool.hip -- caching device allocator behind DevBuf (see common.h)
 #include <map>
 #include <mutex>
+#include <thread>
 #include <unordered_map>
 
 #include "common.h"
 
 namespace {
+// A cached block may still have work pending on the stream of the context that freed it.  One host thread drives one
+// context at a time (streams of one context are ordered by its own events), so a block handed to the thread that freed
+// it needs nothing; a block that changes threads -- two contexts on one device used from different host threads, e.g. the
+// per-device workers of the multi-device entry points -- is handed over only after the device has drained.
+struct Cached { void *p; std::thread::id by; };
 struct Pool {
     std::mutex mu;
-    std::multimap<size_t, void *> free_blocks;          // size -> block
+    std::multimap<size_t, Cached> free_blocks;          // size -> block
     std::unordered_map<void *, size_t> size_of;          // every live or cached block
 };
 Pool &pool_for_current_device()
@@ -29,9 +35,10 @@ void *pool_alloc(size_t bytes)
         std::lock_guard<std::mutex> lk(P.mu);
         auto it = P.free_blocks.lower_bound(bytes);
         if (it != P.free_blocks.end() && it->first <= bytes + bytes / 2 + (1u << 20)) {
-            void *p = it->second;
+            const Cached c = it->second;
             P.free_blocks.erase(it);
-            return p;
+            if (c.by != std::this_thread::get_id()) (void)hipDeviceSynchronize();
+            return c.p;
         }
     }
     void *p = nullptr;
@@ -53,13 +60,13 @@ void pool_free(void *p)
     std::lock_guard<std::mutex> lk(P.mu);
     auto it = P.size_of.find(p);
     if (it == P.size_of.end()) { (void)hipFree(p); return; }
-    P.free_blocks.emplace(it->second, p);
+    P.free_blocks.emplace(it->second, Cached{p, std::this_thread::get_id()});
 }
 
 void pool_trim()
 {
     Pool &P = pool_for_current_device();
     std::lock_guard<std::mutex> lk(P.mu);
-    for (auto &kv : P.free_blocks) { (void)hipFree(kv.second); P.size_of.erase(kv.second); }
+    for (auto &kv : P.free_blocks) { (void)hipFree(kv.second.p); P.size_of.erase(kv.second.p); }
     P.free_blocks.clear();
 }

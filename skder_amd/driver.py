@@ -5,7 +5,7 @@ Only the flow around the hot path is reproduced (no downloads, MGE filtering, pl
 formats follow the reference so that outputs can be diffed against its result directories.
 
     python -m skder_amd.driver -g GENOME_DIR_OR_FILES... -o OUT/ [-d greedy|dynamic|low_mem_greedy]
-                               [-i 99.5] [-f 50.0] [-a 10.0] [-n] [-p "-s 89.5"] [--store FILE]
+                               [-i 99.5] [-f 50.0] [-a 10.0] [-n] [-l] [-p "-s 89.5"] [--store FILE] [--devices 0,1,..]
 
 The FASTA files are read ONCE: the pass that uploads them also yields Concatenated_N50.txt
 (SURVEY.md 8f-2), the edge rows reach the selection step in memory (8f-1; the text table is still
@@ -14,7 +14,9 @@ later run over the same listing skips ingest (8f-4).
 """
 import argparse
 import gzip
+import json
 import os
+import shutil
 import sys
 from collections import OrderedDict
 
@@ -60,23 +62,45 @@ def list_genomes(inputs):
     return out
 
 
-def open_database(listing, genomes, n50_file, store=None):
+def _file_stamps(genomes):
+    """[path, size, mtime in ns] of every FASTA file: what a sketch store was built from"""
+    out = []
+    for g in genomes:
+        st = os.stat(g)
+        out.append([g, st.st_size, st.st_mtime_ns])
+    return out
+
+
+def open_database(listing, genomes, n50_file, store=None, devices=None):
     """the resident sketch database of the listing + its N50 table; reuses a sketch store when it
-    describes exactly these paths"""
-    if store and os.path.isfile(store):
-        db = Database.load(store)
-        if db.paths == list(genomes):
-            with open(n50_file, "w") as f:
-                f.write("".join("%s\t%d\n" % kv for kv in zip(db.paths, db.n50)))
-            return db
-        db.close()
-    db = Database.from_listing(listing, n50_file)
+    describes exactly these files: same paths in the same order AND unchanged size and modification
+    time of every file (a store does not notice a FASTA file replaced in place by itself)"""
+    stamps_file = store + ".files.json" if store else None
+    if store and os.path.isfile(store) and os.path.isfile(stamps_file):
+        try:
+            fresh = json.load(open(stamps_file)) == _file_stamps(genomes)
+        except (OSError, ValueError):
+            fresh = False
+        if fresh:
+            db = Database.load(store)
+            if db.paths == list(genomes):
+                with open(n50_file, "w") as f:
+                    f.write("".join("%s\t%d\n" % kv for kv in zip(db.paths, db.n50)))
+                return db
+            db.close()
+        else:
+            sys.stderr.write("sketch store %s is stale (files changed since it was written): re-reading the FASTA files\n" % store)
+    stamps = _file_stamps(genomes) if store else None
+    db = Database.from_listing(listing, n50_file, devices=devices)
     if store:
         db.save(store)
+        with open(stamps_file, "w") as f:
+            json.dump(stamps, f)
     return db
 
 
-def run(genomes, outdir, mode="greedy", ani=99.5, af=50.0, max_af_dist=10.0, clusters=False, params="-s X", store=None):
+def run(genomes, outdir, mode="greedy", ani=99.5, af=50.0, max_af_dist=10.0, clusters=False, params="-s X", store=None,
+        symlink=False, devices=None):
     outdir = os.path.abspath(outdir) + "/"
     os.makedirs(outdir, exist_ok=True)
     if params == "-s X":                          # bin/skder:199-201
@@ -89,23 +113,23 @@ def run(genomes, outdir, mode="greedy", ani=99.5, af=50.0, max_af_dist=10.0, clu
     with open(listing, "w") as f:
         f.write("".join(g + "\n" for g in genomes))
     n50_file = outdir + "Concatenated_N50.txt"
-    db = open_database(listing, genomes, n50_file, store)
+    db = open_database(listing, genomes, n50_file, store, devices)
     try:
-        return _run(db, genomes, outdir, mode, ani, af, af_tri, max_af_dist, clusters, params, listing, n50_file)
+        return _run(db, genomes, outdir, mode, ani, af, af_tri, max_af_dist, clusters, params, listing, n50_file, symlink)
     finally:
         db.close()
 
 
-def _run(db, genomes, outdir, mode, ani, af, af_tri, max_af_dist, clusters, params, listing, n50_file):
+def _run(db, genomes, outdir, mode, ani, af, af_tri, max_af_dist, clusters, params, listing, n50_file, symlink=False):
     n50 = OrderedDict(zip(db.paths, db.n50))
     result_file = outdir + "skDER_Results.txt"
     edge_file = outdir + "Skani_Triangle_Edge_Output.txt"
     if mode == "low_mem_greedy":
-        ws = outdir + "skder_lm_workspace/"
+        ws = outdir + "skDER_iterative_greedy_workspace/"      # bin/skder:438
         os.makedirs(ws, exist_ok=True)
         lowMemGreedyDerep(listing, ws, n50_file, result_file, outdir, ani, af, None, database=db)
         if clusters:
-            cdir = outdir + "Clustering_Workspace/"
+            cdir = outdir + "skani_dist_Workspace/"              # bin/skder:466
             os.makedirs(cdir, exist_ok=True)
             edge_file = outdir + "Skani_Dist_Output.txt"
             runSkaniDist(cdir, result_file, listing, edge_file, params, af, mode, False, None)
@@ -134,10 +158,14 @@ def _run(db, genomes, outdir, mode, ani, af, af_tri, max_af_dist, clusters, para
             f.write("".join(l + "\n" for l in selection.determine_clusters(reps, edges, af, ani)))
     rep_dir = outdir + "Dereplicated_Representative_Genomes/"
     os.makedirs(rep_dir, exist_ok=True)
-    for r in reps:
+    for r in reps:                                  # util.py:411-427: copies unless -l / --symlink was given
         dst = rep_dir + os.path.basename(r)
-        if not os.path.lexists(dst):
+        if os.path.lexists(dst):
+            continue
+        if symlink:
             os.symlink(r, dst)
+        else:
+            shutil.copy2(r, rep_dir)
     with open(outdir + "COMPLETED.txt", "w") as f:
         f.write("skDER completed successfully!\n")
     return reps
@@ -153,10 +181,14 @@ def main(argv=None):
     ap.add_argument("-a", "--max-af-distance-cutoff", type=float, default=10.0)
     ap.add_argument("-p", "--skani-triangle-parameters", default="-s X")
     ap.add_argument("-n", "--determine-clusters", action="store_true")
-    ap.add_argument("--store", default=None, help="sketch store file: loaded if present, written otherwise")
+    ap.add_argument("-l", "--symlink", action="store_true", help="symlink the representatives instead of copying them (bin/skder:106)")
+    ap.add_argument("--store", default=None, help="sketch store file: loaded if present and still describing these files, written otherwise")
+    ap.add_argument("--devices", default=None, help="comma-separated GPU indices (default: $SKDER_AMD_DEVICE or 0): with several, the genomes "
+                                                    "are sketched in shares, the sketches exchanged between the GPUs and the pair matrix dealt out by rows")
     a = ap.parse_args(argv)
     reps = run(list_genomes(a.genomes), a.output_directory, a.dereplication_mode, a.percent_identity_cutoff,
-               a.aligned_fraction_cutoff, a.max_af_distance_cutoff, a.determine_clusters, a.skani_triangle_parameters, a.store)
+               a.aligned_fraction_cutoff, a.max_af_distance_cutoff, a.determine_clusters, a.skani_triangle_parameters, a.store,
+               a.symlink, [int(x) for x in a.devices.split(",")] if a.devices else None)
     print("%d representative genomes -> %s" % (len(reps), os.path.join(a.output_directory, "skDER_Results.txt")))
 
 

@@ -5,7 +5,6 @@ expected output is not produced, cf. util.runCmd, /root/reference/src/skDER/util
 instead of `subprocess.call('skani ...')` each one calls the C ABI of libskder_amd.so."""
 import ctypes as C
 import os
-from operator import itemgetter
 
 from . import _lib
 
@@ -62,21 +61,9 @@ def runSkaniDist(cluster_dir, skder_result_file, genome_listing_file, skani_resu
     """Replaces skder.py:30-63: representatives vs non-representatives with `skani dist`.
     As in the reference, aligned_fraction_cutoff is NOT forwarded (skani's default min-af applies)."""
     try:
-        rep_file_names = set([])
-        with open(skder_result_file) as orf:
-            for line in orf:
-                line = line.strip()
-                rep_file_names.add(line.split('/')[-1])
         rep_listing_file = cluster_dir + 'Reps_Listing.txt'
         nonrep_listing_file = cluster_dir + 'NonReps_Listing.txt'
-        with open(rep_listing_file, 'w') as rlf, open(nonrep_listing_file, 'w') as nlf, open(genome_listing_file) as oglf:
-            for line in oglf:
-                line = line.strip()
-                base_name = line.split('/')[-1]
-                if base_name in rep_file_names:
-                    rlf.write(line + '\n')
-                else:
-                    nlf.write(line + '\n')
+        _split_listing(genome_listing_file, skder_result_file, rep_listing_file, nonrep_listing_file)
         screen = parse_skani_params(skani_dist_parameters)
         err = C.create_string_buffer(_lib.ERRLEN)
         rc = _lib.lib().skder_amd_dist(rep_listing_file.encode(), nonrep_listing_file.encode(), SKANI_DEFAULT_MIN_AF,
@@ -85,6 +72,39 @@ def runSkaniDist(cluster_dir, skder_result_file, genome_listing_file, skani_resu
             raise RuntimeError('Had an issue running: skder_amd_dist: %s' % err.value.decode())
     except Exception as e:
         raise RuntimeError('Error running skani dist command: %s' % e)
+
+
+def _split_listing(listing_file, reps_file, reps_out, others_out):
+    """Reps_Listing.txt / NonReps_Listing.txt of skder.py:36-56: a genome of the listing is a representative when the
+    last component of its path equals the last component of a line of the result file (the reference compares base
+    names, so two genomes with one base name in different directories count as one)."""
+    rep_names = {os.path.basename(l.rstrip('\n').strip()) for l in open(reps_file) if l.strip()}
+    with open(listing_file) as src, open(reps_out, 'w') as reps, open(others_out, 'w') as others:
+        for path in (l.strip() for l in src):
+            (reps if path.rsplit('/', 1)[-1] in rep_names else others).write(path + '\n')
+
+
+def _read_n50_table(path):
+    """Concatenated_N50.txt -> [(genome path, N50 as float)] in file order (skder.py:106-111 parses the N50 with float())"""
+    table = []
+    for row in open(path):
+        genome, _, n50 = row.rstrip('\n').strip().partition('\t')
+        table.append((genome, float(n50)))
+    return table
+
+
+def _accounted_by_search_table(tsv, ani_cutoff, af_cutoff):
+    """the Ref_file entries of a `skani search` table that skder.py:122-129 marks as accounted for: third column >= the
+    ANI cut-off and FIFTH column >= the AF cut-off (the reference names that column align_frac_ref; in the table's header
+    it is Align_fraction_query)"""
+    hit = set()
+    with open(tsv) as f:
+        next(f, None)                                   # header
+        for row in f:
+            col = row.rstrip('\n').split('\t')
+            if len(col) == 7 and float(col[2]) >= ani_cutoff and float(col[4]) >= af_cutoff:
+                hit.add(col[0])
+    return hit
 
 
 class Database:
@@ -192,13 +212,8 @@ def lowMemGreedyDerep(all_genomes_listing_file, skder_lm_workspace, concat_n50_r
         search_batch = int(os.environ.get('SKDER_AMD_SEARCH_BATCH', '0'))
     db = database if database is not None else Database.from_listing(all_genomes_listing_file)
     try:
-        n50_data = []
-        with open(concat_n50_result_file) as ocnrf:
-            for line in ocnrf:
-                line = line.strip()
-                genome, n50 = line.split('\t')
-                n50_data.append([genome, float(n50)])
-        order = sorted(n50_data, key=itemgetter(1), reverse=True)
+        # N50 descending; Python's sort is stable, so equal N50s keep the listing's order (skder.py:116)
+        order = sorted(_read_n50_table(concat_n50_result_file), key=lambda gn: gn[1], reverse=True)
         skder_result_handle = open(skder_result_file, 'w')
         accounted_genomes = set([])
 
@@ -218,14 +233,7 @@ def lowMemGreedyDerep(all_genomes_listing_file, skder_lm_workspace, concat_n50_r
                                                  skani_search_result.encode(), err, _lib.ERRLEN)
                 if rc != 0 or not os.path.isfile(skani_search_result):
                     raise RuntimeError('Had an issue running: skder_amd_search %s: %s' % (gn[0], err.value.decode()))
-                with open(skani_search_result) as ossr:
-                    for i, line in enumerate(ossr):
-                        if i == 0:
-                            continue
-                        line = line.strip('\n')
-                        ref_file, query_file, ani, align_frac_query, align_frac_ref, ref_name, query_name = line.split('\t')
-                        if float(ani) >= ani_cutoff and float(align_frac_ref) >= af_cutoff:
-                            accounted_genomes.add(ref_file)
+                accounted_genomes |= _accounted_by_search_table(skani_search_result, ani_cutoff, af_cutoff)
                 emit(gn[0])
         else:
             width = search_batch if search_batch > 1 else 4       # 0: adaptive, starting at 4

@@ -9,7 +9,8 @@ int main(int argc, char **argv) {
     for (int fi = 1; fi < argc; fi++) {
         const char *f = argv[fi];
         HostGenome a, b;
-        read_fasta(f, a);
+        try { read_fasta(f, a); }
+        catch (const std::exception &e) { printf("%-12s ERRORED %s\n", f, e.what()); continue; }    // (a truncated gzip file must be refused)
         struct stat sb; stat(f, &sb);
         size_t cap = (((size_t)sb.st_size + sb.st_size / 15 + 256) + 31) & ~(size_t)31;
         std::string name(f);

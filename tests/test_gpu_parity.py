@@ -294,9 +294,18 @@ def test_driver_end_to_end_listings(gpu, tmp_path):
         want = [l.strip() for l in open(os.path.join(GOLDEN, "downstream", "tc", "skDER_Results_ANI%s_AF50.0.txt" % ani))]
         assert [os.path.basename(r) for r in reps] == want
         assert os.path.isfile(tmp_path / ("greedy%s" % ani) / "skDER_Clustering.txt")
+        # secondary clustering: genome -> nearest representative -> category as the imported reference's determineClusters
+        # assigns them from skani's table (tests/golden/make_generated.py); the ANI / AF cells carry the engine's values
+        gen = os.path.join(GOLDEN, "downstream", "generated")
+        cols = lambda path: [[os.path.basename(c[0]), os.path.basename(c[1]), c[4]] for c in (l.rstrip("\n").split("\t") for l in open(path))]
+        assert cols(tmp_path / ("greedy%s" % ani) / "skDER_Clustering.txt") == cols(os.path.join(gen, "clusters__G5__greedy__ANI%s_AF50.0.txt" % ani))
     reps_g = driver.run(genomes, str(tmp_path / "g"), "greedy", 99.5, 50.0)
-    reps_d = driver.run(genomes, str(tmp_path / "d"), "dynamic", 99.5, 50.0)
     reps_l = driver.run(genomes, str(tmp_path / "l"), "low_mem_greedy", 99.5, 50.0, clusters=True)
+    # dynamic mode: the listing of the reference's own skDERcore on skani's table (generated golden), order included
+    for ani in (99.5, 99.0):
+        reps_d = driver.run(genomes, str(tmp_path / ("d%s" % ani)), "dynamic", ani, 50.0)
+        want = [l.strip() for l in open(os.path.join(gen, "dynamic__G5__ANI%s_AF50.0_D10.0.txt" % ani))]
+        assert [os.path.basename(r) for r in reps_d] == want, ani
     assert 0 < len(reps_d) <= len(reps_g)                          # dynamic is the more concise mode (README)
     assert 0 < len(reps_l) <= len(genomes) and os.path.isfile(tmp_path / "l" / "Skani_Dist_Output.txt")
     assert set(reps_l) <= set(genomes)

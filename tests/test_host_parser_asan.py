@@ -57,14 +57,19 @@ def test_parser_under_sanitizers(tmp_path):
         with gzip.open(tmp_path / (k + ".gz"), "wb") as f:
             f.write(files[k])
         want[k + ".gz"] = want[k]
-    names = sorted(want)
+    # a gzip stream cut short must be refused, not taken for a shorter genome (zlib reports it through gzerror only)
+    whole = (tmp_path / "plain.fa.gz").read_bytes()
+    (tmp_path / "cut.fa.gz").write_bytes(whole[:len(whole) * 2 // 3])
+    names = sorted(want) + ["cut.fa.gz"]
     out = subprocess.run([exe] + names, cwd=tmp_path, capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"),
                          timeout=300)
     assert out.returncode == 0, out.stderr[-3000:]
     assert "ERROR" not in out.stderr and "runtime error" not in out.stderr, out.stderr[-3000:]
     lines = [l.split() for l in out.stdout.splitlines()]
     assert len(lines) == len(names)
-    for l in lines:
+    cut = [l for l in lines if l[0] == "cut.fa.gz"]
+    assert len(cut) == 1 and cut[0][1] == "ERRORED" and "gzip" in " ".join(cut[0]), cut
+    for l in [l for l in lines if l[0] != "cut.fa.gz"]:
         nrec, nbases, n50, first = want[l[0]]
         assert int(l[2]) == nrec and int(l[4]) == nbases and int(l[8]) == n50, l
         assert l[-2:] == ["same", "1"], l                    # own-memory and region layouts agree byte for byte

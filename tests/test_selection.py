@@ -46,6 +46,49 @@ def test_greedy_reproduces_all_30_cutoff_files():
             assert S.greedy_from_edges(edges, n50, a, f) == want, (a, f)
 
 
+def _generated():
+    d = os.path.join(D, "generated")
+    return d, sorted(os.listdir(d))
+
+
+def test_dynamic_mode_reproduces_the_generated_goldens():
+    """skDERcore's listings (tests/golden/make_generated.py: the reference's own binary on G1 / G5) from selection.dynamic,
+    byte for byte -- the reference's test run holds no dynamic-mode output of its own"""
+    from skder_amd import selection as S
+    d, names = _generated()
+    tables = {"G1": ("G1_triangle_minaf50_s89.tsv", "skder_results__Concatenated_N50.txt"),
+              "G5": ("G5_triangle_minaf10_s89.5.tsv", "skder_gtdb_results__Concatenated_N50.txt")}
+    seen = 0
+    for fn in names:
+        if not fn.startswith("dynamic__"):
+            continue
+        _, tag, rest = fn[:-4].split("__")
+        ani, af, maxd = (float(x[len(k):]) for x, k in zip(rest.split("_"), ("ANI", "AF", "D")))
+        edges, n50 = S.edges_from_table(os.path.join(GOLDEN, tables[tag][0])), S.read_n50(os.path.join(D, tables[tag][1]))
+        assert S.dynamic(edges, n50, ani, af, maxd) == _lines(os.path.join(d, fn)), fn
+        seen += 1
+    assert seen == 12
+
+
+def test_clustering_reproduces_the_generated_goldens():
+    """skDER_Clustering.txt as the imported reference's determineClusters writes it for the greedy and the dynamic
+    listings of G1 / G5 (tests/golden/make_generated.py)"""
+    from skder_amd import selection as S
+    d, names = _generated()
+    tables = {"G1": "G1_triangle_minaf50_s89.tsv", "G5": "G5_triangle_minaf10_s89.5.tsv"}
+    seen = 0
+    for fn in names:
+        if not fn.startswith("clusters__"):
+            continue
+        _, tag, mode, rest = fn[:-4].split("__")
+        ani, af = (float(x[len(k):]) for x, k in zip(rest.split("_"), ("ANI", "AF")))
+        reps = _lines(os.path.join(d, "reps__" + fn[len("clusters__"):]))
+        edges = S.edges_from_table(os.path.join(GOLDEN, tables[tag]))
+        assert S.determine_clusters(reps, edges, af, ani) == _lines(os.path.join(d, fn)), fn
+        seen += 1
+    assert seen == 10
+
+
 @pytest.mark.skipif(not os.path.isfile(os.path.join(ROOT, "oracle", "_ref", "skDERcore")), reason="oracle/_ref not built")
 def test_against_reference_binaries(tmp_path):
     """skDERsum / skDERcore compiled from the reference's sources: identical stdout"""
