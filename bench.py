@@ -4,8 +4,9 @@
 One "step" = one pass of the hot path over the whole batch: FracMinHash sketching of every genome
 (bases already resident in HBM), index, marker screen, anchors + chaining + ANI/AF of every screened
 pair, edge records back on the host.  value = N(N-1)/2 / step time.  With --gpus G > 1 (launched by
-torch.distributed.run) each rank sketches N/G genomes, the sketches are all-gathered over RCCL and
-the triangle rows are dealt cyclically: total work is fixed, so scaling is "strong".
+torch.distributed.run) each rank sketches N/G genomes, the sketches are all-gathered over RCCL, every rank
+indexes the genomes it owns, screens its share of the rows and chains the pairs that probe its genomes
+(skder_amd/multigpu.py): total work is fixed, so scaling is "strong".
 
 The JSON line also carries `roofline` (dominant kernel: algorithmic bytes / HIP-event time vs the
 8 TB/s HBM peak) and `cpu_baseline` (the CPU oracle timed on a bounded sample on this host)."""
@@ -300,6 +301,7 @@ def main():
     ap.add_argument("--batch-genomes", type=int, default=2500, help="genomes per resident input batch (one sketch call each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--e2e-genomes", type=int, default=256, help="genomes in the file-based end-to-end sample (0: skip)")
+    ap.add_argument("--dump-edges", default=None, metavar="FILE.npy", help="rank 0 writes the last step's edge records, sorted by (ref, query)")
     ap.add_argument("--no-realistic", action="store_true", help="skip the extra workloads (real genomes, indels, mixed sizes)")
     ap.add_argument("--indel-genomes", type=int, default=48, help="genomes of the host-generated indel family")
     ap.add_argument("--mixed-genomes", type=int, default=5000, help="genomes of the mixed 1-8 Mb extra workload (0: skip)")
@@ -361,7 +363,11 @@ def main():
             sk = multigpu.sketches_from_raw(ctx, raw)
         t2 = time.perf_counter()
         # no explicit sk.index(): triangle_rows builds the seed index itself, on a second stream beside the marker screen
-        edges = sk.triangle_rows(rank, world, args.screen, copy=False)   # a view of the library's host buffer
+        if dist_on:
+            # index only the genomes this rank owns, screen its rows, chain the pairs that probe its genomes
+            edges = multigpu.triangle_sharded(sk, rank, world, args.screen, copy=False)
+        else:
+            edges = sk.triangle_rows(rank, world, args.screen, copy=False)   # a view of the library's host buffer
         t4 = time.perf_counter()
         wall["sketch"] += t1 - t0; wall["exchange"] += t2 - t1; wall["triangle"] += t4 - t2
         t = ctx.timing()
@@ -402,6 +408,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         n_chained_all = float(t.item())
 
+    if rank == 0 and args.dump_edges:
+        e = np.array(edges, copy=True)
+        np.save(args.dump_edges, e[np.lexsort((e["query"], e["ref"]))])
     if rank == 0:
         # dominant kernel and its roofline (algorithmic bytes, DESIGN.md "Kernels")
         n_chained, n_anchors = tm[6], tm[7]

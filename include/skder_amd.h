@@ -53,6 +53,18 @@ int skder_amd_search(skder_db_t *db, const char *query_path, double min_af_pct, 
                      const char *out_tsv, char *err, size_t errlen);
 void skder_amd_db_free(skder_db_t *db);
 
+/* The same over SEVERAL GPUs of the node from one process (`skani ... -t T` means "use the whole machine",
+ * skder.py:18): `devices` lists n_devices GPU indices.  GPU d reads and sketches the d-th share of the listing; the raw
+ * sketches are exchanged between the GPUs (peer copies over xGMI); GPU d builds the k-mer index of the genomes it owns
+ * (listing index mod n_devices), screens every n_devices-th row and chains the pairs that probe one of its genomes.
+ * The table and its row order are those of the one-GPU call.  A database handle from skder_amd_sketch_multi serves
+ * skder_amd_search / _search_batch / _db_triangle the same way (queries are chained on the GPU that owns the database
+ * genome of a pair); skder_amd_db_save writes the same store as a one-GPU database. */
+int skder_amd_triangle_multi(const char *listing, double min_af_pct, double screen_pct, const int *devices, int n_devices,
+                             const char *out_tsv, const char *n50_tsv /* may be NULL */, char *err, size_t errlen);
+skder_db_t *skder_amd_sketch_multi(const char *listing, const int *devices, int n_devices, const char *n50_tsv /* may be NULL */,
+                                   char *err, size_t errlen);
+
 /* The `-p` free-text skani parameter string (bin/skder:132,199-201): accepts "-s <float>" only and
  * rejects any other skani flag loudly.  On success *screen_pct is set (unchanged if no -s). */
 int skder_amd_parse_skani_params(const char *params, double *screen_pct, char *err, size_t errlen);
@@ -141,6 +153,27 @@ int skder_amd_triangle_rows(skder_sketches_t *s, uint32_t row_begin, uint32_t ro
 /* rectangle: every genome of `refs` against every genome of `queries` (dist / search) */
 int skder_amd_rectangle(skder_sketches_t *refs, skder_sketches_t *queries, double screen_pct,
                         const skder_edge_t **edges, uint64_t *n_edges);
+
+/* ---- one pair matrix over several GPUs.  Every GPU holds the raw sketches of ALL genomes (all-gather),
+ * but builds the k-mer bucket index only for the genomes it OWNS (full[g] != 0; the others get their chunk tables only)
+ * and chains the pairs that PROBE one of its genomes; the marker screen is dealt out by rows.  skder_amd/multigpu.py
+ * (one process per GPU, RCCL) and skder_amd_triangle_multi below (one process, several GPUs) are built from these. */
+int skder_amd_sketches_index_part(skder_sketches_t *s, const uint8_t *full /* n_genomes flags; NULL: all */);
+/* repetitive-k-mer cut-off of every genome: what this set computed for the genomes it indexed fully, 0xFFFFFFFF ("unknown
+ * here") for the others; the element-wise minimum over the GPUs is the table to install with _set_rep_cuts */
+int skder_amd_sketches_rep_cuts(skder_sketches_t *s, uint32_t *out /* n_genomes */);
+int skder_amd_sketches_set_rep_cuts(skder_sketches_t *s, const uint32_t *in /* n_genomes */);
+/* candidate pairs (marker screen) of triangle rows row_begin, row_begin + row_stride, ...: host arrays owned by the
+ * context, valid until its next call */
+int skder_amd_screen_rows(skder_sketches_t *s, uint32_t row_begin, uint32_t row_stride, double screen_pct,
+                          const uint32_t **ref, const uint32_t **query, uint64_t *n_pairs);
+/* the genome each pair probes (the other one is cut into 20 kb chunks): its index, and whether it is the pair's query */
+int skder_amd_pairs_probed(skder_sketches_t *refs, skder_sketches_t *queries, const uint32_t *ref, const uint32_t *query,
+                           uint64_t n_pairs, uint32_t *probed, uint8_t *probed_is_query /* may be NULL */);
+/* anchors, chaining, ANI / AF of an explicit list of pairs (ref in `refs`, query in `queries`; the same set twice for a
+ * triangle).  A probed genome that has only chunk tables here gets its index built first. */
+int skder_amd_chain_pairs(skder_sketches_t *refs, skder_sketches_t *queries, const uint32_t *ref, const uint32_t *query,
+                          uint64_t n_pairs, const skder_edge_t **edges, uint64_t *n_edges);
 
 /* device-to-device copy on the context's stream, complete on return (lets a caller that holds device
  * memory of its own -- e.g. a torch tensor for the RCCL exchange -- take a copy of the raw arrays) */

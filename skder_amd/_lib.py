@@ -51,6 +51,14 @@ SYMBOLS = {
     "skder_amd_sketches_view": (C.c_int, [C.c_void_p, C.POINTER(RawView)]),
     "skder_amd_sketches_append_raw": (C.c_int, [C.c_void_p, C.POINTER(RawView)]),
     "skder_amd_sketches_index": (C.c_int, [C.c_void_p]),
+    "skder_amd_sketches_index_part": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "skder_amd_sketches_rep_cuts": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "skder_amd_sketches_set_rep_cuts": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "skder_amd_screen_rows": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_double, C.POINTER(C.POINTER(C.c_uint32)),
+                                        C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_uint64)]),
+    "skder_amd_pairs_probed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "skder_amd_chain_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                        C.POINTER(C.POINTER(Edge)), C.POINTER(C.c_uint64)]),
     "skder_amd_triangle_rows": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_double,
                                           C.POINTER(C.POINTER(Edge)), C.POINTER(C.c_uint64)]),
     "skder_amd_rectangle": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.POINTER(C.POINTER(Edge)),
@@ -64,6 +72,9 @@ SYMBOLS = {
     "skder_amd_triangle_n50": (C.c_int, [C.c_char_p, C.c_double, C.c_double, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p,
                                          C.c_size_t]),
     "skder_amd_sketch_n50": (C.c_void_p, [C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_size_t]),
+    "skder_amd_triangle_multi": (C.c_int, [C.c_char_p, C.c_double, C.c_double, C.POINTER(C.c_int), C.c_int, C.c_char_p, C.c_char_p,
+                                           C.c_char_p, C.c_size_t]),
+    "skder_amd_sketch_multi": (C.c_void_p, [C.c_char_p, C.POINTER(C.c_int), C.c_int, C.c_char_p, C.c_char_p, C.c_size_t]),
     "skder_amd_db_size": (C.c_uint32, [C.c_void_p]),
     "skder_amd_db_path": (C.c_char_p, [C.c_void_p, C.c_uint32]),
     "skder_amd_db_n50": (C.c_uint64, [C.c_void_p, C.c_uint32]),

@@ -1,10 +1,12 @@
 // api.hip -- the C ABI of include/skder_amd.h.
 #include <algorithm>
 #include <numeric>
+#include <thread>
 
 #include "device_utils.h"
 #include "engine.h"
 #include "host_io.h"
+#include "screen.h"
 #include "synth.h"
 
 static void set_err(char *err, size_t errlen, const std::string &msg)
@@ -182,10 +184,10 @@ extern "C" int skder_amd_sketches_append_raw(skder_sketches_t *s, const skder_ra
     s->seed_ctg.resize(sb + raw->n_seeds, st);
     s->markers.resize(mb + raw->n_markers, st);
     if (raw->n_seeds) {
-        HIPCHECK(hipMemcpyAsync(s->seed_kmer.p + sb, raw->d_seed_kmer, raw->n_seeds * 4, hipMemcpyDeviceToDevice, st));
-        HIPCHECK(hipMemcpyAsync(s->seed_gpos.p + sb, raw->d_seed_gpos, raw->n_seeds * 4, hipMemcpyDeviceToDevice, st));
+        HIPCHECK(hipMemcpyAsync(s->seed_kmer.p + sb, raw->d_seed_kmer, raw->n_seeds * 4, hipMemcpyDefault /* the source may live on another GPU */, st));
+        HIPCHECK(hipMemcpyAsync(s->seed_gpos.p + sb, raw->d_seed_gpos, raw->n_seeds * 4, hipMemcpyDefault /* the source may live on another GPU */, st));
         if (raw->d_seed_ctg)
-            HIPCHECK(hipMemcpyAsync(s->seed_ctg.p + sb, raw->d_seed_ctg, raw->n_seeds * 4, hipMemcpyDeviceToDevice, st));
+            HIPCHECK(hipMemcpyAsync(s->seed_ctg.p + sb, raw->d_seed_ctg, raw->n_seeds * 4, hipMemcpyDefault /* the source may live on another GPU */, st));
     }
     if (raw->n_seeds && !raw->d_seed_ctg) {
         // no record indices given: derive them from the positions and the record tables
@@ -209,7 +211,7 @@ extern "C" int skder_amd_sketches_append_raw(skder_sketches_t *s, const skder_ra
         HIPCHECK(hipStreamSynchronize(st));
     }
     if (raw->n_markers)
-        HIPCHECK(hipMemcpyAsync(s->markers.p + mb, raw->d_markers, raw->n_markers * 8, hipMemcpyDeviceToDevice, st));
+        HIPCHECK(hipMemcpyAsync(s->markers.p + mb, raw->d_markers, raw->n_markers * 8, hipMemcpyDefault /* the source may live on another GPU */, st));
     HIPCHECK(hipStreamSynchronize(st));
     size_t rg = 0;
     for (uint32_t g = 0; g < raw->n_genomes; g++) {
@@ -264,6 +266,75 @@ extern "C" int skder_amd_triangle_rows(skder_sketches_t *s, uint32_t row_begin, 
     if (n_edges) *n_edges = s->ctx->edges.size();
     return 0;
     API_CATCH_CTX(s->ctx, 2)
+}
+
+extern "C" int skder_amd_sketches_index_part(skder_sketches_t *s, const uint8_t *full)
+{
+    if (!s) return 1;
+    API_TRY
+    HIPCHECK(hipSetDevice(s->ctx->device));
+    if (s->indexed || s->index_pending) throw SkError("sketch set already indexed");
+    index_begin(s, s->ctx->stream, full);
+    index_finish(s);
+    return 0;
+    API_CATCH_CTX(s->ctx, 2)
+}
+
+extern "C" int skder_amd_sketches_rep_cuts(skder_sketches_t *s, uint32_t *out)
+{
+    if (!s || !out || !s->indexed) return 1;
+    for (uint32_t g = 0; g < s->n_genomes; g++) out[g] = s->full_index[g] ? s->h_meta[g].rep_cut : 0xFFFFFFFFu;
+    return 0;
+}
+
+extern "C" int skder_amd_sketches_set_rep_cuts(skder_sketches_t *s, const uint32_t *in)
+{
+    if (!s || !in) return 1;
+    API_TRY
+    HIPCHECK(hipSetDevice(s->ctx->device));
+    std::vector<uint8_t> mask(s->n_genomes);
+    for (uint32_t g = 0; g < s->n_genomes; g++) mask[g] = s->full_index[g] ? 0 : 1;     // own values stay
+    index_set_rep_cuts(s, in, mask.data());
+    return 0;
+    API_CATCH_CTX(s->ctx, 2)
+}
+
+extern "C" int skder_amd_screen_rows(skder_sketches_t *s, uint32_t row_begin, uint32_t row_stride, double screen_pct,
+                                     const uint32_t **ref, const uint32_t **query, uint64_t *n_pairs)
+{
+    if (!s) return 1;
+    API_TRY
+    HIPCHECK(hipSetDevice(s->ctx->device));
+    if (!s->indexed) throw SkError("screen_rows: index the set first (skder_amd_sketches_index or _index_part)");
+    screen_rows_impl(s, row_begin, row_stride, screen_pct, s->ctx->pairs_ref, s->ctx->pairs_query);
+    if (ref) *ref = s->ctx->pairs_ref.data();
+    if (query) *query = s->ctx->pairs_query.data();
+    if (n_pairs) *n_pairs = s->ctx->pairs_ref.size();
+    return 0;
+    API_CATCH_CTX(s->ctx, 2)
+}
+
+extern "C" int skder_amd_pairs_probed(skder_sketches_t *refs, skder_sketches_t *queries, const uint32_t *ref, const uint32_t *query,
+                                      uint64_t n_pairs, uint32_t *probed, uint8_t *probed_is_query)
+{
+    if (!refs || !queries || (n_pairs && (!ref || !query || !probed))) return 1;
+    API_TRY
+    pairs_probed_impl(refs, queries, ref, query, n_pairs, probed, probed_is_query);
+    return 0;
+    API_CATCH_CTX(refs->ctx, 2)
+}
+
+extern "C" int skder_amd_chain_pairs(skder_sketches_t *refs, skder_sketches_t *queries, const uint32_t *ref, const uint32_t *query,
+                                     uint64_t n_pairs, const skder_edge_t **edges, uint64_t *n_edges)
+{
+    if (!refs || !queries || refs->ctx != queries->ctx || (n_pairs && (!ref || !query))) return 1;
+    API_TRY
+    HIPCHECK(hipSetDevice(refs->ctx->device));
+    chain_pairs_impl(refs, queries, ref, query, n_pairs);
+    if (edges) *edges = refs->ctx->edges.data();
+    if (n_edges) *n_edges = refs->ctx->edges.size();
+    return 0;
+    API_CATCH_CTX(refs->ctx, 2)
 }
 
 extern "C" int skder_amd_rectangle(skder_sketches_t *refs, skder_sketches_t *queries, double screen_pct,
@@ -340,9 +411,13 @@ extern "C" int skder_amd_synth_fill(skder_ctx_t *ctx, uint8_t *d_bases, const sk
 // ---------------------------------------------------------------------------------------------
 // drop-in entry points
 
+// a further GPU of a multi-GPU database: the raw sketches of ALL genomes, the bucket index of the genomes it owns
+struct Replica { skder_ctx *ctx = nullptr; skder_sketches *refs = nullptr; };
+
 struct skder_db {
     skder_ctx *ctx = nullptr;
-    skder_sketches *refs = nullptr;          // genomes in LISTING order, indexed
+    skder_sketches *refs = nullptr;          // genomes in LISTING order, indexed (multi-GPU: GPU 0's replica)
+    std::vector<Replica> more;               // GPUs 1 .. n-1 (empty: one GPU)
     GenomeNames names;
     std::vector<std::pair<std::string, uint32_t>> by_path;   // sorted (path, index)
     std::vector<skder_edge_t> rows;          // last table handed out in memory
@@ -387,9 +462,65 @@ static void db_finish(skder_db *db)
 static void db_destroy(skder_db *db)
 {
     if (!db) return;
+    for (Replica &r : db->more) { skder_amd_sketches_free(r.refs); skder_amd_ctx_destroy(r.ctx); }
     skder_amd_sketches_free(db->refs);
     skder_amd_ctx_destroy(db->ctx);
     delete db;
+}
+
+// ---- several GPUs in one process: one host thread per GPU for every stage
+static uint32_t db_gpus(const skder_db *db) { return 1u + (uint32_t)db->more.size(); }
+static skder_sketches *db_refs(skder_db *db, uint32_t d) { return d == 0 ? db->refs : db->more[d - 1].refs; }
+
+template <typename F>
+static void per_gpu(uint32_t n, F fn)
+{
+    std::vector<std::string> errs(n);
+    std::vector<std::thread> th;
+    auto run = [&](uint32_t d) {
+        try { fn(d); } catch (const std::exception &e) { errs[d] = e.what()[0] ? e.what() : "error"; }
+    };
+    for (uint32_t d = 1; d < n; d++) th.emplace_back(run, d);
+    run(0);
+    for (auto &t : th) t.join();
+    for (uint32_t d = 0; d < n; d++)
+        if (!errs[d].empty()) throw SkError("GPU " + std::to_string(d) + ": " + errs[d]);
+}
+
+// pairs to the GPU that owns (index mod n) the genome they probe; `probe_side`: the set the routing looks at
+static void route_by_probed(skder_sketches *SA, skder_sketches *SB, const std::vector<uint32_t> &ref, const std::vector<uint32_t> &query,
+                            uint32_t n, bool by_ref_only, std::vector<std::vector<uint32_t>> &oref, std::vector<std::vector<uint32_t>> &oquery)
+{
+    oref.assign(n, {}); oquery.assign(n, {});
+    std::vector<uint32_t> probed(ref.size());
+    if (!ref.empty() && !by_ref_only) pairs_probed_impl(SA, SB, ref.data(), query.data(), ref.size(), probed.data(), nullptr);
+    for (size_t p = 0; p < ref.size(); p++) {
+        const uint32_t d = (by_ref_only ? ref[p] : probed[p]) % n;
+        oref[d].push_back(ref[p]); oquery[d].push_back(query[p]);
+    }
+}
+
+// all-pairs edges of a multi-GPU database: rows screened in shares, pairs chained by the owner of the probed genome
+static void db_triangle_edges_multi(skder_db *db, double screen_pct, std::vector<skder_edge_t> &E)
+{
+    const uint32_t n = db_gpus(db);
+    std::vector<std::vector<uint32_t>> sref(n), squery(n);
+    per_gpu(n, [&](uint32_t d) {
+        skder_sketches *s = db_refs(db, d);
+        HIPCHECK(hipSetDevice(s->ctx->device));
+        screen_rows_impl(s, d, n, screen_pct, sref[d], squery[d]);
+    });
+    std::vector<uint32_t> ref, query;
+    for (uint32_t d = 0; d < n; d++) { ref.insert(ref.end(), sref[d].begin(), sref[d].end()); query.insert(query.end(), squery[d].begin(), squery[d].end()); }
+    std::vector<std::vector<uint32_t>> oref, oquery;
+    route_by_probed(db->refs, db->refs, ref, query, n, false, oref, oquery);
+    per_gpu(n, [&](uint32_t d) {
+        skder_sketches *s = db_refs(db, d);
+        HIPCHECK(hipSetDevice(s->ctx->device));
+        chain_pairs_impl(s, s, oref[d].data(), oquery[d].data(), oref[d].size());
+    });
+    E.clear();
+    for (uint32_t d = 0; d < n; d++) { const auto &e = db_refs(db, d)->ctx->edges; E.insert(E.end(), e.begin(), e.end()); }
 }
 
 extern "C" skder_db_t *skder_amd_sketch_n50(const char *listing, int device, const char *n50_tsv, char *err, size_t errlen)
@@ -413,6 +544,86 @@ extern "C" skder_db_t *skder_amd_sketch_n50(const char *listing, int device, con
     }
 }
 
+extern "C" skder_db_t *skder_amd_sketch_multi(const char *listing, const int *devices, int n_devices, const char *n50_tsv, char *err,
+                                              size_t errlen)
+{
+    if (!listing || !devices || n_devices < 1) { set_err(err, errlen, "null argument"); return nullptr; }
+    if (n_devices == 1) return skder_amd_sketch_n50(listing, devices[0], n50_tsv, err, errlen);
+    const uint32_t n = (uint32_t)n_devices;
+    skder_db *db = new skder_db();
+    std::vector<skder_sketches *> part(n, nullptr);
+    try {
+        std::vector<std::string> paths = read_listing(listing);
+        const size_t G = paths.size();
+        // one context per GPU; GPU d reads and sketches the d-th contiguous share of the listing
+        db->more.resize(n - 1);
+        for (uint32_t d = 0; d < n; d++) {
+            skder_ctx *c = skder_amd_ctx_create(devices[d], err, errlen);
+            if (!c) throw SkError(std::string("cannot open GPU ") + std::to_string(devices[d]) + ": " + (err ? err : ""));
+            if (d == 0) db->ctx = c; else db->more[d - 1].ctx = c;
+        }
+        auto ctx_of = [&](uint32_t d) { return d == 0 ? db->ctx : db->more[d - 1].ctx; };
+        std::vector<GenomeNames> names(n);
+        per_gpu(n, [&](uint32_t d) {
+            HIPCHECK(hipSetDevice(ctx_of(d)->device));
+            part[d] = skder_amd_sketches_new(ctx_of(d));
+            const size_t lo = G * d / n, hi = G * (d + 1) / n;
+            sketch_files(part[d], std::vector<std::string>(paths.begin() + lo, paths.begin() + hi), names[d]);
+        });
+        for (uint32_t d = 0; d < n; d++) {
+            db->names.path.insert(db->names.path.end(), names[d].path.begin(), names[d].path.end());
+            db->names.first_name.insert(db->names.first_name.end(), names[d].first_name.begin(), names[d].first_name.end());
+            db->names.n50.insert(db->names.n50.end(), names[d].n50.begin(), names[d].n50.end());
+        }
+        // "all-gather": every GPU pulls the raw sketches of every share (peer copies over xGMI), in listing order;
+        // then the bucket index of the genomes it owns (index mod n) and everybody's chunk tables
+        std::vector<skder_raw_view_t> views(n);
+        for (uint32_t d = 0; d < n; d++) if (skder_amd_sketches_view(part[d], &views[d]) != 0) throw SkError("sketches_view failed");
+        per_gpu(n, [&](uint32_t d) {
+            HIPCHECK(hipSetDevice(ctx_of(d)->device));
+            skder_sketches *all = skder_amd_sketches_new(ctx_of(d));
+            if (d == 0) db->refs = all; else db->more[d - 1].refs = all;
+            for (uint32_t e = 0; e < n; e++)
+                if (views[e].n_genomes && skder_amd_sketches_append_raw(all, &views[e]) != 0) throw SkError(ctx_of(d)->last_error);
+            std::vector<uint8_t> own(G);
+            for (size_t g = 0; g < G; g++) own[g] = (g % n == d) ? 1 : 0;
+            index_begin(all, ctx_of(d)->stream, own.data());
+            index_finish(all);
+        });
+        for (uint32_t d = 0; d < n; d++) { skder_amd_sketches_free(part[d]); part[d] = nullptr; }
+        // repetitive-k-mer cut-offs: each genome's from its owner
+        std::vector<uint32_t> rep(G, 0xFFFFFFFFu);
+        for (size_t g = 0; g < G; g++) rep[g] = db_refs(db, (uint32_t)(g % n))->h_meta[g].rep_cut;
+        per_gpu(n, [&](uint32_t d) {
+            HIPCHECK(hipSetDevice(ctx_of(d)->device));
+            std::vector<uint8_t> mask(G);
+            for (size_t g = 0; g < G; g++) mask[g] = (g % n == d) ? 0 : 1;
+            index_set_rep_cuts(db_refs(db, d), rep.data(), mask.data());
+        });
+        db->by_path.clear();
+        for (uint32_t i = 0; i < db->names.path.size(); i++) db->by_path.emplace_back(db->names.path[i], i);
+        std::stable_sort(db->by_path.begin(), db->by_path.end());
+        if (n50_tsv) write_n50_tsv(n50_tsv, db->names);
+        return db;
+    } catch (const std::exception &e) {
+        set_err(err, errlen, e.what());
+        for (auto *p : part) skder_amd_sketches_free(p);
+        db_destroy(db);
+        return nullptr;
+    }
+}
+
+extern "C" int skder_amd_triangle_multi(const char *listing, double min_af_pct, double screen_pct, const int *devices, int n_devices,
+                                        const char *out_tsv, const char *n50_tsv, char *err, size_t errlen)
+{
+    if (!listing || !out_tsv) { set_err(err, errlen, "null argument"); return 1; }
+    skder_db *db = skder_amd_sketch_multi(listing, devices, n_devices, n50_tsv, err, errlen);
+    if (!db) return 1;
+    int rc = skder_amd_db_triangle(db, min_af_pct, screen_pct, out_tsv, nullptr, nullptr, err, errlen);
+    db_destroy(db);
+    return rc;
+}
+
 extern "C" skder_db_t *skder_amd_sketch(const char *listing, int device, char *err, size_t errlen)
 {
     return skder_amd_sketch_n50(listing, device, nullptr, err, errlen);
@@ -434,8 +645,9 @@ static void db_triangle_rows(skder_db *db, double min_af_pct, double screen_pct)
     const uint32_t n = (uint32_t)db->names.path.size();
     std::vector<uint32_t> rank(n), perm(n);
     for (uint32_t r = 0; r < n; r++) { perm[r] = db->by_path[r].second; rank[perm[r]] = r; }
-    triangle_rows_impl(db->refs, 0, 1, screen_pct);
-    std::vector<skder_edge_t> E(db->ctx->edges);
+    std::vector<skder_edge_t> E;
+    if (db->more.empty()) { triangle_rows_impl(db->refs, 0, 1, screen_pct); E = db->ctx->edges; }
+    else db_triangle_edges_multi(db, screen_pct, E);
     for (auto &e : E) {
         uint32_t a = rank[e.ref], b = rank[e.query];
         if (a > b) { std::swap(a, b); std::swap(e.af_ref, e.af_query); }
@@ -549,9 +761,48 @@ extern "C" int skder_amd_search_batch(skder_db_t *db, const char *const *query_p
             }
         }
         db->rows.clear();
-        if (n_queries) {
+        if (n_queries && db->more.empty()) {
             rectangle_impl(db->refs, q, screen_pct);
             db->rows = rect_rows_ordered(db->ctx->edges, min_af_pct);
+        } else if (n_queries) {
+            // several GPUs: every GPU gets the queries' sketches (a peer copy of GPU 0's), screens a share of the queries
+            // against all markers and chains the pairs whose DATABASE genome it owns -- if the pair probes that genome its
+            // index is there, if it probes the query every GPU has indexed the queries
+            const uint32_t n = db_gpus(db);
+            skder_raw_view_t qv;
+            if (skder_amd_sketches_view(q, &qv) != 0) throw SkError("sketches_view failed");
+            std::vector<skder_sketches *> qs(n, nullptr);
+            qs[0] = q;
+            std::vector<std::vector<uint32_t>> sref(n), squery(n), oref, oquery;
+            try {
+                per_gpu(n, [&](uint32_t d) {
+                    skder_sketches *refs = db_refs(db, d);
+                    HIPCHECK(hipSetDevice(refs->ctx->device));
+                    if (d) {
+                        qs[d] = skder_amd_sketches_new(refs->ctx);
+                        if (skder_amd_sketches_append_raw(qs[d], &qv) != 0) throw SkError(refs->ctx->last_error);
+                    }
+                    index_impl(qs[d]);
+                    std::vector<uint32_t> rows;
+                    for (uint32_t k = d; k < n_queries; k += n) rows.push_back(k);
+                    if (!rows.empty()) screen_pairs(refs, qs[d], rows, false, screen_pct, squery[d], sref[d]);
+                });
+                std::vector<uint32_t> ref, query;
+                for (uint32_t d = 0; d < n; d++) { ref.insert(ref.end(), sref[d].begin(), sref[d].end()); query.insert(query.end(), squery[d].begin(), squery[d].end()); }
+                route_by_probed(db->refs, q, ref, query, n, true, oref, oquery);
+                per_gpu(n, [&](uint32_t d) {
+                    skder_sketches *refs = db_refs(db, d);
+                    HIPCHECK(hipSetDevice(refs->ctx->device));
+                    chain_pairs_impl(refs, qs[d], oref[d].data(), oquery[d].data(), oref[d].size());
+                });
+            } catch (...) {
+                for (uint32_t d = 1; d < n; d++) skder_amd_sketches_free(qs[d]);
+                throw;
+            }
+            std::vector<skder_edge_t> E;
+            for (uint32_t d = 0; d < n; d++) { const auto &e = db_refs(db, d)->ctx->edges; E.insert(E.end(), e.begin(), e.end()); }
+            for (uint32_t d = 1; d < n; d++) skder_amd_sketches_free(qs[d]);
+            db->rows = rect_rows_ordered(E, min_af_pct);
         }
         if (out_tsvs) {
             size_t lo = 0;

@@ -2285,3 +2285,61 @@ void rectangle_impl(skder_sketches *refs, skder_sketches *queries, double screen
         if (b1 >= rows.size()) break;
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// pieces of triangle_rows / rectangle for callers that spread one pair matrix over several GPUs: candidate pairs of some
+// rows (every GPU holds all markers), the genome each pair probes (its owner chains the pair), chaining of a pair list
+
+void screen_rows_impl(skder_sketches *s, uint32_t row_begin, uint32_t row_stride, double screen_pct,
+                      std::vector<uint32_t> &pref, std::vector<uint32_t> &pquery)
+{
+    skder_ctx *ctx = s->ctx;
+    pref.clear(); pquery.clear();
+    std::vector<uint32_t> rows;
+    for (uint32_t i = row_begin; i < s->n_genomes; i += (row_stride ? row_stride : 1)) rows.push_back(i);
+    const size_t rpb = rows_per_block(s->n_genomes);
+    std::vector<uint32_t> a, b, sub;
+    for (size_t b0 = 0; b0 < rows.size(); b0 += rpb) {
+        const size_t b1 = b0 + rpb < rows.size() ? b0 + rpb : rows.size();
+        sub.assign(rows.begin() + b0, rows.begin() + b1);
+        screen_pairs(s, s, sub, true, screen_pct, a, b);
+        pref.insert(pref.end(), a.begin(), a.end());
+        pquery.insert(pquery.end(), b.begin(), b.end());
+    }
+    (void)ctx;
+}
+
+// the genome pair (ref, query) PROBES (the other one is cut into chunks): index inside the set
+void pairs_probed_impl(skder_sketches *SA, skder_sketches *SB, const uint32_t *ref, const uint32_t *query, uint64_t n, uint32_t *probed,
+                       uint8_t *probed_is_query)
+{
+    if (!SA->indexed || !SB->indexed) throw SkError("pairs_probed: index the sets first");
+    for (uint64_t p = 0; p < n; p++) {
+        if (ref[p] >= SA->n_genomes || query[p] >= SB->n_genomes) throw SkError("pairs_probed: genome index out of range");
+        const bool cq = chunk_the_query(SA->h_meta[ref[p]], SB->h_meta[query[p]]);
+        probed[p] = cq ? ref[p] : query[p];
+        if (probed_is_query) probed_is_query[p] = cq ? 0 : 1;
+    }
+}
+
+void chain_pairs_impl(skder_sketches *SA, skder_sketches *SB, const uint32_t *ref, const uint32_t *query, uint64_t n)
+{
+    skder_ctx *ctx = SA->ctx;
+    if (!SA->indexed || !SB->indexed) throw SkError("chain_pairs: index the sets first");
+    ctx->edges.clear();
+    chain_timing_reset(ctx);
+    std::vector<uint32_t> pr(ref, ref + n), pq(query, query + n);
+    // the probed genome of every pair needs its bucket index here; a chunked genome whose own repetitive-k-mer filter is
+    // active needs it as well (slow chaining path): build what is missing
+    std::vector<uint32_t> needA, needB;
+    for (uint64_t p = 0; p < n; p++) {
+        const GenomeMeta &mr = SA->h_meta[pr[p]], &mq = SB->h_meta[pq[p]];
+        const bool cq = chunk_the_query(mr, mq);
+        if (cq) { if (!SA->full_index[pr[p]]) needA.push_back(pr[p]); if (mq.rep_cut != 0xFFFFFFFFu && !SB->full_index[pq[p]]) needB.push_back(pq[p]); }
+        else { if (!SB->full_index[pq[p]]) needB.push_back(pq[p]); if (mr.rep_cut != 0xFFFFFFFFu && !SA->full_index[pr[p]]) needA.push_back(pr[p]); }
+    }
+    if (SA == SB) { needA.insert(needA.end(), needB.begin(), needB.end()); needB.clear(); }
+    index_promote(SA, needA);
+    if (SA != SB) index_promote(SB, needB);
+    chain_pairs(SA, SB, pr, pq, ctx->edges);
+}

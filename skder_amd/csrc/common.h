@@ -92,6 +92,7 @@ struct skder_ctx {
     double timing_runs = 0;          // ms of the run-extraction kernel in the last call
     double timing_index = 0;         // ms of the last index build (device)
     std::vector<skder_edge_t> edges;
+    std::vector<uint32_t> pairs_ref, pairs_query;   // candidate pairs of the last screen_rows call
     uint32_t *d_flags = nullptr;   // [0] overflow / error flags from kernels
     uint64_t counters[4] = {0, 0, 0, 0};   // [0] chunks processed, [1] chunks sent to the slow path
     bool chain_attr_set = false;           // large-LDS opt-in of the join / finalize kernels done on this context's device

@@ -41,6 +41,7 @@ struct skder_sketches {
     DevBuf<uint32_t> idx_list;             // genome lists of the index kernels, alive until index_finish
     DevBuf<uint4> idx_packed;              // (k-mer, position, record, -) per seed: one gather instead of three, index build only
     std::vector<uint32_t> idx_small, idx_big;
+    std::vector<uint8_t> full_index;        // per genome: bucket index built here (else chunk tables only: another GPU owns it)
     hipStream_t idx_stream = nullptr;
     // raw sketches
     DevBuf<uint32_t> seed_kmer, seed_gpos, seed_ctg;   // position order
@@ -62,10 +63,18 @@ struct skder_sketches {
 
 void sketch_batch_impl(skder_sketches *s, const uint8_t *d_bases, const skder_batch_t *b);
 void index_impl(skder_sketches *s);                       // build the index and wait for it
-void index_begin(skder_sketches *s, hipStream_t st);     // enqueue the index build on st (after what ctx->stream holds now)
+void index_begin(skder_sketches *s, hipStream_t st, const uint8_t *full = nullptr);   // enqueue the index build on st (after what ctx->stream
+                                                                                      // holds now); full[g] == 0: chunk tables only for genome g
+void index_promote(skder_sketches *s, const std::vector<uint32_t> &genomes);          // full index for some of those afterwards
+void index_set_rep_cuts(skder_sketches *s, const uint32_t *in, const uint8_t *mask);
 void index_finish(skder_sketches *s);                    // wait for it, fetch the per-genome results
 void triangle_rows_impl(skder_sketches *s, uint32_t row_begin, uint32_t row_stride, double screen_pct);
 void rectangle_impl(skder_sketches *refs, skder_sketches *queries, double screen_pct);
+void screen_rows_impl(skder_sketches *s, uint32_t row_begin, uint32_t row_stride, double screen_pct,
+                      std::vector<uint32_t> &pref, std::vector<uint32_t> &pquery);
+void pairs_probed_impl(skder_sketches *SA, skder_sketches *SB, const uint32_t *ref, const uint32_t *query, uint64_t n, uint32_t *probed,
+                       uint8_t *probed_is_query);
+void chain_pairs_impl(skder_sketches *SA, skder_sketches *SB, const uint32_t *ref, const uint32_t *query, uint64_t n);
 void synth_fill_impl(skder_ctx *ctx, uint8_t *d_bases, const skder_batch_t *b, const uint64_t *lineage,
                      const uint32_t *params);
 

@@ -395,6 +395,45 @@ __global__ __launch_bounds__(IDXF_THREADS) void index_genome_lds_kernel(
     }
 }
 
+// chunk tables only (chunk id and chunk-start flag of every seed, first seed of every chunk): what a genome needs as the
+// CHUNKED side of a pair.  Multi-GPU runs build the bucket index of a genome only on the GPU that owns it (the pairs that
+// probe it are chained there) and these tables everywhere.  rep_cut is left alone: the owner's value is installed by the
+// caller (index_set_rep_cuts).
+__global__ __launch_bounds__(IDX_THREADS) void chunk_tables_kernel(
+    GenomeMeta *__restrict__ meta, const uint32_t *__restrict__ list, const uint32_t *__restrict__ rec_goff,
+    const uint32_t *__restrict__ seed_gpos, const uint32_t *__restrict__ seed_ctg,
+    uint32_t *__restrict__ pchunk, uint32_t *__restrict__ chunk_start_all, uint8_t *__restrict__ pcs)
+{
+    __shared__ uint32_t wsum[IDX_THREADS / 64];
+    const uint32_t g = list[blockIdx.x], tid = threadIdx.x;
+    const GenomeMeta m = meta[g];
+    const uint32_t n = m.n_seeds;
+    const uint32_t *pg = seed_gpos + m.seed_off, *pc = seed_ctg + m.seed_off;
+    const uint32_t *rg = rec_goff + m.rec_goff_off;
+    uint32_t crun = 0;
+    for (uint32_t base = 0; base < n; base += IDX_THREADS) {
+        const uint32_t s = base + tid;
+        uint32_t flag = 0;
+        if (s < n) {
+            const uint32_t c = pc[s], ck = (pg[s] - rg[c]) / ANI_CHUNK_LEN;
+            if (s == 0) flag = 1;
+            else {
+                const uint32_t c2 = pc[s - 1], ck2 = (pg[s - 1] - rg[c2]) / ANI_CHUNK_LEN;
+                flag = (c != c2) || (ck != ck2);
+            }
+        }
+        uint32_t total;
+        const uint32_t ex = block_excl_scan<IDX_THREADS / 64>(flag, wsum, total);
+        if (s < n) {
+            pchunk[m.seed_off + s] = crun + ex + flag - 1u;
+            pcs[m.seed_off + s] = (uint8_t)flag;
+            if (flag) chunk_start_all[m.chunk_off + crun + ex] = s;
+        }
+        crun += total;
+    }
+    if (tid == 0) { meta[g].n_chunks = crun; chunk_start_all[m.chunk_off + crun] = n; }
+}
+
 void index_impl(skder_sketches *s)
 {
     if (s->indexed) return;
@@ -402,7 +441,55 @@ void index_impl(skder_sketches *s)
     index_finish(s);
 }
 
-void index_begin(skder_sketches *s, hipStream_t st)
+// index kernels for the genomes of `which`: the full index where full_index says so, chunk tables otherwise
+static void index_launch(skder_sketches *s, const std::vector<uint32_t> &which, hipStream_t st)
+{
+    // genomes whose tables fit in LDS take the LDS-resident kernel, the others the general one
+    const size_t lds_limit = 150 * 1024;
+    std::vector<uint32_t> &small = s->idx_small, &big = s->idx_big;
+    std::vector<uint32_t> light;
+    small.clear(); big.clear();
+    size_t small_bytes = 0;
+    uint32_t max_bits = 12;   // the general kernel's multiplicity histogram needs 4096 counters
+    for (uint32_t g : which) {
+        const GenomeMeta &m = s->h_meta[g];
+        if (!s->full_index[g]) { light.push_back(g); continue; }
+        const size_t need = idxf_smem_bytes(1u << m.bucket_bits, m.n_seeds);
+        if (m.n_seeds < 65536u && need <= lds_limit) {
+            small.push_back(g);
+            small_bytes = need > small_bytes ? need : small_bytes;
+        } else {
+            big.push_back(g);
+            max_bits = m.bucket_bits > max_bits ? m.bucket_bits : max_bits;
+        }
+    }
+    DevBuf<uint32_t> &d_list = s->idx_list;
+    d_list.resize(which.size() + 1, st);
+    if (!small.empty()) HIPCHECK(hipMemcpyAsync(d_list.p, small.data(), small.size() * 4, hipMemcpyHostToDevice, st));
+    if (!big.empty()) HIPCHECK(hipMemcpyAsync(d_list.p + small.size(), big.data(), big.size() * 4, hipMemcpyHostToDevice, st));
+    if (!light.empty())
+        HIPCHECK(hipMemcpyAsync(d_list.p + small.size() + big.size(), light.data(), light.size() * 4, hipMemcpyHostToDevice, st));
+    if (!small.empty()) {
+        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(index_genome_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds_limit));
+        hipLaunchKernelGGL(index_genome_lds_kernel, dim3((unsigned)small.size()), dim3(IDXF_THREADS), small_bytes, st, s->d_meta.p, d_list.p,
+                           s->d_rec_goff.p, s->seed_kmer.p, s->seed_gpos.p, s->seed_ctg.p, s->skmer.p, s->sgpos.p, s->sctg.p, s->stag.p, s->boff.p,
+                           s->pchunk.p, s->chunk_start.p, s->idx_packed.p, s->pcs.p);
+    }
+    if (!big.empty()) {
+        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(index_genome_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)((1u << max_bits) * 4)));
+        hipLaunchKernelGGL(index_genome_kernel, dim3((unsigned)big.size()), dim3(IDX_THREADS), (1u << max_bits) * 4, st, s->d_meta.p,
+                           d_list.p + small.size(), s->d_rec_goff.p, s->seed_kmer.p, s->seed_gpos.p, s->seed_ctg.p, s->skmer.p, s->sgpos.p,
+                           s->sctg.p, s->stag.p, s->boff.p, s->pchunk.p, s->chunk_start.p, s->pcs.p);
+    }
+    if (!light.empty())
+        hipLaunchKernelGGL(chunk_tables_kernel, dim3((unsigned)light.size()), dim3(IDX_THREADS), 0, st, s->d_meta.p,
+                           d_list.p + small.size() + big.size(), s->d_rec_goff.p, s->seed_gpos.p, s->seed_ctg.p, s->pchunk.p, s->chunk_start.p,
+                           s->pcs.p);
+}
+
+void index_begin(skder_sketches *s, hipStream_t st, const uint8_t *full)
 {
     if (s->indexed || s->index_pending) return;
     skder_ctx *ctx = s->ctx;
@@ -448,42 +535,12 @@ void index_begin(skder_sketches *s, hipStream_t st)
             HIPCHECK(hipStreamWaitEvent(st, ctx->ev[11], 0));
         }
         HIPCHECK(hipEventRecord(ctx->ev[3], st));
-        // genomes whose tables fit in LDS take the LDS-resident kernel, the others the general one
-        const size_t lds_limit = 150 * 1024;
-        std::vector<uint32_t> &small = s->idx_small, &big = s->idx_big;
-        small.clear(); big.clear();
-        size_t small_bytes = 0;
-        uint32_t max_bits = 12;   // the general kernel's multiplicity histogram needs 4096 counters
-        for (uint32_t g = 0; g < G; g++) {
-            const GenomeMeta &m = s->h_meta[g];
-            const size_t need = idxf_smem_bytes(1u << m.bucket_bits, m.n_seeds);
-            if (m.n_seeds < 65536u && need <= lds_limit) {
-                small.push_back(g);
-                small_bytes = need > small_bytes ? need : small_bytes;
-            } else {
-                big.push_back(g);
-                max_bits = m.bucket_bits > max_bits ? m.bucket_bits : max_bits;
-            }
-        }
-        DevBuf<uint32_t> &d_list = s->idx_list;
+        s->full_index.assign(G, 1);
+        if (full) for (uint32_t g = 0; g < G; g++) s->full_index[g] = full[g] ? 1 : 0;
+        std::vector<uint32_t> all(G);
+        for (uint32_t g = 0; g < G; g++) all[g] = g;
         s->idx_packed.resize(ns + 1, st);
-        d_list.resize(G + 1, st);
-        if (!small.empty()) HIPCHECK(hipMemcpyAsync(d_list.p, small.data(), small.size() * 4, hipMemcpyHostToDevice, st));
-        if (!big.empty()) HIPCHECK(hipMemcpyAsync(d_list.p + small.size(), big.data(), big.size() * 4, hipMemcpyHostToDevice, st));
-        if (!small.empty()) {
-            HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(index_genome_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)lds_limit));
-            hipLaunchKernelGGL(index_genome_lds_kernel, dim3((unsigned)small.size()), dim3(IDXF_THREADS), small_bytes, st, s->d_meta.p, d_list.p,
-                               s->d_rec_goff.p, s->seed_kmer.p, s->seed_gpos.p, s->seed_ctg.p, s->skmer.p, s->sgpos.p, s->sctg.p, s->stag.p, s->boff.p,
-                               s->pchunk.p, s->chunk_start.p, s->idx_packed.p, s->pcs.p);
-        }
-        if (!big.empty()) {
-            HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(index_genome_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)((1u << max_bits) * 4)));
-            hipLaunchKernelGGL(index_genome_kernel, dim3((unsigned)big.size()), dim3(IDX_THREADS), (1u << max_bits) * 4, st, s->d_meta.p,
-                               d_list.p + small.size(), s->d_rec_goff.p, s->seed_kmer.p, s->seed_gpos.p, s->seed_ctg.p, s->skmer.p, s->sgpos.p,
-                               s->sctg.p, s->stag.p, s->boff.p, s->pchunk.p, s->chunk_start.p, s->pcs.p);
-        }
+        index_launch(s, all, st);
         HIPCHECK(hipGetLastError());
         HIPCHECK(hipEventRecord(ctx->ev[4], st));
     }
@@ -506,4 +563,35 @@ void index_finish(skder_sketches *s)
     s->idx_packed.release();
     s->index_pending = false;
     s->indexed = true;
+}
+
+// full index for genomes that so far have chunk tables only (a chunked genome whose own repetitive-k-mer filter is active
+// needs its bucket index on the slow chaining path); complete on return
+void index_promote(skder_sketches *s, const std::vector<uint32_t> &genomes)
+{
+    if (!s->indexed) throw SkError("index_promote: the set is not indexed");
+    std::vector<uint32_t> todo;
+    for (uint32_t g : genomes)
+        if (g < s->n_genomes && !s->full_index[g]) { s->full_index[g] = 1; todo.push_back(g); }
+    if (todo.empty()) return;
+    hipStream_t st = s->ctx->stream;
+    const uint64_t ns = s->h_seed_off[s->n_genomes];
+    // the kernels overwrite rep_cut with what they compute (the same value the owner found) and n_chunks (unchanged)
+    s->idx_packed.resize(ns + 1, st);
+    index_launch(s, todo, st);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpyAsync(s->h_meta.data(), s->d_meta.p, s->n_genomes * sizeof(GenomeMeta), hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    s->idx_list.release();
+    s->idx_packed.release();
+}
+
+// repetitive-k-mer cut-offs found by the owners of the genomes this set holds chunk tables of (mask[g] != 0: install in[g])
+void index_set_rep_cuts(skder_sketches *s, const uint32_t *in, const uint8_t *mask)
+{
+    if (!s->indexed) throw SkError("index_set_rep_cuts: the set is not indexed");
+    for (uint32_t g = 0; g < s->n_genomes; g++)
+        if (!mask || mask[g]) s->h_meta[g].rep_cut = in[g];
+    HIPCHECK(hipMemcpyAsync(s->d_meta.p, s->h_meta.data(), s->n_genomes * sizeof(GenomeMeta), hipMemcpyHostToDevice, s->ctx->stream));
+    HIPCHECK(hipStreamSynchronize(s->ctx->stream));
 }

@@ -66,9 +66,26 @@ def _file_stamps(genomes):
     """[path, size, mtime in ns] of every FASTA file: what a sketch store was built from"""
     out = []
     for g in genomes:
-        st = os.stat(g)
-        out.append([g, st.st_size, st.st_mtime_ns])
+        try:
+            st = os.stat(g)
+            out.append([g, st.st_size, st.st_mtime_ns])
+        except OSError:
+            out.append([g, None, None])          # gone: nothing to compare with
     return out
+
+
+def _store_is_fresh(stamps_then, stamps_now):
+    """same paths in the same order; every file that still exists has the size and modification time it had when the store
+    was written (a file that is gone cannot contradict the store: skani's sketch directory does not need the FASTA files
+    afterwards either)"""
+    if len(stamps_then) != len(stamps_now):
+        return False
+    for then, now in zip(stamps_then, stamps_now):
+        if then[0] != now[0]:
+            return False
+        if now[1] is not None and (then[1], then[2]) != (now[1], now[2]):
+            return False
+    return True
 
 
 def open_database(listing, genomes, n50_file, store=None, devices=None):
@@ -78,7 +95,7 @@ def open_database(listing, genomes, n50_file, store=None, devices=None):
     stamps_file = store + ".files.json" if store else None
     if store and os.path.isfile(store) and os.path.isfile(stamps_file):
         try:
-            fresh = json.load(open(stamps_file)) == _file_stamps(genomes)
+            fresh = _store_is_fresh(json.load(open(stamps_file)), _file_stamps(genomes))
         except (OSError, ValueError):
             fresh = False
         if fresh:
@@ -162,10 +179,13 @@ def _run(db, genomes, outdir, mode, ani, af, af_tri, max_af_dist, clusters, para
         dst = rep_dir + os.path.basename(r)
         if os.path.lexists(dst):
             continue
-        if symlink:
-            os.symlink(r, dst)
-        else:
-            shutil.copy2(r, rep_dir)
+        try:
+            if symlink:
+                os.symlink(r, dst)
+            else:
+                shutil.copy2(r, rep_dir)
+        except OSError:                               # util.py:425-427: a warning, not an error
+            sys.stderr.write('Warning: issues copying over representative genome %s to final dereplicated sub-directory.\n' % r)
     with open(outdir + "COMPLETED.txt", "w") as f:
         f.write("skDER completed successfully!\n")
     return reps

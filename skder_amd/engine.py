@@ -186,6 +186,45 @@ class Sketches:
     def index(self):
         self.ctx.check(_lib.lib().skder_amd_sketches_index(self.h), "sketches_index")
 
+    # ---- one pair matrix over several GPUs (include/skder_amd.h, "one pair matrix over several GPUs")
+    def index_part(self, full: np.ndarray):
+        """bucket index for the genomes with full[g] != 0 (the ones this GPU owns), chunk tables for the others"""
+        full = np.ascontiguousarray(full, np.uint8)
+        self.ctx.check(_lib.lib().skder_amd_sketches_index_part(self.h, full.ctypes.data), "sketches_index_part")
+
+    def rep_cuts(self, n_genomes: int) -> np.ndarray:
+        out = np.empty(n_genomes, np.uint32)
+        self.ctx.check(_lib.lib().skder_amd_sketches_rep_cuts(self.h, out.ctypes.data), "sketches_rep_cuts")
+        return out
+
+    def set_rep_cuts(self, values: np.ndarray):
+        values = np.ascontiguousarray(values, np.uint32)
+        self.ctx.check(_lib.lib().skder_amd_sketches_set_rep_cuts(self.h, values.ctypes.data), "sketches_set_rep_cuts")
+
+    def screen_rows(self, row_begin: int, row_stride: int, screen_pct: float):
+        """candidate pairs (ref, query) of triangle rows row_begin, row_begin + row_stride, ..."""
+        pr, pq, n = C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint32)(), C.c_uint64(0)
+        self.ctx.check(_lib.lib().skder_amd_screen_rows(self.h, row_begin, row_stride, screen_pct, C.byref(pr), C.byref(pq), C.byref(n)),
+                       "screen_rows")
+        return _np_from(pr, n.value, np.uint32), _np_from(pq, n.value, np.uint32)
+
+    def pairs_probed(self, ref: np.ndarray, query: np.ndarray, queries: "Sketches" = None) -> np.ndarray:
+        """index of the genome each pair probes (the pair is chained on the GPU that owns it)"""
+        ref = np.ascontiguousarray(ref, np.uint32)
+        query = np.ascontiguousarray(query, np.uint32)
+        out = np.empty(len(ref), np.uint32)
+        self.ctx.check(_lib.lib().skder_amd_pairs_probed(self.h, (queries or self).h, ref.ctypes.data, query.ctypes.data, len(ref),
+                                                         out.ctypes.data, None), "pairs_probed")
+        return out
+
+    def chain_pairs(self, ref: np.ndarray, query: np.ndarray, queries: "Sketches" = None, copy: bool = True) -> np.ndarray:
+        ref = np.ascontiguousarray(ref, np.uint32)
+        query = np.ascontiguousarray(query, np.uint32)
+        p, n = C.POINTER(Edge)(), C.c_uint64(0)
+        self.ctx.check(_lib.lib().skder_amd_chain_pairs(self.h, (queries or self).h, ref.ctypes.data, query.ctypes.data, len(ref),
+                                                        C.byref(p), C.byref(n)), "chain_pairs")
+        return self._edges(p, n, copy)
+
     def _edges(self, p, n, copy=True) -> np.ndarray:
         if not n.value:
             return np.zeros(0, EDGE_DTYPE)

@@ -2,10 +2,15 @@
 
 One process per GPU.  Each rank sketches a contiguous block of genomes, the raw sketches
 (position-ordered seeds: k-mer + position, 8 B/seed; sorted markers: 8 B/marker; record tables) are all-gathered
-with torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests),
-every rank builds the lookup index for ALL genomes (cheap next to sketching) and then computes the
-upper-triangle rows i = rank, rank + world, ... (cyclic, because row i has N-1-i entries).  Edge
-records are gathered on rank 0.  The only collective on the data path is the sketch all-gather."""
+with torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+`triangle_sharded` then shares the work out so that nothing big is done twice:
+  * rank r builds the k-mer bucket index only for the genomes it OWNS (g mod world == r) -- every genome's chunk
+    tables, which are cheap, everywhere;
+  * the marker screen is dealt out by rows (i = r, r + world, ...: row i has N-1-i entries);
+  * every candidate pair goes to the rank that owns the genome it PROBES, which chains it;
+  * edge records are gathered on rank 0.
+Collectives: the sketch all-gather (the only large one), the repetitive-cut-off table (4 B per genome), the candidate
+pair lists (8 B per pair) and the edge gather."""
 from typing import Dict, List
 
 import numpy as np
@@ -170,3 +175,37 @@ def sketches_from_raw(ctx, raw: Dict):
                  raw["markers"].data_ptr(), raw["seed_off"], raw["marker_off"], raw["genome_len"], raw["genome_nrec"],
                  raw["rec_goff"])
     return s
+
+
+def route_pairs(ref: np.ndarray, query: np.ndarray, probed: np.ndarray, world: int, rank: int, group=None):
+    """all ranks' candidate pairs, each kept by the rank that owns the genome it probes (owner = genome mod world).
+    The lists are small (8 B per pair): one padded all-gather of (ref << 32 | query, probed) instead of an all-to-all."""
+    nccl = dist.get_backend(group) == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
+    packed = np.empty(2 * len(ref), np.int64)
+    packed[0::2] = (ref.astype(np.int64) << 32) | query.astype(np.int64)
+    packed[1::2] = probed.astype(np.int64)
+    n = torch.tensor([len(packed)], dtype=torch.int64, device=dev)
+    sizes = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(sizes, n, group=group)
+    allp = _allgather_var(torch.from_numpy(packed).to(dev), [int(x) for x in sizes.cpu().tolist()], group).cpu().numpy()
+    pr, pb = allp[0::2], allp[1::2]
+    mine = (pb % world) == rank
+    return (pr[mine] >> 32).astype(np.uint32), (pr[mine] & 0xFFFFFFFF).astype(np.uint32)
+
+
+def triangle_sharded(sk, rank: int, world: int, screen_pct: float, group=None, copy: bool = True) -> np.ndarray:
+    """this rank's share of the all-pairs table of `sk` (a set holding ALL genomes, not indexed yet): see the module text"""
+    n = sk.view()["n_genomes"]
+    owned = (np.arange(n) % world == rank).astype(np.uint8)
+    sk.index_part(owned)
+    nccl = dist.get_backend(group) == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
+    # repetitive-k-mer cut-offs: every rank knows its own genomes' (others: 0xFFFFFFFF), the minimum is the table
+    rc = torch.from_numpy(sk.rep_cuts(n).astype(np.int64)).to(dev)
+    dist.all_reduce(rc, op=dist.ReduceOp.MIN, group=group)
+    sk.set_rep_cuts(rc.cpu().numpy().astype(np.uint32))
+    ref, query = sk.screen_rows(rank, world, screen_pct)
+    probed = sk.pairs_probed(ref, query)
+    ref, query = route_pairs(ref, query, probed, world, rank, group)
+    return sk.chain_pairs(ref, query, copy=copy)

@@ -17,6 +17,17 @@ def _device() -> int:
     return int(os.environ.get("SKDER_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
 
 
+def _devices():
+    """GPUs of the drop-in entry points: SKDER_AMD_DEVICES="0,1,2,3" spreads one call over several (skani's `-t T` asks
+    for the whole machine, skder.py:18); default: the single GPU of _device()"""
+    v = os.environ.get("SKDER_AMD_DEVICES", "").strip()
+    return [int(x) for x in v.split(",") if x.strip() != ""] if v else [_device()]
+
+
+def _c_devices(devices):
+    return (C.c_int * len(devices))(*devices), len(devices)
+
+
 def parse_skani_params(params: str, default_screen: float = SKANI_DEFAULT_SCREEN) -> float:
     """The `-p` string of bin/skder:132,199-201: '-s <float>' only; anything else raises."""
     screen = C.c_double(default_screen)
@@ -45,9 +56,10 @@ def runSkaniTriangle(genome_listing_file, skani_result_file, skani_triangle_para
         what = 'skder_amd_triangle(%s, min_af=%s, screen=%s) -> %s' % (genome_listing_file, min_af, screen, skani_result_file)
         _log(logObject, 'info', 'Running %s' % what)
         err = C.create_string_buffer(_lib.ERRLEN)
-        rc = _lib.lib().skder_amd_triangle_n50(genome_listing_file.encode(), min_af, screen, _device(),
-                                               skani_result_file.encode(), n50_file.encode() if n50_file else None,
-                                               err, _lib.ERRLEN)
+        devs, nd = _c_devices(_devices())
+        rc = _lib.lib().skder_amd_triangle_multi(genome_listing_file.encode(), min_af, screen, devs, nd,
+                                                 skani_result_file.encode(), n50_file.encode() if n50_file else None,
+                                                 err, _lib.ERRLEN)
         if rc != 0 or not os.path.isfile(skani_result_file):
             _log(logObject, 'error', 'Had an issue running: %s: %s' % (what, err.value.decode()))
             raise RuntimeError('Had an issue running: %s: %s' % (what, err.value.decode()))
@@ -119,10 +131,13 @@ class Database:
         self.n50 = [int(L.skder_amd_db_n50(handle, i)) for i in range(n)]
 
     @classmethod
-    def from_listing(cls, listing_file, n50_file=None, device=None):
+    def from_listing(cls, listing_file, n50_file=None, device=None, devices=None):
+        """devices: several GPU indices -> the database is spread over them (include/skder_amd.h, skder_amd_sketch_multi)"""
         err = C.create_string_buffer(_lib.ERRLEN)
-        h = _lib.lib().skder_amd_sketch_n50(listing_file.encode(), _device() if device is None else device,
-                                            n50_file.encode() if n50_file else None, err, _lib.ERRLEN)
+        if devices is None:
+            devices = _devices() if device is None else [device]
+        devs, nd = _c_devices(list(devices))
+        h = _lib.lib().skder_amd_sketch_multi(listing_file.encode(), devs, nd, n50_file.encode() if n50_file else None, err, _lib.ERRLEN)
         if not h:
             raise RuntimeError('Had an issue running: skder_amd_sketch: %s' % err.value.decode())
         return cls(h)

@@ -259,26 +259,76 @@ def test_dropin_tables_match_oracle_and_golden(gpu, oracle, tmp_path):
         _lib.lib().skder_amd_db_free(db)
 
 
-def test_two_ranks_share_the_triangle(gpu):
-    """N > 1 path end to end on the real kernels: two ranks (gloo, both on this GPU) sketch half of the
-    genomes each, exchange raw sketches, deal the rows cyclically; rank 0 must see the same edge count
-    as a single-rank run"""
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_share_the_triangle(gpu, tmp_path, world):
+    """N > 1 path end to end on the real kernels: `world` ranks (gloo, all on this GPU) sketch a share of the genomes
+    each, exchange raw sketches, index the genomes they own, screen their rows and chain the pairs that probe their
+    genomes (skder_amd/multigpu.py triangle_sharded).  The edge RECORDS gathered on rank 0 -- sorted by (ref, query) --
+    must equal the single-rank run's bit for bit, every field."""
     import json
     import subprocess
     import sys
     from conftest import ROOT
     env = dict(os.environ, SKDER_AMD_DIST_BACKEND="gloo")
     common = ["--genomes", "40", "--genome-len", "200000", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
-    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, env=env, timeout=600)
+    f1, f2 = str(tmp_path / "one.npy"), str(tmp_path / "many.npy")
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common + ["--dump-edges", f1], capture_output=True, text=True,
+                         env=env, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                          "127.0.0.1", "--master-port", str(29600 + os.getpid() % 300), os.path.join(ROOT, "bench.py"), "--gpus", "2"]
-                         + common, capture_output=True, text=True, env=env, timeout=900)
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+                          "127.0.0.1", "--master-port", str(29600 + os.getpid() % 300 + world), os.path.join(ROOT, "bench.py"), "--gpus", str(world)]
+                         + common + ["--dump-edges", f2], capture_output=True, text=True, env=env, timeout=900)
     assert two.returncode == 0, two.stderr[-2000:]
     j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
-    assert j2["n_gpus"] == 2 and j1["config"]["edges"] == j2["config"]["edges"] > 0
+    assert j2["n_gpus"] == world and j1["config"]["edges"] == j2["config"]["edges"] > 0
     assert j1["config"]["chained_pairs"] == j2["config"]["chained_pairs"]
+    e1, e2 = np.load(f1), np.load(f2)
+    assert e1.dtype == e2.dtype and len(e1) == len(e2) > 0
+    assert e1.tobytes() == e2.tobytes()
+
+
+def test_several_gpus_in_one_process(gpu, tmp_path):
+    """the multi-GPU entry points of the C ABI (skder_amd_triangle_multi / skder_amd_sketch_multi) with the one GPU of this
+    box opened three times: shares of the listing sketched per "GPU", raw sketches pulled across, ownership index, rows
+    screened in shares, pairs chained by the owner of the probed genome.  The triangle table must be the one-GPU table
+    byte for byte, `search` tables and the low_mem_greedy listing likewise."""
+    import ctypes as C
+    from skder_amd import _lib, skder
+    gdir = os.path.join(GOLDEN, "genomes")
+    names = sorted(os.listdir(gdir))[:14]
+    listing = tmp_path / "l.txt"
+    listing.write_text("".join(os.path.join(gdir, n) + "\n" for n in reversed(names)))
+    err = C.create_string_buffer(2048)
+    one, many = tmp_path / "one.tsv", tmp_path / "many.tsv"
+    n1, n3 = tmp_path / "n50_one.tsv", tmp_path / "n50_many.tsv"
+    assert _lib.lib().skder_amd_triangle_n50(str(listing).encode(), 10.0, 89.5, 0, str(one).encode(), str(n1).encode(), err, 2048) == 0, err.value
+    devs = (C.c_int * 3)(0, 0, 0)
+    assert _lib.lib().skder_amd_triangle_multi(str(listing).encode(), 10.0, 89.5, devs, 3, str(many).encode(), str(n3).encode(), err, 2048) == 0, err.value
+    assert one.read_text() == many.read_text() and len(one.read_text().splitlines()) == 1 + 14 * 13 // 2
+    assert n1.read_text() == n3.read_text()
+    # search on a database spread over the "GPUs": same tables as the one-GPU database, batch and single
+    db1 = skder.Database.from_listing(str(listing), devices=[0])
+    db3 = skder.Database.from_listing(str(listing), devices=[0, 0, 0])
+    try:
+        qs = [db1.paths[2], db1.paths[9], os.path.join(gdir, sorted(os.listdir(gdir))[20])]      # two residents, one outsider
+        o1 = [str(tmp_path / ("s1_%d.tsv" % k)) for k in range(3)]
+        o3 = [str(tmp_path / ("s3_%d.tsv" % k)) for k in range(3)]
+        r1 = db1.search_batch(qs, out_tsvs=o1)
+        r3 = db3.search_batch(qs, out_tsvs=o3)
+        assert r1.tobytes() == r3.tobytes() and len(r1) > 3
+        for a, b in zip(o1, o3):
+            assert open(a).read() == open(b).read()
+        assert db1.triangle(50.0, 89.5).tobytes() == db3.triangle(50.0, 89.5).tobytes()
+        # low_mem_greedy on the spread database
+        for db, tag in ((db1, "a"), (db3, "b")):
+            ws = tmp_path / ("ws" + tag)
+            ws.mkdir()
+            skder.lowMemGreedyDerep(str(listing), str(ws) + "/", str(n1), str(tmp_path / ("lm_%s.txt" % tag)), str(tmp_path) + "/", 99.0, 50.0, None, database=db)
+        assert (tmp_path / "lm_a.txt").read_text() == (tmp_path / "lm_b.txt").read_text() != ""
+    finally:
+        db1.close()
+        db3.close()
 
 
 def test_driver_end_to_end_listings(gpu, tmp_path):
@@ -672,6 +722,17 @@ def test_sketch_store_round_trip(gpu, tmp_path):
         shutil.copy(p, gcopy / os.path.basename(p))
         genomes.append(str(gcopy / os.path.basename(p)))
     r1 = driver.run(genomes, str(tmp_path / "run1"), "greedy", 99.5, 50.0, store=str(tmp_path / "drv.skdb"))
+    # a FASTA file replaced in place: the store notices (size / modification time) and the files are read again
+    victim = genomes[3]
+    other = [g for g in genomes if os.path.getsize(g) != os.path.getsize(victim)][0]
+    keep = open(victim, "rb").read()
+    shutil.copyfile(other, victim)
+    rx = driver.run(genomes, str(tmp_path / "runx"), "greedy", 99.5, 50.0, store=str(tmp_path / "drv.skdb"))
+    n50x = dict(l.rstrip("\n").split("\t") for l in open(tmp_path / "runx" / "Concatenated_N50.txt"))
+    assert n50x[victim] == n50x[other]                       # ... so the table describes the new content
+    open(victim, "wb").write(keep)
+    r1b = driver.run(genomes, str(tmp_path / "run1b"), "greedy", 99.5, 50.0, store=str(tmp_path / "drv.skdb"))
+    assert r1b == r1 and len(rx) > 0
     shutil.rmtree(gcopy)
     r2 = driver.run(genomes, str(tmp_path / "run2"), "greedy", 99.5, 50.0, store=str(tmp_path / "drv.skdb"))
     assert r1 == r2 and len(r1) > 0

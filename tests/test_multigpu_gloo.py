@@ -120,3 +120,60 @@ def test_exchange_with_an_empty_rank():
         assert np.array_equal(m["rec_goff"], np.concatenate([x["rec_goff"] for x in raws]))
     assert len(res[0][1]) == 2 + 4 and len(res[1][1]) == 0 and len(res[2][1]) == 0
     assert sorted(res[0][1]["ref"].tolist()) == [0, 0, 2, 2, 2, 2]
+
+
+def _route_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from skder_amd import multigpu
+    ref, query, probed = _fake_pairs(rank, world)
+    r, qy = multigpu.route_pairs(ref, query, probed, world, rank)
+    q.put((rank, r, qy))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _fake_pairs(rank, world):
+    """candidate pairs of the rows rank, rank + world, ... of a 23-genome triangle; the probed genome is the one with the
+    smaller (index * 7) % 23, an arbitrary rule that does not follow the row"""
+    n = 23
+    ref, query = [], []
+    for i in range(rank, n, world):
+        for j in range(i + 1, n):
+            if (i * j) % 3 != 1:          # "the screen" lets two thirds through
+                ref.append(i)
+                query.append(j)
+    ref, query = np.array(ref, np.uint32), np.array(query, np.uint32)
+    probed = np.where((ref * 7) % 23 < (query * 7) % 23, ref, query).astype(np.uint32)
+    return ref, query, probed
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_pairs_go_to_the_owner_of_the_probed_genome(world):
+    """multigpu.route_pairs: every candidate pair ends up on exactly one rank, the owner (genome mod world) of the genome it probes"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000 + world
+    procs = [ctx.Process(target=_route_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, a, b = q.get(timeout=120)
+        got[r] = (a, b)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = {}
+    for r in range(world):
+        ref, query, probed = _fake_pairs(r, world)
+        for a, b, c in zip(ref, query, probed):
+            want[(int(a), int(b))] = int(c) % world
+    seen = {}
+    for r in range(world):
+        for a, b in zip(*got[r]):
+            assert (int(a), int(b)) not in seen
+            seen[(int(a), int(b))] = r
+    assert seen == want and len(want) > 100
