@@ -3,6 +3,7 @@ Integer products must be bit-equal; ANI/AF doubles must be bit-equal as well (th
 + - * / in a fixed order).  Run on the GPU box with `pytest -m gpu`."""
 import gzip
 import os
+import shutil
 
 import numpy as np
 import pytest
@@ -1163,3 +1164,89 @@ def test_low_complexity_tiles(gpu, oracle):
     _check_edges(edges, _oracle_edges(oracle, og2, p, 0.0))
     assert int(edges[0]["n_anchors"]) > 500000 and ctx.counters()[3] > 0     # the over list was used
     s.close()
+
+
+def _synthetic_files(gpu, tmp_path, n, genome_len=None, len_range=None, n_species=None, seed=None):
+    """n synthetic genomes generated on the device and written as FASTA files (bench.write_sample_files); listing order = index"""
+    import bench
+    from skder_amd import synth
+    engine, ctx, torch = gpu
+    kw = dict(n_species=n_species) if n_species else {}
+    if seed is not None:
+        kw["seed"] = seed
+    recipe = synth.make_recipe(n, genome_len=genome_len or 3_000_000, len_range=len_range, **kw)
+    paths, step = [], 250
+    for b0 in range(0, n, step):
+        gs = range(b0, min(b0 + step, n))
+        layout = engine.BatchLayout([recipe.rec_lens[g] for g in gs])
+        d = torch.empty(layout.total_bytes, dtype=torch.uint8, device="cuda")
+        ctx.synth_fill(d.data_ptr(), layout, recipe.lineage[gs.start:gs.stop], recipe.params[gs.start:gs.stop])
+        tmp, ps, _ = bench.write_sample_files([(layout, d)], len(gs))
+        for k, src in enumerate(ps):
+            dst = str(tmp_path / ("g%05d.fasta" % (b0 + k)))
+            shutil.move(src, dst)
+            paths.append(dst)
+        shutil.rmtree(tmp, ignore_errors=True)
+        del d
+    return recipe, paths
+
+
+def test_config4_low_mem_greedy_at_scale(gpu, oracle, tmp_path):
+    """BASELINE.json configs[3]'s shape on one GPU: lowMemGreedyDerep (skder.py:95-134) over 2,000 synthetic 2.8 Mb genomes
+    (20 species): the speculative search batches give the listing of the one-search-per-representative loop, and sampled
+    `search` tables equal the oracle's text.  (The reference ran this mode on 20,000 Staphylococcus genomes in 2.25 h.)"""
+    import skder_amd
+    from skder_amd.skder import Database
+    if shutil.disk_usage(str(tmp_path)).free < 9e9:
+        pytest.skip("needs 6 GB of scratch space for the FASTA files")
+    n = 2000
+    recipe, paths = _synthetic_files(gpu, tmp_path, n, genome_len=2_800_000)
+    listing = tmp_path / "listing.txt"
+    listing.write_text("".join(p + "\n" for p in paths))
+    n50_file = tmp_path / "n50.txt"
+    with Database.from_listing(str(listing), str(n50_file)) as db:
+        assert db.paths == paths and len(db.n50) == n
+        out = {}
+        for width in (1, 0):
+            ws = tmp_path / ("ws%d" % width)
+            ws.mkdir()
+            res = ws / "reps.txt"
+            skder_amd.lowMemGreedyDerep(str(listing), str(ws) + "/", str(n50_file), str(res), str(ws) + "/", 99.5, 50.0, None,
+                                        search_batch=width, database=db)
+            out[width] = res.read_text()
+        assert out[0] == out[1]
+        reps = out[1].split()
+        assert 20 <= len(reps) < n and len(set(reps)) == len(reps)               # at least one per species; isolates of a strain differ by up to 1 %
+        species_of = {p: int(recipe.species[i]) for i, p in enumerate(paths)}
+        assert {species_of[r] for r in reps} == set(range(20))
+        # sampled search tables against the oracle: the query's whole species (100 genomes) is the oracle's database --
+        # no genome of another species can pass the screen
+        p = oracle.default_params()
+        for q in (paths[7], paths[1234]):
+            sp = [x for x in paths if species_of[x] == species_of[q]]
+            sub = tmp_path / "sub.txt"
+            sub.write_text("".join(x + "\n" for x in sp))
+            want = tmp_path / "oracle_search.tsv"
+            oracle.search(str(sub), q, 15.0, 80.0, 8, str(want), p)
+            got = tmp_path / "search.tsv"
+            db.search_batch([q], out_tsvs=[str(got)])
+            assert got.read_text() == want.read_text() and got.read_text().count("\n") > 50
+
+
+def test_config5_mixed_sizes_with_the_af_filter(gpu, oracle, tmp_path):
+    """BASELINE.json configs[4]'s shape through the filtering drop-in: genomes of 1.2, 4.5 and 8 Mb (index in LDS, one join
+    pass / index in global memory, two passes), `--min-af 50`: skder_amd_triangle's table equals the oracle's text"""
+    import ctypes as C
+    from skder_amd import _lib
+    recipe, paths = _synthetic_files(gpu, tmp_path, 24, len_range=(1_000_000, 8_000_000), n_species=3, seed=77)
+    lens = sorted({recipe.total_len(g) for g in range(24)})
+    assert lens[0] < 4_000_000 < lens[-1] and lens[-1] > 5_700_000, lens              # both index kernels, both join modes
+    listing = tmp_path / "listing.txt"
+    listing.write_text("".join(p + "\n" for p in reversed(paths)))
+    got, want = tmp_path / "tri.tsv", tmp_path / "oracle.tsv"
+    err = C.create_string_buffer(2048)
+    assert _lib.lib().skder_amd_triangle(str(listing).encode(), 50.0, 80.0, 0, str(got).encode(), err, 2048) == 0, err.value
+    oracle.triangle(str(listing), 50.0, 80.0, 8, str(want), oracle.default_params())
+    assert got.read_text() == want.read_text()
+    rows = got.read_text().splitlines()
+    assert len(rows) == 1 + 3 * (8 * 7 // 2)                                              # every within-species pair, none across
