@@ -16,4 +16,8 @@ if [ ! -x profiles/calib/fetch_calib ]; then hipcc --offload-arch=gfx950 -O3 -o 
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/calib_fetch -o calib --output-format csv -- profiles/calib/fetch_calib > $OUT/calib_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/calib_write -o calib --output-format csv -- profiles/calib/fetch_calib > $OUT/calib_write.log 2>&1
 python3 bench.py > $OUT/bench_line.json 2> $OUT/bench.log
+bash profiles/tools/pmc.sh join_probe_kernel > $OUT/pmc_join_probe_kernel.txt 2>&1
+bash profiles/tools/pmc.sh run_extract_kernel > $OUT/pmc_run_extract_kernel.txt 2>&1
+bash profiles/tools/pmc.sh chain_single_kernel > $OUT/pmc_chain_single_kernel.txt 2>&1
+bash profiles/tools/pmc.sh sketch_tiles_kernel > $OUT/pmc_sketch_tiles_kernel.txt 2>&1
 tail -c 600 $OUT/bench_line.json

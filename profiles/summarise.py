@@ -25,7 +25,10 @@ DST = os.path.join(ROOT, "profiles")
 PATTERN = {
     "sketch_tiles_kernel": ("read16_coalesced", "write4_coalesced"),
     "join_probe_kernel": ("read4_coalesced", "write4_coalesced"),
-    "chain_fast_kernel": ("read_line_per_lane", "write4_coalesced"),
+    "chain_fast_kernel": ("read_line_per_lane", "write4_coalesced"),            # round 1's chaining kernel
+    "run_extract_kernel": ("read16_coalesced", "write4_coalesced"),
+    "chain_single_kernel": ("read_line_per_lane", "write4_coalesced"),
+    "chain_runs_kernel": ("read_line_per_lane", "write4_coalesced"),
 }
 
 
@@ -80,7 +83,7 @@ def main():
     json.dump(traffic, open(os.path.join(DST, R + "_pmc_traffic.json"), "w"), indent=1)
     line = json.loads([l for l in open(os.path.join(SRC, "bench_line.json")) if l.startswith("{")][-1])
     # the bench line was printed before this summary existed: put this collection's traffic into it
-    dom = line["roofline"]["kernel"]
+    dom = line["roofline"]["kernel"].split("+")[0]
     if dom in traffic:
         line["roofline"]["traffic"] = sum(traffic[dom][c].get("corrected_bytes", traffic[dom][c]["sum_counter_kb"] * 1024.0)
                                           for c in ("FETCH_SIZE", "WRITE_SIZE"))
