@@ -724,6 +724,7 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, c
         __syncthreads();
     }
     const uint32_t n_items = g_off[GEN_LISTS];
+    if (blockIdx.x == 0 && threadIdx.x == 0) slow_count[11] = n_items;      // for the host's statistics
     for (uint32_t w0 = blockIdx.x * 256u; w0 < n_items; w0 += gridDim.x * 256u) {
     const uint32_t w = w0 + threadIdx.x;
     const bool live = w < n_items;
