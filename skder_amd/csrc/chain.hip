@@ -321,7 +321,7 @@ struct __attribute__((aligned(16))) RunRec {
 };
 #define SEG_SEEDS 256u
 #define RUN_GAP 10
-#define REC_LINK 0xFFFFFFFEu      // qi of a link record; its q0 is the index of the next record
+#define REC_LINK 0xFFFFFFFEu      // qi of a link record; its q0 is the index of the next record, its hw the first seed of the next quarter
 #define REC_END 0xFFFFFFFFu       // qi of the terminator
 static_assert(2 * RUN_GAP <= ANI_ANCHOR_SCORE, "run links must keep at least half of the anchor score");
 
@@ -461,7 +461,10 @@ __global__ __launch_bounds__(256) void run_extract_kernel(SetView A, SetView B, 
     if (overflow) { if (lane == 0) atomicOr(&pair_over[blockIdx.x], 1u << wv); return; }      // the chunks of this quarter take the slow path
     if (lane == 0) {
         RunRec r;       // closes the last run of the quarter; leads on to the next quarter, or ends the pair
-        r.qi = wv == 3u ? REC_END : REC_LINK; r.q0 = (wv + 1u) * cap4; r.hw = HIT_NONE; r.cn = run_nm;
+        // a link also says where the next quarter's seeds begin: a chunk that ends in front of them is finished at the link,
+        // and nobody has to look into a quarter that may have overflowed (its region then holds stale records)
+        const uint32_t next_v = sg_hi * SEG_SEEDS;
+        r.qi = wv == 3u ? REC_END : REC_LINK; r.q0 = (wv + 1u) * cap4; r.hw = next_v > a ? next_v - a : 0u; r.cn = run_nm;
         r.pq = car_q; r.pw = car_w; r.pqi = car_v == 0xFFFFFFFFu ? 0xFFFFFFFFu : car_v - a; r.cg = run_g;
         out_base[reg0 + run_rec] = r;
     }
@@ -544,8 +547,7 @@ __global__ __launch_bounds__(256) void chain_single_kernel(SetView A, SetView B,
             const uint4 *rp = reinterpret_cast<const uint4 *>(recs + pd.rec_base) + 2u * idx0;
             uint4 a0 = rp[0], a1 = rp[1];
             // the next three records are requested at once (a chunk seldom has more; the region has room behind its last record)
-            uint4 f0 = rp[2], f1 = rp[3], f2 = a0, f3 = a0, f4 = a0, f5 = a0;
-            if (!(xcd_remap & 512)) { f2 = rp[4]; f3 = rp[5]; f4 = rp[6]; f5 = rp[7]; }
+            uint4 f0 = rp[2], f1 = rp[3], f2 = rp[4], f3 = rp[5], f4 = rp[6], f5 = rp[7];
             bool fail = false, main_on = false;
             uint32_t n = 0, G = 0, nstray = 0, anchors = 0, nfin = 0, npath = 0;
             uint32_t m_qi = 0, m_q0 = 0, m_hw = 0, l_q = 0, l_hw = 0, l_qi = 0;     // current path: first anchor; last anchor
@@ -567,16 +569,15 @@ __global__ __launch_bounds__(256) void chain_single_kernel(SetView A, SetView B,
                     const uint32_t ra = m_hw & HIT_POS_MASK, rb = l_hw & HIT_POS_MASK;                                \
                     cr.r0 = ra < rb ? ra : rb; cr.r1 = ra > rb ? ra : rb;                                             \
                     cr.chunk = c;                                                                                     \
-                    if (!(xcd_remap & 256)) slots[nfin] = cr;                                                          \
-                    nfin++;                                                                                           \
+                    slots[nfin++] = cr;                                                                               \
                 }                                                                                                     \
             } while (0)
             for (int k = 0; k < SIEVE_RECORDS + 1; k++) {
-                if (a0.x >= s1) { if (a0.x == REC_LINK) { fail = true; SIEVE_WHY(8); } break; }      // (a link: the chunk goes on in another quarter)
+                if (a0.x >= s1) { if (a0.x == REC_LINK && s1 > a0.z) { fail = true; SIEVE_WHY(8); } break; }      // (a link: the chunk may go on in the next quarter)
                 if (k == SIEVE_RECORDS || a0.z == HIT_MANY) { fail = true; SIEVE_WHY(k == SIEVE_RECORDS ? 12 : 13); break; }
                 rp += 2;
                 uint4 b0, b1;                                // the record behind closes this one
-                if (k < ((xcd_remap & 512) ? 1 : 3)) { b0 = f0; b1 = f1; f0 = f2; f1 = f3; f2 = f4; f3 = f5; }
+                if (k < 3) { b0 = f0; b1 = f1; f0 = f2; f1 = f3; f2 = f4; f3 = f5; }
                 else { b0 = rp[0]; b1 = rp[1]; }
                 const uint32_t rn = b0.w - a0.w, rg = b1.w - a1.w;
                 // does a hit continue the current path behind its last anchor?
@@ -829,7 +830,8 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, c
         struct { uint32_t qi, q0, hw, q1, qi1, hw1, n, gsum; } rc;
         rc.qi = 0; rc.q0 = 0; rc.hw = HIT_NONE; rc.hw1 = HIT_NONE; rc.q1 = 0; rc.qi1 = 0; rc.n = 0; rc.gsum = 0;
         if (!done) {
-            if (a0.x == REC_LINK) {                       // the chunk goes on in the next quarter of the region
+            if (a0.x == REC_LINK && s1 <= a0.z) done = true;       // the chunk ends with its quarter
+            else if (a0.x == REC_LINK) {                  // the chunk goes on in the next quarter of the region
                 idx = a0.y;
                 a0 = prec[2u * idx]; a1 = prec[2u * idx + 1u];
                 if (a0.x < REC_LINK) { b0 = prec[2u * idx + 2u]; b1 = prec[2u * idx + 3u]; }
@@ -1661,7 +1663,8 @@ __global__ __launch_bounds__(256) void finalize_kernel_t(SetView A, SetView B, c
         if (!u) break;
     }
     // sums over the kept chains; the cells (chunks) that hold one are marked in global memory -- a pair
-    // can have any number of chunks -- and their seed counts summed from the chunk table afterwards
+    // can have any number of chunks -- and their seed counts summed from the chunk table afterwards (an LDS bitmap for the
+    // marks was measured: slower, 4.4 against 4.0 ms)
     uint32_t *mark = chunk_mark + pd.chunk_base;
     for (uint32_t i = tid; i < pd.n_chunks; i += 256) mark[i] = 0u;
     __syncthreads();
@@ -1678,7 +1681,7 @@ __global__ __launch_bounds__(256) void finalize_kernel_t(SetView A, SetView B, c
     __syncthreads();
     {
         const SetView &QS = (pd.flags & 2u) ? B : A;
-        const uint32_t *cst = QS.chunk_start + QS.meta[pd.q].chunk_off;
+        const uint32_t *cst = QS.chunk_start + pd.q_chunk_off;
         for (uint32_t i = tid; i < pd.n_chunks; i += 256)
             if (mark[i]) cs += cst[i + 1] - cst[i];
     }
@@ -1807,7 +1810,6 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
     // debugging switches: SKDER_AMD_NO_XCD keeps the launch order; SKDER_AMD_FORCE_SLOW sends every chunk down the slow path;
     // SKDER_AMD_FAST_ONLY_CHUNK=k lets only chunk k of a batch take the fast path (to find the chunk behind a parity failure)
     int xcd_remap = (getenv("SKDER_AMD_NO_XCD") ? 0 : 1) | (getenv("SKDER_AMD_FORCE_SLOW") ? 2 : 0);
-    if (const char *e = getenv("SKDER_AMD_EXPERIMENT")) xcd_remap |= atoi(e);
     if (const char *e = getenv("SKDER_AMD_FAST_ONLY_CHUNK")) xcd_remap |= (atoi(e) + 1) << 2;
     double t_fast = 0, t_slow = 0, t_fin = 0, t_join = 0, t_runs = 0;
     uint64_t tot_anchors = 0, tot_slow = 0, tot_chunks = 0, tot_over = 0;

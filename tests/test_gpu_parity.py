@@ -1250,3 +1250,45 @@ def test_config5_mixed_sizes_with_the_af_filter(gpu, oracle, tmp_path):
     assert got.read_text() == want.read_text()
     rows = got.read_text().splitlines()
     assert len(rows) == 1 + 3 * (8 * 7 // 2)                                              # every within-species pair, none across
+
+
+def test_overflowed_record_quarter_next_to_a_finished_chunk(gpu, oracle):
+    """found by tests/tools/fuzz_repeats.py (seed 3400382 after 3400375..81 in ONE context): a chunk that ends exactly with its
+    quarter of the run-record region is closed by the quarter's link record; the run loop used to follow the link into the
+    next quarter, and when THAT quarter had overflowed (nothing valid written, stale records of an earlier batch in the
+    reused buffer) it chained garbage.  Replays the sequence: every seed's triangle and rectangle against the oracle."""
+    import importlib.util
+    import sys
+    engine, ctx, torch = gpu
+    p = oracle.default_params()
+    spec = importlib.util.spec_from_file_location("fuzz_repeats", os.path.join(os.path.dirname(__file__), "tools", "fuzz_repeats.py"))
+    fr = importlib.util.module_from_spec(spec)
+    argv, sys.argv = sys.argv, [sys.argv[0], "0", "0"]
+    try:
+        spec.loader.exec_module(fr)
+    finally:
+        sys.argv = argv
+    for seed in range(3400375, 3400383):
+        rng = np.random.RandomState(seed)
+        anc = fr.ancestor(rng)
+        n = rng.randint(3, 7)
+        gl = [fr.descend(rng, anc, i) for i in range(n)]
+        bases, lens = [g[0] for g in gl], [g[1] for g in gl]
+        s, _ = _sketch(gpu, lens, bases)
+        og = [oracle.Genome.from_bases(b, l, p) for b, l in zip(bases, lens)]
+        screen = 0.0 if rng.rand() < 0.7 else 80.0
+        _check_edges(s.triangle_rows(0, 1, screen), _oracle_edges(oracle, og, p, screen))
+        q, _ = _sketch(gpu, lens[-2:], bases[-2:])
+        got = {(int(e["ref"]), int(e["query"])): e for e in s.rectangle(q, screen)}
+        for r in range(n):
+            for qi in range(2):
+                ok, _ = oracle.screen(og[r], og[n - 2 + qi], screen, p)
+                pr = oracle.pair(og[r], og[n - 2 + qi], p) if ok else None
+                if pr is not None and pr.n_chains and pr.ani > 0:
+                    e = got[(r, qi)]
+                    assert int(e["n_anchors"]) == pr.n_anchors and int(e["sum_anchors"]) == pr.sum_anchors, (seed, r, qi)
+                    assert int(e["cell_seeds"]) == pr.cell_seeds and float(e["ani"]) == pr.ani and float(e["af_ref"]) == pr.af_ref, (seed, r, qi)
+                else:
+                    assert (r, qi) not in got, (seed, r, qi)
+        q.close()
+        s.close()
