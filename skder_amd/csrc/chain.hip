@@ -329,7 +329,8 @@ __global__ __launch_bounds__(256) void run_extract_kernel(SetView A, SetView B, 
                                                           const uint32_t *__restrict__ hits, RunRec *__restrict__ recs,
                                                           uint32_t *__restrict__ pair_over, uint32_t *__restrict__ chunk_rec0)
 {
-    const PairDesc pd = pairs[blockIdx.x];
+    const uint32_t pid = blockIdx.x;       // (an order by chunked genome, per XCD, to share its positions in L2 measured no faster)
+    const PairDesc pd = pairs[pid];
     const SetView &QS = (pd.flags & 2u) ? B : A;
     const GenomeMeta *Qm = QS.meta + pd.q;
     const uint32_t nq = Qm->n_seeds, a = (uint32_t)(Qm->seed_off & 3u), nv = nq + a;
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(256) void run_extract_kernel(SetView A, SetView B, 
         }
 #undef SEL4
     }
-    if (overflow) { if (lane == 0) atomicOr(&pair_over[blockIdx.x], 1u << wv); return; }      // the chunks of this quarter take the slow path
+    if (overflow) { if (lane == 0) atomicOr(&pair_over[pid], 1u << wv); return; }      // the chunks of this quarter take the slow path
     if (lane == 0) {
         RunRec r;       // closes the last run of the quarter; leads on to the next quarter, or ends the pair
         // a link also says where the next quarter's seeds begin: a chunk that ends in front of them is finished at the link,
@@ -507,13 +508,9 @@ __global__ __launch_bounds__(256) void chain_single_kernel(SetView A, SetView B,
                                                            uint32_t *__restrict__ gen_cnt, uint32_t gen_cap,
                                                            uint32_t *__restrict__ pair_na, int xcd_remap)
 {
-    // XCD-aware work mapping: workgroups are dealt round-robin to the 8 XCDs, so give every XCD one
-    // contiguous eighth of the (R-sorted) work list
-    uint32_t wg = blockIdx.x;
-    if (xcd_remap & 1) {
-        const uint32_t nwg = gridDim.x, xcd = wg & 7u, idx = wg >> 3, q8 = nwg >> 3, r8 = nwg & 7u;
-        wg = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + idx;
-    }
+    // workgroups in launch order (dealt round-robin to the 8 XCDs): every record is read once, there is nothing an XCD's L2
+    // could share, and one contiguous stream over the chip measured 1.8 ms per step faster than an eighth of the list per XCD
+    const uint32_t wg = blockIdx.x;
     const uint32_t t = wg * 256u + threadIdx.x;
     const bool in = t < total_chunks;
     uint32_t pi = 0, n_add = 0;
@@ -548,7 +545,7 @@ __global__ __launch_bounds__(256) void chain_single_kernel(SetView A, SetView B,
             uint4 a0 = rp[0], a1 = rp[1];
             // the next three records are requested at once (a chunk seldom has more; the region has room behind its last record)
             uint4 f0 = rp[2], f1 = rp[3], f2 = rp[4], f3 = rp[5], f4 = rp[6], f5 = rp[7];
-            bool fail = false, main_on = false;
+            bool fail = (xcd_remap & 1024) != 0, main_on = false;      // 1024: SKDER_AMD_NO_SIEVE
             uint32_t n = 0, G = 0, nstray = 0, anchors = 0, nfin = 0, npath = 0;
             uint32_t m_qi = 0, m_q0 = 0, m_hw = 0, l_q = 0, l_hw = 0, l_qi = 0;     // current path: first anchor; last anchor
             uint32_t st_hw0 = 0, st_q0 = 0, st_hw1 = 0, st_q1 = 0;                  // the strays
@@ -572,7 +569,7 @@ __global__ __launch_bounds__(256) void chain_single_kernel(SetView A, SetView B,
                     slots[nfin++] = cr;                                                                               \
                 }                                                                                                     \
             } while (0)
-            for (int k = 0; k < SIEVE_RECORDS + 1; k++) {
+            for (int k = 0; k < SIEVE_RECORDS + 1 && !fail; k++) {
                 if (a0.x >= s1) { if (a0.x == REC_LINK && s1 > a0.z) { fail = true; SIEVE_WHY(8); } break; }      // (a link: the chunk may go on in the next quarter)
                 if (k == SIEVE_RECORDS || a0.z == HIT_MANY) { fail = true; SIEVE_WHY(k == SIEVE_RECORDS ? 12 : 13); break; }
                 rp += 2;
@@ -704,6 +701,7 @@ struct Run {
     int32_t pmax;                     // highest score among the earlier anchors of the path
     uint32_t r_first;                 // ref pos of the run's first anchor
     uint32_t seg;                     // summary key: changes along a path only at score-lowering indels
+    int32_t gs;                       // diagonal steps inside the run: its earlier anchors lie at most this far off the last one's diagonal
 };
 
 __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs, uint32_t npairs,
@@ -754,6 +752,7 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, c
     r0.qi_last = r1.qi_last = r2.qi_last = r3.qi_last = 0; r0.idx_last = r1.idx_last = r2.idx_last = r3.idx_last = 0;
     r0.pmax = r1.pmax = r2.pmax = r3.pmax = NEG; r0.r_first = r1.r_first = r2.r_first = r3.r_first = 0;
     r0.seg = r1.seg = r2.seg = r3.seg = 0;
+    r0.gs = r1.gs = r2.gs = r3.gs = 0;
     uint32_t ia = 0, nfin = 0, nevict = 0;
     int32_t runmax = NEG;
     // summaries of runs that left the ring: the most recent segment, plus one conservative scalar
@@ -793,7 +792,7 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, c
                                                    : (int32_t)((E).rr_last & HIT_POS_MASK) - (int32_t)(E).q_last; \
             if ((E).seg == s0_seg) {                                                         \
                 s0_f = (E).f > s0_f ? (E).f : s0_f; s0_q = (E).q_last > s0_q ? (E).q_last : s0_q; \
-                s0_dlo = d3 < s0_dlo ? d3 : s0_dlo; s0_dhi = d3 > s0_dhi ? d3 : s0_dhi;      \
+                s0_dlo = d3 - (E).gs < s0_dlo ? d3 - (E).gs : s0_dlo; s0_dhi = d3 + (E).gs > s0_dhi ? d3 + (E).gs : s0_dhi; \
             } else {                                                                         \
                 if (s0_seg != 0xFFFFFFFFu) {                                                 \
                     if (lost_f == NEG) { lost_dlo = s0_dlo; lost_dhi = s0_dhi; }             \
@@ -811,7 +810,7 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, c
                     }                                                                        \
                     lost_f = s0_f > lost_f ? s0_f : lost_f; lost_q = s0_q > lost_q ? s0_q : lost_q; \
                 }                                                                            \
-                s0_seg = (E).seg; s0_key = k3; s0_f = (E).f; s0_q = (E).q_last; s0_dlo = d3; s0_dhi = d3; \
+                s0_seg = (E).seg; s0_key = k3; s0_f = (E).f; s0_q = (E).q_last; s0_dlo = d3 - (E).gs; s0_dhi = d3 + (E).gs; \
             }                                                                                \
         }                                                                                    \
     } while (0)
@@ -882,7 +881,9 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, c
                             const int32_t dr = rev ? rpj - rp : rp - rpj;                               \
                             const int32_t ed = rev ? rpj + (int32_t)(E).q_last : rpj - (int32_t)(E).q_last; /* run diagonal */ \
                             const int32_t off = dg > ed ? dg - ed : ed - dg;                            \
-                            if (off <= ANI_MAX_GAP) {                                                   \
+                            /* an earlier anchor of a run with steps may be in reach where the last one is not */ \
+                            if (off > ANI_MAX_GAP && off - (E).gs <= ANI_MAX_GAP) { cplx = true; cause = 7; } \
+                            else if (off <= ANI_MAX_GAP) {                                              \
                                 /* an INTERIOR anchor of the run could be a valid predecessor where the last one is not */ \
                                 const int32_t rf = (int32_t)(E).r_first;                                \
                                 const bool inside = rev ? (rp < rf && dr <= 0) : (rp > rf && dr <= 0);  \
@@ -931,7 +932,7 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, c
                         e.cnt = (r0.cnt & ~SUCC_BIT) + 1u; e.first_qi = r0.first_qi; e.q_first = r0.q_first;
                         e.r_pfirst = r0.r_pfirst;
                         e.qi_last = s; e.idx_last = ia; e.pmax = r0.f > r0.pmax ? r0.f : r0.pmax;
-                        e.r_first = (uint32_t)rp; e.seg = pgap >= ANI_ANCHOR_SCORE ? ia : r0.seg;
+                        e.r_first = (uint32_t)rp; e.seg = pgap >= ANI_ANCHOR_SCORE ? ia : r0.seg; e.gs = 0;
                         r0.cnt |= SUCC_BIT;
                         // the predecessor run goes back to where it was: the ring is ordered by the LAST ANCHOR of
                         // its runs (the look-back stops at the first run beyond a band and trusts that older ones,
@@ -946,7 +947,7 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, c
                     Run e;
                     e.q_last = (uint32_t)qp; e.rr_last = rr; e.f = best;
                     e.cnt = 1; e.first_qi = s; e.q_first = (uint32_t)qp; e.r_pfirst = (uint32_t)rp;
-                    e.qi_last = s; e.idx_last = ia; e.pmax = NEG; e.r_first = (uint32_t)rp; e.seg = ia;
+                    e.qi_last = s; e.idx_last = ia; e.pmax = NEG; e.r_first = (uint32_t)rp; e.seg = ia; e.gs = 0;
                     EVICT(r3);
                     r3 = r2; r2 = r1; r1 = r0; r0 = e;
                 }
@@ -969,7 +970,7 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, c
                                                  : (int32_t)((E).rr_last & HIT_POS_MASK) - (int32_t)(E).q_last) - d0)
     #define HARMLESS(E)                                                                                   \
                 (!(E).cnt || ((E).rr_last & HIT_KEY_MASK) != k0 || qp - (int32_t)(E).q_last > ANI_BP_BAND ||    \
-                 DIAG_OFF(E) - G > ANI_MAX_GAP || (E).f - DIAG_OFF(E) <= f0)
+                 DIAG_OFF(E) - G - (E).gs > ANI_MAX_GAP || (E).f - DIAG_OFF(E) <= f0)
                 bool domr = !(r0.cnt & SUCC_BIT) && HARMLESS(r1) && HARMLESS(r2) && HARMLESS(r3);
     #undef HARMLESS
     #undef DIAG_OFF
@@ -996,6 +997,7 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, c
                 r0.cnt += ext;
                 r0.idx_last = ia + ext - 1u; ia += ext;
                 r0.qi_last = rc.qi1;
+                r0.gs += G;
             }
         } while (0);
         if (cplx) done = true;
@@ -1759,7 +1761,7 @@ struct ChainSlot {
     DevBuf<ChainRec> fast_chains, chains;
     DevBuf<PairOut> d_out;
     std::vector<PairDesc> hp;
-    std::vector<JoinGroup> h_groups;
+    std::vector<JoinGroup> h_groups, h_groups2;
     // pinned host mirrors of the small results
     PairOut *h_out = nullptr;
     size_t h_out_cap = 0;
@@ -1807,10 +1809,10 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
     if (const char *e = getenv("SKDER_AMD_CHUNK_BUDGET")) budget = strtoull(e, nullptr, 10);
     ChainWork &W = *chain_work(ctx);
     const SetView VA = view_of(SA), VB = view_of(SB);
-    // debugging switches: SKDER_AMD_NO_XCD keeps the launch order; SKDER_AMD_FORCE_SLOW sends every chunk down the slow path;
-    // SKDER_AMD_FAST_ONLY_CHUNK=k lets only chunk k of a batch take the fast path (to find the chunk behind a parity failure)
+    // debugging switches: SKDER_AMD_NO_XCD keeps the join's groups in launch order; SKDER_AMD_FORCE_SLOW sends every chunk down the slow path;
+    // SKDER_AMD_NO_SIEVE hands every chunk with hits to chain_runs_kernel (to tell the two fast kernels apart behind a parity failure)
     int xcd_remap = (getenv("SKDER_AMD_NO_XCD") ? 0 : 1) | (getenv("SKDER_AMD_FORCE_SLOW") ? 2 : 0);
-    if (const char *e = getenv("SKDER_AMD_FAST_ONLY_CHUNK")) xcd_remap |= (atoi(e) + 1) << 2;
+    if (const char *e = getenv("SKDER_AMD_NO_SIEVE")) xcd_remap |= atoi(e) ? 1024 : 0;
     double t_fast = 0, t_slow = 0, t_fin = 0, t_join = 0, t_runs = 0;
     uint64_t tot_anchors = 0, tot_slow = 0, tot_chunks = 0, tot_over = 0;
     // orientation of every pair, then order the work by the probed genome (R): consecutive
@@ -2016,6 +2018,19 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
                 g.pair_begin = i; g.pair_end = j;
                 hg.push_back(g);
                 i = j;
+            }
+            if ((xcd_remap & 1) && hg.size() >= 64) {
+                // workgroups are dealt round-robin to the 8 XCDs: give every XCD a CONTIGUOUS eighth of the groups, so that
+                // the three or four groups that probe one genome (and their neighbours, which stream the same chunked
+                // genomes past it) run on one XCD at about the same time and share its L2 instead of filling all eight
+                std::vector<JoinGroup> &tmp = S.h_groups2;
+                tmp.resize(hg.size());
+                const size_t n = hg.size(), per = n / 8, extra = n % 8;       // XCD x takes per (+1 if x < extra) groups
+                size_t start[9];
+                start[0] = 0;
+                for (size_t x = 0; x < 8; x++) start[x + 1] = start[x] + per + (x < extra ? 1 : 0);
+                for (size_t bidx = 0; bidx < n; bidx++) tmp[bidx] = hg[start[bidx % 8] + bidx / 8];
+                hg.swap(tmp);
             }
             S.groups.resize(hg.size() * 2, st);
             HIPCHECK(hipMemcpyAsync(S.groups.p, hg.data(), hg.size() * sizeof(JoinGroup), hipMemcpyHostToDevice, st));

@@ -115,3 +115,27 @@ def test_synthetic_recipe_mixed_lengths():
     assert len(set(lens)) == 6
     a, b = synth.make_recipe(60, genome_len=50000, n_species=3), synth.make_recipe(60, genome_len=50000, n_species=3, len_range=None)
     assert all(np.array_equal(x, y) for x, y in zip(a.rec_lens, b.rec_lens))
+
+
+def test_sketch_store_staleness_rule(tmp_path):
+    """driver._store_is_fresh: a store is reused only while every FASTA file that still exists has the size and
+    modification time it had when the store was written; a file that is gone cannot contradict it; other paths or another
+    order are another listing"""
+    from skder_amd import driver
+    files = []
+    for i in range(3):
+        p = tmp_path / ("g%d.fa" % i)
+        p.write_text(">r\n" + "ACGT" * (200 + i) + "\n")
+        files.append(str(p))
+    then = driver._file_stamps(files)
+    assert driver._store_is_fresh(then, driver._file_stamps(files))
+    os.utime(files[1], ns=(1, 1))                                    # touched: modification time differs
+    assert not driver._store_is_fresh(then, driver._file_stamps(files))
+    then = driver._file_stamps(files)
+    open(files[2], "a").write("ACGT\n")                              # grown in place
+    assert not driver._store_is_fresh(then, driver._file_stamps(files))
+    then = driver._file_stamps(files)
+    os.remove(files[0])                                              # gone: nothing to compare with
+    assert driver._store_is_fresh(then, driver._file_stamps(files))
+    assert not driver._store_is_fresh(then, driver._file_stamps(files[::-1]))
+    assert not driver._store_is_fresh(then, driver._file_stamps(files[:2]))

@@ -1252,15 +1252,9 @@ def test_config5_mixed_sizes_with_the_af_filter(gpu, oracle, tmp_path):
     assert len(rows) == 1 + 3 * (8 * 7 // 2)                                              # every within-species pair, none across
 
 
-def test_overflowed_record_quarter_next_to_a_finished_chunk(gpu, oracle):
-    """found by tests/tools/fuzz_repeats.py (seed 3400382 after 3400375..81 in ONE context): a chunk that ends exactly with its
-    quarter of the run-record region is closed by the quarter's link record; the run loop used to follow the link into the
-    next quarter, and when THAT quarter had overflowed (nothing valid written, stale records of an earlier batch in the
-    reused buffer) it chained garbage.  Replays the sequence: every seed's triangle and rectangle against the oracle."""
+def _fuzz_repeats_module():
     import importlib.util
     import sys
-    engine, ctx, torch = gpu
-    p = oracle.default_params()
     spec = importlib.util.spec_from_file_location("fuzz_repeats", os.path.join(os.path.dirname(__file__), "tools", "fuzz_repeats.py"))
     fr = importlib.util.module_from_spec(spec)
     argv, sys.argv = sys.argv, [sys.argv[0], "0", "0"]
@@ -1268,27 +1262,57 @@ def test_overflowed_record_quarter_next_to_a_finished_chunk(gpu, oracle):
         spec.loader.exec_module(fr)
     finally:
         sys.argv = argv
+    return fr
+
+
+def _replay_repeat_family(gpu, oracle, fr, seed, batch_env=None):
+    """one family of tests/tools/fuzz_repeats.py (same random stream): triangle and rectangle against the oracle.
+    batch_env: a monkeypatch -- the tool's 'batch' mode, which draws a small chunk budget per family"""
+    p = oracle.default_params()
+    rng = np.random.RandomState(seed)
+    anc = fr.ancestor(rng)
+    n = rng.randint(3, 7)
+    if batch_env is not None:
+        batch_env.setenv("SKDER_AMD_CHUNK_BUDGET", str(rng.randint(50, 3000)))
+    gl = [fr.descend(rng, anc, i) for i in range(n)]
+    bases, lens = [g[0] for g in gl], [g[1] for g in gl]
+    s, _ = _sketch(gpu, lens, bases)
+    og = [oracle.Genome.from_bases(b, l, p) for b, l in zip(bases, lens)]
+    screen = 0.0 if rng.rand() < 0.7 else 80.0
+    _check_edges(s.triangle_rows(0, 1, screen), _oracle_edges(oracle, og, p, screen))
+    q, _ = _sketch(gpu, lens[-2:], bases[-2:])
+    got = {(int(e["ref"]), int(e["query"])): e for e in s.rectangle(q, screen)}
+    for r in range(n):
+        for qi in range(2):
+            ok, _ = oracle.screen(og[r], og[n - 2 + qi], screen, p)
+            pr = oracle.pair(og[r], og[n - 2 + qi], p) if ok else None
+            if pr is not None and pr.n_chains and pr.ani > 0:
+                e = got[(r, qi)]
+                assert int(e["n_anchors"]) == pr.n_anchors and int(e["sum_anchors"]) == pr.sum_anchors, (seed, r, qi)
+                assert int(e["sum_seeds"]) == pr.sum_seeds, (seed, r, qi)
+                assert int(e["cell_seeds"]) == pr.cell_seeds and float(e["ani"]) == pr.ani and float(e["af_ref"]) == pr.af_ref, (seed, r, qi)
+            else:
+                assert (r, qi) not in got, (seed, r, qi)
+    q.close()
+    s.close()
+
+
+def test_overflowed_record_quarter_next_to_a_finished_chunk(gpu, oracle):
+    """found by tests/tools/fuzz_repeats.py (seed 3400382 after 3400375..81 in ONE context): a chunk that ends exactly with its
+    quarter of the run-record region is closed by the quarter's link record; the run loop used to follow the link into the
+    next quarter, and when THAT quarter had overflowed (nothing valid written, stale records of an earlier batch in the
+    reused buffer) it chained garbage.  Replays the sequence: every seed's triangle and rectangle against the oracle."""
+    fr = _fuzz_repeats_module()
     for seed in range(3400375, 3400383):
-        rng = np.random.RandomState(seed)
-        anc = fr.ancestor(rng)
-        n = rng.randint(3, 7)
-        gl = [fr.descend(rng, anc, i) for i in range(n)]
-        bases, lens = [g[0] for g in gl], [g[1] for g in gl]
-        s, _ = _sketch(gpu, lens, bases)
-        og = [oracle.Genome.from_bases(b, l, p) for b, l in zip(bases, lens)]
-        screen = 0.0 if rng.rand() < 0.7 else 80.0
-        _check_edges(s.triangle_rows(0, 1, screen), _oracle_edges(oracle, og, p, screen))
-        q, _ = _sketch(gpu, lens[-2:], bases[-2:])
-        got = {(int(e["ref"]), int(e["query"])): e for e in s.rectangle(q, screen)}
-        for r in range(n):
-            for qi in range(2):
-                ok, _ = oracle.screen(og[r], og[n - 2 + qi], screen, p)
-                pr = oracle.pair(og[r], og[n - 2 + qi], p) if ok else None
-                if pr is not None and pr.n_chains and pr.ani > 0:
-                    e = got[(r, qi)]
-                    assert int(e["n_anchors"]) == pr.n_anchors and int(e["sum_anchors"]) == pr.sum_anchors, (seed, r, qi)
-                    assert int(e["cell_seeds"]) == pr.cell_seeds and float(e["ani"]) == pr.ani and float(e["af_ref"]) == pr.af_ref, (seed, r, qi)
-                else:
-                    assert (r, qi) not in got, (seed, r, qi)
-        q.close()
-        s.close()
+        _replay_repeat_family(gpu, oracle, fr, seed)
+
+
+def test_anchor_in_reach_of_an_earlier_anchor_of_a_run_with_steps(gpu, oracle, monkeypatch):
+    """found by tests/tools/fuzz_repeats.py (batch mode, seed 4602238): a run whose anchors step from diagonal to diagonal
+    (short indels) was kept in the run loop's ring with its LAST anchor's diagonal only; a later anchor more than max_gap
+    off that diagonal but within max_gap of an EARLIER anchor of the run chains to that one in the unabridged algorithm.
+    The ring now keeps the run's diagonal steps and declines such a chunk (checked with and without the sieve in front)."""
+    fr = _fuzz_repeats_module()
+    _replay_repeat_family(gpu, oracle, fr, 4602238, batch_env=monkeypatch)
+    monkeypatch.setenv("SKDER_AMD_NO_SIEVE", "1")
+    _replay_repeat_family(gpu, oracle, fr, 4602238, batch_env=monkeypatch)

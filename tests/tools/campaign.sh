@@ -1,0 +1,13 @@
+mkdir -p gpurun_out/fuzz3
+python -m pytest tests -m gpu -x -q > gpurun_out/fuzz3/pytest.log 2>&1; echo "pytest rc $?" 
+t() { timeout $1 python tests/tools/$2 $3 $4 $5 > gpurun_out/fuzz3/$6.log 2>&1; grep -c " ok" gpurun_out/fuzz3/$6.log; grep MISMATCH gpurun_out/fuzz3/$6.log | head -3; }
+t 240 fuzz_structural.py 5000000 5003000 "" structural
+FUZZ_REAL=1 t 240 fuzz_structural.py 5100000 5103000 "" real
+t 240 fuzz_repeats.py 5200000 5203000 "" repeats
+t 120 fuzz_repeats.py 5300000 5301000 rep rep
+t 300 fuzz_repeats.py 5400000 5404000 batch batch
+t 120 fuzz_repeats.py 5500000 5501000 big big
+t 120 fuzz_repeats.py 5700000 5702000 append append
+t 100 fuzz_dropin.py 5600000 5601000 "" dropin
+python bench.py --no-realistic 2>/dev/null | tail -1 > gpurun_out/fuzz3/bench.json; python -c "
+import json; d=json.load(open('gpurun_out/fuzz3/bench.json')); print(d['ms_per_step'], d['value'], d.get('phases_ms'))"
