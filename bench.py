@@ -195,6 +195,10 @@ def _triangle_stats(engine, ctx, torch, rec_lens_list, bases_list, screen, steps
     sk = engine.Sketches(ctx)
     sk.sketch_batch(d.data_ptr(), layout)
     best = None
+    # the stage times below are sums of per-kernel event brackets: keep the batches on one queue (on two, the brackets of
+    # overlapping batches include each other's share of the chip)
+    queues_env = os.environ.get("SKDER_AMD_QUEUES")
+    os.environ["SKDER_AMD_QUEUES"] = "1"
     for _ in range(steps + 1):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -209,6 +213,10 @@ def _triangle_stats(engine, ctx, torch, rec_lens_list, bases_list, screen, steps
             best = cur
     sk.close()
     del d
+    if queues_env is None:
+        del os.environ["SKDER_AMD_QUEUES"]
+    else:
+        os.environ["SKDER_AMD_QUEUES"] = queues_env
     n = len(rec_lens_list)
     stage = best["join_ms"] + best["run_extract_ms"] + best["chain_fast_ms"] + best["chain_slow_ms"] + best["finalize_ms"]
     best.update({"genomes": n, "pairs": n * (n - 1) // 2, "slow_path_fraction": best["slow_path_chunks"] / max(best["chunks"], 1),
@@ -424,6 +432,24 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     pairs = N * (N - 1) // 2
     tm = np.mean(tms, axis=0)
+    # In the timed region the chaining batches alternate between two queues and overlap, so the event bracket
+    # of a chain-stage kernel there includes the chip time it shared with the other queue.  Per-kernel durations of that
+    # stage are therefore taken from two extra steps, outside the timed region, with all batches on one queue; the sketch
+    # kernel (the longest, never overlapped) keeps the timed region's figure.
+    overlapped = {"join_probe_kernel": float(step.counters[2]) / 1000.0, "run_extract_kernel": float(step.runs_ms),
+                  "chain_single_kernel+chain_runs_kernel": float(tm[3]), "chain_slow_path": float(tm[4]), "finalize": float(tm[5])}
+    one_queue_ms = None
+    if not dist_on and os.environ.get("SKDER_AMD_QUEUES") is None:
+        os.environ["SKDER_AMD_QUEUES"] = "1"
+        t1q = time.perf_counter()
+        tq = []
+        for _ in range(2):
+            _, t_ = step()
+            tq.append(t_)
+        torch.cuda.synchronize()
+        one_queue_ms = (time.perf_counter() - t1q) / 2 * 1e3
+        del os.environ["SKDER_AMD_QUEUES"]
+        tm[2:6] = np.mean(tq, axis=0)[2:6]
     n_chained_all = float(tm[6])
     if dist_on:
         t = torch.tensor([tm[6]], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
@@ -446,7 +472,7 @@ def main():
             seeds_per_genome = float((w * sl).sum() / max(w.sum(), 1.0)) / 125.0
         # join_probe_kernel: per chained pair the chunked genome's position-ordered k-mers are read once
         # (4 B per seed), one hit word per seed is written (4 B) and the matched position is gathered for
-        # about 70 % of the seeds (4 B); the probed genome's index is staged in LDS once per <= 16 pairs;
+        # about 70 % of the seeds (4 B); the probed genome's index is staged in LDS once per <= 8 pairs;
         # run_extract_kernel: per chained pair the hit word, the position and the chunk-start flag of every seed are
         # read (9 B), the run records written are two orders of magnitude fewer;
         # chain_single_kernel (+ chain_runs_kernel for the 9 % of chunks it leaves): per chunk the first-record index (4 B),
@@ -501,6 +527,11 @@ def main():
                          "limited_by": limiter[dom], "algorithmic_bytes": dbytes,
                          "survey_8d": {"sketch": s8_sketch, "chain": s8_chain, "step": s8_all},
                          "kernel_ms": {k: float(v[0]) for k, v in cand.items()},
+                         "kernel_ms_note": "chain-stage kernels (join, run extraction, sieve + run loop, slow path, finalize): HIP-event "
+                                           "durations of two extra steps with all batches on ONE queue; in the timed region the batches "
+                                           "alternate between two queues and overlap, and their event brackets (kernel_ms_two_queues) "
+                                           "include the wait for the other queue's share of the chip",
+                         "kernel_ms_two_queues": overlapped, "ms_per_step_one_queue": one_queue_ms,
                          "host_wall_ms": {k: 1e3 * v / (args.steps + args.warmup) for k, v in wall.items()},
                          "kernel_GBs": {k: float(v[1] / (v[0] * 1e-3) / 1e9) if v[0] > 0 else 0.0 for k, v in cand.items()},
                          "other_ms": {"sketch_post": float(tm[1]), "index_beside_screen": float(step.index_ms), "screen": float(tm[2]), "chain_slow_path": float(tm[4]),

@@ -91,7 +91,7 @@ __device__ __forceinline__ uint32_t find_pair(const PairDesc *__restrict__ pairs
 
 // ---------------------------------------------------------------------------------------------
 // JOIN: hit words for every (pair, seed of the chunked genome), R-stationary.
-// Pairs are sorted by the probed genome R.  One 1024-thread workgroup takes a group of pairs that
+// Pairs are sorted by the probed genome R.  One 1024-thread workgroup takes a group of (at most 8) pairs that
 // share R, loads R's bucket offsets and, per bucket-ordered seed, the REMAINDER of its k-mer (the
 // 30 - bits bits of the mixed k-mer that the bucket number does not fix: 16 bits for genomes of
 // 16 k seeds and more) into LDS once -- 80 KB for a 3 Mb genome, so two workgroups share a CU --
@@ -348,8 +348,9 @@ __global__ __launch_bounds__(256) void run_extract_kernel(SetView A, SetView B, 
     RunRec *out_base = recs + pd.rec_base;
     uint32_t run_rec = 0, run_nm = 0, run_g = 0;                     // totals of the segments so far (wave-uniform)
     uint32_t car_q = 0, car_w = HIT_NONE, car_v = 0xFFFFFFFFu;       // last hit of the segments so far
-    bool car_cs = true;                                              // a chunk began since (or there is no hit yet)
+    bool car_ok = false;                                             // there is such a hit and no chunk began since
     bool overflow = false;
+    const unsigned long long lowbits = (1ull << lane) - 1ull;
     for (uint32_t sg = sg_lo; sg < sg_hi; sg++) {
         const uint32_t v0 = sg * SEG_SEEDS + lane * 4u;
         uint32_t hv[4], qv[4], csw = 0;
@@ -369,61 +370,77 @@ __global__ __launch_bounds__(256) void run_extract_kernel(SetView A, SetView B, 
                 csw |= in ? (uint32_t)cs_al[v] << (8 * u) : 0u;
             }
         }
-#define SEL4(X, I) ((I) == 0 ? X[0] : ((I) == 1 ? X[1] : ((I) == 2 ? X[2] : X[3])))
-        // A. the lane's own four seeds
-        uint32_t nmmask = 0, csmask = 0;
+        // A. the lane's own four seeds: hit or not, chunk start or not, and the DIAGONAL WORD of a hit -- the hit word with
+        // the position replaced by one value per diagonal (position - q forward, -position - 1 - q reverse, modulo
+        // 2^32 across the record tag and strand above it): for two hits of the same record and strand the difference
+        // of the words is the difference of their diagonals, and q - q' plus that difference is how far the second
+        // lies AHEAD of the first on the other genome (in the direction of the strand)
+        bool nm[4], cs[4];
+        uint32_t yv[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            nmmask |= (hv[u] != HIT_NONE ? 1u : 0u) << u;
-            csmask |= ((csw >> (8 * u)) & 1u) << u;
+            nm[u] = hv[u] != HIT_NONE;
+            cs[u] = ((csw >> (8 * u)) & 1u) != 0u;
+            const uint32_t sgn = (uint32_t)((int32_t)hv[u] >> 31);
+            yv[u] = (hv[u] ^ (sgn & HIT_POS_MASK)) - qv[u];
         }
-        const bool has_nm = nmmask != 0u;
-        const uint32_t ul = has_nm ? 31u - (uint32_t)__clz((int)nmmask) : 0u;
-        const uint32_t w_l = SEL4(hv, ul), q_l = SEL4(qv, ul);
+        const bool has_nm = nm[0] | nm[1] | nm[2] | nm[3];
+        const uint32_t ul = nm[3] ? 3u : (nm[2] ? 2u : (nm[1] ? 1u : 0u));                       // the lane's last hit
+        const uint32_t w_l = nm[3] ? hv[3] : (nm[2] ? hv[2] : (nm[1] ? hv[1] : hv[0]));
+        const uint32_t q_l = nm[3] ? qv[3] : (nm[2] ? qv[2] : (nm[1] ? qv[1] : qv[0]));
         // a chunk starts behind the lane's last hit (anywhere, if the lane has none): the next hit cannot continue
-        const bool tail_cs = has_nm ? (csmask >> (ul + 1u)) != 0u : csmask != 0u;
+        bool tail_cs = false;
+#pragma unroll
+        for (int u = 0; u < 4; u++) tail_cs = (tail_cs | cs[u]) & !nm[u];
         const unsigned long long M = __ballot(has_nm), T = __ballot(tail_cs);
         // B. the previous hit: from the nearest lane below that has one, else the last hit of the segments before
-        const unsigned long long lowbits = (1ull << lane) - 1ull, below = M & lowbits;
+        const unsigned long long below = M & lowbits, tbelow = T & lowbits;
         const bool pin = below != 0ull;
         const uint32_t P = pin ? 63u - (uint32_t)__clzll((long long)below) : 0u;
         const uint32_t sw = (uint32_t)__shfl((int)w_l, (int)P, 64), sq = (uint32_t)__shfl((int)q_l, (int)P, 64);
         const uint32_t sv = (uint32_t)__shfl((int)(v0 + ul), (int)P, 64);
         const uint32_t pw_in = pin ? sw : car_w, pq_in = pin ? sq : car_q, pv_in = pin ? sv : car_v;
-        const bool pv = pin ? ((T >> P) & ((1ull << (lane - P)) - 1ull)) == 0ull
-                            : (car_v != 0xFFFFFFFFu && !car_cs && (T & lowbits) == 0ull);
-        // C. run starts among the lane's seeds; diagonal step of every continuing seed.  firstmask: starts that may be
-        // the first record of their chunk (a chunk began since the previous hit, or there is none)
-        uint32_t startmask = 0, firstmask = 0, gl[4] = {0, 0, 0, 0};
+        // no chunk start between that hit and this lane: no tail flag in the lanes [P, lane)
+        const bool pv = pin ? tbelow < (1ull << P) : (car_ok && tbelow == 0ull);
+        // C. run starts among the lane's seeds; diagonal step of every continuing seed.  first: starts that may be the
+        // first record of their chunk (a chunk began since the previous hit, or there is none).  Straight-line code:
+        // every seed is classified, the results of the missing ones are masked out
+        bool st[4], fi[4];
+        uint32_t gl[4];
         {
             uint32_t pw = pw_in, pq = pq_in;
+            uint32_t py = (pw ^ ((uint32_t)((int32_t)pw >> 31) & HIT_POS_MASK)) - pq;
             bool pending = !pv;
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                if ((csmask >> u) & 1u) pending = true;
-                if ((nmmask >> u) & 1u) {
-                    const uint32_t w = hv[u], q = qv[u];
-                    const uint32_t sgw = (uint32_t)((int32_t)w >> 31), sgp = (uint32_t)((int32_t)pw >> 31);
-                    const int32_t dgw = (int32_t)(((w & HIT_POS_MASK) ^ sgw) - q), dgp = (int32_t)(((pw & HIT_POS_MASK) ^ sgp) - pq);   // one value per diagonal
-                    const int32_t dd = dgw - dgp, g = dd < 0 ? -dd : dd;
-                    const int32_t drs = (int32_t)(w & HIT_POS_MASK) - (int32_t)(pw & HIT_POS_MASK);       // ahead on the other genome
-                    const bool cont = !pending && !((w | pw) & 0x40000000u) && !((w ^ pw) & HIT_KEY_MASK) && g <= RUN_GAP &&
-                                      (q - pq) <= (uint32_t)ANI_BP_BAND && (sgw ? drs < 0 : drs > 0);
-                    startmask |= (cont ? 0u : 1u) << u;
-                    firstmask |= (pending ? 1u : 0u) << u;
-                    gl[u] = cont ? (uint32_t)g : 0u;
-                    pw = w; pq = q; pending = false;
-                }
+                pending = pending | cs[u];
+                const uint32_t w = hv[u], q = qv[u], y = yv[u];
+                const int32_t dd = (int32_t)(y - py);                       // diagonal step (same record and strand)
+                const uint32_t dq = q - pq;
+                const uint32_t kb = (w ^ pw) | (w & 0x40000000u);           // < 2^24: same record and strand, both single hits
+                const bool cont = nm[u] & !pending & (kb < (1u << HIT_POS_BITS)) & ((uint32_t)(dd + RUN_GAP) <= 2u * RUN_GAP) &
+                                  (dq <= (uint32_t)ANI_BP_BAND) & ((int32_t)(dq + (uint32_t)dd) > 0);
+                st[u] = nm[u] & !cont;
+                fi[u] = nm[u] & pending;
+                const int32_t ad = dd < 0 ? -dd : dd;
+                gl[u] = cont ? (uint32_t)ad : 0u;
+                pw = nm[u] ? w : pw; pq = nm[u] ? q : pq; py = nm[u] ? y : py;
+                pending = pending & !nm[u];
             }
         }
         // D. running counts in front of the lane: hits, records, diagonal steps (one packed scan)
-        const uint32_t cnt_l = (uint32_t)__popc(nmmask), nrec_l = (uint32_t)__popc(startmask);
+        const uint32_t cnt_l = (uint32_t)nm[0] + (uint32_t)nm[1] + (uint32_t)nm[2] + (uint32_t)nm[3];
+        const uint32_t nrec_l = (uint32_t)st[0] + (uint32_t)st[1] + (uint32_t)st[2] + (uint32_t)st[3];
         const uint32_t g_l = gl[0] + gl[1] + gl[2] + gl[3];
         uint32_t tot;
         const uint32_t ex = wave_excl_scan(cnt_l | (nrec_l << 10) | (g_l << 20), tot);
         const uint32_t seg_rec = (tot >> 10) & 1023u;
         if (run_rec + seg_rec + 1u > cap4) { overflow = true; break; }       // + the closing record; wave-uniform
-        if (startmask) {
+        if (nrec_l) {
+#define SEL4(X, I) ((I) == 0 ? X[0] : ((I) == 1 ? X[1] : ((I) == 2 ? X[2] : X[3])))
+            const uint32_t nmmask = (uint32_t)nm[0] | ((uint32_t)nm[1] << 1) | ((uint32_t)nm[2] << 2) | ((uint32_t)nm[3] << 3);
+            const uint32_t startmask = (uint32_t)st[0] | ((uint32_t)st[1] << 1) | ((uint32_t)st[2] << 2) | ((uint32_t)st[3] << 3);
+            const uint32_t firstmask = (uint32_t)fi[0] | ((uint32_t)fi[1] << 1) | ((uint32_t)fi[2] << 2) | ((uint32_t)fi[3] << 3);
             const uint32_t pex = ex & 1023u, rex = (ex >> 10) & 1023u, gex = ex >> 20;
             uint32_t sm = startmask, j = 0;
             while (sm) {
@@ -446,6 +463,7 @@ __global__ __launch_bounds__(256) void run_extract_kernel(SetView A, SetView B, 
                 if ((firstmask >> u) & 1u) atomicMin(&rec0[ck_of[r.qi]], at);
                 j++;
             }
+#undef SEL4
         }
         // E. carry into the next segment
         run_nm += tot & 1023u; run_rec += seg_rec; run_g += tot >> 20;
@@ -453,11 +471,10 @@ __global__ __launch_bounds__(256) void run_extract_kernel(SetView A, SetView B, 
             const uint32_t topl = 63u - (uint32_t)__clzll((long long)M);
             car_q = (uint32_t)__shfl((int)q_l, (int)topl, 64); car_w = (uint32_t)__shfl((int)w_l, (int)topl, 64);
             car_v = (uint32_t)__shfl((int)(v0 + ul), (int)topl, 64);
-            car_cs = (T >> topl) != 0ull;
+            car_ok = (T >> topl) == 0ull;
         } else {
-            car_cs = car_cs || T != 0ull;
+            car_ok = car_ok && T == 0ull;
         }
-#undef SEL4
     }
     if (overflow) { if (lane == 0) atomicOr(&pair_over[pid], 1u << wv); return; }      // the chunks of this quarter take the slow path
     if (lane == 0) {
@@ -1771,16 +1788,20 @@ struct ChainSlot {
     uint32_t nb = 0, lds_cap = 0;
     uint64_t nchunks = 0, nrecs = 0;
     bool busy = false;
+    hipStream_t st_join = nullptr, st = nullptr;     // the queues of the join and of the later stages (set per call)
+    hipEvent_t ev_join = nullptr;                    // the join is done
     ~ChainSlot()
     {
         if (h_out) (void)hipHostFree(h_out);
         if (h_cnt) (void)hipHostFree(h_cnt);
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+        if (ev_join) (void)hipEventDestroy(ev_join);
     }
 };
 struct PairJob { uint32_t q, r, flags, orig; };
+#define CHAIN_SLOTS 3
 struct ChainWork {
-    ChainSlot slot[2];
+    ChainSlot slot[CHAIN_SLOTS];
     std::vector<PairJob> jobs, jobs_sorted;
     std::vector<uint32_t> sort_start;
     // rare path (chunks with more anchors than the wave kernel holds in LDS)
@@ -1788,6 +1809,9 @@ struct ChainWork {
     DevBuf<int32_t> F;
     DevBuf<uint64_t> ORD;
     ScanWorkspace ws;
+    hipEvent_t ev_order = nullptr;
+    hipStream_t stream3 = nullptr;
+    ~ChainWork() { if (ev_order) (void)hipEventDestroy(ev_order); if (stream3) (void)hipStreamDestroy(stream3); }
 };
 static ChainWork *chain_work(skder_ctx *ctx)
 {
@@ -1806,6 +1830,10 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
     hipStream_t st = ctx->stream;
     const size_t np = pref.size();
     size_t budget = 6u << 20;   // chunks (work items) per batch
+    int nqueues = 1;
+    uint32_t join_group_max = 8;       // pairs per join workgroup (8: 24.6 ms per step of the benchmark; 16: 25.9; 4: 24.7; 32: 28.8)
+    if (const char *e = getenv("SKDER_AMD_JOIN_GROUP")) join_group_max = (uint32_t)atoi(e);
+    hipStream_t queues[3] = {st, st, st};
     if (const char *e = getenv("SKDER_AMD_CHUNK_BUDGET")) budget = strtoull(e, nullptr, 10);
     ChainWork &W = *chain_work(ctx);
     const SetView VA = view_of(SA), VB = view_of(SB);
@@ -1876,37 +1904,37 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
     // ---- the chaining stage of a batch whose hit words exist: fast path, slow path, finalize, results
     auto chain_stage = [&](ChainSlot &S) {
         const uint32_t nb = S.nb;
-        HIPCHECK(hipMemsetAsync(S.pair_nch.p, 0, nb * 4, st));
-        HIPCHECK(hipMemsetAsync(S.pair_na.p, 0, nb * 4, st));
-        HIPCHECK(hipMemsetAsync(S.counters.p, 0, 128, st));
-        HIPCHECK(hipMemsetAsync(S.flags.p, 0, 64, st));
-        HIPCHECK(hipEventRecord(S.ev[1], st));
+        HIPCHECK(hipMemsetAsync(S.pair_nch.p, 0, nb * 4, S.st));
+        HIPCHECK(hipMemsetAsync(S.pair_na.p, 0, nb * 4, S.st));
+        HIPCHECK(hipMemsetAsync(S.counters.p, 0, 128, S.st));
+        HIPCHECK(hipMemsetAsync(S.flags.p, 0, 64, S.st));
+        HIPCHECK(hipEventRecord(S.ev[1], S.st));
         if (S.nchunks) {
-            HIPCHECK(hipMemsetAsync(S.chunk_rec0.p, 0xFF, S.nchunks * 4, st));
-            HIPCHECK(hipMemsetAsync(S.pair_over.p, 0, nb * 4, st));
-            hipLaunchKernelGGL(run_extract_kernel, dim3(nb), dim3(256), 0, st, VA, VB, S.d_pairs.p, S.hits.p, S.recs.p, S.pair_over.p, S.chunk_rec0.p);
-            HIPCHECK(hipEventRecord(S.ev[6], st));
+            HIPCHECK(hipMemsetAsync(S.chunk_rec0.p, 0xFF, S.nchunks * 4, S.st));
+            HIPCHECK(hipMemsetAsync(S.pair_over.p, 0, nb * 4, S.st));
+            hipLaunchKernelGGL(run_extract_kernel, dim3(nb), dim3(256), 0, S.st, VA, VB, S.d_pairs.p, S.hits.p, S.recs.p, S.pair_over.p, S.chunk_rec0.p);
+            HIPCHECK(hipEventRecord(S.ev[6], S.st));
             const unsigned nwg = (unsigned)((S.nchunks + 255) / 256);
             const uint32_t gen_cap = ((nwg + GEN_LISTS - 1u) / GEN_LISTS) * 256u;
-            HIPCHECK(hipMemsetAsync(S.gen_cnt.p, 0, GEN_LISTS * 4, st));
-            hipLaunchKernelGGL(chain_single_kernel, dim3(nwg), dim3(256), 0, st, VA, VB, S.d_pairs.p, nb, (uint32_t)S.nchunks, S.recs.p,
+            HIPCHECK(hipMemsetAsync(S.gen_cnt.p, 0, GEN_LISTS * 4, S.st));
+            hipLaunchKernelGGL(chain_single_kernel, dim3(nwg), dim3(256), 0, S.st, VA, VB, S.d_pairs.p, nb, (uint32_t)S.nchunks, S.recs.p,
                                S.pair_over.p, S.chunk_rec0.p, S.wg_pair.p, S.multi.p, S.fast_chains.p, S.chunk_state.p, S.slow_list.p, S.counters.p,
                                S.gen_list.p, S.gen_cnt.p, gen_cap, S.pair_na.p, xcd_remap);
-            hipLaunchKernelGGL(chain_runs_kernel, dim3(nwg < 4096u ? nwg : 4096u), dim3(256), 0, st, VA, VB, S.d_pairs.p, nb, S.gen_list.p,
+            hipLaunchKernelGGL(chain_runs_kernel, dim3(nwg < 4096u ? nwg : 4096u), dim3(256), 0, S.st, VA, VB, S.d_pairs.p, nb, S.gen_list.p,
                                S.gen_cnt.p, gen_cap, S.recs.p, S.chunk_rec0.p, S.multi.p, S.fast_chains.p, S.chunk_state.p, S.slow_list.p, S.counters.p, S.pair_na.p);
         } else {
-            HIPCHECK(hipEventRecord(S.ev[6], st));
+            HIPCHECK(hipEventRecord(S.ev[6], S.st));
         }
-        HIPCHECK(hipEventRecord(S.ev[2], st));
+        HIPCHECK(hipEventRecord(S.ev[2], S.st));
         // declined chunks: one wavefront each, in LDS (count read on the device); the rare chunk with more
         // than 1024 anchors is put on over_list and dealt with after the batch's results are back
         if (S.nchunks) {
             const uint64_t want = (S.nchunks + SLOWW_WAVES - 1) / SLOWW_WAVES;
-            hipLaunchKernelGGL(slow_wave_kernel, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(64 * SLOWW_WAVES), 0, st, VA, VB,
+            hipLaunchKernelGGL(slow_wave_kernel, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(64 * SLOWW_WAVES), 0, S.st, VA, VB,
                                S.d_pairs.p, nb, S.slow_list.p, S.counters.p, S.hits.p, S.multi.p, S.chains.p, S.pair_nch.p, S.pair_na.p, S.over_list.p,
                                S.counters.p + 15, S.flags.p);
         }
-        HIPCHECK(hipEventRecord(S.ev[3], st));
+        HIPCHECK(hipEventRecord(S.ev[3], S.st));
         // LDS capacity of the finalize step: the most chains any pair of the batch can plausibly have
         // (1.5 per chunk + slack), rounded up; a batch in which some pair has more is finalized again with
         // the full 4096 (140 KB) when its results are read
@@ -1916,22 +1944,22 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         while (lds_cap < FAST_SLOTS * max_chunks / 2 + 128 && lds_cap < 4096) lds_cap <<= 1;   // retried with more if a pair needs it
         S.lds_cap = lds_cap;
         if (nb)
-            hipLaunchKernelGGL(finalize_kernel_t<false>, dim3(nb), dim3(256), lds_cap * 35u, st, VA, VB, S.d_pairs.p, S.fast_chains.p, S.chunk_state.p,
+            hipLaunchKernelGGL(finalize_kernel_t<false>, dim3(nb), dim3(256), lds_cap * 35u, S.st, VA, VB, S.d_pairs.p, S.fast_chains.p, S.chunk_state.p,
                                S.chains.p, S.pair_nch.p, S.pair_na.p, S.d_out.p, S.flags.p, S.chunk_mark.p, lds_cap, nullptr, nullptr, nullptr, nullptr);
         HIPCHECK(hipGetLastError());     // a rejected launch (resources) must not pass as an empty result
-        HIPCHECK(hipEventRecord(S.ev[4], st));
-        HIPCHECK(hipMemcpyAsync(S.h_out, S.d_out.p, nb * sizeof(PairOut), hipMemcpyDeviceToHost, st));
-        HIPCHECK(hipMemcpyAsync(S.h_cnt, S.counters.p, 64, hipMemcpyDeviceToHost, st));
-        HIPCHECK(hipMemcpyAsync(S.h_cnt + 16, S.flags.p, 4, hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipEventRecord(S.ev[4], S.st));
+        HIPCHECK(hipMemcpyAsync(S.h_out, S.d_out.p, nb * sizeof(PairOut), hipMemcpyDeviceToHost, S.st));
+        HIPCHECK(hipMemcpyAsync(S.h_cnt, S.counters.p, 64, hipMemcpyDeviceToHost, S.st));
+        HIPCHECK(hipMemcpyAsync(S.h_cnt + 16, S.flags.p, 4, hipMemcpyDeviceToHost, S.st));
 #ifdef SKDER_SIEVE_STATS
-        HIPCHECK(hipMemcpyAsync(S.h_cnt + 24, S.counters.p + 24, 32, hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipMemcpyAsync(S.h_cnt + 24, S.counters.p + 24, 32, hipMemcpyDeviceToHost, S.st));
 #endif
-        HIPCHECK(hipEventRecord(S.ev[5], st));
+        HIPCHECK(hipEventRecord(S.ev[5], S.st));
     };
     // ---- one batch: descriptors (host), then everything on the stream without a host round trip
     uint32_t rec_div = 4;      // room for one run record per four seeds of the chunked genome (the 34 real C. granulosum genomes need one per six)
     if (const char *e = getenv("SKDER_AMD_REC_DIV")) rec_div = (uint32_t)atoi(e);
-    auto enqueue = [&](ChainSlot &S, size_t p0) -> size_t {
+    auto enqueue = [&](ChainSlot &S, size_t p0, size_t batch_budget) -> size_t {
         std::vector<PairDesc> &hp = S.hp;
         hp.clear();
         uint64_t nchunks = 0, ccap = 0, nhits = 0, nmulti = 0, nrecs = 0;
@@ -1952,7 +1980,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
             d.c_cap = 4u * Q.n_chunks + 64u;       // slow-path chains of the pair; made exact and retried when a pair needs more
             d.multi_cap = 256u + Q.n_seeds / 8u;
             if (d.multi_cap > 0x00FFFFF0u) d.multi_cap = 0x00FFFFF0u;
-            if (!hp.empty() && nchunks + d.n_chunks > budget) break;
+            if (!hp.empty() && nchunks + d.n_chunks > batch_budget) break;
             if (nchunks + d.n_chunks > 0x7FFF0000ull || ccap + d.c_cap > 0xFFFF0000ull || nhits + Q.n_seeds + 32u > 0xFFFF0000ull ||
                 nmulti + d.multi_cap > 0xFFFF0000ull || nrecs + Q.n_seeds / rec_div + 64u > 0xFFFF0000ull) break;
             // hit words of the pair start at an entry congruent (mod 16) to the genome's seed offset:
@@ -1970,6 +1998,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         const uint32_t nb = (uint32_t)hp.size();
         S.p0 = p0; S.nb = nb; S.nchunks = nchunks; S.nrecs = nrecs; S.busy = true;
         for (auto &e : S.ev) if (!e) HIPCHECK(hipEventCreate(&e));
+        if (!S.ev_join) HIPCHECK(hipEventCreate(&S.ev_join));
         if (!S.h_cnt) HIPCHECK(hipHostMalloc(&S.h_cnt, 32 * sizeof(uint32_t)));
         if (S.h_out_cap < nb) {
             if (S.h_out) (void)hipHostFree(S.h_out);
@@ -1978,19 +2007,19 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
             HIPCHECK(hipHostMalloc(&S.h_out, S.h_out_cap * sizeof(PairOut)));
         }
         const auto t_al0 = std::chrono::steady_clock::now();
-        S.d_pairs.resize(nb, st);
-        S.chunk_state.resize(nchunks + 1, st); S.chunk_mark.resize(nchunks + 1, st); S.slow_list.resize(nchunks + 1, st); S.over_list.resize(nchunks + 1, st);
-        S.fast_chains.resize(nchunks * FAST_SLOTS + 1, st);
-        S.counters.resize(32, st); S.flags.resize(16, st);
-        S.pair_na.resize(nb, st); S.pair_nch.resize(nb, st); S.pair_nmulti.resize(nb, st);
-        S.hits.resize(nhits + 64, st); S.multi.resize(nmulti + 1, st);
-        S.recs.resize(nrecs + 8, st); S.pair_over.resize(nb + 1, st); S.chunk_rec0.resize(nchunks + 1, st); S.gen_list.resize(nchunks + 256ull * GEN_LISTS + 1, st); S.gen_cnt.resize(GEN_LISTS, st);
-        S.chains.resize(ccap + 1, st);
-        S.d_out.resize(nb, st);
+        S.d_pairs.resize(nb, S.st_join);
+        S.chunk_state.resize(nchunks + 1, S.st_join); S.chunk_mark.resize(nchunks + 1, S.st_join); S.slow_list.resize(nchunks + 1, S.st_join); S.over_list.resize(nchunks + 1, S.st_join);
+        S.fast_chains.resize(nchunks * FAST_SLOTS + 1, S.st_join);
+        S.counters.resize(32, S.st_join); S.flags.resize(16, S.st_join);
+        S.pair_na.resize(nb, S.st_join); S.pair_nch.resize(nb, S.st_join); S.pair_nmulti.resize(nb, S.st_join);
+        S.hits.resize(nhits + 64, S.st_join); S.multi.resize(nmulti + 1, S.st_join);
+        S.recs.resize(nrecs + 8, S.st_join); S.pair_over.resize(nb + 1, S.st_join); S.chunk_rec0.resize(nchunks + 1, S.st_join); S.gen_list.resize(nchunks + 256ull * GEN_LISTS + 1, S.st_join); S.gen_cnt.resize(GEN_LISTS, S.st_join);
+        S.chains.resize(ccap + 1, S.st_join);
+        S.d_out.resize(nb, S.st_join);
         if (getenv("SKDER_AMD_DEBUG"))
             fprintf(stderr, "[skder_amd] host: work buffers of the batch ready after %.2f ms\n",
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_al0).count());
-        HIPCHECK(hipMemcpyAsync(S.d_pairs.p, hp.data(), nb * sizeof(PairDesc), hipMemcpyHostToDevice, st));
+        HIPCHECK(hipMemcpyAsync(S.d_pairs.p, hp.data(), nb * sizeof(PairDesc), hipMemcpyHostToDevice, S.st_join));
         {
             // first pair of every 256-chunk workgroup of the chaining kernel
             std::vector<uint32_t> &wp = S.h_wg_pair;
@@ -2002,18 +2031,18 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
                 while (pi + 1u < nb && hp[pi + 1u].chunk_base <= t0) pi++;
                 wp[w] = pi;
             }
-            S.wg_pair.resize(nwg + 1, st);
-            if (nwg) HIPCHECK(hipMemcpyAsync(S.wg_pair.p, wp.data(), nwg * 4, hipMemcpyHostToDevice, st));
+            S.wg_pair.resize(nwg + 1, S.st_join);
+            if (nwg) HIPCHECK(hipMemcpyAsync(S.wg_pair.p, wp.data(), nwg * 4, hipMemcpyHostToDevice, S.st_join));
         }
-        HIPCHECK(hipMemsetAsync(S.pair_nmulti.p, 0, nb * 4, st));
-        HIPCHECK(hipEventRecord(S.ev[0], st));
+        HIPCHECK(hipMemsetAsync(S.pair_nmulti.p, 0, nb * 4, S.st_join));
+        HIPCHECK(hipEventRecord(S.ev[0], S.st_join));
         {
-            // groups of consecutive pairs that probe the same genome, at most 16 pairs each (load balance)
+            // groups of consecutive pairs that probe the same genome, at most 8 pairs each (load balance: a workgroup's ragged end)
             std::vector<JoinGroup> &hg = S.h_groups;
             hg.clear();
             for (uint32_t i = 0; i < nb;) {
                 uint32_t j = i;
-                while (j < nb && j - i < 16 && hp[j].r == hp[i].r && (hp[j].flags & 4u) == (hp[i].flags & 4u)) j++;
+                while (j < nb && j - i < join_group_max && hp[j].r == hp[i].r && (hp[j].flags & 4u) == (hp[i].flags & 4u)) j++;
                 JoinGroup g;
                 g.pair_begin = i; g.pair_end = j;
                 hg.push_back(g);
@@ -2032,8 +2061,8 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
                 for (size_t bidx = 0; bidx < n; bidx++) tmp[bidx] = hg[start[bidx % 8] + bidx / 8];
                 hg.swap(tmp);
             }
-            S.groups.resize(hg.size() * 2, st);
-            HIPCHECK(hipMemcpyAsync(S.groups.p, hg.data(), hg.size() * sizeof(JoinGroup), hipMemcpyHostToDevice, st));
+            S.groups.resize(hg.size() * 2, S.st_join);
+            HIPCHECK(hipMemcpyAsync(S.groups.p, hg.data(), hg.size() * sizeof(JoinGroup), hipMemcpyHostToDevice, S.st_join));
             if (!ctx->chain_attr_set) {      // per context: the attribute belongs to the device, and a process may use several
                 HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(join_probe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              JOIN_SMEM_MAX + 64));
@@ -2051,10 +2080,13 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
             }
             uint32_t join_smem = (uint32_t)(want < JOIN_SMEM_MAX ? want : JOIN_SMEM_MAX) / 64u * 64u + 64u;
             if (want <= JOIN_SMEM_TWO && join_smem > JOIN_SMEM_TWO) join_smem = JOIN_SMEM_TWO;
-            hipLaunchKernelGGL(join_probe_kernel, dim3((unsigned)hg.size()), dim3(JOIN_THREADS), join_smem, st, VA, VB, S.d_pairs.p,
+            hipLaunchKernelGGL(join_probe_kernel, dim3((unsigned)hg.size()), dim3(JOIN_THREADS), join_smem, S.st_join, VA, VB, S.d_pairs.p,
                                reinterpret_cast<const JoinGroup *>(S.groups.p), S.hits.p, S.multi.p, S.pair_nmulti.p, join_smem);
             HIPCHECK(hipGetLastError());
         }
+        // the later stages run on the slot's second queue, behind the join
+        HIPCHECK(hipEventRecord(S.ev_join, S.st_join));
+        if (S.st != S.st_join) HIPCHECK(hipStreamWaitEvent(S.st, S.ev_join, 0));
         chain_stage(S);
         return p;
     };
@@ -2069,7 +2101,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         S.busy = false;
         const uint32_t nb = S.nb, nslow = S.h_cnt[0], nover = S.h_cnt[15];
         float ms;
-        HIPCHECK(hipEventElapsedTime(&ms, S.ev[0], S.ev[1])); t_join += ms;
+        HIPCHECK(hipEventElapsedTime(&ms, S.ev[0], S.ev_join)); t_join += ms;
         HIPCHECK(hipEventElapsedTime(&ms, S.ev[1], S.ev[6])); t_runs += ms;
         HIPCHECK(hipEventElapsedTime(&ms, S.ev[6], S.ev[2])); t_fast += ms;
         HIPCHECK(hipEventElapsedTime(&ms, S.ev[2], S.ev[3])); t_slow += ms;
@@ -2089,30 +2121,30 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         //    holds the number wanted: every pair gets exactly that and the chaining stage runs again;
         //  * flag 16: a pair has more chains than the LDS capacity chosen for finalize: again at 4096.
         auto finalize_and_fetch = [&]() {
-            hipLaunchKernelGGL(finalize_kernel_t<false>, dim3(nb), dim3(256), S.lds_cap * 35u, st, VA, VB, S.d_pairs.p, S.fast_chains.p, S.chunk_state.p,
+            hipLaunchKernelGGL(finalize_kernel_t<false>, dim3(nb), dim3(256), S.lds_cap * 35u, S.st, VA, VB, S.d_pairs.p, S.fast_chains.p, S.chunk_state.p,
                                S.chains.p, S.pair_nch.p, S.pair_na.p, S.d_out.p, S.flags.p, S.chunk_mark.p, S.lds_cap, nullptr, nullptr, nullptr, nullptr);
             HIPCHECK(hipGetLastError());
-            HIPCHECK(hipMemcpyAsync(S.h_out, S.d_out.p, nb * sizeof(PairOut), hipMemcpyDeviceToHost, st));
-            HIPCHECK(hipMemcpyAsync(S.h_cnt + 16, S.flags.p, 4, hipMemcpyDeviceToHost, st));
-            HIPCHECK(hipStreamSynchronize(st));
+            HIPCHECK(hipMemcpyAsync(S.h_out, S.d_out.p, nb * sizeof(PairOut), hipMemcpyDeviceToHost, S.st));
+            HIPCHECK(hipMemcpyAsync(S.h_cnt + 16, S.flags.p, 4, hipMemcpyDeviceToHost, S.st));
+            HIPCHECK(hipStreamSynchronize(S.st));
         };
         for (int attempt = 0;; attempt++) {
             uint32_t flags_seen = S.h_cnt[16];
             const uint32_t nover_now = S.h_cnt[15];
             if (nover_now) {
-                W.cap.resize(nover_now + 1, st); W.abase.resize(nover_now + 1, st); W.slow_n.resize(nover_now + 1, st);
-                HIPCHECK(hipMemsetAsync(S.flags.p, 0, 64, st));
-                hipLaunchKernelGGL(slow_caps_kernel, dim3((nover_now + 4) / 4), dim3(256), 0, st, VA, VB, S.d_pairs.p, nb, S.over_list.p,
+                W.cap.resize(nover_now + 1, S.st); W.abase.resize(nover_now + 1, S.st); W.slow_n.resize(nover_now + 1, S.st);
+                HIPCHECK(hipMemsetAsync(S.flags.p, 0, 64, S.st));
+                hipLaunchKernelGGL(slow_caps_kernel, dim3((nover_now + 4) / 4), dim3(256), 0, S.st, VA, VB, S.d_pairs.p, nb, S.over_list.p,
                                    nover_now, W.cap.p);
-                exclusive_scan_u32(W.cap.p, W.abase.p, nover_now + 1, W.ws, st);
+                exclusive_scan_u32(W.cap.p, W.abase.p, nover_now + 1, W.ws, S.st);
                 uint32_t atotal = 0;
-                HIPCHECK(hipMemcpyAsync(&atotal, W.abase.p + nover_now, 4, hipMemcpyDeviceToHost, st));
-                HIPCHECK(hipStreamSynchronize(st));
-                W.a_qi.resize(atotal + 1, st); W.a_r.resize(atotal + 1, st); W.a_rctg.resize(atotal + 1, st);
-                W.F.resize(atotal + 1, st); W.BP.resize(atotal + 1, st); W.ORD.resize(atotal + 1, st);
-                hipLaunchKernelGGL(slow_anchors_kernel, dim3((nover_now + 3) / 4), dim3(256), 0, st, VA, VB, S.d_pairs.p, nb, S.over_list.p,
+                HIPCHECK(hipMemcpyAsync(&atotal, W.abase.p + nover_now, 4, hipMemcpyDeviceToHost, S.st));
+                HIPCHECK(hipStreamSynchronize(S.st));
+                W.a_qi.resize(atotal + 1, S.st); W.a_r.resize(atotal + 1, S.st); W.a_rctg.resize(atotal + 1, S.st);
+                W.F.resize(atotal + 1, S.st); W.BP.resize(atotal + 1, S.st); W.ORD.resize(atotal + 1, S.st);
+                hipLaunchKernelGGL(slow_anchors_kernel, dim3((nover_now + 3) / 4), dim3(256), 0, S.st, VA, VB, S.d_pairs.p, nb, S.over_list.p,
                                    nover_now, W.abase.p, W.a_qi.p, W.a_r.p, W.a_rctg.p, W.slow_n.p, S.flags.p);
-                hipLaunchKernelGGL(slow_chain_kernel, dim3((nover_now + 3) / 4), dim3(256), 0, st, VA, VB, S.d_pairs.p, nb, S.over_list.p,
+                hipLaunchKernelGGL(slow_chain_kernel, dim3((nover_now + 3) / 4), dim3(256), 0, S.st, VA, VB, S.d_pairs.p, nb, S.over_list.p,
                                    nover_now, W.abase.p, W.slow_n.p, W.a_qi.p, W.a_r.p, W.a_rctg.p, W.F.p, W.BP.p, W.ORD.p, S.chains.p, S.pair_nch.p,
                                    S.pair_na.p, S.flags.p);
                 finalize_and_fetch();
@@ -2120,8 +2152,8 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
             }
             if ((flags_seen & 8u) && attempt == 0) {
                 std::vector<uint32_t> want(nb);
-                HIPCHECK(hipMemcpyAsync(want.data(), S.pair_nch.p, nb * 4ull, hipMemcpyDeviceToHost, st));
-                HIPCHECK(hipStreamSynchronize(st));
+                HIPCHECK(hipMemcpyAsync(want.data(), S.pair_nch.p, nb * 4ull, hipMemcpyDeviceToHost, S.st));
+                HIPCHECK(hipStreamSynchronize(S.st));
                 uint64_t ccap = 0;
                 for (uint32_t i = 0; i < nb; i++) {
                     PairDesc &d = S.hp[i];
@@ -2130,15 +2162,15 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
                     ccap += d.c_cap;
                     if (ccap > 0xFFFF0000ull) throw SkError("chain buffer overflow: more than 2^32 slow-path chains in one batch of pairs");
                 }
-                S.chains.resize(ccap + 1, st);
-                HIPCHECK(hipMemcpyAsync(S.d_pairs.p, S.hp.data(), nb * sizeof(PairDesc), hipMemcpyHostToDevice, st));
+                S.chains.resize(ccap + 1, S.st);
+                HIPCHECK(hipMemcpyAsync(S.d_pairs.p, S.hp.data(), nb * sizeof(PairDesc), hipMemcpyHostToDevice, S.st));
                 chain_stage(S);
                 HIPCHECK(hipEventSynchronize(S.ev[5]));
                 continue;     // the over-list part runs again against the new regions
             }
             if ((flags_seen & 16u) && S.lds_cap < 4096) {
                 S.lds_cap = 4096;
-                HIPCHECK(hipMemsetAsync(S.flags.p, 0, 64, st));
+                HIPCHECK(hipMemsetAsync(S.flags.p, 0, 64, S.st));
                 finalize_and_fetch();
                 flags_seen = (flags_seen & ~16u) | S.h_cnt[16];
             }
@@ -2160,18 +2192,18 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
                     DevBuf<uint32_t> d_list, d_cap;
                     DevBuf<uint64_t> d_off;
                     const size_t ng = glist.size();
-                    gws.resize(bytes + 256, st); d_list.resize(ng, st); d_cap.resize(ng, st); d_off.resize(ng, st);
-                    HIPCHECK(hipMemcpyAsync(d_list.p, glist.data(), ng * 4, hipMemcpyHostToDevice, st));
-                    HIPCHECK(hipMemcpyAsync(d_cap.p, gcap.data(), ng * 4, hipMemcpyHostToDevice, st));
-                    HIPCHECK(hipMemcpyAsync(d_off.p, goff.data(), ng * 8, hipMemcpyHostToDevice, st));
-                    HIPCHECK(hipMemsetAsync(S.flags.p, 0, 64, st));
-                    hipLaunchKernelGGL(finalize_kernel_t<true>, dim3((unsigned)ng), dim3(256), 0, st, VA, VB, S.d_pairs.p, S.fast_chains.p,
+                    gws.resize(bytes + 256, S.st); d_list.resize(ng, S.st); d_cap.resize(ng, S.st); d_off.resize(ng, S.st);
+                    HIPCHECK(hipMemcpyAsync(d_list.p, glist.data(), ng * 4, hipMemcpyHostToDevice, S.st));
+                    HIPCHECK(hipMemcpyAsync(d_cap.p, gcap.data(), ng * 4, hipMemcpyHostToDevice, S.st));
+                    HIPCHECK(hipMemcpyAsync(d_off.p, goff.data(), ng * 8, hipMemcpyHostToDevice, S.st));
+                    HIPCHECK(hipMemsetAsync(S.flags.p, 0, 64, S.st));
+                    hipLaunchKernelGGL(finalize_kernel_t<true>, dim3((unsigned)ng), dim3(256), 0, S.st, VA, VB, S.d_pairs.p, S.fast_chains.p,
                                        S.chunk_state.p, S.chains.p, S.pair_nch.p, S.pair_na.p, S.d_out.p, S.flags.p, S.chunk_mark.p, 0u, gws.p,
                                        d_off.p, d_list.p, d_cap.p);
                     HIPCHECK(hipGetLastError());
-                    HIPCHECK(hipMemcpyAsync(S.h_out, S.d_out.p, nb * sizeof(PairOut), hipMemcpyDeviceToHost, st));
-                    HIPCHECK(hipMemcpyAsync(S.h_cnt + 16, S.flags.p, 4, hipMemcpyDeviceToHost, st));
-                    HIPCHECK(hipStreamSynchronize(st));
+                    HIPCHECK(hipMemcpyAsync(S.h_out, S.d_out.p, nb * sizeof(PairOut), hipMemcpyDeviceToHost, S.st));
+                    HIPCHECK(hipMemcpyAsync(S.h_cnt + 16, S.flags.p, 4, hipMemcpyDeviceToHost, S.st));
+                    HIPCHECK(hipStreamSynchronize(S.st));
                     flags_seen = (flags_seen & ~16u) | S.h_cnt[16];
                 }
             }
@@ -2198,20 +2230,41 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         }
     };
     edges.reserve(edges.size() + np);
-    // ---- two batches in flight: the next one is enqueued before the previous one's results are read
+    // ---- several batches in flight, slot j on queue j: the stages of a batch are bound by different things (join: memory
+    // latency at a third of the lanes' issue slots, long workgroups with a ragged end; run extraction: HBM; sieve and
+    // finalize: dependent loads), so batches on different queues fill one another's gaps.  The first batches are
+    // shorter (1/Q, 2/Q, ... of a batch), which puts the queues out of step.  SKDER_AMD_QUEUES=1: batch after batch
+    // on the main queue.  (All joins on one queue and the later stages on a second one, behind their joins, measured no
+    // gain at all: the join's two workgroups per CU take every wave slot and its next workgroup wins a freed one.)
+    {
+        uint64_t est = 0;
+        for (size_t i = 0; i < np && est <= budget; i++) est += ((jobs[i].flags & 2u) ? SB->h_meta[jobs[i].q] : SA->h_meta[jobs[i].q]).n_chunks;
+        nqueues = 2;              // three measured no faster than two (85.6 against 84.9 ms per step of the benchmark; one: 90.1)
+        if (const char *e = getenv("SKDER_AMD_QUEUES")) nqueues = atoi(e);
+        if (nqueues < 1 || est <= budget / 4 || !ctx->stream2) nqueues = 1;
+        if (nqueues > CHAIN_SLOTS) nqueues = CHAIN_SLOTS;
+        if (nqueues > 2 && !W.stream3) HIPCHECK(hipStreamCreateWithFlags(&W.stream3, hipStreamNonBlocking));
+        queues[0] = st; queues[1] = ctx->stream2; queues[2] = W.stream3;
+        for (auto &S : W.slot) S.st_join = S.st = st;
+        if (nqueues > 1) {      // what the caller queued on the main queue comes first
+            if (!W.ev_order) HIPCHECK(hipEventCreateWithFlags(&W.ev_order, hipEventDisableTiming));
+            HIPCHECK(hipEventRecord(W.ev_order, st));
+            for (int j = 1; j < nqueues; j++) HIPCHECK(hipStreamWaitEvent(queues[j], W.ev_order, 0));
+        }
+    }
     const auto t_loop0 = std::chrono::steady_clock::now();
     try {
-        size_t p0 = 0;
-        int cur = 0;
-        while (p0 < np) {
-            p0 = enqueue(W.slot[cur], p0);
-            if (W.slot[cur ^ 1].busy) consume(W.slot[cur ^ 1]);
-            cur ^= 1;
+        size_t p0 = 0, k = 0;
+        for (; p0 < np; k++) {
+            ChainSlot &S = W.slot[k % CHAIN_SLOTS];
+            if (S.busy) consume(S);            // batch k - CHAIN_SLOTS: results in batch order
+            S.st_join = S.st = queues[k % (size_t)nqueues];
+            p0 = enqueue(S, p0, k + 1 < (size_t)nqueues ? budget * (k + 1) / nqueues : budget);
         }
-        if (W.slot[cur ^ 1].busy) consume(W.slot[cur ^ 1]);
+        for (size_t j = k < CHAIN_SLOTS ? 0 : k - CHAIN_SLOTS; j < k; j++)
+            if (W.slot[j % CHAIN_SLOTS].busy) consume(W.slot[j % CHAIN_SLOTS]);
     } catch (...) {
-        (void)hipStreamSynchronize(st);
-        W.slot[0].busy = W.slot[1].busy = false;
+        for (auto &S : W.slot) { (void)hipStreamSynchronize(S.st); (void)hipStreamSynchronize(S.st_join); S.busy = false; }
         throw;
     }
     if (getenv("SKDER_AMD_DEBUG"))
