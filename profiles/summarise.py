@@ -52,6 +52,8 @@ def find(d, suffix):
 def main():
     shutil.copy(find(os.path.join(SRC, "stats"), "kernel_stats.csv"), os.path.join(DST, R + "_kernel_stats.csv"))
     shutil.copy(find(os.path.join(SRC, "stats"), "domain_stats.csv"), os.path.join(DST, R + "_domain_stats.csv"))
+    if os.path.isdir(os.path.join(SRC, "stats1q")):     # the same command with SKDER_AMD_QUEUES=1 (no overlap between chaining batches)
+        shutil.copy(find(os.path.join(SRC, "stats1q"), "kernel_stats.csv"), os.path.join(DST, R + "_kernel_stats_one_queue.csv"))
     known = {}
     for line in open(os.path.join(SRC, "calib_fetch.log")):
         if line.startswith("known_bytes"):
