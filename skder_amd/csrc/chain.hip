@@ -1779,6 +1779,7 @@ struct ChainSlot {
     DevBuf<PairOut> d_out;
     std::vector<PairDesc> hp;
     std::vector<JoinGroup> h_groups, h_groups2;
+    std::vector<uint32_t> xcd_list[8];
     // pinned host mirrors of the small results
     PairOut *h_out = nullptr;
     size_t h_out_cap = 0;
@@ -2049,16 +2050,42 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
                 i = j;
             }
             if ((xcd_remap & 1) && hg.size() >= 64) {
-                // workgroups are dealt round-robin to the 8 XCDs: give every XCD a CONTIGUOUS eighth of the groups, so that
-                // the three or four groups that probe one genome (and their neighbours, which stream the same chunked
-                // genomes past it) run on one XCD at about the same time and share its L2 instead of filling all eight
+                // Workgroups are dealt round-robin to the 8 XCDs (workgroup b runs on XCD b mod 8).  The groups that probe
+                // one genome -- consecutive in the list -- go to ONE XCD, so that they run there at about the same time
+                // and share its L2 (the probed genome's positions are gathered from it) instead of filling all eight;
+                // the genomes are dealt to the XCD with the least work so far (work: seeds streamed past), because an
+                // XCD works through its own list and the kernel lasts as long as the slowest does -- equal eighths of
+                // the list cost 60 % more join time on genomes of mixed sizes.  List ends are evened out at the end.
                 std::vector<JoinGroup> &tmp = S.h_groups2;
-                tmp.resize(hg.size());
-                const size_t n = hg.size(), per = n / 8, extra = n % 8;       // XCD x takes per (+1 if x < extra) groups
-                size_t start[9];
-                start[0] = 0;
-                for (size_t x = 0; x < 8; x++) start[x + 1] = start[x] + per + (x < extra ? 1 : 0);
-                for (size_t bidx = 0; bidx < n; bidx++) tmp[bidx] = hg[start[bidx % 8] + bidx / 8];
+                const size_t n = hg.size();
+                tmp.resize(n);
+                std::vector<uint32_t> (&lst)[8] = S.xcd_list;
+                uint64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (auto &l : lst) l.clear();
+                for (size_t g0 = 0; g0 < n;) {
+                    size_t g1 = g0;
+                    uint64_t work = 0;
+                    const PairDesc &first = hp[hg[g0].pair_begin];
+                    while (g1 < n && hp[hg[g1].pair_begin].r == first.r && (hp[hg[g1].pair_begin].flags & 4u) == (first.flags & 4u)) {
+                        for (uint32_t i = hg[g1].pair_begin; i < hg[g1].pair_end; i++)
+                            work += ((hp[i].flags & 2u) ? SB->h_meta[hp[i].q] : SA->h_meta[hp[i].q]).n_seeds;
+                        g1++;
+                    }
+                    int x = 0;
+                    for (int y = 1; y < 8; y++) if (load[y] < load[x]) x = y;
+                    load[x] += work;
+                    for (size_t g = g0; g < g1; g++) lst[x].push_back((uint32_t)g);
+                    g0 = g1;
+                }
+                size_t at[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (size_t bidx = 0; bidx < n; bidx++) {
+                    int x = (int)(bidx % 8);
+                    if (at[x] < lst[x].size()) { tmp[bidx] = hg[lst[x][at[x]++]]; continue; }
+                    int y = 0;              // this XCD's list is used up: the last group of the list with the most left
+                    for (int z = 1; z < 8; z++) if (lst[z].size() - at[z] > lst[y].size() - at[y]) y = z;
+                    tmp[bidx] = hg[lst[y].back()];
+                    lst[y].pop_back();
+                }
                 hg.swap(tmp);
             }
             S.groups.resize(hg.size() * 2, S.st_join);
@@ -2240,8 +2267,9 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         uint64_t est = 0;
         for (size_t i = 0; i < np && est <= budget; i++) est += ((jobs[i].flags & 2u) ? SB->h_meta[jobs[i].q] : SA->h_meta[jobs[i].q]).n_chunks;
         nqueues = 2;              // three measured no faster than two (85.6 against 84.9 ms per step of the benchmark; one: 90.1)
-        if (const char *e = getenv("SKDER_AMD_QUEUES")) nqueues = atoi(e);
-        if (nqueues < 1 || est <= budget / 4 || !ctx->stream2) nqueues = 1;
+        if (est <= budget / 4) nqueues = 1;          // a small job: one or two batches, nothing to overlap
+        if (const char *e = getenv("SKDER_AMD_QUEUES")) nqueues = atoi(e);       // (tests force several queues on small jobs)
+        if (nqueues < 1 || !ctx->stream2) nqueues = 1;
         if (nqueues > CHAIN_SLOTS) nqueues = CHAIN_SLOTS;
         if (nqueues > 2 && !W.stream3) HIPCHECK(hipStreamCreateWithFlags(&W.stream3, hipStreamNonBlocking));
         queues[0] = st; queues[1] = ctx->stream2; queues[2] = W.stream3;

@@ -1022,6 +1022,31 @@ def test_repeat_rich_randomized(gpu, oracle):
         s.close()
 
 
+@pytest.mark.parametrize("queues", [2, 3])
+def test_small_batches_on_several_queues(gpu, oracle, monkeypatch, queues):
+    """the chaining batches of a call alternate between two queues (three slots of work buffers) and overlap; jobs this
+    small stay on one queue by themselves, so the test forces several queues and batches of a few hundred chunks on
+    repeat-rich families, whose pairs also take the rare paths that run again inside a batch (more slow-path chains than
+    a pair's region holds, chunks beyond the wave kernel): triangle and rectangle against the oracle, and the edge
+    records in the order of the one-queue run"""
+    engine, ctx, torch = gpu
+    fr = _fuzz_repeats_module()
+    monkeypatch.setenv("SKDER_AMD_QUEUES", str(queues))
+    for seed in (12, 258, 4602238, 3400382):
+        _replay_repeat_family(gpu, oracle, fr, seed, batch_env=monkeypatch)
+    p = oracle.default_params()
+    rng = np.random.RandomState(5)
+    fam = _repeat_rich_family(rng)
+    bases, lens = [g[0] for g in fam], [g[1] for g in fam]
+    s, _ = _sketch(gpu, lens, bases)
+    monkeypatch.setenv("SKDER_AMD_CHUNK_BUDGET", "150")
+    several = np.array(s.triangle_rows(0, 1, 0.0), copy=True)
+    monkeypatch.setenv("SKDER_AMD_QUEUES", "1")
+    one = np.array(s.triangle_rows(0, 1, 0.0), copy=True)
+    assert several.tobytes() == one.tobytes()
+    s.close()
+
+
 def test_repetitive_cutoff_and_large_genome(gpu, oracle):
     """(a) genomes in which one 4 kb segment occurs 32 times: the repetitive cut-off becomes active (own
     multiplicity filter, every chunk on the slow path, look-ups through the bucket index); (b) a 15 Mb

@@ -7,6 +7,8 @@ t 240 fuzz_repeats.py 5200000 5203000 "" repeats
 t 120 fuzz_repeats.py 5300000 5301000 rep rep
 t 300 fuzz_repeats.py 5400000 5404000 batch batch
 t 120 fuzz_repeats.py 5500000 5501000 big big
+SKDER_AMD_QUEUES=2 t 200 fuzz_repeats.py 5800000 5803000 batch batch_two_queues
+SKDER_AMD_QUEUES=3 t 100 fuzz_repeats.py 5900000 5902000 batch batch_three_queues
 t 120 fuzz_repeats.py 5700000 5702000 append append
 t 100 fuzz_dropin.py 5600000 5601000 "" dropin
 python bench.py --no-realistic 2>/dev/null | tail -1 > gpurun_out/fuzz3/bench.json; python -c "
