@@ -520,11 +520,8 @@ void sketch_batch_impl(skder_sketches *s, const uint8_t *d_bases, const skder_ba
     for (uint32_t g = 0; g < b->n_genomes; g++) max_raw = std::max(max_raw, h_goff[g + 1] - h_goff[g]);
     uint32_t sort_cap = 1024;
     while (sort_cap < max_raw && sort_cap < MARK_SORT_CAP) sort_cap <<= 1;
-    static bool sort_attr_set = false;
-    if (!sort_attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(marker_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MARK_SORT_CAP * 8);
-        sort_attr_set = true;
-    }
+    // (every call: the attribute belongs to the device, and a process may use several)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(marker_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MARK_SORT_CAP * 8);
     hipLaunchKernelGGL(marker_sort_kernel, dim3(b->n_genomes), dim3(256), sort_cap * 8, st, raw_marks.p, d_goff.p,
                        d_nuniq.p, ctx->d_flags);
     for (uint32_t g = 0; g < b->n_genomes; g++)
