@@ -2008,15 +2008,17 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
             HIPCHECK(hipHostMalloc(&S.h_out, S.h_out_cap * sizeof(PairOut)));
         }
         const auto t_al0 = std::chrono::steady_clock::now();
-        S.d_pairs.resize(nb, S.st_join);
-        S.chunk_state.resize(nchunks + 1, S.st_join); S.chunk_mark.resize(nchunks + 1, S.st_join); S.slow_list.resize(nchunks + 1, S.st_join); S.over_list.resize(nchunks + 1, S.st_join);
-        S.fast_chains.resize(nchunks * FAST_SLOTS + 1, S.st_join);
-        S.counters.resize(32, S.st_join); S.flags.resize(16, S.st_join);
-        S.pair_na.resize(nb, S.st_join); S.pair_nch.resize(nb, S.st_join); S.pair_nmulti.resize(nb, S.st_join);
-        S.hits.resize(nhits + 64, S.st_join); S.multi.resize(nmulti + 1, S.st_join);
-        S.recs.resize(nrecs + 8, S.st_join); S.pair_over.resize(nb + 1, S.st_join); S.chunk_rec0.resize(nchunks + 1, S.st_join); S.gen_list.resize(nchunks + 256ull * GEN_LISTS + 1, S.st_join); S.gen_cnt.resize(GEN_LISTS, S.st_join);
-        S.chains.resize(ccap + 1, S.st_join);
-        S.d_out.resize(nb, S.st_join);
+        // work buffers hold nothing worth keeping between batches: a buffer that has to grow is replaced, not copied
+        auto grow = [&](auto &buf, size_t n) { buf.reserve(n, 0, S.st_join); buf.n = n; };
+        grow(S.d_pairs, nb);
+        grow(S.chunk_state, nchunks + 1); grow(S.chunk_mark, nchunks + 1); grow(S.slow_list, nchunks + 1); grow(S.over_list, nchunks + 1);
+        grow(S.fast_chains, nchunks * FAST_SLOTS + 1);
+        grow(S.counters, 32); grow(S.flags, 16);
+        grow(S.pair_na, nb); grow(S.pair_nch, nb); grow(S.pair_nmulti, nb);
+        grow(S.hits, nhits + 64); grow(S.multi, nmulti + 1);
+        grow(S.recs, nrecs + 8); grow(S.pair_over, nb + 1); grow(S.chunk_rec0, nchunks + 1); grow(S.gen_list, nchunks + 256ull * GEN_LISTS + 1); grow(S.gen_cnt, GEN_LISTS);
+        grow(S.chains, ccap + 1);
+        grow(S.d_out, nb);
         if (getenv("SKDER_AMD_DEBUG"))
             fprintf(stderr, "[skder_amd] host: work buffers of the batch ready after %.2f ms\n",
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_al0).count());
