@@ -10,6 +10,11 @@ indexes the genomes it owns, screens its share of the rows and chains the pairs 
 
 The JSON line also carries `roofline` (dominant kernel: algorithmic bytes / HIP-event time vs the
 8 TB/s HBM peak) and `cpu_baseline` (the CPU oracle timed on a bounded sample on this host)."""
+import os as _os
+# ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  Under torch.distributed RCCL and torch own
+# several streams, and the library's two chaining queues then share ONE hardware queue and stop overlapping (measured:
+# the chain stage 45 ms instead of 42); must be set before the HIP runtime initialises.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import argparse
 import json
 import os

@@ -164,6 +164,8 @@ int skder_amd_rectangle(skder_sketches_t *refs, skder_sketches_t *queries, doubl
  * but builds the k-mer bucket index only for the genomes it OWNS (full[g] != 0; the others get their chunk tables only)
  * and chains the pairs that PROBE one of its genomes; the marker screen is dealt out by rows.  skder_amd/multigpu.py
  * (one process per GPU, RCCL) and skder_amd_triangle_multi below (one process, several GPUs) are built from these. */
+/* The build is enqueued on the context's second queue and returns: skder_amd_screen_rows, which reads the markers only, runs
+ * beside it; every call that needs the index or its per-genome results (_rep_cuts, _pairs_probed, _chain_pairs) waits for it. */
 int skder_amd_sketches_index_part(skder_sketches_t *s, const uint8_t *full /* n_genomes flags; NULL: all */);
 /* repetitive-k-mer cut-off of every genome: what this set computed for the genomes it indexed fully, 0xFFFFFFFF ("unknown
  * here") for the others; the element-wise minimum over the GPUs is the table to install with _set_rep_cuts */

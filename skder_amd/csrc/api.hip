@@ -236,12 +236,16 @@ extern "C" int skder_amd_sketches_index(skder_sketches_t *s)
     API_CATCH_CTX(s->ctx, 2)
 }
 
+static void settle_index(skder_sketches *s);     // an index build left pending by skder_amd_sketches_index_part: wait for it
+
 // debugging / parity-test accessors: copy a genome's index-stage products to the host
 extern "C" int skder_amd_debug_genome(skder_sketches_t *s, uint32_t g, uint32_t *n_chunks, uint32_t *rep_cut, uint32_t *bucket_bits,
                                       uint32_t *h_skmer, uint32_t *h_sgpos, uint32_t *h_sctg, uint32_t *h_pchunk)
 {
-    if (!s || g >= s->n_genomes || !s->indexed) return 1;
+    if (!s || g >= s->n_genomes) return 1;
     API_TRY
+    settle_index(s);
+    if (!s->indexed) return 1;
     HIPCHECK(hipSetDevice(s->ctx->device));
     const GenomeMeta &m = s->h_meta[g];
     if (n_chunks) *n_chunks = m.n_chunks;
@@ -274,17 +278,30 @@ extern "C" int skder_amd_sketches_index_part(skder_sketches_t *s, const uint8_t 
     API_TRY
     HIPCHECK(hipSetDevice(s->ctx->device));
     if (s->indexed || s->index_pending) throw SkError("sketch set already indexed");
-    index_begin(s, s->ctx->stream, full);
-    index_finish(s);
+    // enqueued on the second queue and left pending: skder_amd_screen_rows, which does not read the index, runs beside it;
+    // the calls that need the index or its per-genome results (rep_cuts, pairs_probed, chain_pairs, ...) wait for it
+    index_begin(s, s->ctx->stream2 ? s->ctx->stream2 : s->ctx->stream, full);
     return 0;
     API_CATCH_CTX(s->ctx, 2)
 }
 
+static void settle_index(skder_sketches *s)
+{
+    if (s->index_pending) {
+        HIPCHECK(hipSetDevice(s->ctx->device));
+        index_finish(s);
+    }
+}
+
 extern "C" int skder_amd_sketches_rep_cuts(skder_sketches_t *s, uint32_t *out)
 {
-    if (!s || !out || !s->indexed) return 1;
+    if (!s || !out) return 1;
+    API_TRY
+    settle_index(s);
+    if (!s->indexed) return 1;
     for (uint32_t g = 0; g < s->n_genomes; g++) out[g] = s->full_index[g] ? s->h_meta[g].rep_cut : 0xFFFFFFFFu;
     return 0;
+    API_CATCH_CTX(s->ctx, 2)
 }
 
 extern "C" int skder_amd_sketches_set_rep_cuts(skder_sketches_t *s, const uint32_t *in)
@@ -292,6 +309,7 @@ extern "C" int skder_amd_sketches_set_rep_cuts(skder_sketches_t *s, const uint32
     if (!s || !in) return 1;
     API_TRY
     HIPCHECK(hipSetDevice(s->ctx->device));
+    settle_index(s);
     std::vector<uint8_t> mask(s->n_genomes);
     for (uint32_t g = 0; g < s->n_genomes; g++) mask[g] = s->full_index[g] ? 0 : 1;     // own values stay
     index_set_rep_cuts(s, in, mask.data());
@@ -305,7 +323,7 @@ extern "C" int skder_amd_screen_rows(skder_sketches_t *s, uint32_t row_begin, ui
     if (!s) return 1;
     API_TRY
     HIPCHECK(hipSetDevice(s->ctx->device));
-    if (!s->indexed) throw SkError("screen_rows: index the set first (skder_amd_sketches_index or _index_part)");
+    if (!s->indexed && !s->index_pending) throw SkError("screen_rows: index the set first (skder_amd_sketches_index or _index_part)");
     screen_rows_impl(s, row_begin, row_stride, screen_pct, s->ctx->pairs_ref, s->ctx->pairs_query);
     if (ref) *ref = s->ctx->pairs_ref.data();
     if (query) *query = s->ctx->pairs_query.data();
@@ -319,6 +337,8 @@ extern "C" int skder_amd_pairs_probed(skder_sketches_t *refs, skder_sketches_t *
 {
     if (!refs || !queries || (n_pairs && (!ref || !query || !probed))) return 1;
     API_TRY
+    settle_index(refs);
+    settle_index(queries);
     pairs_probed_impl(refs, queries, ref, query, n_pairs, probed, probed_is_query);
     return 0;
     API_CATCH_CTX(refs->ctx, 2)
@@ -330,6 +350,8 @@ extern "C" int skder_amd_chain_pairs(skder_sketches_t *refs, skder_sketches_t *q
     if (!refs || !queries || refs->ctx != queries->ctx || (n_pairs && (!ref || !query))) return 1;
     API_TRY
     HIPCHECK(hipSetDevice(refs->ctx->device));
+    settle_index(refs);
+    settle_index(queries);
     chain_pairs_impl(refs, queries, ref, query, n_pairs);
     if (edges) *edges = refs->ctx->edges.data();
     if (n_edges) *n_edges = refs->ctx->edges.size();

@@ -196,16 +196,35 @@ def route_pairs(ref: np.ndarray, query: np.ndarray, probed: np.ndarray, world: i
 
 def triangle_sharded(sk, rank: int, world: int, screen_pct: float, group=None, copy: bool = True) -> np.ndarray:
     """this rank's share of the all-pairs table of `sk` (a set holding ALL genomes, not indexed yet): see the module text"""
+    import os
+    import sys
+    import time
+    dbg = os.environ.get("SKDER_AMD_DEBUG") is not None
+    t = [time.perf_counter()]
+
+    def lap():
+        if dbg:
+            t.append(time.perf_counter())
+
     n = sk.view()["n_genomes"]
     owned = (np.arange(n) % world == rank).astype(np.uint8)
-    sk.index_part(owned)
+    sk.index_part(owned)          # enqueued on the second queue: the marker screen below runs beside it
+    lap()
+    ref, query = sk.screen_rows(rank, world, screen_pct)
+    lap()
     nccl = dist.get_backend(group) == "nccl"
     dev = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
     # repetitive-k-mer cut-offs: every rank knows its own genomes' (others: 0xFFFFFFFF), the minimum is the table
-    rc = torch.from_numpy(sk.rep_cuts(n).astype(np.int64)).to(dev)
+    rc = torch.from_numpy(sk.rep_cuts(n).astype(np.int64)).to(dev)          # (waits for the index build)
     dist.all_reduce(rc, op=dist.ReduceOp.MIN, group=group)
     sk.set_rep_cuts(rc.cpu().numpy().astype(np.uint32))
-    ref, query = sk.screen_rows(rank, world, screen_pct)
+    lap()
     probed = sk.pairs_probed(ref, query)
     ref, query = route_pairs(ref, query, probed, world, rank, group)
-    return sk.chain_pairs(ref, query, copy=copy)
+    lap()
+    edges = sk.chain_pairs(ref, query, copy=copy)
+    lap()
+    if dbg and rank == 0:
+        names = ("index_part (enqueue)", "screen_rows", "index wait + rep_cuts", "route_pairs", "chain_pairs")
+        print("[skder_amd] triangle_sharded: " + ", ".join("%s %.2f ms" % (k, 1e3 * (t[i + 1] - t[i])) for i, k in enumerate(names)), file=sys.stderr)
+    return edges
