@@ -326,8 +326,8 @@ def cpu_baseline_files(tmp, paths, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)     # the first steps of the first process on a box run a few ms slower
     ap.add_argument("--genomes", type=int, default=5000)
     ap.add_argument("--genome-len", type=int, default=3_000_000)
     ap.add_argument("--len-range", type=int, nargs=2, default=None, metavar=("LO", "HI"),
