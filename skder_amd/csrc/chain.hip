@@ -1811,6 +1811,8 @@ struct ChainWork {
     DevBuf<uint64_t> ORD;
     ScanWorkspace ws;
     hipEvent_t ev_order = nullptr;
+    const uint32_t *oriented_ref = nullptr;      // chain_pairs_orient ran for this pair list (W.jobs holds the ordered work)
+    size_t oriented_np = 0;
     hipStream_t stream3 = nullptr;
     ~ChainWork() { if (ev_order) (void)hipEventDestroy(ev_order); if (stream3) (void)hipStreamDestroy(stream3); }
 };
@@ -1823,29 +1825,13 @@ static ChainWork *chain_work(skder_ctx *ctx)
     return static_cast<ChainWork *>(ctx->chain_work);
 }
 
-// pairs: (ref genome in set A, query genome in set B); for the triangle A == B.
-void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint32_t> &pref, const std::vector<uint32_t> &pquery,
-                 std::vector<skder_edge_t> &edges)
+// orientation of every pair, then the work ordered by the probed genome (R): consecutive workgroups probe the same hash
+// table, which keeps it in the XCD's L2.  Needs the genome table's lengths and counts only (there from index_begin on), so
+// triangle_rows_impl / rectangle_impl call it while the index kernels are still running; chain_pairs does it itself otherwise.
+static void chain_pairs_orient(skder_sketches *SA, skder_sketches *SB, const std::vector<uint32_t> &pref, const std::vector<uint32_t> &pquery)
 {
-    skder_ctx *ctx = SA->ctx;
-    hipStream_t st = ctx->stream;
+    ChainWork &W = *chain_work(SA->ctx);
     const size_t np = pref.size();
-    size_t budget = 6u << 20;   // chunks (work items) per batch
-    int nqueues = 1;
-    uint32_t join_group_max = 8;       // pairs per join workgroup (8: 24.6 ms per step of the benchmark; 16: 25.9; 4: 24.7; 32: 28.8)
-    if (const char *e = getenv("SKDER_AMD_JOIN_GROUP")) join_group_max = (uint32_t)atoi(e);
-    hipStream_t queues[3] = {st, st, st};
-    if (const char *e = getenv("SKDER_AMD_CHUNK_BUDGET")) budget = strtoull(e, nullptr, 10);
-    ChainWork &W = *chain_work(ctx);
-    const SetView VA = view_of(SA), VB = view_of(SB);
-    // debugging switches: SKDER_AMD_NO_XCD keeps the join's groups in launch order; SKDER_AMD_FORCE_SLOW sends every chunk down the slow path;
-    // SKDER_AMD_NO_SIEVE hands every chunk with hits to chain_runs_kernel (to tell the two fast kernels apart behind a parity failure)
-    int xcd_remap = (getenv("SKDER_AMD_NO_XCD") ? 0 : 1) | (getenv("SKDER_AMD_FORCE_SLOW") ? 2 : 0);
-    if (const char *e = getenv("SKDER_AMD_NO_SIEVE")) xcd_remap |= atoi(e) ? 1024 : 0;
-    double t_fast = 0, t_slow = 0, t_fin = 0, t_join = 0, t_runs = 0;
-    uint64_t tot_anchors = 0, tot_slow = 0, tot_chunks = 0, tot_over = 0;
-    // orientation of every pair, then order the work by the probed genome (R): consecutive
-    // workgroups probe the same hash table, which keeps it in the XCD's L2
     const auto t_host0 = std::chrono::steady_clock::now();
     std::vector<PairJob> &jobs = W.jobs, &sorted = W.jobs_sorted;     // kept across calls: no fresh pages to fault in
     jobs.resize(np); sorted.resize(np);
@@ -1898,10 +1884,37 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         run(scatter);
         jobs.swap(sorted);
     }
-    const auto t_host1 = std::chrono::steady_clock::now();
+    W.oriented_ref = pref.data(); W.oriented_np = np;
     if (getenv("SKDER_AMD_DEBUG"))
         fprintf(stderr, "[skder_amd] host: orient+sort of %zu pairs %.2f ms\n", np,
-                std::chrono::duration<double, std::milli>(t_host1 - t_host0).count());
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count());
+}
+
+// pairs: (ref genome in set A, query genome in set B); for the triangle A == B.
+void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint32_t> &pref, const std::vector<uint32_t> &pquery,
+                 std::vector<skder_edge_t> &edges)
+{
+    skder_ctx *ctx = SA->ctx;
+    hipStream_t st = ctx->stream;
+    const size_t np = pref.size();
+    size_t budget = 6u << 20;   // chunks (work items) per batch
+    int nqueues = 1;
+    uint32_t join_group_max = 8;       // pairs per join workgroup (8: 24.6 ms per step of the benchmark; 16: 25.9; 4: 24.7; 32: 28.8)
+    if (const char *e = getenv("SKDER_AMD_JOIN_GROUP")) join_group_max = (uint32_t)atoi(e);
+    hipStream_t queues[3] = {st, st, st};
+    if (const char *e = getenv("SKDER_AMD_CHUNK_BUDGET")) budget = strtoull(e, nullptr, 10);
+    ChainWork &W = *chain_work(ctx);
+    const SetView VA = view_of(SA), VB = view_of(SB);
+    // debugging switches: SKDER_AMD_NO_XCD keeps the join's groups in launch order; SKDER_AMD_FORCE_SLOW sends every chunk down the slow path;
+    // SKDER_AMD_NO_SIEVE hands every chunk with hits to chain_runs_kernel (to tell the two fast kernels apart behind a parity failure)
+    int xcd_remap = (getenv("SKDER_AMD_NO_XCD") ? 0 : 1) | (getenv("SKDER_AMD_FORCE_SLOW") ? 2 : 0);
+    if (const char *e = getenv("SKDER_AMD_NO_SIEVE")) xcd_remap |= atoi(e) ? 1024 : 0;
+    double t_fast = 0, t_slow = 0, t_fin = 0, t_join = 0, t_runs = 0;
+    uint64_t tot_anchors = 0, tot_slow = 0, tot_chunks = 0, tot_over = 0;
+    // orientation + order by probed genome: done already if the caller used the wait for the index kernels for it
+    if (!(W.oriented_ref == pref.data() && W.oriented_np == np)) chain_pairs_orient(SA, SB, pref, pquery);
+    W.oriented_ref = nullptr; W.oriented_np = 0;
+    std::vector<PairJob> &jobs = W.jobs;
     // ---- the chaining stage of a batch whose hit words exist: fast path, slow path, finalize, results
     auto chain_stage = [&](ChainSlot &S) {
         const uint32_t nb = S.nb;
@@ -2348,6 +2361,7 @@ void triangle_rows_impl(skder_sketches *s, uint32_t row_begin, uint32_t row_stri
         float ms;
         HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[9], ctx->ev[10]));
         ctx->timing[2] += ms;
+        if (s->index_pending) chain_pairs_orient(s, s, prow, ppart);     // host work beside the index kernels
         index_impl(s);
         // triangle row (i, j): Ref = i, Query = j
         const auto t0 = std::chrono::steady_clock::now();
