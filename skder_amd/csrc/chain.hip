@@ -1509,7 +1509,9 @@ __device__ __forceinline__ double root_k(uint64_t num, uint64_t den)
         double yp = 1.0;
 #pragma unroll
         for (int i = 0; i < ANI_K - 1; i++) yp = yp * y;
-        y = (km1 * y + x / yp) / kk;
+        const double yn = (km1 * y + x / yp) / kk;
+        if (yn == y) break;      // a fixed point: every further iteration returns the same value (the result is unchanged)
+        y = yn;
     }
     return y;
 }
@@ -1565,28 +1567,33 @@ __global__ __launch_bounds__(256) void finalize_kernel_t(SetView A, SetView B, c
     const PairDesc pd = pairs[pidx];
     const uint32_t tid = threadIdx.x;
     if (tid == 0) { s_cells = 0; s_seeds = 0; s_anch = 0; s_span = 0; s_kept = 0; s_unknown = 0; s_n = 0; }
+    // what the last lane standing needs at the very end is requested now (the workgroup holds its LDS until then)
+    const uint64_t len_q = ((pd.flags & 2u) ? B : A).meta[pd.q].total_len, len_r = ((pd.flags & 4u) ? B : A).meta[pd.r].total_len;
+    const uint32_t n_anchors_pair = pair_na[pidx];
     __syncthreads();
     // gather: chains of the fast path (per-chunk slots) and of the slow path (per-pair list)
     uint32_t nslow = pair_nch[pidx];
     if (nslow > pd.c_cap) nslow = pd.c_cap;
-    const uint32_t nfast_items = pd.n_chunks * FAST_SLOTS;
-    for (uint32_t i = tid; i < nfast_items + nslow; i += 256) {
-        ChainRec c;
-        if (i < nfast_items) {
-            const uint32_t ck = i / FAST_SLOTS, k = i - ck * FAST_SLOTS;
-            const uint32_t st = chunk_state[pd.chunk_base + ck];
-            if (st == CHUNK_SLOW || k >= st) continue;
-            c = fast_chains[(uint64_t)(pd.chunk_base + ck) * FAST_SLOTS + k];
-        } else {
-            c = chains[pd.c_base + (i - nfast_items)];
-        }
+    auto put = [&](const ChainRec &c) {
         const uint32_t d = atomicAdd(&s_n, 1u);
         if (d < lds_cap) {
             sc[d] = c.score; q0[d] = c.q0; q1[d] = c.q1; r0[d] = c.r0; r1[d] = c.r1; ckc[d] = c.chunk;
             na[d] = c.n; nsd[d] = c.n_seeds;
             state[d] = 0;
         }
+    };
+    // one chunk per thread: its state, then all of its chains at once (a 3 Mb genome has 150 chunks: one trip)
+    for (uint32_t ck = tid; ck < pd.n_chunks; ck += 256) {
+        const uint32_t st = chunk_state[pd.chunk_base + ck];
+        if (st == CHUNK_SLOW || st == 0u) continue;
+        const ChainRec *fc = fast_chains + (uint64_t)(pd.chunk_base + ck) * FAST_SLOTS;
+        ChainRec c[FAST_SLOTS];
+#pragma unroll
+        for (uint32_t k = 0; k < FAST_SLOTS; k++) if (k < st) c[k] = fc[k];
+#pragma unroll
+        for (uint32_t k = 0; k < FAST_SLOTS; k++) if (k < st) put(c[k]);
     }
+    for (uint32_t i = tid; i < nslow; i += 256) put(chains[pd.c_base + i]);
     __syncthreads();
     uint32_t n = s_n;
     if (n > lds_cap) {
@@ -1716,20 +1723,23 @@ __global__ __launch_bounds__(256) void finalize_kernel_t(SetView A, SetView B, c
         atomicAdd(&s_kept, kept);
     }
     __syncthreads();
+    if (tid >= 64) return;
+    // the two 15-th roots are serial double arithmetic: one lane each
+    double root = 0.0;
+    if (tid < 2 && s_seeds) root = root_k(s_anch, tid == 0 ? s_cells : s_seeds);
+    const double root_cell = __shfl(root, 0, 64), root_span = __shfl(root, 1, 64);
     if (tid == 0) {
-        const SetView &QS = (pd.flags & 2u) ? B : A;
-        const SetView &RS = (pd.flags & 4u) ? B : A;
         PairOut o;
         o.cell_seeds = s_cells; o.sum_seeds = s_seeds; o.sum_anchors = s_anch; o.sum_span = s_span;
-        o.n_chains = s_kept; o.n_chains_all = n; o.n_anchors = pair_na[pidx]; o.pad = 0;
+        o.n_chains = s_kept; o.n_chains_all = n; o.n_anchors = n_anchors_pair; o.pad = 0;
         o.ani_raw = 0.0; o.ani_span = 0.0; o.ani = 0.0;
         if (s_seeds) {
-            o.ani_raw = root_k(s_anch, s_cells);
-            o.ani_span = root_k(s_anch, s_seeds);
+            o.ani_raw = root_cell;
+            o.ani_span = root_span;
             o.ani = model_ani(o.ani_raw, o.ani_span);
         }
         const double Bv = (double)(s_span + (unsigned long long)ANI_PAD * s_kept);
-        const uint64_t tq = QS.meta[pd.q].total_len, tr = RS.meta[pd.r].total_len;
+        const uint64_t tq = len_q, tr = len_r;
         double afq = tq ? Bv / (double)tq : 0.0, afr = tr ? Bv / (double)tr : 0.0;
         if (afq > 1.0) afq = 1.0;
         if (afr > 1.0) afr = 1.0;
