@@ -535,14 +535,18 @@ __global__ __launch_bounds__(256) void chain_single_kernel(SetView A, SetView B,
     if (in) {
         const uint32_t idx0 = chunk_rec0[t];                 // independent of the descriptor: in flight beside it
         pi = wg_pair[wg];
-        {
-            // a workgroup's 256 chunks rarely span more than three pairs: their first chunks in one go, no dependent search
-            const uint32_t p1 = pi + 1u < npairs ? pi + 1u : pi, p2 = pi + 2u < npairs ? pi + 2u : p1;
-            const uint32_t cb1 = pairs[p1].chunk_base, cb2 = pairs[p2].chunk_base;
-            if (p2 != p1 && cb2 <= t) { pi = p2; while (pi + 1u < npairs && pairs[pi + 1u].chunk_base <= t) pi++; }
-            else if (p1 != pi && cb1 <= t) pi = p1;
-        }
-        const PairDesc pd = pairs[pi];
+        // a workgroup's 256 chunks rarely span more than three pairs.  The descriptors of the first two are requested whole
+        // at once (the same two addresses for the whole wavefront) and the third one's first chunk beside them: the
+        // usual chunk then has its descriptor without a dependent load; only a chunk of the third pair or beyond looks again
+        const uint32_t p1 = pi + 1u < npairs ? pi + 1u : pi, p2 = pi + 2u < npairs ? pi + 2u : p1;
+        const PairDesc pd0 = pairs[pi], pd1 = pairs[p1];
+        const uint32_t cb2 = pairs[p2].chunk_base;
+        PairDesc pd = pd0;
+        if (p2 != p1 && cb2 <= t) {
+            pi = p2;
+            while (pi + 1u < npairs && pairs[pi + 1u].chunk_base <= t) pi++;
+            pd = pairs[pi];
+        } else if (p1 != pi && pd1.chunk_base <= t) { pi = p1; pd = pd1; }
         uint32_t over = pair_over[pi];
         const uint32_t c = t - pd.chunk_base;
         const SetView &QS = (pd.flags & 2u) ? B : A;
