@@ -252,12 +252,19 @@ __global__ __launch_bounds__(IDXF_THREADS) void index_genome_lds_kernel(
             // sorted in registers by (k-mer, seed index) -- seeds are in position order, so the seed index
             // orders equal k-mers by position
             uint64_t key[9];
+            // the longest bucket among the lanes here decides how many entries are fetched at all (mostly 3 or 4 of the 8)
+            uint32_t kmax = 2;
+#pragma unroll
+            for (int i = 2; i < 8; i++) if (__any(k > (uint32_t)i)) kmax = (uint32_t)i + 1u;
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-                const bool in = (uint32_t)i < k;
-                const uint32_t si = in ? perm[lo + i] : 0u;
-                const uint32_t kk = packed[si].x & SK_SEED_MASK;
-                key[i] = in ? (((uint64_t)kk << 16) | si) : ~0ull;
+                key[i] = ~0ull;
+                if ((uint32_t)i < kmax) {       // wave-uniform
+                    const bool in = (uint32_t)i < k;
+                    const uint32_t si = in ? perm[lo + i] : 0u;
+                    const uint32_t kk = packed[si].x & SK_SEED_MASK;
+                    key[i] = in ? (((uint64_t)kk << 16) | si) : ~0ull;
+                }
             }
             key[8] = ~0ull;
 #define CE(A_, B_) { const uint64_t x_ = key[A_], y_ = key[B_]; const bool sw_ = y_ < x_; key[A_] = sw_ ? y_ : x_; key[B_] = sw_ ? x_ : y_; }

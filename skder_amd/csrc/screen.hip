@@ -12,6 +12,8 @@
 #define MK_EMPTY 0xFFFFFFFFFFFFFFFFULL
 #define SCREEN_JTILE 8192
 #define SCREEN_U 4             // markers per wave and trip of screen_rows_kernel
+#define SCREEN_THREADS 1024    // 16 waves per row: the kernel is a chain of dependent loads per marker, and a CU's LDS holds
+#define SCREEN_WAVES (SCREEN_THREADS / 64u)   // few rows' counters -- more waves per row put more loads in flight
 
 __device__ __forceinline__ uint64_t mix64(uint64_t x)
 {
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(256) void table_fill_kernel(const GenomeMeta *__res
 // one workgroup per row: count shared markers with every partner genome of the current j-tile in
 // LDS, decide, and write the row's pass bits.  triangle != 0: only partners j > row are counted.
 // q_slot_of: slot of each of the row genome's markers in the reference table, or 0xFFFFFFFF.
-__global__ __launch_bounds__(256) void screen_rows_kernel(
+__global__ __launch_bounds__(SCREEN_THREADS) void screen_rows_kernel(
     const GenomeMeta *__restrict__ qmeta, const uint32_t *__restrict__ q_slot_of, const GenomeMeta *__restrict__ rmeta,
     uint32_t n_ref, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ list,
     const uint32_t *__restrict__ rows, int triangle, double cutoff, int screen_on,
@@ -75,16 +77,16 @@ __global__ __launch_bounds__(256) void screen_rows_kernel(
     if (tid == 0) s_rowcnt = 0;
     for (uint32_t j0 = 0; j0 < n_ref; j0 += SCREEN_JTILE) {
         const uint32_t j1 = j0 + SCREEN_JTILE < n_ref ? j0 + SCREEN_JTILE : n_ref;
-        for (uint32_t j = tid; j < SCREEN_JTILE; j += 256) cnt[j] = 0;
+        for (uint32_t j = tid; j < SCREEN_JTILE; j += SCREEN_THREADS) cnt[j] = 0;
         __syncthreads();
         if (!(triangle && j1 <= row + 1)) {
             // one wave per marker, SCREEN_U markers per trip: their slots, then their list bounds, then the first
             // 128 entries of every list are requested together (three dependent loads per marker otherwise)
-            for (uint32_t e0 = wave; e0 < q.n_markers; e0 += 4 * SCREEN_U) {
+            for (uint32_t e0 = wave; e0 < q.n_markers; e0 += SCREEN_WAVES * SCREEN_U) {
                 uint32_t slot[SCREEN_U], lo[SCREEN_U], hi[SCREEN_U], ja[SCREEN_U], jb[SCREEN_U];
 #pragma unroll
                 for (int u = 0; u < SCREEN_U; u++) {
-                    const uint32_t e = e0 + 4u * u;
+                    const uint32_t e = e0 + SCREEN_WAVES * u;
                     slot[u] = e < q.n_markers ? q_slot_of[q.marker_off + e] : 0xFFFFFFFFu;
                 }
 #pragma unroll
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(256) void screen_rows_kernel(
         }
         __syncthreads();
         // decisions, 64 partners per wave-iteration -> one 64-bit word of the row bitmap
-        for (uint32_t jb = j0 + wave * 64; jb < j1; jb += 256) {
+        for (uint32_t jb = j0 + wave * 64; jb < j1; jb += SCREEN_THREADS) {
             const uint32_t j = jb + lane;
             bool pass = false;
             if (j < j1 && (!triangle || j > row)) {
@@ -237,7 +239,7 @@ void screen_pairs(skder_sketches *refs, skder_sketches *queries, const std::vect
     HIPCHECK(hipMemsetAsync(row_count.p + nrows, 0, 4, st));
     HIPCHECK(hipMemsetAsync(pass_bits.p, 0, (size_t)nrows * wpr * 8, st));
     const double cutoff = screen_cutoff(screen_pct);
-    hipLaunchKernelGGL(screen_rows_kernel, dim3(nrows), dim3(256), 0, st, queries->d_meta.p, q_slot_ptr, refs->d_meta.p, nref,
+    hipLaunchKernelGGL(screen_rows_kernel, dim3(nrows), dim3(SCREEN_THREADS), 0, st, queries->d_meta.p, q_slot_ptr, refs->d_meta.p, nref,
                        loff.p, list.p, d_rows.p, triangle ? 1 : 0, cutoff, screen_pct > 0.0 ? 1 : 0, pass_bits.p, wpr,
                        row_count.p);
     HIPCHECK(hipGetLastError());
