@@ -23,10 +23,14 @@
 // ---------------------------------------------------------------------------------------------
 // device helpers
 
+// mm_hash64 (include/skder_amd_spec.h).  The complement of the first step is moved behind the first xor-shift, where it is one
+// xor of the high word: with p = key + (key << 21), ~p ^ (~p >> 24) == p ^ (p >> 24) ^ 0xFFFFFF0000000000.
+// (Spelling the constant multiplications out as v_mad_u64_u32 for the low word plus v_mul_lo_u32 and an add for the high
+// word -- instead of the two v_mad_u64_u32 and two register moves the compiler takes -- was measured: 31.0 instead of 29.5 ms.)
 __device__ __forceinline__ uint64_t mm_hash64(uint64_t key)
 {
-    key = ~(key + (key << 21));      // skani's Rust spelling of the first step: include/skder_amd_spec.h
-    key = key ^ (key >> 24);
+    key = key + (key << 21);
+    key = key ^ (key >> 24) ^ 0xFFFFFF0000000000ull;
     key = (key + (key << 3)) + (key << 8);
     key = key ^ (key >> 14);
     key = (key + (key << 2)) + (key << 4);
