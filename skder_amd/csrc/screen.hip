@@ -39,7 +39,10 @@ __global__ __launch_bounds__(256) void table_insert_kernel(const GenomeMeta *__r
         const uint64_t key = markers[m.marker_off + e];
         uint64_t slot = mix64(key) & mask;
         for (;;) {
-            unsigned long long old = atomicCAS(&keys[slot], (unsigned long long)MK_EMPTY, (unsigned long long)key);
+            // a slot goes from empty to its key once and stays: a plain load that already shows the key (about 49 of 50
+            // occurrences in a set of related genomes) saves the compare-and-swap; a stale "empty" just takes it
+            unsigned long long old = __builtin_nontemporal_load(&keys[slot]);
+            if (old == MK_EMPTY) old = atomicCAS(&keys[slot], (unsigned long long)MK_EMPTY, (unsigned long long)key);
             if (old == MK_EMPTY || old == key) break;
             slot = (slot + 1) & mask;
         }
