@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256) void run_extract_kernel(SetView A, SetView B, 
                 } else { r.pq = pq_in; r.pw = pw_in; r.pqi = pv_in == 0xFFFFFFFFu ? 0xFFFFFFFFu : pv_in - a; }
                 const uint32_t at = reg0 + run_rec + rex + j;
                 out_base[at] = r;
-                if ((firstmask >> u) & 1u) atomicMin(&rec0[ck_of[r.qi]], at);
+                if ((firstmask >> u) & 1u) atomicMin(&rec0[ck_of[r.qi]], at);      // (a plain store where no other quarter can have the chunk: measured slower, 11.9 against 10.8 ms)
                 j++;
             }
 #undef SEL4
