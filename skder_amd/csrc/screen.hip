@@ -32,7 +32,7 @@ __global__ void table_clear_kernel(uint64_t *keys, uint32_t *cnt, uint64_t ts)
 // one workgroup per reference genome: claim a slot for every marker, count occurrences
 __global__ __launch_bounds__(256) void table_insert_kernel(const GenomeMeta *__restrict__ meta, const uint64_t *__restrict__ markers,
                                                            unsigned long long *keys, uint32_t *cnt, uint64_t mask,
-                                                           uint32_t *__restrict__ slot_of)
+                                                           uint32_t *__restrict__ slot_of, uint32_t *__restrict__ pos_of)
 {
     const GenomeMeta m = meta[blockIdx.x];
     for (uint32_t e = threadIdx.x; e < m.n_markers; e += 256) {
@@ -46,20 +46,20 @@ __global__ __launch_bounds__(256) void table_insert_kernel(const GenomeMeta *__r
             if (old == MK_EMPTY || old == key) break;
             slot = (slot + 1) & mask;
         }
-        atomicAdd(&cnt[slot], 1u);
+        // the count before this occurrence is its place in the marker's genome list: table_fill_kernel needs no atomic of its own
+        pos_of[m.marker_off + e] = atomicAdd(&cnt[slot], 1u);
         slot_of[m.marker_off + e] = (uint32_t)slot;
     }
 }
 
 __global__ __launch_bounds__(256) void table_fill_kernel(const GenomeMeta *__restrict__ meta, const uint32_t *__restrict__ slot_of,
-                                                         const uint32_t *__restrict__ loff, uint32_t *cursor,
+                                                         const uint32_t *__restrict__ loff, const uint32_t *__restrict__ pos_of,
                                                          uint32_t *__restrict__ list)
 {
     const GenomeMeta m = meta[blockIdx.x];
     for (uint32_t e = threadIdx.x; e < m.n_markers; e += 256) {
-        uint32_t slot = slot_of[m.marker_off + e];
-        uint32_t p = atomicAdd(&cursor[slot], 1u);
-        list[loff[slot] + p] = blockIdx.x;
+        const uint32_t slot = slot_of[m.marker_off + e];
+        list[loff[slot] + pos_of[m.marker_off + e]] = blockIdx.x;
     }
 }
 
@@ -210,16 +210,15 @@ void screen_pairs(skder_sketches *refs, skder_sketches *queries, const std::vect
         uint64_t ts = 1024;
         while (ts < 2 * total_marks) ts <<= 1;
         if (ts > 0x80000000ull) throw SkError("marker table too large");
-        DevBuf<uint32_t> cnt, cursor;
-        X.keys.resize(ts, st); cnt.resize(ts + 1, st); X.loff.resize(ts + 1, st); cursor.resize(ts, st);
+        DevBuf<uint32_t> cnt, pos_of;
+        X.keys.resize(ts, st); cnt.resize(ts + 1, st); X.loff.resize(ts + 1, st); pos_of.resize(total_marks + 1, st);
         X.slot_of.resize(total_marks + 1, st); X.list.resize(total_marks + 1, st);
         hipLaunchKernelGGL(table_clear_kernel, dim3(2048), dim3(256), 0, st, X.keys.p, cnt.p, ts);
         HIPCHECK(hipMemsetAsync(cnt.p + ts, 0, 4, st));
-        HIPCHECK(hipMemsetAsync(cursor.p, 0, ts * 4, st));
         hipLaunchKernelGGL(table_insert_kernel, dim3(nref), dim3(256), 0, st, refs->d_meta.p, refs->markers.p,
-                           reinterpret_cast<unsigned long long *>(X.keys.p), cnt.p, ts - 1, X.slot_of.p);
+                           reinterpret_cast<unsigned long long *>(X.keys.p), cnt.p, ts - 1, X.slot_of.p, pos_of.p);
         exclusive_scan_u32(cnt.p, X.loff.p, ts + 1, ws, st);
-        hipLaunchKernelGGL(table_fill_kernel, dim3(nref), dim3(256), 0, st, refs->d_meta.p, X.slot_of.p, X.loff.p, cursor.p, X.list.p);
+        hipLaunchKernelGGL(table_fill_kernel, dim3(nref), dim3(256), 0, st, refs->d_meta.p, X.slot_of.p, X.loff.p, pos_of.p, X.list.p);
         X.ts = ts;
         X.built = true;
     }
