@@ -1779,8 +1779,8 @@ static bool chunk_the_query(const GenomeMeta &ref, const GenomeMeta &query)
 }
 
 // work buffers of chain_pairs, kept across calls (grow-only) so that steady-state calls allocate nothing.
-// Two complete sets (slots): while the device works on the batch of one slot, the host reads back and
-// post-processes the other slot's results and prepares the descriptors of the next batch.
+// CHAIN_SLOTS complete sets (slots): while the device works on the batches of two slots (one per queue), the host reads
+// back and post-processes the third slot's results and prepares the descriptors of the next batch.
 struct ChainSlot {
     DevBuf<PairDesc> d_pairs;
     DevBuf<uint32_t> chunk_state, chunk_mark, slow_list, counters, pair_na, pair_nch;
@@ -2170,7 +2170,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
             fprintf(stderr, "[skder_amd] batch: over %u; %u pairs %llu chunks, room for %llu run records, %u to the run loop, slow %u (none %u, slots %u, hits %u, ring %u, branch %u, score %u, qrep %u, inside %u, records-full %u, run-not-dominant %u)\n",
                     nover, nb, (unsigned long long)S.nchunks, (unsigned long long)S.nrecs, hcnt[11], nslow, hcnt[1], hcnt[2], hcnt[3], hcnt[4], hcnt[5], hcnt[6], hcnt[7], hcnt[8], hcnt[9], hcnt[10]);
         }
-        // Rare-path fix-ups; the slot's buffers are untouched since (the batch in flight uses the other slot).
+        // Rare-path fix-ups; the slot's buffers are untouched since (the batches in flight use the other slots).
         //  * nover: chunks the wave kernel could not hold go through the global-memory kernels;
         //  * flag 8: a pair produced more slow-path chains than its region holds (repeats: one chunk can
         //    chain to every copy).  pair_nch keeps counting past the capacity, so after a complete attempt it
