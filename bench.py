@@ -134,8 +134,18 @@ def golden_parity(device):
                 afr, afq = (float(c[3]), float(c[4])) if os.path.basename(c[0]) == g[3] else (float(c[4]), float(c[3]))
                 d_ani.append(float(c[2]) - g[0])
                 d_af += [afr - g[1], afq - g[2]]
+        # the real engine, if this box has it (oracle/skani_ref.py): the same listing through `skani triangle`, cell by cell
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import skani_ref
+        live = "skani unavailable on this host (not on PATH): the golden table of the reference's own run stands in"
+        if skani_ref.find():
+            sk_out = os.path.join(tmp, "tri_skani.tsv")
+            run = skani_ref.triangle(listing, sk_out, 10.0, 89.5, os.cpu_count() or 1)
+            live = skani_ref.compare_tables(out, sk_out)
+            live.update({"skani_version": run["version"], "skani_seconds": run["seconds"], "command": run["command"]})
     d_ani, d_af = np.array(d_ani), np.array(d_af)
-    return {"max_abs_dANI": float(np.abs(d_ani).max()), "rms_dANI": float(np.sqrt((d_ani ** 2).mean())),
+    return {"live_skani": live,
+            "max_abs_dANI": float(np.abs(d_ani).max()), "rms_dANI": float(np.sqrt((d_ani ** 2).mean())),
             "max_abs_dAF": float(np.abs(d_af).max()), "rms_dAF": float(np.sqrt((d_af ** 2).mean())),
             "pairs": seen, "golden_pairs": len(want), "unit": "percentage points",
             "drop_in_call": {"seconds": call_s, "gz_bytes": gz_bytes, "what": "skder_amd_triangle_n50 on the reference's 34 .fasta.gz files (listing -> N50 table + edge table on disk), one call incl. context creation"},
@@ -321,6 +331,24 @@ def cpu_baseline_files(tmp, paths, threads):
     per_genome = t_load / n
     per_chained = max(t_full - t_load, 0.0) / max(chained, 1)
     return per_genome, per_pair, per_chained, chained, t_load + t_full + t_screen * npair
+
+
+def cpu_baseline_skani(tmp, paths, threads):
+    """The reference engine itself, when the box has it (oracle/skani_ref.py): `skani triangle -t threads`
+    on the sample files, wall-clocked, next to a run whose screen lets nothing through but identical genomes (-s 100),
+    which prices read + sketch per genome; the difference per chained pair prices the rest.  None when skani is absent."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import skani_ref
+    if not skani_ref.find():
+        return None
+    listing = os.path.join(tmp, "skani_listing.txt")
+    open(listing, "w").write("".join(q + "\n" for q in paths))
+    full = skani_ref.triangle(listing, os.path.join(tmp, "skani_full.tsv"), 50.0, 80.0, threads)
+    load = skani_ref.triangle(listing, os.path.join(tmp, "skani_load.tsv"), 50.0, 100.0, threads)
+    n = len(paths)
+    chained = max(full["rows"], 1)
+    return {"per_genome": load["seconds"] / n, "per_chained": max(full["seconds"] - load["seconds"], 0.0) / chained, "chained": full["rows"],
+            "seconds": full["seconds"], "sample_pairs_per_s": n * (n - 1) / 2 / full["seconds"], "version": full["version"], "command": full["command"]}
 
 
 def main():
@@ -566,13 +594,25 @@ def main():
                                 "uncompressed FASTA bytes, gz_MB_per_s compressed ones; page cache hot" % (len(gz_paths), nbytes / max(gz_bytes, 1)))
                 out["end_to_end_gz"] = eg
                 threads = max(1, min(32, os.cpu_count() or 1))
-                pg, pp, pc, chained, spent = cpu_baseline_files(tmp, paths, threads)
-                est = N * pg + pairs * pp + n_chained * pc
-                out["cpu_baseline"] = {"value": pairs / est, "unit": "genome-pairs/s", "cores": threads, "kind": "port",
-                                       "sample": "oracle (CPU restatement, OpenMP, %d threads, wall clock) on the same %d FASTA files: "
-                                                 "%.4f s/genome read+sketch, %.2e s/pair marker screen, %.5f s/chained pair (%d pairs); "
-                                                 "%.1f s of wall time spent; extrapolated to %d genomes, %d pairs, %d chained pairs"
-                                                 % (threads, len(paths), pg, pp, pc, chained, spent, N, pairs, int(n_chained))}
+                sk = cpu_baseline_skani(tmp, paths, os.cpu_count() or 1)
+                if sk is not None:
+                    # the reference engine is on this box: it IS the baseline (kind "reference")
+                    est = N * sk["per_genome"] + n_chained * sk["per_chained"]
+                    out["cpu_baseline"] = {"value": pairs / est, "unit": "genome-pairs/s", "cores": os.cpu_count() or 1, "kind": "reference",
+                                           "skani_version": sk["version"],
+                                           "sample": "%s on the same %d FASTA files, wall clock %.1f s (%.0f pairs/s on the sample itself, %d rows): "
+                                                     "%.4f s/genome read+sketch (a -s 100 run), %.5f s per chained pair; extrapolated to %d genomes, "
+                                                     "%d chained pairs" % (sk["command"], len(paths), sk["seconds"], sk["sample_pairs_per_s"], sk["chained"],
+                                                                           sk["per_genome"], sk["per_chained"], N, int(n_chained))}
+                else:
+                    pg, pp, pc, chained, spent = cpu_baseline_files(tmp, paths, threads)
+                    est = N * pg + pairs * pp + n_chained * pc
+                    out["cpu_baseline"] = {"value": pairs / est, "unit": "genome-pairs/s", "cores": threads, "kind": "port",
+                                           "skani": "unavailable on this host (oracle/skani_ref.py looked for it on PATH): the repo's own CPU restatement is timed instead",
+                                           "sample": "oracle (CPU restatement, OpenMP, %d threads, wall clock) on the same %d FASTA files: "
+                                                     "%.4f s/genome read+sketch, %.2e s/pair marker screen, %.5f s/chained pair (%d pairs); "
+                                                     "%.1f s of wall time spent; extrapolated to %d genomes, %d pairs, %d chained pairs"
+                                                     % (threads, len(paths), pg, pp, pc, chained, spent, N, pairs, int(n_chained))}
             finally:
                 shutil.rmtree(tmp, ignore_errors=True)
         if world == 1 and not args.no_realistic and not args.no_cpu_baseline:

@@ -57,7 +57,8 @@ def features():
     for (a, b), gold in rows.items():
         r = O.pair(gs[a], gs[b], p)
         out.append(dict(a=a, b=b, gold=gold, d_cell=100.0 * (1.0 - r.ani_raw), d_span=100.0 * (1.0 - r.ani_span),
-                        span=r.sum_span, chains=r.n_chains, t_ref=gs[a].total_len, t_query=gs[b].total_len))
+                        span=r.sum_span, chains=r.n_chains, t_ref=gs[a].total_len, t_query=gs[b].total_len,
+                        af=(r.af_ref, r.af_query)))
     return out
 
 

@@ -109,6 +109,10 @@ extern "C" void skder_amd_sketches_free(skder_sketches_t *s)
     if (!s) return;
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
+    // an index build left pending (skder_amd_sketches_index_part, or a triangle / rectangle call that failed half way)
+    // still writes this set's buffers from the second queue: they go back to the allocator only once it is done
+    if (s->ctx->stream2) (void)hipStreamSynchronize(s->ctx->stream2);
+    if (s->idx_stream && s->idx_stream != s->ctx->stream && s->idx_stream != s->ctx->stream2) (void)hipStreamSynchronize(s->idx_stream);
     delete s;
 }
 

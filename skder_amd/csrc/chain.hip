@@ -2353,6 +2353,8 @@ static size_t rows_per_block(uint32_t n_partners)
     return (size_t)(r ? r : 1u);
 }
 
+static void ensure_probed_indexed(skder_sketches *SA, skder_sketches *SB, const std::vector<uint32_t> &pr, const std::vector<uint32_t> &pq);
+
 void triangle_rows_impl(skder_sketches *s, uint32_t row_begin, uint32_t row_stride, double screen_pct)
 {
     skder_ctx *ctx = s->ctx;
@@ -2377,6 +2379,7 @@ void triangle_rows_impl(skder_sketches *s, uint32_t row_begin, uint32_t row_stri
         ctx->timing[2] += ms;
         if (s->index_pending) chain_pairs_orient(s, s, prow, ppart);     // host work beside the index kernels
         index_impl(s);
+        ensure_probed_indexed(s, s, prow, ppart);
         // triangle row (i, j): Ref = i, Query = j
         const auto t0 = std::chrono::steady_clock::now();
         chain_pairs(s, s, prow, ppart, ctx->edges);
@@ -2409,6 +2412,7 @@ void rectangle_impl(skder_sketches *refs, skder_sketches *queries, double screen
         HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[9], ctx->ev[10]));
         ctx->timing[2] += ms;
         index_impl(refs);
+        ensure_probed_indexed(refs, queries, ppart, prow);
         // rows are queries, partners are references
         chain_pairs(refs, queries, ppart, prow, ctx->edges);
         if (b1 >= rows.size()) break;
@@ -2451,17 +2455,15 @@ void pairs_probed_impl(skder_sketches *SA, skder_sketches *SB, const uint32_t *r
     }
 }
 
-void chain_pairs_impl(skder_sketches *SA, skder_sketches *SB, const uint32_t *ref, const uint32_t *query, uint64_t n)
+// The probed genome of every pair needs its bucket index here; a chunked genome whose own repetitive-k-mer filter is
+// active needs it as well (slow chaining path).  A set indexed with skder_amd_sketches_index_part holds chunk tables only
+// for the genomes another GPU owns: whatever a pair list needs beyond that is built first, so that no caller of the
+// device-level interface (triangle_rows, rectangle, chain_pairs) can probe an index that was never written.
+static void ensure_probed_indexed(skder_sketches *SA, skder_sketches *SB, const std::vector<uint32_t> &pr, const std::vector<uint32_t> &pq)
 {
-    skder_ctx *ctx = SA->ctx;
-    if (!SA->indexed || !SB->indexed) throw SkError("chain_pairs: index the sets first");
-    ctx->edges.clear();
-    chain_timing_reset(ctx);
-    std::vector<uint32_t> pr(ref, ref + n), pq(query, query + n);
-    // the probed genome of every pair needs its bucket index here; a chunked genome whose own repetitive-k-mer filter is
-    // active needs it as well (slow chaining path): build what is missing
+    if (SA->partial_index == 0 && SB->partial_index == 0) return;      // every genome has its bucket index: the usual case
     std::vector<uint32_t> needA, needB;
-    for (uint64_t p = 0; p < n; p++) {
+    for (size_t p = 0; p < pr.size(); p++) {
         const GenomeMeta &mr = SA->h_meta[pr[p]], &mq = SB->h_meta[pq[p]];
         const bool cq = chunk_the_query(mr, mq);
         if (cq) { if (!SA->full_index[pr[p]]) needA.push_back(pr[p]); if (mq.rep_cut != 0xFFFFFFFFu && !SB->full_index[pq[p]]) needB.push_back(pq[p]); }
@@ -2470,5 +2472,17 @@ void chain_pairs_impl(skder_sketches *SA, skder_sketches *SB, const uint32_t *re
     if (SA == SB) { needA.insert(needA.end(), needB.begin(), needB.end()); needB.clear(); }
     index_promote(SA, needA);
     if (SA != SB) index_promote(SB, needB);
+}
+
+void chain_pairs_impl(skder_sketches *SA, skder_sketches *SB, const uint32_t *ref, const uint32_t *query, uint64_t n)
+{
+    skder_ctx *ctx = SA->ctx;
+    if (!SA->indexed || !SB->indexed) throw SkError("chain_pairs: index the sets first");
+    for (uint64_t p = 0; p < n; p++)
+        if (ref[p] >= SA->n_genomes || query[p] >= SB->n_genomes) throw SkError("chain_pairs: genome index out of range");
+    ctx->edges.clear();
+    chain_timing_reset(ctx);
+    std::vector<uint32_t> pr(ref, ref + n), pq(query, query + n);
+    ensure_probed_indexed(SA, SB, pr, pq);
     chain_pairs(SA, SB, pr, pq, ctx->edges);
 }

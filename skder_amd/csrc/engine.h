@@ -42,6 +42,7 @@ struct skder_sketches {
     DevBuf<uint4> idx_packed;              // (k-mer, position, record, -) per seed: one gather instead of three, index build only
     std::vector<uint32_t> idx_small, idx_big;
     std::vector<uint8_t> full_index;        // per genome: bucket index built here (else chunk tables only: another GPU owns it)
+    uint32_t partial_index = 0;             // genomes that have chunk tables only (0: every genome can be probed)
     hipStream_t idx_stream = nullptr;
     // raw sketches
     DevBuf<uint32_t> seed_kmer, seed_gpos, seed_ctg;   // position order

@@ -543,7 +543,8 @@ void index_begin(skder_sketches *s, hipStream_t st, const uint8_t *full)
         }
         HIPCHECK(hipEventRecord(ctx->ev[3], st));
         s->full_index.assign(G, 1);
-        if (full) for (uint32_t g = 0; g < G; g++) s->full_index[g] = full[g] ? 1 : 0;
+        s->partial_index = 0;
+        if (full) for (uint32_t g = 0; g < G; g++) { s->full_index[g] = full[g] ? 1 : 0; s->partial_index += full[g] ? 0u : 1u; }
         std::vector<uint32_t> all(G);
         for (uint32_t g = 0; g < G; g++) all[g] = g;
         s->idx_packed.resize(ns + 1, st);
@@ -579,7 +580,7 @@ void index_promote(skder_sketches *s, const std::vector<uint32_t> &genomes)
     if (!s->indexed) throw SkError("index_promote: the set is not indexed");
     std::vector<uint32_t> todo;
     for (uint32_t g : genomes)
-        if (g < s->n_genomes && !s->full_index[g]) { s->full_index[g] = 1; todo.push_back(g); }
+        if (g < s->n_genomes && !s->full_index[g]) { s->full_index[g] = 1; s->partial_index--; todo.push_back(g); }
     if (todo.empty()) return;
     hipStream_t st = s->ctx->stream;
     const uint64_t ns = s->h_seed_off[s->n_genomes];

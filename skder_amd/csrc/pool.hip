@@ -19,10 +19,12 @@ struct Pool {
 };
 Pool &pool_for_current_device()
 {
-    static Pool pools[16];
+    constexpr int MAX_DEVICES = 64;       // a node holds 8 MI355X; partitioned (CPX) modes show up to 64 logical devices
+    static Pool pools[MAX_DEVICES];
     int dev = 0;
     (void)hipGetDevice(&dev);
-    return pools[dev & 15];
+    if (dev < 0 || dev >= MAX_DEVICES) throw SkError("device index " + std::to_string(dev) + " is beyond the allocator's " + std::to_string(MAX_DEVICES) + " per-device pools");
+    return pools[dev];
 }
 }   // namespace
 
@@ -56,7 +58,10 @@ void *pool_alloc(size_t bytes)
 void pool_free(void *p)
 {
     if (!p) return;
-    Pool &P = pool_for_current_device();
+    Pool *pp = nullptr;
+    try { pp = &pool_for_current_device(); } catch (...) {}      // called from destructors: never throws
+    if (!pp) { (void)hipFree(p); return; }
+    Pool &P = *pp;
     std::lock_guard<std::mutex> lk(P.mu);
     auto it = P.size_of.find(p);
     if (it == P.size_of.end()) { (void)hipFree(p); return; }

@@ -200,6 +200,55 @@ def test_triangle_synthetic_with_screen(gpu, oracle):
     _check_edges(np.concatenate(parts), want)
 
 
+def test_partly_indexed_set_through_every_device_level_call(gpu, oracle):
+    """A set indexed with index_part (bucket index for the genomes this GPU owns, chunk tables for the rest) must give
+    the fully indexed result through EVERY device-level call: triangle_rows, rectangle and chain_pairs build what a pair
+    list needs beyond the owned genomes instead of probing tables that were never written.  Also: a
+    pair list with an index out of range is refused, and a set freed while its index build is pending is safe."""
+    engine, ctx, torch = gpu
+    from skder_amd import synth
+    p = oracle.default_params()
+    rec = synth.make_recipe(10, genome_len=250000, n_species=2, strains_per_species=2)
+    layout = engine.BatchLayout(rec.rec_lens)
+    d = torch.zeros(layout.total_bytes, dtype=torch.uint8, device="cuda")
+    ctx.synth_fill(d.data_ptr(), layout, rec.lineage, rec.params)
+    og = [oracle.Genome.from_bases(synth.bases_numpy(rec, g), rec.rec_lens[g], p) for g in range(rec.n)]
+    want = _oracle_edges(oracle, og, p, 80.0)
+    own = np.array([1 if g % 3 == 0 else 0 for g in range(rec.n)], np.uint8)
+    # triangle_rows straight after index_part (the build is still pending on the second queue)
+    s = engine.Sketches(ctx)
+    s.sketch_batch(d.data_ptr(), layout)
+    s.index_part(own)
+    _check_edges(s.triangle_rows(0, 1, 80.0), want)
+    s.close()
+    # rectangle of a partly indexed set against itself, and chain_pairs on an explicit list
+    s = engine.Sketches(ctx)
+    s.sketch_batch(d.data_ptr(), layout)
+    s.index_part(own)
+    q = engine.Sketches(ctx)
+    q.sketch_batch(d.data_ptr(), layout)
+    rect = s.rectangle(q, 80.0)
+    rect = rect[rect["ref"] < rect["query"]]
+    _check_edges(rect, want)
+    pr = np.array([k[0] for k in want], np.uint32)
+    pq = np.array([k[1] for k in want], np.uint32)
+    _check_edges(s.chain_pairs(pr, pq), want)
+    with pytest.raises(RuntimeError, match="out of range"):
+        s.chain_pairs(np.array([0, rec.n], np.uint32), np.array([1, 1], np.uint32))
+    q.close()
+    s.close()
+    # freed with the index build pending: the buffers go back to the pool only after the second queue has drained
+    for _ in range(3):
+        s = engine.Sketches(ctx)
+        s.sketch_batch(d.data_ptr(), layout)
+        s.index_part(own)
+        s.close()
+    s = engine.Sketches(ctx)
+    s.sketch_batch(d.data_ptr(), layout)
+    _check_edges(s.triangle_rows(0, 1, 80.0), want)
+    s.close()
+
+
 def test_dropin_tables_match_oracle_and_golden(gpu, oracle, tmp_path):
     """file in, TSV out through the reference-shaped functions; text-identical with the oracle's
     drivers, and within the oracle's measured tolerance of the reference's golden table G1"""
@@ -225,8 +274,9 @@ def test_dropin_tables_match_oracle_and_golden(gpu, oracle, tmp_path):
     assert [key(r) for r in rows] == [key(r) for r in grows]          # same rows, same order
     for r, g in zip(rows, grows):
         assert r[5:] == g[5:]
-        assert abs(float(r[2]) - float(g[2])) <= 0.65
-        assert abs(float(r[3]) - float(g[3])) <= 1.5 and abs(float(r[4]) - float(g[4])) <= 1.5
+        # the same bounds as the CPU test of the oracle on this table (tests/test_oracle_golden.py: measured 0.28 / 0.88)
+        assert abs(float(r[2]) - float(g[2])) <= 0.30
+        assert abs(float(r[3]) - float(g[3])) <= 0.95 and abs(float(r[4]) - float(g[4])) <= 0.95
     # rejected skani flags fail loudly
     with pytest.raises(RuntimeError):
         skder_amd.runSkaniTriangle(str(listing), str(tmp_path / "x.tsv"), "--no-learned-ani", 50.0, "greedy", False, None)
@@ -335,7 +385,10 @@ def test_several_gpus_in_one_process(gpu, tmp_path):
 def test_driver_end_to_end_listings(gpu, tmp_path):
     """bin/skder's flow on the 34 reference genomes through the GPU engine: the representative listing
     equals the reference's golden listing at the cut-offs skDER is run with (greedy, -i 99.5 / 99.0),
-    and the three selection modes run to completion (low_mem_greedy drives sketch + search on the device)"""
+    and the three selection modes run to completion (low_mem_greedy drives sketch + search on the device).
+    The -i 99.0 half is a FIT CHECK, not a margin: one deciding edge (skani 99.13) sits 0.13 points from the cut-off,
+    inside the ANI stand-in's residual, and flips for model constants 0.01 away from the shipped ones
+    (tests/test_selection.py::test_listing_at_99_hangs_on_the_model_constants; INTEGRATION.md section 1)."""
     from skder_amd import driver
     gdir = os.path.join(GOLDEN, "genomes")
     n50_gold = [l.split("\t")[0] for l in open(os.path.join(GOLDEN, "downstream", "skder_gtdb_results__Concatenated_N50.txt"))]

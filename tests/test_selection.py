@@ -135,3 +135,42 @@ def test_oracle_table_gives_the_reference_listings_where_not_knife_edge(oracle, 
     # 97-98 % cut-offs sit inside the bulk of this species' pair ANIs, where the 0.16-point residual of the
     # restatement flips individual edges: measured 19 of 30 listings identical
     assert same >= 18, "only %d of 30 listings identical" % same
+
+
+def test_listing_at_99_hangs_on_the_model_constants(oracle):
+    """How much the golden representative listings depend on the two constants of the ANI stand-in
+    (include/skder_amd_spec.h ANI_CAL_CELL / ANI_CAL_SPAN).  The 561 pairs' integer-derived divergences come from the
+    oracle once; the model line is then applied for every (cell, span) within +-0.01 of the least-squares optimum
+    and the 30 `-tc` listings are recomputed.  What this pins, and what it admits:
+      * -i 99.5 (skDER's default): identical for EVERY constant pair of the grid -- robust;
+      * -i 99.0 (the reference's own test run): identical only on one side of a line that passes through the optimum --
+        the deciding edge (skani 99.13) lies 0.13 points from the cut-off, inside the stand-in's residual.  The shipped
+        constants are on the reproducing side; the listing equality at 99.0 is therefore a fit, not evidence of margin."""
+    import importlib.util
+    import numpy as np
+    from skder_amd import selection as S
+    spec = importlib.util.spec_from_file_location("fit_calibration", os.path.join(ROOT, "oracle", "fit_calibration.py"))
+    fc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fc)
+    recs = fc.features()
+    coef, _, _ = fc.validate(recs, n_split=1)
+    n50 = S.read_n50(os.path.join(D, "skder_gtdb_results__Concatenated_N50.txt"))
+    want = {(a, f): _lines(os.path.join(D, "tc", "skDER_Results_ANI%s_AF%s.txt" % (a, f))) for a in ANI_CUTS for f in AF_CUTS}
+
+    def tv(x):
+        return float("%.2f" % float(np.float32(x) * np.float32(100)))
+
+    def identical(ca, cb):
+        edges = [(r["a"], r["b"], tv(1.0 - (ca * r["d_cell"] + cb * r["d_span"]) / 100.0), tv(r["af"][0]), tv(r["af"][1])) for r in recs]
+        return {k: S.greedy_from_edges(edges, n50, k[0], k[1]) == w for k, w in want.items()}
+
+    shipped = identical(0.53, 0.71)
+    assert all(shipped[(a, f)] for a in (99.0, 99.5) for f in AF_CUTS)
+    assert sum(shipped.values()) >= 18
+    grid = [(round(coef[0] + da, 3), round(coef[1] + db, 3)) for da in (-0.01, -0.005, 0.0, 0.005, 0.01) for db in (-0.01, -0.005, 0.0, 0.005, 0.01)]
+    res = {g: identical(*g) for g in grid}
+    assert all(r[(99.5, f)] for r in res.values() for f in AF_CUTS)                   # the default cut-off: robust
+    holds = [g for g, r in res.items() if all(r[(99.0, f)] for f in AF_CUTS)]
+    assert 0 < len(holds) < len(grid)                                                  # knife-edge, on record
+    # the reproducing side is the lower-divergence side of the line through the deciding edge
+    assert (round(coef[0] - 0.01, 3), round(coef[1] - 0.01, 3)) in holds and (round(coef[0] + 0.01, 3), round(coef[1] + 0.01, 3)) not in holds
