@@ -224,6 +224,14 @@ uint32_t skder_amd_db_size(skder_db_t *db);
 const char *skder_amd_db_path(skder_db_t *db, uint32_t i);
 uint64_t skder_amd_db_n50(skder_db_t *db, uint32_t i);
 
+/* A database from a sketch set that is ALREADY in HBM (built with the device-level interface of section B, e.g. by a
+ * caller that produced the bases on the device or received the sketches from another GPU): the raw sketches are copied
+ * (device to device) into a database of their own on `device` and indexed; `s` stays the caller's.  paths / first_names:
+ * n strings each (the Ref_file / Ref_name columns; first_names may be NULL: empty names), n50 may be NULL (zeros).
+ * A query path that equals one of `paths` is served from the resident sketch, as with skder_amd_sketch. */
+skder_db_t *skder_amd_db_from_sketches(skder_sketches_t *s, int device, const char *const *paths, const char *const *first_names,
+                                       const uint64_t *n50, char *err, size_t errlen);
+
 /* 8f-1  edge list handed over IN MEMORY.  All-pairs table of the resident database: the rows of
  * `skani triangle` (Ref = the genome whose path sorts first, skani's row order, --min-af applied),
  * `ref`/`query` being LISTING indices.  out_tsv may be NULL (no text round trip: the selection step

@@ -75,6 +75,8 @@ SYMBOLS = {
     "skder_amd_triangle_multi": (C.c_int, [C.c_char_p, C.c_double, C.c_double, C.POINTER(C.c_int), C.c_int, C.c_char_p, C.c_char_p,
                                            C.c_char_p, C.c_size_t]),
     "skder_amd_sketch_multi": (C.c_void_p, [C.c_char_p, C.POINTER(C.c_int), C.c_int, C.c_char_p, C.c_char_p, C.c_size_t]),
+    "skder_amd_db_from_sketches": (C.c_void_p, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_void_p, C.c_char_p,
+                                               C.c_size_t]),
     "skder_amd_db_size": (C.c_uint32, [C.c_void_p]),
     "skder_amd_db_path": (C.c_char_p, [C.c_void_p, C.c_uint32]),
     "skder_amd_db_n50": (C.c_uint64, [C.c_void_p, C.c_uint32]),

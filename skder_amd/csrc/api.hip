@@ -570,6 +570,37 @@ extern "C" skder_db_t *skder_amd_sketch_n50(const char *listing, int device, con
     }
 }
 
+extern "C" skder_db_t *skder_amd_db_from_sketches(skder_sketches_t *src, int device, const char *const *paths, const char *const *first_names,
+                                                  const uint64_t *n50, char *err, size_t errlen)
+{
+    if (!src || !paths) { set_err(err, errlen, "null argument"); return nullptr; }
+    skder_ctx *ctx = skder_amd_ctx_create(device, err, errlen);
+    if (!ctx) return nullptr;
+    skder_db *db = new skder_db();
+    db->ctx = ctx;
+    try {
+        HIPCHECK(hipSetDevice(src->ctx->device));
+        HIPCHECK(hipStreamSynchronize(src->ctx->stream));          // the sketches are complete before another context reads them
+        skder_raw_view_t v;
+        if (skder_amd_sketches_view(src, &v) != 0) throw SkError("sketches_view failed");
+        HIPCHECK(hipSetDevice(ctx->device));
+        db->refs = skder_amd_sketches_new(ctx);
+        if (v.n_genomes && skder_amd_sketches_append_raw(db->refs, &v) != 0) throw SkError(ctx->last_error);
+        for (uint32_t g = 0; g < v.n_genomes; g++) {
+            if (!paths[g]) throw SkError("null path");
+            db->names.path.emplace_back(paths[g]);
+            db->names.first_name.emplace_back(first_names && first_names[g] ? first_names[g] : "");
+            db->names.n50.push_back(n50 ? n50[g] : 0);
+        }
+        db_finish(db);
+        return db;
+    } catch (const std::exception &e) {
+        set_err(err, errlen, e.what());
+        db_destroy(db);
+        return nullptr;
+    }
+}
+
 extern "C" skder_db_t *skder_amd_sketch_multi(const char *listing, const int *devices, int n_devices, const char *n50_tsv, char *err,
                                               size_t errlen)
 {

@@ -19,25 +19,10 @@
 #include "common.h"
 #include "device_utils.h"
 #include "engine.h"
+#include "sketch_body.h"
 
 // ---------------------------------------------------------------------------------------------
 // device helpers
-
-// mm_hash64 (include/skder_amd_spec.h).  The complement of the first step is moved behind the first xor-shift, where it is one
-// xor of the high word: with p = key + (key << 21), ~p ^ (~p >> 24) == p ^ (p >> 24) ^ 0xFFFFFF0000000000.
-// (Spelling the constant multiplications out as v_mad_u64_u32 for the low word plus v_mul_lo_u32 and an add for the high
-// word -- instead of the two v_mad_u64_u32 and two register moves the compiler takes -- was measured: 31.0 instead of 29.5 ms.)
-__device__ __forceinline__ uint64_t mm_hash64(uint64_t key)
-{
-    key = key + (key << 21);
-    key = key ^ (key >> 24) ^ 0xFFFFFF0000000000ull;
-    key = (key + (key << 3)) + (key << 8);
-    key = key ^ (key >> 14);
-    key = (key + (key << 2)) + (key << 4);
-    key = key ^ (key >> 28);
-    key = key + (key << 31);
-    return key;
-}
 
 // 4 ASCII bases in a dword -> 4 two-bit codes in the low byte (A=0 C=1 G=2 T=3, case-insensitive,
 // every other byte = 0), first base in the lowest bits.
@@ -77,9 +62,29 @@ __device__ __forceinline__ uint64_t revcomp21(uint64_t f)
 
 // ---------------------------------------------------------------------------------------------
 // HOT KERNEL
+//
+// The kernel is bound by integer issue, not by HBM (1.07 B of traffic per base; profiles/): per position it rolls the
+// forward / reverse 21-mer registers, derives both 15-mers from them, takes the two canonical k-mers and runs mm_hash64 on
+// each.  gfx950 issues the simple 32-bit ALU operations (and / or / xor / not / add / sub / mov / lshrrev_b32 / bitop3) in 2
+// cycles per wavefront and everything else -- shifts left, v_alignbit, v_mad_u64_u32, v_mul_lo_u32, 64-bit shifts and
+// compares, v_lshl_add_u64 -- in 4 (profiles/round1_valu_rates.json), so the instruction SELECTION decides the time:
+//   * hipcc turns every `x + (x << n)` and `x * c` on 64 bits into v_mad_u64_u32(lo) + v_mad_u64_u32(hi) with two register
+//     moves between them (the high product must become the LOW half of an even-aligned pair): 12 cycles.  Spelled as
+//     v_mad_u64_u32(lo, c, 0) + v_mul_lo_u32(hi, c) + v_add_u32 into the pair's high half it is 10 and moves nothing; the
+//     21-mer's first step, whose high word has 10 bits, takes v_mad_u32_u24 for the high half (8); x * 21 is two
+//     v_lshl_add_u64 (8).
+//   * threshold test: v_cmp_gt_u64 against the constant in an SGPR pair, then v_addc_co_u32 mask, mask, mask -- the carry
+//     shifts into the mask (8 cycles; the compiler's compare / v_cndmask / v_or3 chain: 12).  Position j of the lane's 32
+//     ends up at bit 31 - j, one v_bfrev_b32 per mask at the end.
+//   * the 15-mers are NOT rolled separately: the forward one is the low 30 bits of the forward 21-mer, the reverse one the
+//     top 30 bits of the reverse 21-mer (2 + 4 cycles instead of 14).
+// Per position: 21-mer hash 68, 15-mer hash 64, rolling + canonical forms 40 = 172 cycles of issue per wavefront
+// (the compiler's own selection for the same arithmetic: about 240).  SKDER_AMD_SKETCH_VARIANT=0 runs the compiler-selected
+// body (kept for A/B measurements and as the parity reference of the hand-selected one).
 
 #define PACKED_WORDS ((SKDER_TILE + 32) / 16)   // 514
 
+template <int VARIANT>
 __global__ __launch_bounds__(SK_THREADS) void sketch_tiles_kernel(
     const uint8_t *__restrict__ bases, const TileDesc *__restrict__ tiles,
     uint32_t *__restrict__ slot_kmer, uint32_t *__restrict__ slot_gpos, uint64_t *__restrict__ slot_mark,
@@ -106,31 +111,9 @@ __global__ __launch_bounds__(SK_THREADS) void sketch_tiles_kernel(
     const uint32_t w0 = packed[2 * tid], w1 = packed[2 * tid + 1];
     const uint32_t w2 = packed[2 * tid + 2], w3 = packed[2 * tid + 3];
 
-    uint32_t fs = 0, rs = 0;
-    uint64_t fm = 0, rm = 0;
-    // warm-up: window bases 12..31 (the 20 positions in front of this thread's first position)
-#pragma unroll
-    for (int n = 12; n < 32; n++) {
-        uint32_t b = ((n < 16 ? w0 : w1) >> (2 * (n & 15))) & 3u;
-        fs = ((fs << 2) | b) & SK_SEED_MASK;
-        rs = (rs >> 2) | ((3u - b) << 28);
-        fm = ((fm << 2) | b) & SK_MARK_MASK;
-        rm = (rm >> 2) | ((uint64_t)(3u - b) << 40);
-    }
-    uint32_t smask = 0, mmask = 0;
+    uint32_t smask, mmask;
     const uint32_t p0 = tid * SK_POS_PER_THREAD;
-#pragma unroll
-    for (int j = 0; j < 32; j++) {
-        uint32_t b = ((j < 16 ? w2 : w3) >> (2 * (j & 15))) & 3u;
-        fs = ((fs << 2) | b) & SK_SEED_MASK;
-        rs = (rs >> 2) | ((3u - b) << 28);
-        fm = ((fm << 2) | b) & SK_MARK_MASK;
-        rm = (rm >> 2) | ((uint64_t)(3u - b) << 40);
-        uint32_t cs = fs < rs ? fs : rs;
-        uint64_t cm = fm < rm ? fm : rm;
-        if (mm_hash64((uint64_t)cs) < SK_SEED_THR) smask |= 1u << j;
-        if (mm_hash64(cm) < SK_MARK_THR) mmask |= 1u << j;
-    }
+    sketch_body<VARIANT>(w0, w1, w2, w3, smask, mmask);
     // validity: inside the record, and at least marker_k-1 bases in front (ani_oracle.c sketch_contig)
     {
         uint32_t valid = 0xFFFFFFFFu;
@@ -443,9 +426,15 @@ void sketch_batch_impl(skder_sketches *s, const uint8_t *d_bases, const skder_ba
         HIPCHECK(hipMemsetAsync(tile_nm.p + nt, 0, 4, st));
 
         HIPCHECK(hipEventRecord(ctx->ev[0], st));
-        if (nt)
-            hipLaunchKernelGGL(sketch_tiles_kernel, dim3(nt), dim3(SK_THREADS), 0, st, d_bases, d_tiles.p, slot_kmer.p,
-                               slot_gpos.p, slot_mark.p, tile_ns.p, tile_nm.p, ctx->d_flags);
+        if (nt) {
+            static const int variant = getenv("SKDER_AMD_SKETCH_VARIANT") ? atoi(getenv("SKDER_AMD_SKETCH_VARIANT")) : SK_BODY_DEFAULT;
+            if (variant == 0)
+                hipLaunchKernelGGL(sketch_tiles_kernel<0>, dim3(nt), dim3(SK_THREADS), 0, st, d_bases, d_tiles.p, slot_kmer.p,
+                                   slot_gpos.p, slot_mark.p, tile_ns.p, tile_nm.p, ctx->d_flags);
+            else
+                hipLaunchKernelGGL(sketch_tiles_kernel<SK_BODY_DEFAULT>, dim3(nt), dim3(SK_THREADS), 0, st, d_bases, d_tiles.p, slot_kmer.p,
+                                   slot_gpos.p, slot_mark.p, tile_ns.p, tile_nm.p, ctx->d_flags);
+        }
         HIPCHECK(hipEventRecord(ctx->ev[1], st));
 
         // offsets

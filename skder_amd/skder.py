@@ -143,6 +143,22 @@ class Database:
         return cls(h)
 
     @classmethod
+    def from_sketches(cls, sketches, paths, n50=None, first_names=None, device=None):
+        """a database from a sketch set already resident in HBM (skder_amd.engine.Sketches): the raw sketches are copied into
+        a database of their own; `sketches` stays the caller's (include/skder_amd.h, skder_amd_db_from_sketches)"""
+        import numpy as np
+        k = len(paths)
+        ps = (C.c_char_p * max(k, 1))(*[p.encode() for p in paths])
+        fn = (C.c_char_p * max(k, 1))(*[f.encode() for f in first_names]) if first_names is not None else None
+        n50a = np.ascontiguousarray(n50, np.uint64) if n50 is not None else None
+        err = C.create_string_buffer(_lib.ERRLEN)
+        h = _lib.lib().skder_amd_db_from_sketches(sketches.h, _device() if device is None else device, ps, fn,
+                                                  n50a.ctypes.data if n50a is not None else None, err, _lib.ERRLEN)
+        if not h:
+            raise RuntimeError('Had an issue running: skder_amd_db_from_sketches: %s' % err.value.decode())
+        return cls(h)
+
+    @classmethod
     def load(cls, store_file, device=None):
         err = C.create_string_buffer(_lib.ERRLEN)
         h = _lib.lib().skder_amd_db_load(store_file.encode(), _device() if device is None else device, err, _lib.ERRLEN)

@@ -118,3 +118,63 @@ def write_fasta(recipe: Recipe, g: int, path: str, width: int = 80) -> None:
             for i in range(0, len(seq), width):
                 f.write(seq[i:i + width].tobytes())
                 f.write(b"\n")
+
+
+# ---- pairs of KNOWN identity (the generator is the ground truth): an independent check of the ANI estimator and of the
+# "learned ANI" stand-in outside the 96.4-100 % range the reference's golden tables cover
+
+TRUTH_STRAIN_PPM = (0, 300, 1500, 5000, 10000, 20000, 35000, 50000, 65000, 80000)
+
+
+def truth_recipe(genome_len: int = 3_000_000, strain_ppm=TRUTH_STRAIN_PPM, iso_ppm: int = 100, seed: int = SEED) -> Recipe:
+    """one species, one isolate per strain, NO accessory segments: every position of every genome is homologous to the
+    same position of every other one, so the true identity of a pair is simply the fraction of equal bases.  Strain i
+    carries strain_ppm[i] substitutions per million (pairs: ~ the sum of the two rates, 99.97 down to ~85 %)."""
+    n = len(strain_ppm)
+    rec = make_recipe(n, genome_len=genome_len, n_species=1, strains_per_species=n, seed=seed)
+    rec.params[:, 0] = 0
+    rec.params[:, 1] = np.asarray(strain_ppm, np.uint32)
+    rec.params[:, 2] = iso_ppm
+    return rec
+
+
+def true_identity_matrix(recipe: Recipe) -> np.ndarray:
+    """fraction of equal bases of every pair of genomes of a truth_recipe (all positions; no indels in the generator)"""
+    L = min(recipe.total_len(g) for g in range(recipe.n))
+    same = np.zeros((recipe.n, recipe.n), np.int64)
+    step = 1 << 20
+    for p0 in range(0, L, step):
+        pos = np.arange(p0, min(p0 + step, L), dtype=np.uint64)
+        codes = [synth_codes(*[int(x) for x in recipe.lineage[g]], *[int(x) for x in recipe.params[g][:3]], pos) for g in range(recipe.n)]
+        for a in range(recipe.n):
+            for b in range(a + 1, recipe.n):
+                same[a, b] += int((codes[a] == codes[b]).sum())
+    out = same / float(L)
+    return out + out.T + np.eye(recipe.n)
+
+
+def ani_vs_truth(edges, truth: np.ndarray, bins=((99.5, 100.0), (98.0, 99.5), (95.0, 98.0), (90.0, 95.0), (85.0, 90.0))) -> dict:
+    """bias / rms (percentage points) of the engine's two ANI figures against the generator's truth, by true-ANI bin:
+    `raw` = the chunk-level k-mer estimate (A/N)^(1/15) (skder_edge_t.ani_raw), `model` = what the table prints (after the
+    learned-ANI stand-in of include/skder_amd_spec.h).  Pairs the engine did not report count as `missing`."""
+    got = {(int(e["ref"]), int(e["query"])): e for e in edges}
+    out = {}
+    n = truth.shape[0]
+    for lo, hi in bins:
+        d_raw, d_mod, missing = [], [], 0
+        for a in range(n):
+            for b in range(a + 1, n):
+                t = 100.0 * truth[a, b]
+                if not (lo <= t < hi):
+                    continue
+                e = got.get((a, b))
+                if e is None:
+                    missing += 1
+                    continue
+                d_raw.append(100.0 * float(e["ani_raw"]) - t)
+                d_mod.append(100.0 * float(e["ani"]) - t)
+        r, m = np.array(d_raw), np.array(d_mod)
+        out["%g-%g" % (lo, hi)] = {"pairs": len(d_raw), "missing": missing,
+                                   "raw_bias": float(r.mean()) if len(r) else None, "raw_rms": float(np.sqrt((r ** 2).mean())) if len(r) else None,
+                                   "model_bias": float(m.mean()) if len(m) else None, "model_rms": float(np.sqrt((m ** 2).mean())) if len(m) else None}
+    return out

@@ -188,3 +188,37 @@ def test_fixed_point_root_and_hash_known_answers(oracle):
     assert len(vals) == 4096
     # first step ~(key + (key << 21)) (skani's Rust spelling): values from an independent Python restatement
     assert L.oracle_mm_hash64(0) == 0x77CFA1EEF01BCA90 and L.oracle_mm_hash64(1) == 0x1F9A5BE4BFB13E81
+
+
+def test_estimator_against_generator_truth(oracle):
+    """An independent pin outside the golden tables' 96.4-100 %: the synthetic generator knows
+    the true identity of every pair (substitutions only, no accessory segments: skder_amd.synth.truth_recipe), 99.95 down
+    to 86 %.  The chunk-level k-mer estimate (A/N)^(1/15) -- everything in front of the learned-ANI stand-in: sketch, anchors,
+    chaining, overlap filter, cell denominators -- is UNBIASED against that truth (measured on 2 Mb genomes: rms 0.04 points
+    down to 90 %, 0.15 in 85-90 %).  The stand-in itself (fitted to skani's output on real C. granulosum genomes, whose
+    mutations cluster) reads 1.24 x the true divergence on these iid-substitution genomes; that is what the two fitted
+    weights sum to, and it is on record here and in INTEGRATION.md rather than hidden: callers with simulated genomes
+    should read skder_edge_t.ani_raw."""
+    from skder_amd import synth
+    p = oracle.default_params()
+    rec = synth.truth_recipe(2_000_000)
+    truth = synth.true_identity_matrix(rec)
+    og = [oracle.Genome.from_bases(synth.bases_numpy(rec, g), rec.rec_lens[g], p) for g in range(rec.n)]
+    edges = []
+    for a in range(rec.n):
+        for b in range(a + 1, rec.n):
+            assert oracle.screen(og[a], og[b], 80.0, p)[0], (a, b)
+            r = oracle.pair(og[a], og[b], p)
+            assert r.n_chains and r.ani > 0
+            edges.append(dict(ref=a, query=b, ani=r.ani, ani_raw=r.ani_raw))
+    res = synth.ani_vs_truth(edges, truth)
+    assert sum(v["pairs"] for v in res.values()) == 45 and all(v["missing"] == 0 for v in res.values())
+    for name, v in res.items():
+        lo = float(name.split("-")[0])
+        assert abs(v["raw_bias"]) <= (0.05 if lo >= 90 else 0.25), (name, v)
+        assert v["raw_rms"] <= (0.08 if lo >= 90 else 0.30), (name, v)
+    # the stand-in: divergence read / true divergence = ANI_CAL_CELL + ANI_CAL_SPAN (both estimates are unbiased here)
+    for e in edges:
+        t = 100.0 * (1.0 - truth[e["ref"], e["query"]])
+        if t >= 1.0:
+            assert 1.10 <= 100.0 * (1.0 - e["ani"]) / t <= 1.34, (e, t)
