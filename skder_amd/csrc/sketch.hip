@@ -65,22 +65,22 @@ __device__ __forceinline__ uint64_t revcomp21(uint64_t f)
 //
 // The kernel is bound by integer issue, not by HBM (1.07 B of traffic per base; profiles/): per position it rolls the
 // forward / reverse 21-mer registers, derives both 15-mers from them, takes the two canonical k-mers and runs mm_hash64 on
-// each.  gfx950 issues the simple 32-bit ALU operations (and / or / xor / not / add / sub / mov / lshrrev_b32 / bitop3) in 2
-// cycles per wavefront and everything else -- shifts left, v_alignbit, v_mad_u64_u32, v_mul_lo_u32, 64-bit shifts and
-// compares, v_lshl_add_u64 -- in 4 (profiles/round1_valu_rates.json), so the instruction SELECTION decides the time:
-//   * hipcc turns every `x + (x << n)` and `x * c` on 64 bits into v_mad_u64_u32(lo) + v_mad_u64_u32(hi) with two register
-//     moves between them (the high product must become the LOW half of an even-aligned pair): 12 cycles.  Spelled as
-//     v_mad_u64_u32(lo, c, 0) + v_mul_lo_u32(hi, c) + v_add_u32 into the pair's high half it is 10 and moves nothing; the
-//     21-mer's first step, whose high word has 10 bits, takes v_mad_u32_u24 for the high half (8); x * 21 is two
-//     v_lshl_add_u64 (8).
-//   * threshold test: v_cmp_gt_u64 against the constant in an SGPR pair, then v_addc_co_u32 mask, mask, mask -- the carry
-//     shifts into the mask (8 cycles; the compiler's compare / v_cndmask / v_or3 chain: 12).  Position j of the lane's 32
-//     ends up at bit 31 - j, one v_bfrev_b32 per mask at the end.
+// each.  The per-thread body lives in sketch_body.h, one option bit per instruction-selection choice;
+// profiles/calib/sketch_body_bench.hip times the combinations on the device (profiles/round3_sketch_body.json): the compiler's
+// own selection costs 107 ns per position and wavefront, the body the kernel runs (SK_BODY_DEFAULT) 93:
 //   * the 15-mers are NOT rolled separately: the forward one is the low 30 bits of the forward 21-mer, the reverse one the
-//     top 30 bits of the reverse 21-mer (2 + 4 cycles instead of 14).
-// Per position: 21-mer hash 68, 15-mer hash 64, rolling + canonical forms 40 = 172 cycles of issue per wavefront
-// (the compiler's own selection for the same arithmetic: about 240).  SKDER_AMD_SKETCH_VARIANT=0 runs the compiler-selected
-// body (kept for A/B measurements and as the parity reference of the hand-selected one).
+//     top 30 bits of the reverse 21-mer (-5.5 ns);
+//   * threshold test: v_cmp_gt_u64 against the constant in an SGPR pair, then v_addc_co_u32 mask, mask, mask -- the carry
+//     shifts into the mask; position j of the lane's 32 ends up at bit 31 - j, one v_bfrev_b32 per mask at the end (-3.5 ns
+//     against the compiler's compare / v_cndmask / v_or3 chain);
+//   * x * 21 as two v_lshl_add_u64 instead of two v_mad_u64_u32 and two register moves (-0.7 ns);
+//   * the canonical 21-mer through ONE v_min_f64: 42-bit integers are denormal doubles, which order like the integers they
+//     are (f64 denormals are never flushed on this target); the compiler's v_cmp_lt_u64 + two v_cndmask cost 7.6 ns, this 2.8.
+// What did NOT pay, measured in the same table: v_mul_lo_u32, v_mad_u32_u24 and v_lshl_add_u32 for the high words of the
+// multiplications (each several times the price of a v_mad_u64_u32, which is cheap here -- the compiler's pair of multiply-adds
+// with two register moves in between is hard to beat), and both hashes written out as one assembly stream on fixed
+// registers (strictly in order: slower than what the compiler's scheduler makes of the same arithmetic).
+// SKDER_AMD_SKETCH_VARIANT=0 runs the compiler-selected body (A/B measurements; the parity reference of the others).
 
 #define PACKED_WORDS ((SKDER_TILE + 32) / 16)   // 514
 

@@ -103,19 +103,13 @@ __device__ __forceinline__ void push_below(uint32_t &mask, uint64_t h, uint64_t 
     else if (h < thr) mask |= 1u << j;
 }
 
-// Both hashes of one position and their threshold bits as ONE hand-written instruction stream.  Measured issue costs on gfx950
-// at this kernel's occupancy (profiles/round3_sketch_body.json; ns per wavefront instruction per SIMD): simple 32-bit ALU
-// and v_mov 1.05, v_mad_u64_u32 1.1, v_lshl_add_u64 1.5, v_alignbit / v_bfe / v_min / shifts left 1.8, 64-bit shifts 2.1,
-// v_cndmask ~3, v_mul_lo_u32 / v_mad_u32_u24 / v_lshl_add_u32 ~4.  With those prices:
-//   x * c          v_mad_u64_u32(lo, c, 0), v_mad_u64_u32(hi, c, 0), one v_add_u32 into the high half        3.3 ns
-//                  (the compiler: two multiply-adds and two register moves, because the first product's high half must become
-//                   the LOW half of an even-aligned addend pair: 4.3)
-//   x * 21         5 x, then 16 x + 5 x: two v_lshl_add_u64                                                    3.0
-//   x ^= x >> n    v_lshrrev_b64 + two xors (the constant of the first step rides on a v_bitop3_b32)           4.2 - 4.5
-//   threshold      v_cmp_gt_u64 + v_addc_co_u32 mask, mask, mask (position j of 32 lands on bit 31 - j)
-// The two chains are interleaved so that neither waits for the other.  Scratch registers are fixed (v56-v63: the kernel
-// stays at 64 VGPRs = 8 wavefronts per SIMD) because inline assembly cannot name the halves of a 64-bit operand, and one
-// block per position keeps the compiler's post-asm s_nop at one.
+// Both hashes of one position and their threshold bits as ONE hand-written instruction stream (SKB_ASM_HASH; NOT the
+// default: measured 100 ns per position against 93 for the compiler-scheduled default, profiles/round3_sketch_body.json --
+// an assembly block is issued strictly in order, and the compiler's own interleaving of the two chains with the rolling
+// code around them does better; kept as a measured alternative).  Multiplications as two v_mad_u64_u32 and one add, x * 21
+// as two v_lshl_add_u64, xor-shifts as v_lshrrev_b64 + two xors, the threshold bit through the carry.  Scratch registers
+// are fixed (v56-v63: the kernel stays at 64 VGPRs = 8 wavefronts per SIMD) because inline assembly cannot name the halves
+// of a 64-bit operand.
 __device__ __forceinline__ void hash2_push(uint32_t cs, uint32_t cm_lo, uint32_t cm_hi, uint32_t &smask, uint32_t &mmask)
 {
 #define MUL2(P0, P1, T0, T1, C)                                      \
