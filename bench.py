@@ -316,6 +316,96 @@ def realistic_workloads(engine, ctx, torch, synth, args):
     return out
 
 
+def n50_of_lengths(lens):
+    """util.n50_calc's rule (util.py:686-724) on a list of record lengths: descending, half = int(sum / 2), first cumulative >= half"""
+    ls = sorted((int(x) for x in lens), reverse=True)
+    half, cum = int(sum(ls) / 2), 0
+    for l in ls:
+        cum += l
+        if cum >= half:
+            return l
+    return 0
+
+
+def low_mem_greedy_scale(engine, ctx, torch, synth, n, genome_len, device):
+    """The reference's ONE published number (README.md:27): `skder -d low_mem_greedy` on > 20,000 Staphylococcus genomes took
+    2.25 h on 20 threads (machine unspecified): skani sketch once, then one `skani search` process per representative
+    (skder.py:95-134).  Here: the same loop (skder_amd.skder.lowMemGreedyDerep, -i 99.5 -f 50) over n synthetic genomes of
+    BASELINE.json config 4's shape, the sketch database resident in HBM -- built from bases generated on the device (the
+    FASTA ingest is priced separately under end_to_end) and, second, re-loaded from a sketch store on disk --, speculative
+    search batches (the default) and search_batch=1 (one search, one TSV, one parse per representative, call for call)."""
+    import shutil
+    import tempfile
+    from skder_amd.skder import Database, lowMemGreedyDerep
+    t_all = time.perf_counter()
+    recipe = synth.make_recipe(n, genome_len=genome_len)
+    sk = engine.Sketches(ctx)
+    total = sum(recipe.total_len(g) for g in range(n))
+    sk.reserve(total // 120, total // 900)
+    t0 = time.perf_counter()
+    for b0 in range(0, n, 1250):
+        gs = range(b0, min(b0 + 1250, n))
+        layout = engine.BatchLayout([recipe.rec_lens[g] for g in gs])
+        d = torch.empty(layout.total_bytes, dtype=torch.uint8, device="cuda")
+        ctx.synth_fill(d.data_ptr(), layout, recipe.lineage[gs.start:gs.stop], recipe.params[gs.start:gs.stop])
+        sk.sketch_batch(d.data_ptr(), layout)
+        del d
+    torch.cuda.synchronize()
+    t_sketch = time.perf_counter() - t0
+    tmp = tempfile.mkdtemp(prefix="skder_amd_lowmem_")
+    out = {}
+    try:
+        paths = ["/synthetic/species%03d/g%05d.fasta" % (int(recipe.species[g]), g) for g in range(n)]
+        n50 = [n50_of_lengths(recipe.rec_lens[g]) for g in range(n)]
+        listing, n50_file = os.path.join(tmp, "listing.txt"), os.path.join(tmp, "Concatenated_N50.txt")
+        open(listing, "w").write("".join(p + "\n" for p in paths))
+        open(n50_file, "w").write("".join("%s\t%d\n" % kv for kv in zip(paths, n50)))
+        t0 = time.perf_counter()
+        db = Database.from_sketches(sk, paths, n50, device=device)
+        t_db = time.perf_counter() - t0
+        sk.close()
+
+        def run(db, width, tag):
+            ws = os.path.join(tmp, "ws_" + tag) + "/"
+            os.makedirs(ws, exist_ok=True)
+            res = os.path.join(ws, "skDER_Results.txt")
+            t0 = time.perf_counter()
+            lowMemGreedyDerep(listing, ws, n50_file, res, ws, 99.5, 50.0, None, search_batch=width, database=db)
+            dt = time.perf_counter() - t0
+            return dt, open(res).read()
+        t_spec, reps_spec = run(db, 0, "spec")
+        t_seq, reps_seq = run(db, 1, "seq")
+        store = os.path.join(tmp, "sketches.skdr")
+        store_s = load_s = t_store_run = None
+        same_store = None
+        if shutil.disk_usage(tmp).free > 20e9:
+            t0 = time.perf_counter()
+            db.save(store)
+            store_s = time.perf_counter() - t0
+            store_bytes = os.path.getsize(store)
+            db.close()
+            t0 = time.perf_counter()
+            db = Database.load(store, device=device)
+            load_s = time.perf_counter() - t0
+            t_store_run, reps_store = run(db, 0, "store")
+            same_store = reps_store == reps_spec
+        db.close()
+        reps = reps_spec.split()
+        sp = {p: int(recipe.species[i]) for i, p in enumerate(paths)}
+        out = {"genomes": n, "bases": int(total), "representatives": len(reps), "species_represented": len({sp[r] for r in reps}), "species": int(recipe.species.max()) + 1,
+               "seconds_speculative_batches": t_spec, "seconds_one_search_per_representative": t_seq, "listings_identical": reps_spec == reps_seq,
+               "database_from_resident_sketches_s": t_db, "sketching_s_incl_generating_the_bases": t_sketch,
+               "store": None if store_s is None else {"write_s": store_s, "bytes": store_bytes, "load_and_index_s": load_s, "seconds_speculative_batches": t_store_run, "listing_identical": same_store},
+               "reference_published": {"seconds": 2.25 * 3600, "what": "README.md:27: low_mem_greedy on > 20,000 Staphylococcus genomes (GTDB R220), 20 threads, machine unspecified; "
+                                       "not a same-host, same-data comparison -- real genomes, FASTA ingest and skani's own arithmetic on one side, synthetic genomes already sketched on the other"},
+               "total_s_of_this_leg": time.perf_counter() - t_all,
+               "workload": "%d synthetic genomes x %.1f Mb (%d species x 10 strains x 10 isolates), lowMemGreedyDerep -i 99.5 -f 50 (skder.py:95-134) on one MI355X"
+                           % (n, genome_len / 1e6, int(recipe.species.max()) + 1)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
 def cpu_baseline_files(tmp, paths, threads):
     """oracle (CPU restatement, OpenMP) on the sample files, wall clock on `threads` host threads:
       per genome   : read + sketch, from a triangle whose 101 % screen lets no pair through;
@@ -389,6 +479,7 @@ def main():
     ap.add_argument("--no-realistic", action="store_true", help="skip the extra workloads (real genomes, indels, mixed sizes)")
     ap.add_argument("--indel-genomes", type=int, default=48, help="genomes of the host-generated indel family")
     ap.add_argument("--mixed-genomes", type=int, default=5000, help="genomes of the mixed 1-8 Mb extra workload (0: skip)")
+    ap.add_argument("--low-mem-genomes", type=int, default=20000, help="genomes of the low_mem_greedy leg (README.md:27's workload shape: 20000; 0: skip)")
     args = ap.parse_args()
 
     import torch
@@ -640,6 +731,11 @@ def main():
             batches.clear()      # the headline's resident bases are not needed any more
             torch.cuda.empty_cache()
             out["realistic"] = realistic_workloads(engine, ctx, torch, synth, args)
+            if args.low_mem_genomes > 0:
+                try:
+                    out["realistic"]["low_mem_greedy_%d" % args.low_mem_genomes] = low_mem_greedy_scale(engine, ctx, torch, synth, args.low_mem_genomes, 2_800_000, dev)
+                except Exception as ex:
+                    out["realistic"]["low_mem_greedy_%d" % args.low_mem_genomes] = {"error": str(ex)}
         print(json.dumps(out))
     ctx.close()
     if dist_on:

@@ -619,7 +619,13 @@ void store_load(const std::string &path, skder_sketches *s, GenomeNames &names)
     const uint64_t bytes = ns * 12 + nm * 8;
     HIPCHECK(hipHostMalloc(&h, bytes ? bytes : 8));
     struct HostFree { uint8_t *p; ~HostFree() { (void)hipHostFree(p); } } hf{h};
-    io.get(h, bytes);
+    // the checksum runs over the four arrays one after the other, each with its own word / tail-byte split, as store_save wrote
+    // them: one get() over the whole payload would split differently whenever an array's size is not a multiple of 8 (odd
+    // number of seeds) and refuse a good file
+    io.get(h, nm * 8);
+    io.get(h + nm * 8, ns * 4);
+    io.get(h + nm * 8 + ns * 4, ns * 4);
+    io.get(h + nm * 8 + ns * 8, ns * 4);
     uint64_t sum_file = 0, sum_calc = io.h;
     if (fread(&sum_file, 1, 8, f) != 8) throw SkError("sketch store: file is truncated");
     if (sum_file != sum_calc) throw SkError("sketch store: checksum mismatch (file is corrupt)");

@@ -828,6 +828,48 @@ def test_sketch_store_round_trip(gpu, tmp_path):
         (tmp_path / "run2" / "Skani_Triangle_Edge_Output.txt").read_text()
 
 
+def test_store_of_a_database_built_from_resident_sketches(gpu, tmp_path):
+    """skder_amd_db_from_sketches (a database from a sketch set already in HBM) and its sketch store: tables equal those of
+    the sketch set itself, and the store loads again whether the number of seeds is odd or even -- the checksum used to be
+    taken over the payload in one piece on load but array by array on save, which refused every store with an odd number
+    of seeds (found by the 2,000-genome low_mem_greedy run of round 3)."""
+    engine, ctx, torch = gpu
+    from skder_amd import synth
+    from skder_amd.skder import Database
+    rec = synth.make_recipe(9, genome_len=120000, n_species=1, strains_per_species=3)
+    seen = set()
+    for k in range(3, 10):
+        layout = engine.BatchLayout(rec.rec_lens[:k])
+        d = torch.zeros(layout.total_bytes, dtype=torch.uint8, device="cuda")
+        ctx.synth_fill(d.data_ptr(), layout, rec.lineage[:k], rec.params[:k])
+        sk = engine.Sketches(ctx)
+        sk.sketch_batch(d.data_ptr(), layout)
+        n_seeds = int(sk.view()["n_seeds"])
+        if n_seeds % 2 in seen and k < 9:
+            sk.close()
+            continue
+        seen.add(n_seeds % 2)
+        want = sk.triangle_rows(0, 1, 80.0)
+        paths = ["/nowhere/g%d.fa" % g for g in range(k)]
+        n50 = [int(max(rec.rec_lens[g])) for g in range(k)]
+        with Database.from_sketches(sk, paths, n50) as db:
+            sk.close()
+            assert db.paths == paths and db.n50 == n50
+            rows = db.triangle(0.0, 80.0)
+            key = lambda e: (int(e["ref"]), int(e["query"]))
+            a = {key(e): (float(e["ani"]), float(e["af_ref"]), float(e["af_query"])) for e in want}
+            b = {key(e): (float(e["ani"]), float(e["af_ref"]), float(e["af_query"])) for e in rows}
+            assert a == b and len(a) == k * (k - 1) // 2
+            srows = db.search_batch([paths[1]])                      # a resident query: no file is read
+            assert len(srows) == k and any(int(e["ref"]) == 1 and float(e["ani"]) == 1.0 for e in srows)
+            store = tmp_path / ("s%d.skdb" % k)
+            db.save(str(store))
+        with Database.load(str(store)) as db2:
+            assert db2.paths == paths and db2.n50 == n50
+            assert db2.triangle(0.0, 80.0).tobytes() == rows.tobytes()
+    assert seen == {0, 1}, "the recipe no longer yields both an odd and an even number of seeds: adjust it"
+
+
 def test_rccl_process_group_on_one_gpu(gpu):
     """the N > 1 code path with the REAL backend (nccl = RCCL): one rank under torch.distributed.run, device
     tensors through all_gather / all_gather_object / gather_object; same edges as the plain path"""
@@ -1342,6 +1384,55 @@ def test_config4_low_mem_greedy_at_scale(gpu, oracle, tmp_path):
             got = tmp_path / "search.tsv"
             db.search_batch([q], out_tsvs=[str(got)])
             assert got.read_text() == want.read_text() and got.read_text().count("\n") > 50
+
+
+def test_driver_greedy_and_dynamic_on_1000_genomes(gpu, oracle, tmp_path):
+    """BASELINE.json configs[1] / [2] by their own words -- greedy and dynamic selection over >= 1,000 genomes -- through
+    the whole flow of bin/skder (skder_amd.driver.run: FASTA files -> N50 table -> edge table on the GPU -> selection):
+    1,000 synthetic 2.8 Mb genomes = 10 species x 10 strains x 10 isolates.  At -i 98.5 -f 50 the table's edges join exactly
+    the isolates of one strain (within a strain the model ANI is >= 98.7, across strains <= 97.6), so
+      * greedy returns exactly one representative per strain, 100 in all;
+      * Genome_Information_for_Greedy_Clustering.txt equals the stdout of the REFERENCE's own skDERsum (oracle/_ref, compiled
+        from /root/reference/src/skDER/skDERsum.cpp) on the table and N50 file the driver wrote, and the dynamic listing equals
+        the stdout of the reference's skDERcore on them -- the selection counterpart at N = 1,000, not only on 34 genomes;
+      * sampled rows of the 1,000-genome table are text-identical with the oracle's table of those genomes alone."""
+    import subprocess
+    from conftest import ROOT
+    from skder_amd import driver
+    if shutil.disk_usage(str(tmp_path)).free < 5e9:
+        pytest.skip("needs 3 GB of scratch space for the FASTA files")
+    n = 1000
+    fdir = tmp_path / "fasta"
+    fdir.mkdir()
+    recipe, paths = _synthetic_files(gpu, fdir, n, genome_len=2_800_000)
+    strain_of = {p: (g // 100, (g % 100) % 10) for g, p in enumerate(paths)}
+    reps_g = driver.run(paths, str(tmp_path / "greedy"), "greedy", 98.5, 50.0, symlink=True)
+    assert len(reps_g) == 100 and {strain_of[r] for r in reps_g} == {(s, t) for s in range(10) for t in range(10)}
+    reps_d = driver.run(paths, str(tmp_path / "dynamic"), "dynamic", 98.5, 50.0, symlink=True)
+    assert 0 < len(reps_d) <= n and len(set(reps_d)) == len(reps_d) and set(reps_d) <= set(paths)
+    assert {strain_of[r][0] for r in reps_d} == set(range(10))            # no species is lost
+    table = tmp_path / "greedy" / "Skani_Triangle_Edge_Output.txt"
+    assert table.read_text() == (tmp_path / "dynamic" / "Skani_Triangle_Edge_Output.txt").read_text()
+    hdr, rows = load_table(str(table))
+    assert len(rows) == 10 * (100 * 99 // 2)                                # every within-species pair, nothing across species
+    n50_file = tmp_path / "greedy" / "Concatenated_N50.txt"
+    ref_dir = os.path.join(ROOT, "oracle", "_ref")
+    if os.path.isfile(os.path.join(ref_dir, "skDERsum")) and os.path.isfile(os.path.join(ref_dir, "skDERcore")):
+        out = subprocess.run([os.path.join(ref_dir, "skDERsum"), str(table), str(n50_file), "98.5", "50.0"], capture_output=True, text=True, check=True).stdout
+        assert out == (tmp_path / "greedy" / "Genome_Information_for_Greedy_Clustering.txt").read_text()
+        out = subprocess.run([os.path.join(ref_dir, "skDERcore"), str(table), str(n50_file), "98.5", "50.0", "10.0"], capture_output=True, text=True, check=True).stdout
+        assert out.split() == reps_d
+    # sampled rows against the oracle: two strains of species 3 and one of species 7 (30 genomes, 435 pairs of which 390 within a species)
+    pick = [p for p in paths if strain_of[p] in ((3, 0), (3, 7), (7, 4))]
+    sub = tmp_path / "sub.txt"
+    sub.write_text("".join(x + "\n" for x in pick))
+    want = tmp_path / "oracle_tri.tsv"
+    oracle.triangle(str(sub), 50.0, 88.5, 8, str(want), oracle.default_params())
+    _, orows = load_table(str(want))
+    big = {(r[0], r[1]): r for r in rows}
+    assert len(orows) == 20 * 19 // 2 + 10 * 9 // 2
+    for r in orows:
+        assert big[(r[0], r[1])] == r, r[:2]
 
 
 def test_config5_mixed_sizes_with_the_af_filter(gpu, oracle, tmp_path):
