@@ -1,5 +1,6 @@
 // api.hip -- the C ABI of include/skder_amd.h.
 #include <algorithm>
+#include <chrono>
 #include <numeric>
 #include <thread>
 
@@ -549,19 +550,30 @@ static void db_triangle_edges_multi(skder_db *db, double screen_pct, std::vector
     for (uint32_t d = 0; d < n; d++) { const auto &e = db_refs(db, d)->ctx->edges; E.insert(E.end(), e.begin(), e.end()); }
 }
 
+static double wall_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 extern "C" skder_db_t *skder_amd_sketch_n50(const char *listing, int device, const char *n50_tsv, char *err, size_t errlen)
 {
     if (!listing) { set_err(err, errlen, "null argument"); return nullptr; }
+    const double t0 = wall_ms();
     skder_ctx *ctx = skder_amd_ctx_create(device, err, errlen);
     if (!ctx) return nullptr;
     skder_db *db = new skder_db();
     db->ctx = ctx;
     try {
+        const double t1 = wall_ms();
         std::vector<std::string> paths = read_listing(listing);
         db->refs = skder_amd_sketches_new(ctx);
         sketch_files(db->refs, paths, db->names);
+        const double t2 = wall_ms();
         db_finish(db);
         if (n50_tsv) write_n50_tsv(n50_tsv, db->names);
+        if (getenv("SKDER_AMD_DEBUG"))
+            fprintf(stderr, "[skder_amd] database of %zu files: context %.1f ms, listing + ingest + sketch %.1f ms, index + N50 table %.1f ms\n", paths.size(),
+                    t1 - t0, t2 - t1, wall_ms() - t2);
         return db;
     } catch (const std::exception &e) {
         set_err(err, errlen, e.what());
@@ -625,7 +637,7 @@ extern "C" skder_db_t *skder_amd_sketch_multi(const char *listing, const int *de
             HIPCHECK(hipSetDevice(ctx_of(d)->device));
             part[d] = skder_amd_sketches_new(ctx_of(d));
             const size_t lo = G * d / n, hi = G * (d + 1) / n;
-            sketch_files(part[d], std::vector<std::string>(paths.begin() + lo, paths.begin() + hi), names[d]);
+            sketch_files(part[d], std::vector<std::string>(paths.begin() + lo, paths.begin() + hi), names[d], std::max(4u, ingest_threads() / n));
         });
         for (uint32_t d = 0; d < n; d++) {
             db->names.path.insert(db->names.path.end(), names[d].path.begin(), names[d].path.end());
@@ -720,8 +732,12 @@ extern "C" int skder_amd_db_triangle(skder_db_t *db, double min_af_pct, double s
     if (!db) { set_err(err, errlen, "null argument"); return 1; }
     try {
         HIPCHECK(hipSetDevice(db->ctx->device));
+        const double t0 = wall_ms();
         db_triangle_rows(db, min_af_pct, screen_pct);
+        const double t1 = wall_ms();
         if (out_tsv) write_rows_tsv(out_tsv, db->rows.data(), db->rows.size(), db->names, db->names);
+        if (getenv("SKDER_AMD_DEBUG"))
+            fprintf(stderr, "[skder_amd] table of %zu rows: screen + chain + row order %.1f ms, text %.1f ms\n", db->rows.size(), t1 - t0, wall_ms() - t1);
         if (edges) *edges = db->rows.data();
         if (n_edges) *n_edges = db->rows.size();
         return 0;

@@ -38,12 +38,18 @@ struct HostGenome {
 
 // plain or gzip FASTA -> kept records (>= ANI_MIN_CONTIG) in device layout.  region == nullptr: into g.own;
 // else into region[0 .. region_cap) (SkError "region" if it does not fit).  Throws SkError.
-void read_fasta(const std::string &path, HostGenome &g, uint8_t *region = nullptr, size_t region_cap = 0);
+// scratch: a reader thread's reusable working memory (text buffer, inflate state); nullptr: one per calling thread
+struct IoScratch;
+IoScratch *io_scratch_new();
+void io_scratch_free(IoScratch *p);
+void read_fasta(const std::string &path, HostGenome &g, uint8_t *region = nullptr, size_t region_cap = 0, IoScratch *scratch = nullptr);
 std::vector<std::string> read_listing(const std::string &path);
 
 // sketch a list of genomes read from disk into `s` (batched H2D copies); names/paths returned
 struct GenomeNames { std::vector<std::string> path, first_name; std::vector<uint64_t> n50; };
-void sketch_files(skder_sketches *s, const std::vector<std::string> &paths, GenomeNames &names);
+// threads: reader threads of this call (0: SKDER_AMD_IO_THREADS, or one per core up to 128)
+void sketch_files(skder_sketches *s, const std::vector<std::string> &paths, GenomeNames &names, unsigned threads = 0);
+unsigned ingest_threads();
 
 // TSV writers. Atomic: written to a temporary name, then renamed.
 void write_triangle_tsv(const std::string &out, const std::vector<skder_edge_t> &edges, const GenomeNames &names,

@@ -11,7 +11,10 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <future>
+#include <mutex>
 #include <thread>
 
 // growing or fixed output of the parser
@@ -31,9 +34,8 @@ struct OutBuf {
     }
 };
 struct FileCloser {
-    gzFile gz = nullptr;
     int fd = -1;
-    ~FileCloser() { if (gz) gzclose(gz); if (fd >= 0) close(fd); }
+    ~FileCloser() { if (fd >= 0) close(fd); }
 };
 }   // namespace
 
@@ -47,26 +49,104 @@ static bool looks_gzip(const std::string &path)
     return k == 2 && m[0] == 0x1f && m[1] == 0x8b;
 }
 
-void read_fasta(const std::string &path, HostGenome &g, uint8_t *region, size_t region_cap)
+// Per-thread working memory of the reader, reused from file to file: the text buffer the FASTA scan runs over, the
+// compressed-input buffer and the inflate state.  (gzopen / gzread allocate and release two 1 MB buffers per file and a
+// thread_local buffer dies with its thread: with a hundred reader threads those mmap / munmap calls and the page faults
+// behind them serialise on the process's address-space lock and the ingest stops scaling at 16 threads -- measured.)
+struct IoScratch {
+    std::vector<char> text;
+    std::vector<unsigned char> zin;
+    z_stream strm;
+    bool z_ready = false;
+    IoScratch() : text(1u << 20), zin(256u << 10) { memset(&strm, 0, sizeof strm); }
+    ~IoScratch() { if (z_ready) inflateEnd(&strm); }
+    IoScratch(const IoScratch &) = delete;
+    IoScratch &operator=(const IoScratch &) = delete;
+};
+IoScratch *io_scratch_new() { return new IoScratch(); }
+void io_scratch_free(IoScratch *p) { delete p; }
+
+namespace {
+// decoded text of a plain or gzip file, a buffer at a time.  gzip: every member of the file (concatenated members --
+// bgzip writes thousands -- decode to the concatenation of their contents, as zlib's own gzread does); bytes behind the
+// last member that do not start another one are ignored; a stream that ends early or does not decode is an error.
+struct TextSource {
+    const std::string &path;
+    int fd;
+    bool gz;
+    IoScratch &sc;
+    bool member_open = false, input_eof = false, done = false;
+    TextSource(const std::string &p, int f, bool g, IoScratch &s) : path(p), fd(f), gz(g), sc(s)
+    {
+        if (!gz) return;
+        int rc = sc.z_ready ? inflateReset(&sc.strm) : inflateInit2(&sc.strm, 15 + 16);
+        if (rc != Z_OK) throw SkError("zlib initialisation failed for " + path);
+        sc.z_ready = true;
+        sc.strm.avail_in = 0; sc.strm.next_in = sc.zin.data();
+        member_open = true;
+    }
+    void refill()
+    {
+        // keep what is left (at most a byte or two when looking for the next member's magic) and append
+        unsigned char *b = sc.zin.data();
+        const size_t left = sc.strm.avail_in;
+        if (left && sc.strm.next_in != b) memmove(b, sc.strm.next_in, left);
+        const long n = (long)read(fd, b + left, sc.zin.size() - left);
+        if (n < 0) throw SkError("read error in " + path);
+        if (n == 0) input_eof = true;
+        sc.strm.next_in = b; sc.strm.avail_in = (uInt)(left + (size_t)n);
+    }
+    // up to cap bytes into dst; 0 = end of the text
+    long fill(char *dst, size_t cap)
+    {
+        if (!gz) {
+            const long n = (long)read(fd, dst, cap);
+            if (n < 0) throw SkError("read error in " + path);
+            return n;
+        }
+        size_t produced = 0;
+        while (produced < cap && !done) {
+            if (!member_open) {
+                // between members: another gzip header, or the end (trailing bytes that are no header are ignored)
+                while (sc.strm.avail_in < 2 && !input_eof) refill();
+                if (sc.strm.avail_in >= 2 && sc.strm.next_in[0] == 0x1f && sc.strm.next_in[1] == 0x8b) {
+                    if (inflateReset(&sc.strm) != Z_OK) throw SkError("zlib reset failed for " + path);
+                    member_open = true;
+                } else { done = true; break; }
+            }
+            if (sc.strm.avail_in == 0) {
+                if (!input_eof) refill();
+                if (sc.strm.avail_in == 0) throw SkError("truncated or corrupt gzip file " + path + ": unexpected end of file");
+            }
+            sc.strm.next_out = reinterpret_cast<Bytef *>(dst + produced);
+            sc.strm.avail_out = (uInt)(cap - produced);
+            const int rc = inflate(&sc.strm, Z_NO_FLUSH);
+            produced = cap - sc.strm.avail_out;
+            if (rc == Z_STREAM_END) member_open = false;
+            else if (rc != Z_OK && rc != Z_BUF_ERROR)
+                throw SkError("truncated or corrupt gzip file " + path + ": " + (sc.strm.msg ? sc.strm.msg : "zlib data error"));
+        }
+        return (long)produced;
+    }
+};
+}   // namespace
+
+void read_fasta(const std::string &path, HostGenome &g, uint8_t *region, size_t region_cap, IoScratch *scratch)
 {
     g.path = path;
     g.first_name.clear(); g.rec_len.clear(); g.rec_rel.clear(); g.packed_size = 0;
     free(g.own); g.own = nullptr;
+    static thread_local IoScratch own_scratch;       // callers without a pool (one-off reads, the sanitizer harness)
+    IoScratch &sc = scratch ? *scratch : own_scratch;
     FileCloser fc;
     const bool gz = looks_gzip(path);
-    if (gz) {
-        fc.gz = gzopen(path.c_str(), "rb");
-        if (!fc.gz) throw SkError("cannot open " + path);
-        gzbuffer(fc.gz, 1 << 20);
-    } else {
-        fc.fd = open(path.c_str(), O_RDONLY);
-        if (fc.fd < 0) throw SkError("cannot open " + path);
-    }
+    fc.fd = open(path.c_str(), O_RDONLY);
+    if (fc.fd < 0) throw SkError("cannot open " + path);
+    TextSource src(path, fc.fd, gz, sc);
     OutBuf out{region, 0, region ? region_cap : 0, region != nullptr};
     struct OwnGuard { OutBuf &o; bool armed; ~OwnGuard() { if (armed && !o.fixed) free(o.p); } } guard{out, true};
     std::vector<uint64_t> all_len;
-    static thread_local std::vector<char> buf;
-    if (buf.size() < (1u << 20)) buf.resize(1u << 20);
+    std::vector<char> &buf = sc.text;
     std::string cur_name;
     bool in_header = false, have_rec = false, have_first = false;
     size_t rec_start = 0;   // offset in the packed layout where the current record starts (multiple of 32)
@@ -95,19 +175,8 @@ void read_fasta(const std::string &path, HostGenome &g, uint8_t *region, size_t 
     };
     bool at_line_start = true;
     for (;;) {
-        long n = gz ? (long)gzread(fc.gz, buf.data(), (unsigned)buf.size()) : (long)read(fc.fd, buf.data(), buf.size());
-        if (n < 0) throw SkError("read error in " + path);
-        if (n == 0) {
-            // zlib returns 0, not -1, when a gzip stream ends early and reports it through gzerror only: a truncated or
-            // corrupt file must fail as it does in the reference (gzip.open in util.n50_calc, and skani itself), not be
-            // taken for a shorter genome
-            if (gz) {
-                int zerr = Z_OK;
-                const char *msg = gzerror(fc.gz, &zerr);
-                if (zerr != Z_OK && zerr != Z_STREAM_END) throw SkError("truncated or corrupt gzip file " + path + ": " + (msg ? msg : "zlib error"));
-            }
-            break;
-        }
+        const long n = src.fill(buf.data(), buf.size());      // (a gzip stream that ends early or does not decode throws: a truncated file
+        if (n == 0) break;                                    //  must fail as it does in the reference, not be taken for a shorter genome)
         const char *p = buf.data(), *end = p + n;
         // one pass over the buffer decides between the bulk path (no blank characters: lines are copied with
         // memcpy) and the careful path (CRLF files, blanks inside lines): is any byte below 0x21 not a '\n'?
@@ -193,68 +262,175 @@ std::vector<std::string> read_listing(const std::string &path)
     return v;
 }
 
-// run fn(k) for k in [0, n) on up to nthreads host threads; the first exception is re-thrown
-template <class F>
-static void parallel_for(size_t n, unsigned nthreads, F fn)
-{
-    std::atomic<size_t> next(0);
-    std::atomic<bool> failed(false);
-    std::string first_err;
-    std::vector<std::thread> th;
-    const unsigned nt = (unsigned)std::min<size_t>(nthreads, n ? n : 1);
-    for (unsigned t = 0; t < nt; t++)
-        th.emplace_back([&]() {
+// Reader threads of one ingest call: started once, each with its own IoScratch, handed one parallel loop after the other
+// (run(n, fn): fn(k, scratch) for k in [0, n), files dealt out one at a time; the first exception is re-thrown).
+class IoPool {
+  public:
+    explicit IoPool(unsigned nthreads)
+    {
+        for (unsigned t = 0; t < (nthreads ? nthreads : 1u); t++) th_.emplace_back([this]() { worker(); });
+    }
+    ~IoPool()
+    {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_work_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    unsigned size() const { return (unsigned)th_.size(); }
+    template <class F>
+    void run(size_t n, F fn)
+    {
+        if (n == 0) return;
+        std::function<void(size_t, IoScratch &)> f = fn;
+        std::unique_lock<std::mutex> lk(mu_);
+        fn_ = &f; n_ = n; next_ = 0; pending_ = th_.size(); failed_ = false; first_err_.clear();
+        gen_++;
+        cv_work_.notify_all();
+        cv_done_.wait(lk, [this]() { return pending_ == 0; });
+        fn_ = nullptr;
+        if (failed_) throw SkError(first_err_);
+    }
+
+  private:
+    void worker()
+    {
+        IoScratch sc;
+        uint64_t seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_work_.wait(lk, [&]() { return stop_ || gen_ != seen; });
+            if (stop_) return;
+            seen = gen_;
             for (;;) {
-                const size_t k = next.fetch_add(1);
-                if (k >= n || failed.load()) break;
-                try { fn(k); }
+                if (next_ >= n_ || failed_) break;
+                const size_t k = next_++;
+                lk.unlock();
+                try { (*fn_)(k, sc); }
                 catch (const std::exception &e) {
-                    if (!failed.exchange(true)) first_err = e.what();
+                    lk.lock();
+                    if (!failed_) { failed_ = true; first_err_ = e.what(); }
+                    continue;
                 }
+                lk.lock();
             }
-        });
-    for (auto &t : th) t.join();
-    if (failed) throw SkError(first_err);
+            if (--pending_ == 0) cv_done_.notify_all();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_work_, cv_done_;
+    const std::function<void(size_t, IoScratch &)> *fn_ = nullptr;
+    size_t n_ = 0, next_ = 0, pending_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false, failed_ = false;
+    std::string first_err_;
+};
+
+namespace {
+struct Slot { uint8_t *h = nullptr, *d = nullptr; size_t cap = 0; };
+struct StagingSet { Slot sl[2]; bool busy = false; };
+std::mutex g_staging_mu;
+StagingSet g_staging[64];          // per device
+// the device's cached slots if nobody holds them, else a private pair that is freed again
+struct StagingLease {
+    Slot own[2];
+    Slot *slots = own;
+    StagingSet *set = nullptr;
+    explicit StagingLease(int device)
+    {
+        if (device < 0 || device >= 64) return;
+        std::lock_guard<std::mutex> lk(g_staging_mu);
+        if (!g_staging[device].busy) { set = &g_staging[device]; set->busy = true; slots = set->sl; }
+    }
+    ~StagingLease()
+    {
+        if (set) { std::lock_guard<std::mutex> lk(g_staging_mu); set->busy = false; return; }
+        for (auto &s : own) { if (s.d) (void)hipFree(s.d); if (s.h) (void)hipHostFree(s.h); }
+    }
+};
+}   // namespace
+
+// Host threads of the ingest: one per file in flight -- as many as the process may actually RUN at once.  A container is
+// often given fewer CPUs than the machine shows (cgroup CPU quota: the MI355X boxes this was measured on show 256 hardware
+// threads and grant 16 CPUs' worth of time); threads beyond the quota only get throttled, and the ingest was slower with 128
+// threads than with 16 there.  SKDER_AMD_IO_THREADS overrides.
+static unsigned cgroup_cpu_quota()
+{
+    // cgroup v2: "<quota> <period>" or "max <period>"; v1: cpu.cfs_quota_us (-1: none) / cpu.cfs_period_us
+    double quota = -1, period = 100000;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64] = {0};
+        if (fscanf(f, "%63s %lf", q, &period) == 2 && strcmp(q, "max") != 0) quota = atof(q);
+        fclose(f);
+    } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+        if (fscanf(g, "%lf", &quota) != 1) quota = -1;
+        fclose(g);
+        if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lf", &period) != 1) period = 100000; fclose(h); }
+    }
+    if (quota <= 0 || period <= 0) return 0;
+    return (unsigned)std::max(1.0, quota / period + 0.5);
+}
+unsigned ingest_threads()
+{
+    if (const char *e = getenv("SKDER_AMD_IO_THREADS")) return (unsigned)std::max(1, atoi(e));
+    static const unsigned n = []() {
+        unsigned t = std::max(1u, std::min(128u, std::thread::hardware_concurrency()));
+        const unsigned q = cgroup_cpu_quota();
+        return q ? std::min(t, q) : t;
+    }();
+    return n;
 }
 
-void sketch_files(skder_sketches *s, const std::vector<std::string> &paths, GenomeNames &names)
+void sketch_files(skder_sketches *s, const std::vector<std::string> &paths, GenomeNames &names, unsigned threads)
 {
     skder_ctx *ctx = s->ctx;
     hipStream_t st = ctx->stream;
-    size_t batch_bytes = 256ull << 20;   // per batch of bases: small enough that pinning the staging buffer is cheap
+    size_t batch_bytes = 512ull << 20;   // per batch of bases: enough files for every host thread, small enough that pinning the two staging buffers stays cheap
     if (const char *e = getenv("SKDER_AMD_IO_BATCH_MB")) batch_bytes = (size_t)std::max(1, atoi(e)) << 20;
-    unsigned nthreads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
-    if (const char *e = getenv("SKDER_AMD_IO_THREADS")) nthreads = (unsigned)std::max(1, atoi(e));
     const bool dbg = getenv("SKDER_AMD_DEBUG") != nullptr;
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();
     // two staging slots (pinned host + device buffer each), kept across batches and grown when a batch needs
     // more: while the device copies and sketches the batch of one slot, the host threads parse the next batch
-    // into the other
-    struct Slot { uint8_t *h = nullptr, *d = nullptr; size_t cap = 0; };
-    Slot slot[2];
-    struct Staging {
-        Slot *sl;
-        ~Staging() { for (int k = 0; k < 2; k++) { if (sl[k].d) (void)hipFree(sl[k].d); if (sl[k].h) (void)hipHostFree(sl[k].h); } }
-    } staging{slot};
-    // file sizes and kinds up front (parallel stat + 2-byte read): a plain file's packed layout is bounded by
-    // its size (+ 32 bytes of padding per kept record of >= 500 bases), so it can be parsed straight into
-    // its region of the staging buffer; a gzip file is inflated into memory of its own first
-    struct FileInfo { uint64_t size = 0; bool gz = false; };
+    // into the other.  The slots outlive the call (one set per device, handed to one caller at a time): pinning
+    // a few hundred MB costs tens of milliseconds, which a process that ingests more than once -- a search per external
+    // query, a dist after a triangle -- pays once.
+    StagingLease lease(ctx->device);
+    Slot *slot = lease.slots;
+    IoPool pool(std::min<size_t>(threads ? threads : ingest_threads(), paths.size() ? paths.size() : 1));
+    // file sizes and kinds up front (parallel stat + magic): a plain file's packed layout is bounded by its size (+ 32 bytes
+    // of padding per kept record of >= 500 bases), so it is parsed straight into its region of the pinned staging buffer.  A
+    // gzip file says how long its text is in its last four bytes (ISIZE) -- reliably so when it holds ONE member: it gets a
+    // region from that and is inflated + parsed straight into it as well (no memory of its own, no second copy).  Files whose
+    // ISIZE cannot be the whole text (several members, e.g. bgzip; more than 4 GB) and batches in which a region turns out too
+    // small take the two-phase path: into memory of their own first, regions from the exact sizes, then copied in.
+    struct FileInfo { uint64_t size = 0, text = 0; bool gz = false, trusted = true; };
     std::vector<FileInfo> info(paths.size());
-    parallel_for(paths.size(), nthreads, [&](size_t k) {
+    pool.run(paths.size(), [&](size_t k, IoScratch &) {
+        FileCloser fc;
+        fc.fd = open(paths[k].c_str(), O_RDONLY);
         struct stat sb;
-        if (stat(paths[k].c_str(), &sb) != 0) throw SkError("cannot open " + paths[k]);
-        info[k].size = (uint64_t)sb.st_size;
-        info[k].gz = looks_gzip(paths[k]);
+        if (fc.fd < 0 || fstat(fc.fd, &sb) != 0) throw SkError("cannot open " + paths[k]);
+        FileInfo &fi = info[k];
+        fi.size = fi.text = (uint64_t)sb.st_size;
+        unsigned char m[2] = {0, 0}, tail[4] = {0, 0, 0, 0};
+        fi.gz = fi.size >= 2 && pread(fc.fd, m, 2, 0) == 2 && m[0] == 0x1f && m[1] == 0x8b;
+        if (fi.gz) {
+            uint64_t isize = 0;
+            if (fi.size >= 18 && pread(fc.fd, tail, 4, (off_t)fi.size - 4) == 4)
+                isize = (uint64_t)tail[0] | (uint64_t)tail[1] << 8 | (uint64_t)tail[2] << 16 | (uint64_t)tail[3] << 24;
+            // FASTA text deflates 3-4.5 x: a text shorter than the file, or more than 64 x longer, is not one member's size
+            fi.trusted = isize >= fi.size && isize <= 64 * fi.size;
+            fi.text = fi.trusted ? isize : 4 * fi.size;
+        }
     });
     auto bound = [](uint64_t fsize) { return ((fsize + fsize / 15 + 256) + 31) & ~(uint64_t)31; };
-    // the batch starting at i0: files until ~batch_bytes of layout (gzip files are estimated at 4x their size)
+    // the batch starting at i0: files until ~batch_bytes of layout
     auto batch_end = [&](size_t i0) {
         size_t i1 = i0;
         uint64_t est = 0;
         while (i1 < paths.size() && (i1 == i0 || est < batch_bytes)) {
-            est += info[i1].gz ? 4 * info[i1].size : bound(info[i1].size);
+            est += bound(info[i1].text);
             i1++;
         }
         return i1;
@@ -274,39 +450,63 @@ void sketch_files(skder_sketches *s, const std::vector<std::string> &paths, Geno
         Prepared P;
         P.i0 = i0; P.i1 = i1; P.sl = sl;
         const size_t ng = i1 - i0;
-        P.gs.resize(ng);
         std::vector<HostGenome> &gs = P.gs;
-        // phase A: gzip files into memory of their own (exact sizes afterwards)
-        parallel_for(ng, nthreads, [&](size_t k) { if (info[i0 + k].gz) read_fasta(paths[i0 + k], gs[k]); });
-        // regions: 32 readable bytes in front, SKDER_TILE + 64 behind
         std::vector<uint64_t> gbase(ng + 1);
         uint64_t off = 32;
-        for (size_t k = 0; k < ng; k++) {
-            gbase[k] = off;
-            off += info[i0 + k].gz ? gs[k].packed_size : bound(info[i0 + k].size);
-        }
-        gbase[ng] = off;
-        P.total = off + SKDER_TILE + 64;
         Slot &S = slot[sl];
-        if (P.total > S.cap) {
+        auto room = [&](uint64_t total) {            // regions: 32 readable bytes in front, SKDER_TILE + 64 behind
+            if (total <= S.cap) return;
             if (S.d) (void)hipFree(S.d);
             if (S.h) (void)hipHostFree(S.h);
             S.h = S.d = nullptr;
-            S.cap = P.total + P.total / 8;
+            S.cap = total + total / 8;
             HIPCHECK(hipHostMalloc(&S.h, S.cap));
             HIPCHECK(hipMalloc(&S.d, S.cap));
+        };
+        bool direct = getenv("SKDER_AMD_IO_TWO_PHASE") == nullptr;
+        for (size_t k = 0; k < ng; k++) direct = direct && info[i0 + k].trusted;
+        if (direct) {
+            // every file straight into its region
+            gs.clear(); gs.resize(ng);
+            off = 32;
+            for (size_t k = 0; k < ng; k++) { gbase[k] = off; off += bound(info[i0 + k].text); }
+            gbase[ng] = off;
+            room(off + SKDER_TILE + 64);
+            std::atomic<bool> too_small(false);
+            pool.run(ng, [&](size_t k, IoScratch &sc) {
+                if (too_small.load()) return;
+                try { read_fasta(paths[i0 + k], gs[k], S.h + gbase[k], gbase[k + 1] - gbase[k], &sc); }
+                catch (const SkError &e) {
+                    if (std::string(e.what()) != "region") throw;
+                    too_small.store(true);              // the text is longer than the file said: the whole batch again, two-phase
+                }
+            });
+            direct = !too_small.load();
         }
+        if (!direct) {
+            gs.clear(); gs.resize(ng);
+            // phase A: gzip files into memory of their own (exact sizes afterwards)
+            pool.run(ng, [&](size_t k, IoScratch &sc) { if (info[i0 + k].gz) read_fasta(paths[i0 + k], gs[k], nullptr, 0, &sc); });
+            off = 32;
+            for (size_t k = 0; k < ng; k++) {
+                gbase[k] = off;
+                off += info[i0 + k].gz ? gs[k].packed_size : bound(info[i0 + k].size);
+            }
+            gbase[ng] = off;
+            room(off + SKDER_TILE + 64);
+            // phase B: plain files are parsed straight into their regions, inflated ones are copied in
+            pool.run(ng, [&](size_t k, IoScratch &sc) {
+                if (info[i0 + k].gz) {
+                    if (gs[k].packed_size) memcpy(S.h + gbase[k], gs[k].own, gs[k].packed_size);
+                    free(gs[k].own); gs[k].own = nullptr;
+                } else {
+                    read_fasta(paths[i0 + k], gs[k], S.h + gbase[k], gbase[k + 1] - gbase[k], &sc);
+                }
+            });
+        }
+        P.total = off + SKDER_TILE + 64;
         uint8_t *h = S.h;
         memset(h, 'A', 32);
-        // phase B: plain files are parsed straight into their regions, inflated ones are copied in
-        parallel_for(ng, nthreads, [&](size_t k) {
-            if (info[i0 + k].gz) {
-                if (gs[k].packed_size) memcpy(h + gbase[k], gs[k].own, gs[k].packed_size);
-                free(gs[k].own); gs[k].own = nullptr;
-            } else {
-                read_fasta(paths[i0 + k], gs[k], h + gbase[k], gbase[k + 1] - gbase[k]);
-            }
-        });
         memset(h + off, 'A', SKDER_TILE + 64);
         for (size_t k = 0; k < ng; k++) {
             P.gbegin.push_back((uint32_t)P.rec_len.size());

@@ -716,6 +716,58 @@ def test_n50_from_the_ingest_pass(gpu, tmp_path):
         assert db.n50 == [want]
 
 
+def test_gzip_inputs_direct_and_two_phase(gpu, tmp_path, monkeypatch):
+    """The ingest's two routes for .gz files give the table and the N50s of the plain files: one-member files go straight
+    into a region of the staging buffer sized from the gzip trailer (ISIZE); files with several members (bgzip-like), whose
+    trailer says nothing about the whole text, send their batch down the two-phase route; SKDER_AMD_IO_TWO_PHASE forces it;
+    a trailer that understates the text (a crafted file) is caught by the region check and handled the same way."""
+    import skder_amd
+    gdir = tmp_path / "g"
+    gdir.mkdir()
+    names = GENOMES[:6]
+    texts = {n: gzip.open(os.path.join(GOLDEN, "genomes", n), "rb").read() for n in names}
+
+    def table(kind, env=None):
+        d = tmp_path / kind
+        d.mkdir()
+        paths = []
+        for n in names:
+            t = texts[n]
+            base = n[:-3] if n.endswith(".gz") else n
+            if kind == "plain":
+                p = d / base
+                p.write_bytes(t)
+            elif kind == "one":
+                p = d / (base + ".gz")
+                p.write_bytes(gzip.compress(t, 1))
+            elif kind == "members":
+                p = d / (base + ".gz")
+                p.write_bytes(b"".join(gzip.compress(t[i:i + 60000], 1) for i in range(0, len(t), 60000)) + gzip.compress(b""))
+            else:       # "lying": one honest member, then a second one whose (small) size is what the trailer shows
+                p = d / (base + ".gz")
+                cut = len(t) - len(t) // 3
+                cut = t.rfind(b"\n", 0, cut) + 1
+                p.write_bytes(gzip.compress(t[:cut], 1) + gzip.compress(t[cut:], 1))
+            paths.append(str(p))
+        listing = d / "listing.txt"
+        listing.write_text("".join(x + "\n" for x in paths))
+        out, n50 = d / "tri.tsv", d / "n50.tsv"
+        if env:
+            monkeypatch.setenv(env, "1")
+        skder_amd.runSkaniTriangle(str(listing), str(out), "-s 89.5", 10.0, "greedy", False, None, n50_file=str(n50))
+        if env:
+            monkeypatch.delenv(env)
+        strip = lambda text: [[os.path.basename(c).replace(".gz", "") if i < 2 else c for i, c in enumerate(l.split("\t"))] for l in text.splitlines()]
+        return strip(out.read_text()), strip(n50.read_text())
+    want = table("plain")
+    assert len(want[0]) == 1 + 15 and len(want[1]) == 6
+    assert table("one") == want
+    assert table("members") == want
+    assert table("lying") == want
+    shutil.rmtree(tmp_path / "one")
+    assert table("one", env="SKDER_AMD_IO_TWO_PHASE") == want
+
+
 def test_database_table_in_memory_equals_text(gpu, tmp_path):
     """the rows handed over in memory are the rows of the text table (same order, same
     orientation, same 2-decimal values), for a listing that is NOT in path order"""

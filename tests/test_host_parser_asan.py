@@ -57,19 +57,33 @@ def test_parser_under_sanitizers(tmp_path):
         with gzip.open(tmp_path / (k + ".gz"), "wb") as f:
             f.write(files[k])
         want[k + ".gz"] = want[k]
-    # a gzip stream cut short must be refused, not taken for a shorter genome (zlib reports it through gzerror only)
+    # several gzip members in one file decode to the concatenation of their texts (zlib's gzread does that; bgzip writes files
+    # of thousands of small members), member boundaries anywhere -- inside a line, inside a header; bytes behind the last
+    # member that do not start another one are ignored
+    text = files["many.fa"]
+    cuts = [0, 7, 1000, 1003, len(text) // 2, len(text) - 5, len(text)]
+    (tmp_path / "members.fa.gz").write_bytes(b"".join(gzip.compress(text[a:b], 1) for a, b in zip(cuts[:-1], cuts[1:])))
+    want["members.fa.gz"] = want["many.fa"]
+    (tmp_path / "blocks.fa.gz").write_bytes(b"".join(gzip.compress(files["plain.fa"][i:i + 997], 6) for i in range(0, len(files["plain.fa"]), 997)) + gzip.compress(b""))
+    want["blocks.fa.gz"] = want["plain.fa"]
+    (tmp_path / "tail.fa.gz").write_bytes(gzip.compress(files["crlf.fa"]) + b"\0" * 37 + b"not a member")
+    want["tail.fa.gz"] = want["crlf.fa"]
+    # a gzip stream cut short must be refused, not taken for a shorter genome -- in the first member or in a later one
     whole = (tmp_path / "plain.fa.gz").read_bytes()
     (tmp_path / "cut.fa.gz").write_bytes(whole[:len(whole) * 2 // 3])
-    names = sorted(want) + ["cut.fa.gz"]
+    whole = (tmp_path / "members.fa.gz").read_bytes()
+    (tmp_path / "cut2.fa.gz").write_bytes(whole[:len(whole) - 9])
+    names = sorted(want) + ["cut.fa.gz", "cut2.fa.gz"]
     out = subprocess.run([exe] + names, cwd=tmp_path, capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"),
                          timeout=300)
     assert out.returncode == 0, out.stderr[-3000:]
     assert "ERROR" not in out.stderr and "runtime error" not in out.stderr, out.stderr[-3000:]
     lines = [l.split() for l in out.stdout.splitlines()]
     assert len(lines) == len(names)
-    cut = [l for l in lines if l[0] == "cut.fa.gz"]
-    assert len(cut) == 1 and cut[0][1] == "ERRORED" and "gzip" in " ".join(cut[0]), cut
-    for l in [l for l in lines if l[0] != "cut.fa.gz"]:
+    for c in ("cut.fa.gz", "cut2.fa.gz"):
+        cut = [l for l in lines if l[0] == c]
+        assert len(cut) == 1 and cut[0][1] == "ERRORED" and "gzip" in " ".join(cut[0]), cut
+    for l in [l for l in lines if l[0] not in ("cut.fa.gz", "cut2.fa.gz")]:
         nrec, nbases, n50, first = want[l[0]]
         assert int(l[2]) == nrec and int(l[4]) == nbases and int(l[8]) == n50, l
         assert l[-2:] == ["same", "1"], l                    # own-memory and region layouts agree byte for byte
