@@ -714,16 +714,19 @@ static void db_triangle_rows(skder_db *db, double min_af_pct, double screen_pct)
     const uint32_t n = (uint32_t)db->names.path.size();
     std::vector<uint32_t> rank(n), perm(n);
     for (uint32_t r = 0; r < n; r++) { perm[r] = db->by_path[r].second; rank[perm[r]] = r; }
-    std::vector<skder_edge_t> E;
-    if (db->more.empty()) { triangle_rows_impl(db->refs, 0, 1, screen_pct); E = db->ctx->edges; }
+    // ONE copy of the edge list from here on: the engine's buffer is taken over (swap), ordered and filtered in place, and
+    // becomes db->rows
+    std::vector<skder_edge_t> &E = db->rows;
+    E.clear();
+    if (db->more.empty()) { triangle_rows_impl(db->refs, 0, 1, screen_pct); E.swap(db->ctx->edges); }
     else db_triangle_edges_multi(db, screen_pct, E);
     for (auto &e : E) {
         uint32_t a = rank[e.ref], b = rank[e.query];
         if (a > b) { std::swap(a, b); std::swap(e.af_ref, e.af_query); }
         e.ref = a; e.query = b;
     }
-    db->rows = triangle_rows_ordered(E, min_af_pct);
-    for (auto &e : db->rows) { e.ref = perm[e.ref]; e.query = perm[e.query]; }
+    triangle_rows_order_inplace(E, min_af_pct);
+    for (auto &e : E) { e.ref = perm[e.ref]; e.query = perm[e.query]; }
 }
 
 extern "C" int skder_amd_db_triangle(skder_db_t *db, double min_af_pct, double screen_pct, const char *out_tsv,
@@ -836,7 +839,8 @@ extern "C" int skder_amd_search_batch(skder_db_t *db, const char *const *query_p
         db->rows.clear();
         if (n_queries && db->more.empty()) {
             rectangle_impl(db->refs, q, screen_pct);
-            db->rows = rect_rows_ordered(db->ctx->edges, min_af_pct);
+            db->rows.swap(db->ctx->edges);
+            rect_rows_order_inplace(db->rows, min_af_pct);
         } else if (n_queries) {
             // several GPUs: every GPU gets the queries' sketches (a peer copy of GPU 0's), screens a share of the queries
             // against all markers and chains the pairs whose DATABASE genome it owns -- if the pair probes that genome its
@@ -875,7 +879,8 @@ extern "C" int skder_amd_search_batch(skder_db_t *db, const char *const *query_p
             std::vector<skder_edge_t> E;
             for (uint32_t d = 0; d < n; d++) { const auto &e = db_refs(db, d)->ctx->edges; E.insert(E.end(), e.begin(), e.end()); }
             for (uint32_t d = 1; d < n; d++) skder_amd_sketches_free(qs[d]);
-            db->rows = rect_rows_ordered(E, min_af_pct);
+            db->rows.swap(E);
+            rect_rows_order_inplace(db->rows, min_af_pct);
         }
         if (out_tsvs) {
             size_t lo = 0;

@@ -60,6 +60,9 @@ void write_rect_tsv(const std::string &out, const std::vector<skder_edge_t> &edg
 // the same tables as row arrays (the selection step reads these, no text round trip)
 std::vector<skder_edge_t> triangle_rows_ordered(const std::vector<skder_edge_t> &edges, double min_af_pct);
 std::vector<skder_edge_t> rect_rows_ordered(const std::vector<skder_edge_t> &edges, double min_af_pct);
+// the same orders established in place (no copy of the edge list; the callers hand the list over by swap)
+void triangle_rows_order_inplace(std::vector<skder_edge_t> &edges, double min_af_pct);
+void rect_rows_order_inplace(std::vector<skder_edge_t> &edges, double min_af_pct);
 void write_rows_tsv(const std::string &out, const skder_edge_t *rows, size_t n, const GenomeNames &ref_names,
                     const GenomeNames &query_names);
 // Concatenated_N50.txt (util.py:476-501)

@@ -595,15 +595,6 @@ struct FxMap {
     }
 };
 
-static void print_row(FILE *o, const std::string &rf, const std::string &qf, const skder_edge_t &e, const std::string &rn,
-                      const std::string &qn)
-{
-    // skani keeps its results in single precision and prints percentages with two decimals
-    float ani = (float)e.ani, afr = (float)e.af_ref, afq = (float)e.af_query;
-    fprintf(o, "%s\t%s\t%.2f\t%.2f\t%.2f\t%s\t%s\n", rf.c_str(), qf.c_str(), (double)(ani * 100.0f), (double)(afr * 100.0f),
-            (double)(afq * 100.0f), rn.c_str(), qn.c_str());
-}
-
 static bool passes_min_af(const skder_edge_t &e, double min_af_pct)
 {
     float afr = (float)e.af_ref, afq = (float)e.af_query;
@@ -630,9 +621,39 @@ struct TmpFile {
     ~TmpFile() { if (f) { fclose(f); remove(tmp.c_str()); } }
 };
 
+// fn(k) for k in [0, n) on up to nthreads host threads (k dealt out one at a time); the first exception is re-thrown
+template <class F>
+static void host_parallel_for(size_t n, unsigned nthreads, F fn)
+{
+    if (n == 0) return;
+    const unsigned nt = (unsigned)std::min<size_t>(nthreads ? nthreads : 1u, n);
+    if (nt <= 1) { for (size_t k = 0; k < n; k++) fn(k); return; }
+    std::atomic<size_t> next(0);
+    std::atomic<bool> failed(false);
+    std::mutex mu;
+    std::string first_err;
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++)
+        th.emplace_back([&]() {
+            for (;;) {
+                const size_t k = next.fetch_add(1);
+                if (k >= n || failed.load()) break;
+                try { fn(k); }
+                catch (const std::exception &e) {
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (!failed.exchange(true)) first_err = e.what();
+                }
+            }
+        });
+    for (auto &t : th) t.join();
+    if (failed) throw SkError(first_err);
+}
+
+// the simple statement of skani's triangle row order, kept as the reference tests/host_writer_harness.cpp
+// holds the in-place version against: rows by Ref through the outer map's bucket order; inside a row the inner map's,
+// filled in ascending Query order; --min-af when writing
 std::vector<skder_edge_t> triangle_rows_ordered(const std::vector<skder_edge_t> &edges, double min_af_pct)
 {
-    // rows by Ref index; inside a row by Query index ascending (the insertion order of skani's inner map)
     std::vector<skder_edge_t> E(edges), rows;
     std::sort(E.begin(), E.end(), [](const skder_edge_t &a, const skder_edge_t &b) {
         return a.ref != b.ref ? a.ref < b.ref : a.query < b.query;
@@ -658,43 +679,168 @@ std::vector<skder_edge_t> triangle_rows_ordered(const std::vector<skder_edge_t> 
     return rows;
 }
 
+// The same order established IN PLACE: at 50,000 genomes the edge list is 10^7-10^8 records of 88 bytes, and the copies the
+// simple version takes (sorted copy + output) are GBs.  (1) Ref groups are brought into the outer map's order by one
+// in-place pass (cycle-leader permutation over per-group windows, as in an American-flag sort); (2) every group is ordered
+// by its own inner map, groups in parallel on the host threads; (3) rows below --min-af are squeezed out in place.
+void triangle_rows_order_inplace(std::vector<skder_edge_t> &E, double min_af_pct)
+{
+    const size_t n = E.size();
+    if (n == 0) return;
+    uint32_t max_ref = 0;
+    for (const auto &e : E) max_ref = e.ref > max_ref ? e.ref : max_ref;
+    std::vector<uint64_t> cnt((size_t)max_ref + 2, 0);
+    for (const auto &e : E) cnt[e.ref]++;
+    FxMap outer;                                                 // distinct Refs enter in ascending order
+    for (uint32_t r = 0; r <= max_ref; r++) if (cnt[r]) outer.insert(r);
+    // window [begin, end) of every Ref in the outer map's bucket order
+    std::vector<uint64_t> begin((size_t)max_ref + 2, 0), fill((size_t)max_ref + 2, 0);
+    std::vector<uint32_t> group_ref;
+    std::vector<uint64_t> group_begin;
+    uint64_t at = 0;
+    for (uint32_t b = 0; b < outer.buckets; b++) {
+        if (!outer.full[b]) continue;
+        const uint32_t r = (uint32_t)outer.key[b];
+        begin[r] = fill[r] = at;
+        group_ref.push_back(r); group_begin.push_back(at);
+        at += cnt[r];
+    }
+    group_begin.push_back(at);
+    // in-place distribution: every window is filled from its `fill` cursor by swapping misplaced records to where they belong
+    for (size_t g = 0; g < group_ref.size(); g++) {
+        const uint32_t r = group_ref[g];
+        const uint64_t end = begin[r] + cnt[r];
+        while (fill[r] < end) {
+            const uint32_t have = E[fill[r]].ref;
+            if (have == r) { fill[r]++; continue; }
+            std::swap(E[fill[r]], E[fill[have]]);               // the record goes to its own window's cursor
+            fill[have]++;
+        }
+    }
+    // inner order, group by group
+    host_parallel_for(group_ref.size(), ingest_threads(), [&](size_t g) {
+        skder_edge_t *lo = E.data() + group_begin[g], *hi = E.data() + group_begin[g + 1];
+        std::sort(lo, hi, [](const skder_edge_t &a, const skder_edge_t &b) { return a.query < b.query; });
+        FxMap inner;
+        for (skder_edge_t *p = lo; p < hi; p++) inner.insert(p->query);
+        std::vector<skder_edge_t> tmp;
+        tmp.reserve((size_t)(hi - lo));
+        for (uint32_t bb = 0; bb < inner.buckets; bb++) {
+            if (!inner.full[bb]) continue;
+            const uint32_t q = (uint32_t)inner.key[bb];
+            const skder_edge_t *it = std::lower_bound(lo, hi, q, [](const skder_edge_t &e, uint32_t qq) { return e.query < qq; });
+            tmp.push_back(*it);
+        }
+        std::copy(tmp.begin(), tmp.end(), lo);
+    });
+    E.erase(std::remove_if(E.begin(), E.end(), [&](const skder_edge_t &e) { return !passes_min_af(e, min_af_pct); }), E.end());
+}
+
+// dist / search tables: grouped by query in listing order; references by ANI descending
+static bool rect_before(const skder_edge_t &a, const skder_edge_t &b)
+{
+    if (a.query != b.query) return a.query < b.query;
+    float x = (float)a.ani, y = (float)b.ani;
+    if (x != y) return x > y;
+    return a.ref < b.ref;
+}
+void rect_rows_order_inplace(std::vector<skder_edge_t> &E, double min_af_pct)
+{
+    E.erase(std::remove_if(E.begin(), E.end(), [&](const skder_edge_t &e) { return !passes_min_af(e, min_af_pct); }), E.end());
+    const size_t n = E.size();
+    const unsigned T = (unsigned)std::min<size_t>(ingest_threads(), n / 65536 + 1);
+    if (T <= 1) { std::sort(E.begin(), E.end(), rect_before); return; }
+    // pieces sorted in parallel, then merged pairwise (std::inplace_merge)
+    std::vector<size_t> cut(T + 1);
+    for (unsigned t = 0; t <= T; t++) cut[t] = n * t / T;
+    host_parallel_for(T, T, [&](size_t t) { std::sort(E.begin() + cut[t], E.begin() + cut[t + 1], rect_before); });
+    for (unsigned w = 1; w < T; w *= 2) {
+        std::vector<std::pair<size_t, size_t>> jobs;
+        for (unsigned t = 0; t + w < T; t += 2 * w) jobs.emplace_back(t, std::min(t + 2 * w, T));
+        host_parallel_for(jobs.size(), T, [&](size_t j) {
+            const unsigned t = (unsigned)jobs[j].first;
+            std::inplace_merge(E.begin() + cut[t], E.begin() + cut[t + w], E.begin() + cut[jobs[j].second], rect_before);
+        });
+    }
+}
 std::vector<skder_edge_t> rect_rows_ordered(const std::vector<skder_edge_t> &edges, double min_af_pct)
 {
-    // grouped by query in listing order; references by ANI descending
-    std::vector<skder_edge_t> E;
-    for (const auto &e : edges) if (passes_min_af(e, min_af_pct)) E.push_back(e);
-    std::sort(E.begin(), E.end(), [](const skder_edge_t &a, const skder_edge_t &b) {
-        if (a.query != b.query) return a.query < b.query;
-        float x = (float)a.ani, y = (float)b.ani;
-        if (x != y) return x > y;
-        return a.ref < b.ref;
-    });
+    std::vector<skder_edge_t> E(edges);
+    rect_rows_order_inplace(E, min_af_pct);
     return E;
 }
 
+// one row of the table appended to `o`
+static void format_row(std::string &o, const std::string &rf, const std::string &qf, const skder_edge_t &e, const std::string &rn,
+                       const std::string &qn)
+{
+    // skani keeps its results in single precision and prints percentages with two decimals
+    const float ani = (float)e.ani, afr = (float)e.af_ref, afq = (float)e.af_query;
+    char num[96];
+    const int k = snprintf(num, sizeof num, "\t%.2f\t%.2f\t%.2f\t", (double)(ani * 100.0f), (double)(afr * 100.0f), (double)(afq * 100.0f));
+    o.append(rf); o.push_back('\t'); o.append(qf);
+    o.append(num, (size_t)k);
+    o.append(rn); o.push_back('\t'); o.append(qn); o.push_back('\n');
+}
+
+// Rows are formatted in blocks on the host threads and every block is written at ITS offset of the one output file
+// (pwrite): the text of block b starts where block b - 1 ends, which its writer publishes as soon as it knows its own start
+// and length -- formatting runs in parallel, only that hand-over is ordered.  (At 50,000 genomes the table is GBs of text.)
 void write_rows_tsv(const std::string &out, const skder_edge_t *rows, size_t n, const GenomeNames &ref_names,
                     const GenomeNames &query_names)
 {
     TmpFile tf(out);
-    fputs(TSV_HEADER, tf.f);
-    for (size_t i = 0; i < n; i++) {
-        const skder_edge_t &e = rows[i];
-        print_row(tf.f, ref_names.path[e.ref], query_names.path[e.query], e, ref_names.first_name[e.ref],
-                  query_names.first_name[e.query]);
-    }
+    const size_t hdr = strlen(TSV_HEADER);
+    if (fwrite(TSV_HEADER, 1, hdr, tf.f) != hdr || fflush(tf.f) != 0) throw SkError("write error on " + out);
+    const int fd = fileno(tf.f);
+    const size_t BLOCK = 16384;
+    const size_t nblocks = (n + BLOCK - 1) / BLOCK;
+    std::vector<uint64_t> start(nblocks + 1, 0);
+    std::vector<char> known(nblocks + 1, 0);
+    std::mutex mu;
+    std::condition_variable cv;
+    start[0] = hdr; known[0] = 1;
+    host_parallel_for(nblocks, ingest_threads(), [&](size_t b) {
+        std::string text, failure;
+        const size_t lo = b * BLOCK, hi = std::min(n, lo + BLOCK);
+        try {
+            text.reserve((hi - lo) * 160);
+            for (size_t i = lo; i < hi; i++) {
+                const skder_edge_t &e = rows[i];
+                format_row(text, ref_names.path[e.ref], query_names.path[e.query], e, ref_names.first_name[e.ref], query_names.first_name[e.query]);
+            }
+        } catch (const std::exception &e) { failure = e.what()[0] ? e.what() : "out of memory"; text.clear(); }
+        uint64_t at;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&]() { return known[b] != 0; });          // blocks are dealt out in ascending order: b - 1 is being written or done
+            at = start[b];
+            start[b + 1] = at + text.size(); known[b + 1] = 1;     // published whatever happens to this block: nobody waits for ever
+        }
+        cv.notify_all();
+        if (!failure.empty()) throw SkError("edge table: " + failure);
+        size_t done = 0;
+        while (done < text.size()) {
+            const ssize_t w = pwrite(fd, text.data() + done, text.size() - done, (off_t)(at + done));
+            if (w <= 0) throw SkError("write error on " + out);
+            done += (size_t)w;
+        }
+    });
     tf.commit();
 }
 
 void write_triangle_tsv(const std::string &out, const std::vector<skder_edge_t> &edges, const GenomeNames &names, double min_af_pct)
 {
-    std::vector<skder_edge_t> rows = triangle_rows_ordered(edges, min_af_pct);
+    std::vector<skder_edge_t> rows(edges);
+    triangle_rows_order_inplace(rows, min_af_pct);
     write_rows_tsv(out, rows.data(), rows.size(), names, names);
 }
 
 void write_rect_tsv(const std::string &out, const std::vector<skder_edge_t> &edges, const GenomeNames &ref_names,
                     const GenomeNames &query_names, double min_af_pct)
 {
-    std::vector<skder_edge_t> rows = rect_rows_ordered(edges, min_af_pct);
+    std::vector<skder_edge_t> rows(edges);
+    rect_rows_order_inplace(rows, min_af_pct);
     write_rows_tsv(out, rows.data(), rows.size(), ref_names, query_names);
 }
 
