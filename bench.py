@@ -206,6 +206,71 @@ def _indel_descendant(rng, anc):
     return seq, lens
 
 
+_COMP = np.zeros(256, np.uint8)
+for _a, _b in zip(b"ACGTacgtNn", b"TGCAtgcaNn"):
+    _COMP[_a] = _b
+
+
+def _real_descendant(seed, anc, anc_lens):
+    """A descendant of a REAL assembly (concatenated kept records `anc`, record lengths `anc_lens`): substitutions
+    (log-uniform 0.02 - 3 %), short indels (one per ~12 substitutions, geometric lengths, mean 2.5: the FUZZ_REAL model of
+    tests/tools), and 0 - 3 structural events (inversion, translocation or deletion of 0.5 - 20 kb).  Vectorised: one
+    np.delete / np.insert pass per genome.  The assembly's record boundaries are carried through the edits."""
+    rng = np.random.RandomState(seed)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    seq = anc.copy()
+    L = len(seq)
+    sub = 10 ** rng.uniform(-3.7, -1.5)
+    k = rng.binomial(L, sub)
+    if k:
+        idx = rng.randint(0, L, k)
+        seq[idx] = alpha[(np.searchsorted(alpha, seq[idx] & 0xDF) + 1 + rng.randint(0, 3, k)) % 4]
+    bounds = np.concatenate([[0], np.cumsum(anc_lens.astype(np.int64))])
+    n_ev = max(1, int(L * sub / 12.0))
+    at = np.sort(rng.randint(1, L - 1, n_ev))
+    ln = rng.geometric(0.4, n_ev)
+    ins = rng.rand(n_ev) < 0.5
+    # deletions: a mask of the bases that stay
+    d_at, d_ln = at[~ins], ln[~ins]
+    diff = np.zeros(L + 1, np.int32)
+    np.add.at(diff, d_at, 1)
+    np.add.at(diff, np.minimum(d_at + d_ln, L), -1)
+    keep = np.cumsum(diff[:L]) == 0
+    new_index = np.concatenate([[0], np.cumsum(keep)])          # index of original base i among the kept ones
+    seq = seq[keep]
+    bounds = new_index[bounds]
+    # insertions, positions in the kept sequence
+    i_at, i_ln = new_index[at[ins]], ln[ins]
+    if len(i_at):
+        seq = np.insert(seq, np.repeat(i_at, i_ln), alpha[rng.randint(0, 4, int(i_ln.sum()))])
+        shift = np.concatenate([[0], np.cumsum(i_ln)])
+        bounds = bounds + shift[np.searchsorted(i_at, bounds, side="left")]
+    for _ in range(rng.randint(0, 4)):
+        if len(seq) < 100000:
+            break
+        n, ev = rng.randint(500, 20000), rng.randint(0, 3)
+        a = rng.randint(0, len(seq) - n - 1)
+        seg = seq[a:a + n]
+        if ev == 0:
+            seq[a:a + n] = _COMP[seg[::-1]]
+        elif ev == 1:
+            rest = np.concatenate([seq[:a], seq[a + n:]])
+            b = rng.randint(0, len(rest))
+            seq = np.concatenate([rest[:b], seg, rest[b:]])
+        else:
+            seq = np.concatenate([seq[:a], seq[a + n:]])
+            bounds = np.where(bounds > a + n, bounds - n, np.minimum(bounds, a))
+    bounds[-1] = len(seq)
+    lens = np.diff(np.maximum.accumulate(np.minimum(bounds, len(seq))))
+    keep_l = []
+    for l in lens:                                  # records below 500 bases join their neighbour
+        if keep_l and (l < 500 or keep_l[-1] < 500):
+            keep_l[-1] += l
+        else:
+            keep_l.append(l)
+    return seq, np.array(keep_l, np.uint32)
+
+
 def _triangle_stats(engine, ctx, torch, rec_lens_list, bases_list, screen, steps=2):
     """sketch + triangle of host genomes through the device API; per-step times of the chaining stage and path counters"""
     layout = engine.BatchLayout(rec_lens_list)
@@ -248,6 +313,7 @@ def realistic_workloads(engine, ctx, torch, synth, args):
     engine's best case -- no indels, so nearly every chunk is one run."""
     out = {}
     gold = os.path.join(ROOT, "tests", "golden", "genomes")
+    recs = []
     if os.path.isdir(gold):
         recs = [_read_fasta_records(os.path.join(gold, n)) for n in sorted(os.listdir(gold))]
         r = _triangle_stats(engine, ctx, torch, [x[0] for x in recs], [x[1] for x in recs], 89.5)
@@ -274,6 +340,26 @@ def realistic_workloads(engine, ctx, torch, synth, args):
                                        % (rec.n, args.genome_len / 1e6, rec.n * (rec.n - 1) // 2)}
     except Exception as ex:      # never lose the headline over an extra
         out["ani_vs_truth"] = {"error": str(ex)}
+    # REAL genome structure at scale: every one of the 34 assemblies with args.real_derived descendants (substitutions, short
+    # indels, inversions / translocations / deletions): one species, > 1,000 genomes, every pair chained -- what dereplicating
+    # a well-sampled species looks like to the engine (contig ends, repeats, 10 % of the chunks on the unabridged path)
+    if os.path.isdir(gold) and args.real_derived > 0:
+        try:
+            from concurrent.futures import ThreadPoolExecutor
+            t0 = time.perf_counter()
+            jobs = [(1000 * a + d, recs[a][1], recs[a][0]) for a in range(len(recs)) for d in range(args.real_derived)]
+            with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+                fam = list(ex.map(lambda j: _real_descendant(*j), jobs))
+            t_gen = time.perf_counter() - t0
+            r = _triangle_stats(engine, ctx, torch, [g[1] for g in fam], [g[0] for g in fam], 80.0, steps=1)
+            r["generate_s"] = t_gen
+            r["workload"] = ("%d genomes: each of the reference's 34 real C. granulosum assemblies with %d host-generated descendants (0.02-3 %% substitutions, "
+                             "one short indel per ~12 substitutions, up to 3 inversions / translocations / deletions of 0.5-20 kb, the assembly's own contig "
+                             "structure); one species, every pair passes the screen and is chained" % (len(fam), args.real_derived))
+            out["real_derived_%d" % len(fam)] = r
+            del fam
+        except Exception as ex:
+            out["real_derived"] = {"error": repr(ex)}
     rng = np.random.RandomState(11)
     L = args.genome_len
     anc = np.frombuffer(b"ACGT", np.uint8)[rng.randint(0, 4, L)]
@@ -482,6 +568,7 @@ def main():
     ap.add_argument("--no-realistic", action="store_true", help="skip the extra workloads (real genomes, indels, mixed sizes)")
     ap.add_argument("--indel-genomes", type=int, default=48, help="genomes of the host-generated indel family")
     ap.add_argument("--mixed-genomes", type=int, default=5000, help="genomes of the mixed 1-8 Mb extra workload (0: skip)")
+    ap.add_argument("--real-derived", type=int, default=30, help="descendants per real assembly in the real-structure workload (34 x this many genomes; 0: skip)")
     ap.add_argument("--low-mem-genomes", type=int, default=20000, help="genomes of the low_mem_greedy leg (README.md:27's workload shape: 20000; 0: skip)")
     args = ap.parse_args()
 

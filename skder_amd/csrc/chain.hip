@@ -1295,7 +1295,24 @@ __global__ __launch_bounds__(256) void slow_chain_kernel(SetView A, SetView B, c
 // candidates of one anchor (packed max-reduce: score first, nearest predecessor on ties), then extracts
 // chains best end first with back-tracking by lane 0.  Chunks with more than SLOWW_MAXA anchors are
 // passed on to the global-memory kernels above.
+//
+// The kernel is bound by instruction issue (about 60 wavefront instructions per anchor of the DP, 20 per anchor of the
+// back-tracking, one lane busy): on real genomes 10-13 % of the chunks come here and took half of the chain stage.
+// LADDERS = true spends those instructions per STRETCH instead of per anchor, with the same result:
+//   * DP.  Before the loop every anchor is tested, all in parallel, for "continues the anchor in front of it on the same
+//     diagonal": a valid link of gap 0.  At an anchor with that mark whose predecessor holds the highest score so far
+//     (f[i-1] == runmax) the look-back is settled without being run: any candidate offers f[j] + 20 - gap <= runmax + 20 =
+//     f[i-1] + 20, what the predecessor offers, and ties go to the nearest candidate -- the predecessor.  Its score is then
+//     the new maximum, so the argument repeats: the whole stretch of consecutive marks gets f = f[i-1] + 20, 40, ... and
+//     bp = the anchor before, in one step (the main path of a chunk: typically 50-100 anchors between two stray hits).
+//   * Chains.  Anchors with bp = "the anchor before" form ladders; a chain that enters a ladder takes it down to its
+//     bottom, or to the anchors an earlier (better) chain took -- which always form the ladder's lower end, since
+//     every chain walks down until it meets used anchors.  One word per ladder (how far up it is used) replaces the used
+//     bit per anchor; the walk, the count and the extent on the other genome (monotone along a ladder: its two ends)
+//     go ladder by ladder.
+#ifndef SLOWW_MAXA
 #define SLOWW_MAXA 384
+#endif
 #define SLOWW_WAVES 4        // wavefronts (chunks) per workgroup
 
 // maximum over the 64 lanes of a fully active wavefront, in every lane: DPP row shifts inside the four
@@ -1313,6 +1330,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+template <bool LADDERS>
 __global__ __launch_bounds__(64 * SLOWW_WAVES) void slow_wave_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs, uint32_t npairs,
                                                                     const uint32_t *__restrict__ slow_list, const uint32_t *__restrict__ nslow_ptr,
                                                                     const uint32_t *__restrict__ hits, const uint4 *__restrict__ multi,
@@ -1323,7 +1341,9 @@ __global__ __launch_bounds__(64 * SLOWW_WAVES) void slow_wave_kernel(SetView A, 
     __shared__ uint32_t s_qi[SLOWW_WAVES][SLOWW_MAXA], s_qp[SLOWW_WAVES][SLOWW_MAXA], s_rr[SLOWW_WAVES][SLOWW_MAXA];
     __shared__ uint32_t s_rc[SLOWW_WAVES][SLOWW_MAXA], s_bp[SLOWW_WAVES][SLOWW_MAXA];
     __shared__ int32_t s_f[SLOWW_WAVES][SLOWW_MAXA];
+    __shared__ unsigned long long s_mask[SLOWW_WAVES][SLOWW_MAXA / 64 + 1];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    unsigned long long *lmask = s_mask[wv];
     // the number of declined chunks is only known on the device (no host round trip between the fast
     // path and this kernel): a fixed grid strides over the list
     const uint32_t nslow = *nslow_ptr;
@@ -1418,7 +1438,42 @@ __global__ __launch_bounds__(64 * SLOWW_WAVES) void slow_wave_kernel(SetView A, 
     __builtin_amdgcn_wave_barrier();
 
     // 2. banded chaining: lane l examines predecessor i-1-l of anchor i
-    for (uint32_t i = 0; i < n; i++) {
+    if (LADDERS) {
+        // marks: anchor i continues anchor i - 1 by a valid link of gap 0 (the conditions of the look-back below, for j = i - 1)
+        for (uint32_t b0 = 0; b0 < n; b0 += 64) {
+            const uint32_t i = b0 + lane;
+            bool ok = false;
+            if (i >= 1 && i < n) {
+                const uint32_t rr = ar[i], rj = ar[i - 1];
+                const int32_t dq = (int32_t)qp[i] - (int32_t)qp[i - 1];
+                const int32_t rp = (int32_t)(rr & 0x7FFFFFFFu), rpj = (int32_t)(rj & 0x7FFFFFFFu);
+                const int32_t dr = (rr >> 31) ? rpj - rp : rp - rpj;
+                ok = ac[i] == ac[i - 1] && (rr >> 31) == (rj >> 31) && dq > 0 && dq <= ANI_BP_BAND && dq <= ANI_MAX_LIN && dr == dq;
+            }
+            const unsigned long long m = __ballot(ok);
+            if (lane == 0) lmask[b0 >> 6] = m;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    {
+    int32_t fprev = 0, runmax = -0x40000000;
+    for (uint32_t i = 0; i < n;) {
+        if (LADDERS && fprev == runmax) {
+            const uint32_t sh = i & 63u;
+            const unsigned long long m = lmask[i >> 6] >> sh;
+            if (m & 1ull) {
+                // a stretch of marked anchors (up to the end of this block of 64): settled at once
+                uint32_t L = (~m) ? (uint32_t)__ffsll((long long)~m) - 1u : 64u;
+                L = L < 64u - sh ? L : 64u - sh;
+                L = L < n - i ? L : n - i;
+                if (lane < L) { f[i + lane] = fprev + ANI_ANCHOR_SCORE * (int32_t)(lane + 1u); bp[i + lane] = i + lane; }    // bp = predecessor index + 1
+                fprev += ANI_ANCHOR_SCORE * (int32_t)L;
+                runmax = fprev;
+                i += L;
+                __builtin_amdgcn_wave_barrier();
+                continue;
+            }
+        }
         const int32_t qpi = (int32_t)qp[i];
         const uint32_t rr = ar[i], rc = ac[i];
         const int32_t rp = (int32_t)(rr & 0x7FFFFFFFu);
@@ -1441,12 +1496,15 @@ __global__ __launch_bounds__(64 * SLOWW_WAVES) void slow_wave_kernel(SetView A, 
             }
         }
         key = wave_max_u32(key);
-        if (lane == 0) {
-            if (key) { f[i] = (int32_t)(key >> 6); bp[i] = i - (63u - (key & 63u)); }   // bp = predecessor index + 1
-            else { f[i] = ANI_ANCHOR_SCORE; bp[i] = 0; }
-        }
+        const int32_t fi = key ? (int32_t)(key >> 6) : ANI_ANCHOR_SCORE;
+        if (lane == 0) { f[i] = fi; bp[i] = key ? i - (63u - (key & 63u)) : 0u; }   // bp = predecessor index + 1
+        fprev = fi;
+        runmax = fi > runmax ? fi : runmax;
+        i++;
         __builtin_amdgcn_wave_barrier();
     }
+    }
+    if (!LADDERS) {
     // 3. chains: best end first (ties: lowest index); back-track until the start or a used anchor
     for (;;) {
         uint32_t key = 0;     // (score << 10) | (1023 - index)
@@ -1497,6 +1555,77 @@ __global__ __launch_bounds__(64 * SLOWW_WAVES) void slow_wave_kernel(SetView A, 
             }
         }
         __builtin_amdgcn_wave_barrier();
+    }
+    } else {
+    // 3. chains, ladder by ladder.  bp[k] == k: anchor k chains to the anchor before it.  Every anchor learns the bottom of
+    // its ladder (packed above its predecessor: bp = bottom << 16 | predecessor + 1); ut[s], kept where the record tags were,
+    // says how far ladder s is used: anchors [s, ut[s]) belong to chains already taken
+    uint32_t *ut = ac;
+    {
+        uint32_t carry = 0;
+        for (uint32_t b0 = 0; b0 < n; b0 += 64) {
+            const uint32_t k = b0 + lane;
+            const uint32_t b = k < n ? bp[k] : 0u;
+            const unsigned long long lad = __ballot(k >= 1 && k < n && b == k);
+            const unsigned long long z = ~lad & ((2ull << lane) - 1ull);                 // anchors of this block, up to k, that start a ladder
+            const uint32_t bot = z ? b0 + 63u - (uint32_t)__clzll((long long)z) : carry;
+            if (k < n) { bp[k] = (bot << 16) | b; ut[k] = 0u; }
+            carry = ~lad ? b0 + 63u - (uint32_t)__clzll((long long)~lad) : carry;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    for (;;) {
+        uint32_t key = 0;     // (score << 10) | (1023 - index), over the anchors no chain has taken
+        for (uint32_t i = lane; i < n; i += 64) {
+            const int32_t v = f[i];
+            if (v > ANI_ANCHOR_SCORE && ut[bp[i] >> 16] <= i) {
+                const uint32_t k2 = ((uint32_t)v << 10) | (1023u - i);
+                key = k2 > key ? k2 : key;
+            }
+        }
+        key = wave_max_u32(key);
+        if (!key) break;
+        const uint32_t besti = 1023u - (key & 1023u);
+        const int32_t bestv = (int32_t)(key >> 10);
+        if (lane == 0) {
+            // the walk, twice: first counting (a chain needs three anchors), then taking
+            uint32_t cnt = 0, rmin = 0xFFFFFFFFu, rmax = 0, first = besti;
+            for (int take = 0; take < 2; take++) {
+                uint32_t cur = besti;
+                for (;;) {
+                    const uint32_t w = bp[cur], s = w >> 16, u = ut[s];
+                    if (u > cur) break;                                   // this anchor belongs to an earlier chain
+                    const uint32_t lo = u > s ? u : s;                    // the ladder from here down, as far as it is free
+                    if (take) ut[s] = cur + 1u;
+                    else {
+                        cnt += cur - lo + 1u;
+                        first = lo;
+                        const uint32_t ra = ar[cur] & 0x7FFFFFFFu, rb = ar[lo] & 0x7FFFFFFFu;    // monotone along a ladder
+                        const uint32_t mn = ra < rb ? ra : rb, mx = ra > rb ? ra : rb;
+                        rmin = mn < rmin ? mn : rmin;
+                        rmax = mx > rmax ? mx : rmax;
+                    }
+                    if (lo > s) break;                                    // met the used lower end
+                    const uint32_t pb = bp[s] & 0xFFFFu;                  // predecessor of the ladder's bottom, + 1
+                    if (!pb) break;
+                    cur = pb - 1u;
+                }
+                if (cnt < ANI_MIN_ANCHORS) { f[besti] = (int32_t)0x80000000; break; }
+            }
+            if (cnt >= ANI_MIN_ANCHORS) {
+                const uint32_t slot = atomicAdd(&pair_nch[pi], 1u);
+                if (slot < pd.c_cap) {
+                    ChainRec cr;
+                    cr.score = bestv; cr.n = cnt; cr.n_seeds = qi[besti] - qi[first] + 1;
+                    cr.q0 = qp[first]; cr.q1 = qp[besti]; cr.r0 = rmin; cr.r1 = rmax; cr.chunk = c;
+                    chains[pd.c_base + slot] = cr;
+                } else {
+                    atomicOr(&flags[0], 8u);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
     }
     }   // declined chunks of this wave
 }
@@ -1958,7 +2087,8 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         // than 1024 anchors is put on over_list and dealt with after the batch's results are back
         if (S.nchunks) {
             const uint64_t want = (S.nchunks + SLOWW_WAVES - 1) / SLOWW_WAVES;
-            hipLaunchKernelGGL(slow_wave_kernel, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(64 * SLOWW_WAVES), 0, S.st, VA, VB,
+            static const bool ladders = getenv("SKDER_AMD_SLOW_PLAIN") == nullptr;      // (the per-anchor form, for A/B runs)
+            hipLaunchKernelGGL(ladders ? slow_wave_kernel<true> : slow_wave_kernel<false>, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(64 * SLOWW_WAVES), 0, S.st, VA, VB,
                                S.d_pairs.p, nb, S.slow_list.p, S.counters.p, S.hits.p, S.multi.p, S.chains.p, S.pair_nch.p, S.pair_na.p, S.over_list.p,
                                S.counters.p + 15, S.flags.p);
         }

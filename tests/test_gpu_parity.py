@@ -1089,6 +1089,42 @@ def test_structural_variants_randomized(gpu, oracle, realistic):
     assert (slow < 0.15 * chunks) if realistic else (slow > 0.3 * chunks)
 
 
+def test_real_derived_family_sampled_against_oracle(gpu, oracle):
+    """bench.py's `real_derived` workload in small: the 34 real assemblies with two descendants each (substitutions, short
+    indels, inversions / translocations / deletions, the assembly's own contig structure) -- 102 genomes of one species, all
+    5,151 pairs chained on the device; 60 sampled pairs (parent-child, siblings, across assemblies) bit-equal with the oracle."""
+    import bench
+    engine, ctx, torch = gpu
+    p = oracle.default_params()
+    recs = [_read_records(os.path.join(GOLDEN, "genomes", n)) for n in GENOMES]
+    fam, parent = [], []
+    for a, (lens, bases) in enumerate(recs):
+        fam.append((bases, lens)); parent.append(a)
+        for d in range(2):
+            fam.append(bench._real_descendant(77000 + 10 * a + d, bases, lens)); parent.append(a)
+    s, _ = _sketch(gpu, [g[1] for g in fam], [g[0] for g in fam])
+    edges = s.triangle_rows(0, 1, 80.0)
+    c = ctx.counters()
+    s.close()
+    n = len(fam)
+    got = {(int(e["ref"]), int(e["query"])): e for e in edges}
+    assert len(got) == n * (n - 1) // 2                         # one species: every pair passes the screen and has chains
+    assert 0.02 < int(c[1]) / int(c[0]) < 0.35                  # a real share of the chunks takes the unabridged path
+    rng = np.random.RandomState(5)
+    pick = {(3 * a, 3 * a + 1) for a in range(0, 34, 3)} | {(3 * a + 1, 3 * a + 2) for a in range(1, 34, 3)}
+    while len(pick) < 60:
+        i, j = sorted(rng.randint(0, n, 2))
+        if i != j:
+            pick.add((int(i), int(j)))
+    og = {}
+    for i, j in sorted(pick):
+        for g in (i, j):
+            if g not in og:
+                og[g] = oracle.Genome.from_bases(fam[g][0], fam[g][1], p)
+        assert oracle.screen(og[i], og[j], 80.0, p)[0]
+        _check_edges(np.array([got[(i, j)]]), {(i, j): oracle.pair(og[i], og[j], p)})
+
+
 def _repeat_rich_family(rng):
     """an ancestor of 50 kb - 1.6 Mb with dispersed and inverted repeat families, tandem repeats and low-complexity
     stretches; 3-6 descendants with substitutions (0.01 - 12 %), indels, structural events, runs of N, lower-case
