@@ -751,6 +751,7 @@ def main():
             "unit": "genome-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u64 hash / i32 chaining / f64 ANI", "data": "synthetic",
+            "rccl": ({"world_size": dist.get_world_size(), "backend": dist.get_backend(), "devices_visible": ndev} if dist_on else None),
             "config": {"workload": "%d synthetic genomes x %s Mb (%d species x 10 strains x 10 isolates), triangle, screen %.0f"
                        % (N, "%.1f" % (args.genome_len / 1e6) if args.len_range is None else
                           "%.1f-%.1f" % (args.len_range[0] / 1e6, args.len_range[1] / 1e6), max(1, N // 100), args.screen), "genomes": N, "pairs": pairs,

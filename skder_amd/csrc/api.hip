@@ -613,6 +613,69 @@ extern "C" skder_db_t *skder_amd_db_from_sketches(skder_sketches_t *src, int dev
     }
 }
 
+// Peer access from `dev` to every other device of the list (once per process and pair): with it a copy between two GPUs goes
+// over their xGMI link directly; without it the runtime stages it through host memory (still correct, an order of magnitude
+// slower) -- said on stderr under SKDER_AMD_DEBUG, never silently.
+static void enable_peer_access(int dev, const std::vector<int> &devices)
+{
+    HIPCHECK(hipSetDevice(dev));
+    for (int other : devices) {
+        if (other == dev) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, dev, other) != hipSuccess) can = 0;
+        if (can) {
+            const hipError_t e = hipDeviceEnablePeerAccess(other, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) can = 0;
+            (void)hipGetLastError();
+        }
+        if (!can && getenv("SKDER_AMD_DEBUG"))
+            fprintf(stderr, "[skder_amd] GPU %d has no peer access to GPU %d: sketches from there are copied through host memory\n", dev, other);
+    }
+}
+
+// The "all-gather" of one GPU: the raw sketches of every share, in listing order, into `dst` (not indexed yet).  xGMI is
+// point to point -- seven links per GPU, one per peer -- so the pulls from the n - 1 peers are issued on n - 1 STREAMS and run
+// side by side, each over its own link; issued one after the other on one stream they would take (n - 1) x one link's time.
+static void gather_raw_views(skder_sketches *dst, const std::vector<skder_raw_view_t> &views)
+{
+    if (dst->indexed || dst->index_pending || dst->n_genomes) throw SkError("gather_raw_views: the set must be empty");
+    skder_ctx *ctx = dst->ctx;
+    HIPCHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    uint64_t ns = 0, nm = 0;
+    for (const auto &v : views) { ns += v.n_seeds; nm += v.n_markers; }
+    dst->seed_kmer.resize(ns, st);
+    dst->seed_gpos.reserve(ns + 32, 0, st);
+    dst->seed_gpos.resize(ns, st);
+    dst->seed_ctg.resize(ns, st);
+    dst->markers.resize(nm, st);
+    HIPCHECK(hipStreamSynchronize(st));
+    std::vector<hipStream_t> streams(views.size(), nullptr);
+    struct Cleanup { std::vector<hipStream_t> &s; ~Cleanup() { for (auto x : s) if (x) (void)hipStreamDestroy(x); } } cleanup{streams};
+    uint64_t so = 0, mo = 0;
+    for (size_t e = 0; e < views.size(); e++) {
+        const skder_raw_view_t &v = views[e];
+        HIPCHECK(hipStreamCreateWithFlags(&streams[e], hipStreamNonBlocking));
+        if (v.n_seeds) {
+            HIPCHECK(hipMemcpyAsync(dst->seed_kmer.p + so, v.d_seed_kmer, v.n_seeds * 4, hipMemcpyDefault, streams[e]));
+            HIPCHECK(hipMemcpyAsync(dst->seed_gpos.p + so, v.d_seed_gpos, v.n_seeds * 4, hipMemcpyDefault, streams[e]));
+            HIPCHECK(hipMemcpyAsync(dst->seed_ctg.p + so, v.d_seed_ctg, v.n_seeds * 4, hipMemcpyDefault, streams[e]));
+        }
+        if (v.n_markers) HIPCHECK(hipMemcpyAsync(dst->markers.p + mo, v.d_markers, v.n_markers * 8, hipMemcpyDefault, streams[e]));
+        size_t rg = 0;
+        for (uint32_t g = 0; g < v.n_genomes; g++) {
+            dst->h_seed_off.push_back(so + v.h_seed_off[g + 1] - v.h_seed_off[0]);
+            dst->h_marker_off.push_back(mo + v.h_marker_off[g + 1] - v.h_marker_off[0]);
+            dst->h_genome_len.push_back(v.h_genome_len[g]);
+            dst->h_genome_nrec.push_back(v.h_genome_nrec[g]);
+            for (uint32_t r = 0; r <= v.h_genome_nrec[g]; r++) dst->h_rec_goff.push_back(v.h_rec_goff[rg++]);
+        }
+        dst->n_genomes += v.n_genomes;
+        so += v.n_seeds; mo += v.n_markers;
+    }
+    for (auto x : streams) HIPCHECK(hipStreamSynchronize(x));
+}
+
 extern "C" skder_db_t *skder_amd_sketch_multi(const char *listing, const int *devices, int n_devices, const char *n50_tsv, char *err,
                                               size_t errlen)
 {
@@ -632,6 +695,10 @@ extern "C" skder_db_t *skder_amd_sketch_multi(const char *listing, const int *de
             if (d == 0) db->ctx = c; else db->more[d - 1].ctx = c;
         }
         auto ctx_of = [&](uint32_t d) { return d == 0 ? db->ctx : db->more[d - 1].ctx; };
+        {
+            std::vector<int> devs(devices, devices + n);
+            for (uint32_t d = 0; d < n; d++) enable_peer_access(devices[d], devs);
+        }
         std::vector<GenomeNames> names(n);
         per_gpu(n, [&](uint32_t d) {
             HIPCHECK(hipSetDevice(ctx_of(d)->device));
@@ -644,16 +711,16 @@ extern "C" skder_db_t *skder_amd_sketch_multi(const char *listing, const int *de
             db->names.first_name.insert(db->names.first_name.end(), names[d].first_name.begin(), names[d].first_name.end());
             db->names.n50.insert(db->names.n50.end(), names[d].n50.begin(), names[d].n50.end());
         }
-        // "all-gather": every GPU pulls the raw sketches of every share (peer copies over xGMI), in listing order;
-        // then the bucket index of the genomes it owns (index mod n) and everybody's chunk tables
+        // "all-gather": every GPU pulls the raw sketches of every share (peer copies over xGMI, one stream per source so that all
+        // of a GPU's links carry traffic at once), in listing order; then the bucket index of the genomes it owns (index mod n)
+        // and everybody's chunk tables
         std::vector<skder_raw_view_t> views(n);
         for (uint32_t d = 0; d < n; d++) if (skder_amd_sketches_view(part[d], &views[d]) != 0) throw SkError("sketches_view failed");
         per_gpu(n, [&](uint32_t d) {
             HIPCHECK(hipSetDevice(ctx_of(d)->device));
             skder_sketches *all = skder_amd_sketches_new(ctx_of(d));
             if (d == 0) db->refs = all; else db->more[d - 1].refs = all;
-            for (uint32_t e = 0; e < n; e++)
-                if (views[e].n_genomes && skder_amd_sketches_append_raw(all, &views[e]) != 0) throw SkError(ctx_of(d)->last_error);
+            gather_raw_views(all, views);
             std::vector<uint8_t> own(G);
             for (size_t g = 0; g < G; g++) own[g] = (g % n == d) ? 1 : 0;
             index_begin(all, ctx_of(d)->stream, own.data());

@@ -101,6 +101,12 @@ __device__ __forceinline__ uint32_t find_pair(const PairDesc *__restrict__ pairs
 // coalesced 4-byte hit word written per seed -- in position order, so nothing is scattered into HBM
 // and no memset is needed.  Genomes whose index does not fit in LDS are probed in several passes over
 // bucket ranges.
+// Bucket offsets take ONE BYTE per bucket in LDS: four buckets share a 32-bit group word -- the offset of the group's first
+// seed (16 bits, relative to the pass) and the four bucket sizes (4 bits each; 15 = "15 or more": that bucket's bounds are read
+// from the global table) -- so a probe reads one word where it used to read two 16-bit offsets, and the table of a 3 Mb genome
+// (16 K buckets, 25 K remainders) is 66 KB instead of 83: TWO workgroups per CU up to 4 Mb.  (Round 2's layout fitted two only
+// up to 24.5 K seeds -- the benchmark's genomes have 23-25 K, and the kernel's 101 scalar registers admitted one workgroup per
+// CU whatever the LDS said: it ran at half the wavefronts it was designed for.)
 struct JoinGroup { uint32_t pair_begin, pair_end; };
 #define JOIN_THREADS 1024
 #define JOIN_U 4             // seeds per thread and trip
@@ -110,7 +116,7 @@ struct JoinGroup { uint32_t pair_begin, pair_end; };
 // LDS bytes wanted for a whole-table pass over a genome with 2^bits buckets and n seeds
 static inline size_t join_need(uint32_t bits, uint32_t n)
 {
-    return (((size_t)(1u << bits) + 1u) * 2u + 15u) / 16u * 16u + 64u + ((size_t)n + 8u) * (bits >= 14u ? 2u : 4u);
+    return (size_t)(1u << bits) + 64u + ((size_t)n + 8u) * (bits >= 14u ? 2u : 4u);      // one byte per bucket (group words), remainders
 }
 
 // the probe loop of one staged bucket range for all pairs of a group.  FP: remainder type (16 bits once
@@ -120,7 +126,7 @@ static inline size_t join_need(uint32_t bits, uint32_t n)
 template <typename FP, bool FITS, bool WHOLE>
 __device__ __forceinline__ void join_pass(const SetView &A, const SetView &B, const PairDesc *__restrict__ pairs, const JoinGroup g,
                                           uint32_t *__restrict__ hits, uint4 *__restrict__ multi, uint32_t *__restrict__ pair_nmulti,
-                                          const FP *s_fp, const uint16_t *s_boff, const uint32_t *__restrict__ rk,
+                                          const FP *s_fp, const uint32_t *s_grp, const uint32_t *__restrict__ rb, const uint32_t *__restrict__ rk,
                                           const uint32_t *__restrict__ rg, uint32_t base, uint32_t bits, uint32_t bb0, uint32_t bb1,
                                           uint32_t rrep, uint32_t tid)
 {
@@ -152,8 +158,19 @@ __device__ __forceinline__ void join_pass(const SetView &A, const SetView &B, co
                 const uint32_t b = mx >> bsh;
                 remv[u] = mx & rmask;
                 mine[u] = (FULL || s < nq) && (WHOLE || (b >= bb0 && b < bb1));      // else: this seed's bucket belongs to another pass
-                lov[u] = mine[u] ? s_boff[b - bb0] : 0u;
-                hiv[u] = mine[u] ? s_boff[b - bb0 + 1] : 0u;
+                uint32_t lo = 0u, hi = 0u;
+                if (mine[u]) {
+                    if (FITS) {
+                        // group word: first seed of the group | the four bucket sizes above it
+                        const uint32_t w = s_grp[(b - bb0) >> 2], sh = ((b - bb0) & 3u) * 4u, sizes = w >> 16;
+                        const uint32_t below = sizes & ((1u << sh) - 1u);
+                        const uint32_t ne = (sizes >> sh) & 15u;
+                        lo = (w & 0xFFFFu) + (below & 15u) + ((below >> 4) & 15u) + ((below >> 8) & 15u);
+                        hi = lo + ne;
+                        if (ne == 15u) { lo = rb[b] - base; hi = rb[b + 1] - base; }       // 15 or more, or behind such a bucket in its group: the global table knows
+                    } else { lo = rb[b] - base; hi = rb[b + 1] - base; }
+                }
+                lov[u] = lo; hiv[u] = hi;
             }
             bool any_multi = false;
 #pragma unroll
@@ -232,13 +249,13 @@ __device__ __forceinline__ void join_group(const SetView &A, const SetView &B, c
 {
     const uint32_t bits = Rm->bucket_bits, nbk = 1u << bits, rrep = Rm->rep_cut;
     const uint32_t *rk = RS.skmer + Rm->seed_off, *rg = RS.stag + Rm->seed_off, *rb = RS.boff + Rm->bucket_off;   // rg: position | record tag | strand
-    // LDS: [control words | bucket offsets (16-bit, relative to the pass's first seed) | remainders]
+    // LDS: [control words | group words (one per four buckets: first seed of the group relative to the pass, four sizes) | remainders]
     uint32_t *s_ctl = reinterpret_cast<uint32_t *>(smem);           // [0] = end bucket of the pass
-    uint16_t *s_boff = reinterpret_cast<uint16_t *>(smem + 64);
+    uint32_t *s_grp = reinterpret_cast<uint32_t *>(smem + 64);
     // whole table in one pass if it fits; else as many buckets as half of the space takes, at most 65535 seeds per pass
-    const uint32_t whole_off = (uint32_t)((((size_t)nbk + 1u) * 2u + 15u) / 16u * 16u) + 64u;
+    const uint32_t whole_off = nbk + 64u;
     const bool one = whole_off + ((size_t)Rm->n_seeds + 8u) * sizeof(FP) <= smem_bytes;
-    const uint32_t bcap = one ? nbk + 1u : (smem_bytes / 2u - 64u) / 2u;                 // bucket offsets held per pass
+    const uint32_t bcap = one ? nbk : ((smem_bytes / 2u - 64u) & ~3u);                   // buckets held per pass (a multiple of 4)
     const uint32_t fp_off = one ? whole_off : smem_bytes / 2u;
     FP *s_fp = reinterpret_cast<FP *>(smem + fp_off);
     uint32_t kcap = (smem_bytes - fp_off) / (uint32_t)sizeof(FP) - 8u;                   // remainders held per pass
@@ -248,13 +265,13 @@ __device__ __forceinline__ void join_group(const SetView &A, const SetView &B, c
     for (uint32_t bb0 = 0; bb0 < nbk;) {
         __syncthreads();
         if (tid == 0) {
-            // the largest bucket range [bb0, bb1) whose offsets and remainders fit
-            uint32_t hi = bb0 + (bcap - 1) < nbk ? bb0 + (bcap - 1) : nbk, lo = bb0 + 1;
+            // the largest bucket range [bb0, bb1), whole groups of four, whose remainders fit; at least one group
+            uint32_t hi = bb0 + bcap < nbk ? bb0 + bcap : nbk, lo = bb0 + 4u;
             const uint32_t base = rb[bb0];
             if (rb[hi] - base > kcap) {
-                while (lo < hi) {   // largest bb1 in [bb0+1, hi] with rb[bb1] - base <= kcap
-                    const uint32_t mid = (lo + hi + 1) >> 1;
-                    if (rb[mid] - base <= kcap) lo = mid; else hi = mid - 1;
+                while (lo < hi) {   // largest bb1 in [bb0+4, hi], a multiple of 4, with rb[bb1] - base <= kcap
+                    const uint32_t mid = ((lo + hi) / 2u + 3u) & ~3u;
+                    if (rb[mid] - base <= kcap) lo = mid; else hi = mid - 4u;
                 }
                 hi = lo;
             }
@@ -263,22 +280,33 @@ __device__ __forceinline__ void join_group(const SetView &A, const SetView &B, c
         __syncthreads();
         const uint32_t bb1 = s_ctl[0];
         const uint32_t base = rb[bb0], nk = rb[bb1] - base;
-        const bool fits = nk <= kcap;   // false only for one bucket with more than kcap seeds
-        for (uint32_t i = tid; i <= bb1 - bb0; i += JOIN_THREADS) s_boff[i] = (uint16_t)(rb[bb0 + i] - base);
+        const bool fits = nk <= kcap;   // false only for one group of four buckets with more than kcap seeds
         if (fits) {
+            for (uint32_t i = tid; i < (bb1 - bb0) / 4u; i += JOIN_THREADS) {
+                const uint32_t b = bb0 + 4u * i;
+                const uint32_t o0 = rb[b], o1 = rb[b + 1], o2 = rb[b + 2], o3 = rb[b + 3], o4 = rb[b + 4];
+                const uint32_t c0 = o1 - o0, c1 = o2 - o1, c2 = o3 - o2, c3 = o4 - o3;
+                // a bucket of 15 seeds or more is marked 15 and looked up in the global table; the sizes in the word no longer add up
+                // to the starts of the buckets BEHIND it in the group, so those are marked 15 as well
+                const bool v0 = c0 >= 15u, v1 = v0 || c1 >= 15u, v2 = v1 || c2 >= 15u, v3 = v2 || c3 >= 15u;
+                s_grp[i] = (o0 - base) | ((v0 ? 15u : c0) << 16) | ((v1 ? 15u : c1) << 20) | ((v2 ? 15u : c2) << 24) | ((v3 ? 15u : c3) << 28);
+            }
             for (uint32_t i = tid; i < nk; i += JOIN_THREADS) s_fp[i] = (FP)(kmer_mix(rk[base + i] & SK_SEED_MASK) & rmask);
             if (tid < 8) s_fp[nk + tid] = (FP)0;
         }
         __syncthreads();
         const bool whole = bb0 == 0 && bb1 == nbk;
-        if (fits && whole) join_pass<FP, true, true>(A, B, pairs, g, hits, multi, pair_nmulti, s_fp, s_boff, rk, rg, base, bits, bb0, bb1, rrep, tid);
-        else if (fits) join_pass<FP, true, false>(A, B, pairs, g, hits, multi, pair_nmulti, s_fp, s_boff, rk, rg, base, bits, bb0, bb1, rrep, tid);
-        else join_pass<FP, false, false>(A, B, pairs, g, hits, multi, pair_nmulti, s_fp, s_boff, rk, rg, base, bits, bb0, bb1, rrep, tid);
+        if (fits && whole) join_pass<FP, true, true>(A, B, pairs, g, hits, multi, pair_nmulti, s_fp, s_grp, rb, rk, rg, base, bits, bb0, bb1, rrep, tid);
+        else if (fits) join_pass<FP, true, false>(A, B, pairs, g, hits, multi, pair_nmulti, s_fp, s_grp, rb, rk, rg, base, bits, bb0, bb1, rrep, tid);
+        else join_pass<FP, false, false>(A, B, pairs, g, hits, multi, pair_nmulti, s_fp, s_grp, rb, rk, rg, base, bits, bb0, bb1, rrep, tid);
         bb0 = bb1;
     }
 }
 
-__global__ __launch_bounds__(JOIN_THREADS) void join_probe_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs,
+// (amdgpu_waves_per_eu(8): TWO of these 1024-thread workgroups per CU need 8 wavefronts per SIMD, i.e. at most 64 VGPRs and -- the
+// limit that was silently missed before -- at most 80 SGPRs per wavefront.  With the two SetViews in scalar registers the compiler
+// took 101, which admits 6 wavefronts per SIMD: ONE workgroup per CU, half the wavefronts this latency-bound kernel was designed for.)
+__global__ __launch_bounds__(JOIN_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void join_probe_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs,
                                                                   const JoinGroup *__restrict__ groups,
                                                                   uint32_t *__restrict__ hits, uint4 *__restrict__ multi,
                                                                   uint32_t *__restrict__ pair_nmulti, uint32_t smem_bytes)
@@ -523,7 +551,7 @@ __global__ __launch_bounds__(256) void chain_single_kernel(SetView A, SetView B,
                                                            uint32_t *__restrict__ chunk_state, uint32_t *__restrict__ slow_list,
                                                            uint32_t *__restrict__ counters, uint32_t *__restrict__ gen_list,
                                                            uint32_t *__restrict__ gen_cnt, uint32_t gen_cap,
-                                                           uint32_t *__restrict__ pair_na, int xcd_remap)
+                                                           uint32_t *__restrict__ pair_na, int xcd_remap, uint32_t *__restrict__ chunk_pair)
 {
     // workgroups in launch order (dealt round-robin to the 8 XCDs): every record is read once, there is nothing an XCD's L2
     // could share, and one contiguous stream over the chip measured 1.8 ms per step faster than an eighth of the list per XCD
@@ -557,6 +585,7 @@ __global__ __launch_bounds__(256) void chain_single_kernel(SetView A, SetView B,
         }
         if ((pd.flags & 8u) || over || (xcd_remap & 2)) {
             chunk_state[t] = CHUNK_SLOW;
+            chunk_pair[t] = pi;                  // the kernels further down find the chunk's pair without a search
             slow_list[atomicAdd(counters, 1u)] = t;
             atomicAdd(counters + 1 + ((pd.flags & 8u) || (xcd_remap & 2) ? 6 : 8), 1u);
         } else if (idx0 == 0xFFFFFFFFu) {
@@ -665,7 +694,7 @@ __global__ __launch_bounds__(256) void chain_single_kernel(SetView A, SetView B,
                 if (fail) SIEVE_WHY(15);
             }
             if (!fail) { n_add = anchors; chunk_state[t] = nfin; }
-            else to_gen = true;
+            else { to_gen = true; chunk_pair[t] = pi; }
         }
     }
     {
@@ -731,7 +760,7 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, c
                                                          const uint32_t *__restrict__ chunk_rec0, const uint4 *__restrict__ multi,
                                                          ChainRec *__restrict__ fast_chains, uint32_t *__restrict__ chunk_state,
                                                          uint32_t *__restrict__ slow_list, uint32_t *__restrict__ slow_count,
-                                                         uint32_t *__restrict__ pair_na)
+                                                         uint32_t *__restrict__ pair_na, const uint32_t *__restrict__ chunk_pair)
 {
     // the chunks chain_single_kernel could not settle, one per lane; their number is only known on the device: a fixed
     // grid strides over the GEN_LISTS lists laid end to end (offsets by a scan of the 256 counts, in LDS)
@@ -754,7 +783,7 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, c
         while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (g_off[mid] <= w) lo = mid; else hi = mid; }
         t = gen_list[(uint64_t)lo * gen_cap + (w - g_off[lo])];
     }
-    const uint32_t pi = find_pair(pairs, npairs, t);
+    const uint32_t pi = live ? chunk_pair[t] : 0u;        // (chain_single_kernel left it there: a binary search over the pairs is 15 dependent loads)
     const PairDesc pd = pairs[pi];
     const uint32_t idx0 = chunk_rec0[t];
     const uint32_t c = t - pd.chunk_base;
@@ -1336,7 +1365,8 @@ __global__ __launch_bounds__(64 * SLOWW_WAVES) void slow_wave_kernel(SetView A, 
                                                                     const uint32_t *__restrict__ hits, const uint4 *__restrict__ multi,
                                                                     ChainRec *__restrict__ chains, uint32_t *__restrict__ pair_nch,
                                                                     uint32_t *__restrict__ pair_na, uint32_t *__restrict__ over_list,
-                                                                    uint32_t *__restrict__ over_count, uint32_t *__restrict__ flags)
+                                                                    uint32_t *__restrict__ over_count, uint32_t *__restrict__ flags,
+                                                                    const uint32_t *__restrict__ chunk_pair)
 {
     __shared__ uint32_t s_qi[SLOWW_WAVES][SLOWW_MAXA], s_qp[SLOWW_WAVES][SLOWW_MAXA], s_rr[SLOWW_WAVES][SLOWW_MAXA];
     __shared__ uint32_t s_rc[SLOWW_WAVES][SLOWW_MAXA], s_bp[SLOWW_WAVES][SLOWW_MAXA];
@@ -1352,7 +1382,7 @@ __global__ __launch_bounds__(64 * SLOWW_WAVES) void slow_wave_kernel(SetView A, 
     for (uint32_t w = blockIdx.x * SLOWW_WAVES + wv; w < nslow; w += gridDim.x * SLOWW_WAVES) {
     __builtin_amdgcn_wave_barrier();
     const uint32_t t = slow_list[w];
-    const uint32_t pi = find_pair(pairs, npairs, t);
+    const uint32_t pi = chunk_pair[t];
     const PairDesc pd = pairs[pi];
     const SetView &QS = (pd.flags & 2u) ? B : A;
     const SetView &RS = (pd.flags & 4u) ? B : A;
@@ -1436,6 +1466,12 @@ __global__ __launch_bounds__(64 * SLOWW_WAVES) void slow_wave_kernel(SetView A, 
     if (!n) continue;
     if (lane == 0) atomicAdd(&pair_na[pi], n);
     __builtin_amdgcn_wave_barrier();
+#ifdef SKDER_SLOW_STATS
+    uint32_t st_full = 0, st_stretch = 0, st_chains = 0, st_walk = 0;
+#define SLOW_STAT(X) (X)++
+#else
+#define SLOW_STAT(X)
+#endif
 
     // 2. banded chaining: lane l examines predecessor i-1-l of anchor i
     if (LADDERS) {
@@ -1470,6 +1506,7 @@ __global__ __launch_bounds__(64 * SLOWW_WAVES) void slow_wave_kernel(SetView A, 
                 fprev += ANI_ANCHOR_SCORE * (int32_t)L;
                 runmax = fprev;
                 i += L;
+                SLOW_STAT(st_stretch);
                 __builtin_amdgcn_wave_barrier();
                 continue;
             }
@@ -1501,6 +1538,7 @@ __global__ __launch_bounds__(64 * SLOWW_WAVES) void slow_wave_kernel(SetView A, 
         fprev = fi;
         runmax = fi > runmax ? fi : runmax;
         i++;
+        SLOW_STAT(st_full);
         __builtin_amdgcn_wave_barrier();
     }
     }
@@ -1587,6 +1625,7 @@ __global__ __launch_bounds__(64 * SLOWW_WAVES) void slow_wave_kernel(SetView A, 
         if (!key) break;
         const uint32_t besti = 1023u - (key & 1023u);
         const int32_t bestv = (int32_t)(key >> 10);
+        SLOW_STAT(st_chains);
         if (lane == 0) {
             // the walk, twice: first counting (a chain needs three anchors), then taking
             uint32_t cnt = 0, rmin = 0xFFFFFFFFu, rmax = 0, first = besti;
@@ -1594,6 +1633,7 @@ __global__ __launch_bounds__(64 * SLOWW_WAVES) void slow_wave_kernel(SetView A, 
                 uint32_t cur = besti;
                 for (;;) {
                     const uint32_t w = bp[cur], s = w >> 16, u = ut[s];
+                    SLOW_STAT(st_walk);
                     if (u > cur) break;                                   // this anchor belongs to an earlier chain
                     const uint32_t lo = u > s ? u : s;                    // the ladder from here down, as far as it is free
                     if (take) ut[s] = cur + 1u;
@@ -1627,6 +1667,9 @@ __global__ __launch_bounds__(64 * SLOWW_WAVES) void slow_wave_kernel(SetView A, 
         __builtin_amdgcn_wave_barrier();
     }
     }
+#ifdef SKDER_SLOW_STATS
+    if (lane == 0) { atomicAdd(flags + 8, n); atomicAdd(flags + 9, st_full); atomicAdd(flags + 10, st_stretch); atomicAdd(flags + 11, st_chains); atomicAdd(flags + 12, st_walk); atomicAdd(flags + 13, 1u); }
+#endif
     }   // declined chunks of this wave
 }
 
@@ -1916,7 +1959,7 @@ struct ChainSlot {
     DevBuf<uint32_t> hits, pair_nmulti, groups, over_list, flags;
     DevBuf<uint4> multi;
     DevBuf<RunRec> recs;
-    DevBuf<uint32_t> pair_over, chunk_rec0, wg_pair, gen_list, gen_cnt;
+    DevBuf<uint32_t> pair_over, chunk_rec0, wg_pair, gen_list, gen_cnt, chunk_pair;
     std::vector<uint32_t> h_wg_pair;
     DevBuf<ChainRec> fast_chains, chains;
     DevBuf<PairOut> d_out;
@@ -2076,9 +2119,10 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
             HIPCHECK(hipMemsetAsync(S.gen_cnt.p, 0, GEN_LISTS * 4, S.st));
             hipLaunchKernelGGL(chain_single_kernel, dim3(nwg), dim3(256), 0, S.st, VA, VB, S.d_pairs.p, nb, (uint32_t)S.nchunks, S.recs.p,
                                S.pair_over.p, S.chunk_rec0.p, S.wg_pair.p, S.multi.p, S.fast_chains.p, S.chunk_state.p, S.slow_list.p, S.counters.p,
-                               S.gen_list.p, S.gen_cnt.p, gen_cap, S.pair_na.p, xcd_remap);
+                               S.gen_list.p, S.gen_cnt.p, gen_cap, S.pair_na.p, xcd_remap, S.chunk_pair.p);
             hipLaunchKernelGGL(chain_runs_kernel, dim3(nwg < 4096u ? nwg : 4096u), dim3(256), 0, S.st, VA, VB, S.d_pairs.p, nb, S.gen_list.p,
-                               S.gen_cnt.p, gen_cap, S.recs.p, S.chunk_rec0.p, S.multi.p, S.fast_chains.p, S.chunk_state.p, S.slow_list.p, S.counters.p, S.pair_na.p);
+                               S.gen_cnt.p, gen_cap, S.recs.p, S.chunk_rec0.p, S.multi.p, S.fast_chains.p, S.chunk_state.p, S.slow_list.p, S.counters.p, S.pair_na.p,
+                               S.chunk_pair.p);
         } else {
             HIPCHECK(hipEventRecord(S.ev[6], S.st));
         }
@@ -2090,7 +2134,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
             static const bool ladders = getenv("SKDER_AMD_SLOW_PLAIN") == nullptr;      // (the per-anchor form, for A/B runs)
             hipLaunchKernelGGL(ladders ? slow_wave_kernel<true> : slow_wave_kernel<false>, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(64 * SLOWW_WAVES), 0, S.st, VA, VB,
                                S.d_pairs.p, nb, S.slow_list.p, S.counters.p, S.hits.p, S.multi.p, S.chains.p, S.pair_nch.p, S.pair_na.p, S.over_list.p,
-                               S.counters.p + 15, S.flags.p);
+                               S.counters.p + 15, S.flags.p, S.chunk_pair.p);
         }
         HIPCHECK(hipEventRecord(S.ev[3], S.st));
         // LDS capacity of the finalize step: the most chains any pair of the batch can plausibly have
@@ -2109,6 +2153,9 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         HIPCHECK(hipMemcpyAsync(S.h_out, S.d_out.p, nb * sizeof(PairOut), hipMemcpyDeviceToHost, S.st));
         HIPCHECK(hipMemcpyAsync(S.h_cnt, S.counters.p, 64, hipMemcpyDeviceToHost, S.st));
         HIPCHECK(hipMemcpyAsync(S.h_cnt + 16, S.flags.p, 4, hipMemcpyDeviceToHost, S.st));
+#ifdef SKDER_SLOW_STATS
+        HIPCHECK(hipMemcpyAsync(S.h_cnt + 24, S.flags.p + 8, 32, hipMemcpyDeviceToHost, S.st));
+#endif
 #ifdef SKDER_SIEVE_STATS
         HIPCHECK(hipMemcpyAsync(S.h_cnt + 24, S.counters.p + 24, 32, hipMemcpyDeviceToHost, S.st));
 #endif
@@ -2168,7 +2215,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         // work buffers hold nothing worth keeping between batches: a buffer that has to grow is replaced, not copied
         auto grow = [&](auto &buf, size_t n) { buf.reserve(n, 0, S.st_join); buf.n = n; };
         grow(S.d_pairs, nb);
-        grow(S.chunk_state, nchunks + 1); grow(S.chunk_mark, nchunks + 1); grow(S.slow_list, nchunks + 1); grow(S.over_list, nchunks + 1);
+        grow(S.chunk_state, nchunks + 1); grow(S.chunk_mark, nchunks + 1); grow(S.slow_list, nchunks + 1); grow(S.over_list, nchunks + 1); grow(S.chunk_pair, nchunks + 1);
         grow(S.fast_chains, nchunks * FAST_SLOTS + 1);
         grow(S.counters, 32); grow(S.flags, 16);
         grow(S.pair_na, nb); grow(S.pair_nch, nb); grow(S.pair_nmulti, nb);
@@ -2266,6 +2313,11 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
             }
             uint32_t join_smem = (uint32_t)(want < JOIN_SMEM_MAX ? want : JOIN_SMEM_MAX) / 64u * 64u + 64u;
             if (want <= JOIN_SMEM_TWO && join_smem > JOIN_SMEM_TWO) join_smem = JOIN_SMEM_TWO;
+            if (getenv("SKDER_AMD_DEBUG")) {
+                int per_cu = 0;
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(join_probe_kernel), JOIN_THREADS, join_smem);
+                fprintf(stderr, "[skder_amd] join: %zu workgroups of %u threads, %u bytes of LDS each: %d resident per CU (runtime's answer)\n", hg.size(), JOIN_THREADS, join_smem, per_cu);
+            }
             hipLaunchKernelGGL(join_probe_kernel, dim3((unsigned)hg.size()), dim3(JOIN_THREADS), join_smem, S.st_join, VA, VB, S.d_pairs.p,
                                reinterpret_cast<const JoinGroup *>(S.groups.p), S.hits.p, S.multi.p, S.pair_nmulti.p, join_smem);
             HIPCHECK(hipGetLastError());
@@ -2294,6 +2346,9 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         HIPCHECK(hipEventElapsedTime(&ms, S.ev[3], S.ev[4])); t_fin += ms;
 #ifdef SKDER_SIEVE_STATS
         fprintf(stderr, "[skder_amd] sieve: link %u, main-not-started-big %u, second-path %u, too-many-records %u, multi %u, third-stray %u, stray-near-main %u\n", S.h_cnt[24], S.h_cnt[25], S.h_cnt[26], S.h_cnt[28], S.h_cnt[29], S.h_cnt[30], S.h_cnt[31]);
+#endif
+#ifdef SKDER_SLOW_STATS
+        fprintf(stderr, "[skder_amd] slow path: %u chunks, %u anchors, %u full look-backs, %u stretches, %u chain ends, %u ladder visits\n", S.h_cnt[29], S.h_cnt[24], S.h_cnt[25], S.h_cnt[26], S.h_cnt[27], S.h_cnt[28]);
 #endif
         if (getenv("SKDER_AMD_DEBUG")) {
             const uint32_t *hcnt = S.h_cnt;

@@ -373,12 +373,18 @@ def test_ranks_share_the_triangle(gpu, tmp_path, world):
 
 
 def test_several_gpus_in_one_process(gpu, tmp_path):
-    """the multi-GPU entry points of the C ABI (skder_amd_triangle_multi / skder_amd_sketch_multi) with the one GPU of this
-    box opened three times: shares of the listing sketched per "GPU", raw sketches pulled across, ownership index, rows
-    screened in shares, pairs chained by the owner of the probed genome.  The triangle table must be the one-GPU table
-    byte for byte, `search` tables and the low_mem_greedy listing likewise."""
+    """the multi-GPU entry points of the C ABI (skder_amd_triangle_multi / skder_amd_sketch_multi): shares of the listing
+    sketched per GPU, raw sketches pulled across (one stream per source), ownership index, rows screened in shares, pairs
+    chained by the owner of the probed genome.  The triangle table must be the one-GPU table byte for byte, `search` tables
+    and the low_mem_greedy listing likewise.  On a box with several GPUs DISTINCT devices are used (peer copies over xGMI
+    really happen); on a one-GPU box the device is opened three times, which exercises everything but the peer copies --
+    the test says which it was."""
     import ctypes as C
+    import torch
     from skder_amd import _lib, skder
+    ndev = torch.cuda.device_count()
+    ids = [0, 1, 2][:max(2, min(3, ndev))] if ndev > 1 else [0, 0, 0]
+    print("test_several_gpus_in_one_process: devices", ids, "(distinct GPUs)" if ndev > 1 else "(one GPU opened three times: no peer copy is exercised)")
     gdir = os.path.join(GOLDEN, "genomes")
     names = sorted(os.listdir(gdir))[:14]
     listing = tmp_path / "l.txt"
@@ -387,13 +393,13 @@ def test_several_gpus_in_one_process(gpu, tmp_path):
     one, many = tmp_path / "one.tsv", tmp_path / "many.tsv"
     n1, n3 = tmp_path / "n50_one.tsv", tmp_path / "n50_many.tsv"
     assert _lib.lib().skder_amd_triangle_n50(str(listing).encode(), 10.0, 89.5, 0, str(one).encode(), str(n1).encode(), err, 2048) == 0, err.value
-    devs = (C.c_int * 3)(0, 0, 0)
-    assert _lib.lib().skder_amd_triangle_multi(str(listing).encode(), 10.0, 89.5, devs, 3, str(many).encode(), str(n3).encode(), err, 2048) == 0, err.value
+    devs = (C.c_int * len(ids))(*ids)
+    assert _lib.lib().skder_amd_triangle_multi(str(listing).encode(), 10.0, 89.5, devs, len(ids), str(many).encode(), str(n3).encode(), err, 2048) == 0, err.value
     assert one.read_text() == many.read_text() and len(one.read_text().splitlines()) == 1 + 14 * 13 // 2
     assert n1.read_text() == n3.read_text()
     # search on a database spread over the "GPUs": same tables as the one-GPU database, batch and single
     db1 = skder.Database.from_listing(str(listing), devices=[0])
-    db3 = skder.Database.from_listing(str(listing), devices=[0, 0, 0])
+    db3 = skder.Database.from_listing(str(listing), devices=ids)
     try:
         qs = [db1.paths[2], db1.paths[9], os.path.join(gdir, sorted(os.listdir(gdir))[20])]      # two residents, one outsider
         o1 = [str(tmp_path / ("s1_%d.tsv" % k)) for k in range(3)]
