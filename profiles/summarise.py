@@ -13,6 +13,7 @@ import collections
 import csv
 import json
 import os
+import re
 import shutil
 import sys
 
@@ -35,7 +36,7 @@ PATTERN = {
 def counters(path):
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(path)):
-        k = r["Kernel_Name"].split("(")[0]
+        k = re.sub(r"<.*>", "", r["Kernel_Name"].split("(")[0]).replace("void ", "").strip()     # (template kernels: "void name<args>(...)")
         agg[k][0] += 1
         agg[k][1] += float(r["Counter_Value"])
     return agg

@@ -110,6 +110,9 @@ __device__ __forceinline__ uint32_t find_pair(const PairDesc *__restrict__ pairs
 struct JoinGroup { uint32_t pair_begin, pair_end; };
 #define JOIN_THREADS 1024
 #define JOIN_U 4             // seeds per thread and trip
+#ifndef JOIN_PROBE_N
+#define JOIN_PROBE_N 4       // bucket entries compared without a loop
+#endif
 #define JOIN_SMEM_MAX (155u * 1024u)   // dynamic LDS of a workgroup at most
 #define JOIN_SMEM_TWO (80u * 1024u)    // up to here two workgroups fit a CU
 
@@ -177,15 +180,23 @@ __device__ __forceinline__ void join_pass(const SetView &A, const SetView &B, co
             for (int u = 0; u < JOIN_U; u++) {
                 uint32_t cnt = 0, first = 0;
                 if (FITS) {
-                    // buckets hold 1-2 seeds on average, equal k-mers side by side: the first two entries are
-                    // compared without a loop (reads clamped into the table), longer buckets continue
+                    // buckets hold 1-2 seeds on average, equal k-mers side by side: the first JOIN_PROBE_N entries are compared without
+                    // a loop (reads clamped into the table: s_fp has slack behind the last seed), longer buckets continue.  The loop
+                    // costs the whole wavefront its longest lane: with 1.5 seeds per bucket on average 19 % of the lanes have more than
+                    // two entries (some lane of 64 practically always, the longest of them 6-7), 2 % more than four
                     const uint32_t lo = lov[u], ne = hiv[u] - lo, rem = remv[u];
-                    const uint32_t f0 = s_fp[lo], f1 = s_fp[lo + 1];   // s_fp has slack behind the last seed
-                    const bool m0 = ne > 0 && f0 == rem, m1 = ne > 1 && f1 == rem;
-                    cnt = (uint32_t)m0 + (uint32_t)m1;
-                    first = m0 ? lo : lo + 1;
-                    if (ne > 2) {
-                        for (uint32_t e = lo + 2; e < hiv[u]; e++) {
+                    uint32_t fe[JOIN_PROBE_N];
+#pragma unroll
+                    for (int k = 0; k < JOIN_PROBE_N; k++) fe[k] = s_fp[lo + k];
+                    first = lo + JOIN_PROBE_N - 1;
+#pragma unroll
+                    for (int k = JOIN_PROBE_N - 1; k >= 0; k--) {
+                        const bool mk = ne > (uint32_t)k && fe[k] == rem;
+                        cnt += (uint32_t)mk;
+                        first = mk ? lo + (uint32_t)k : first;
+                    }
+                    if (ne > JOIN_PROBE_N) {
+                        for (uint32_t e = lo + JOIN_PROBE_N; e < hiv[u]; e++) {
                             if (s_fp[e] == rem) { if (!cnt) first = e; cnt++; }
                         }
                     }
