@@ -2,6 +2,7 @@
 // skani-format edge table (columns, %.2f, names, filter and row order of SURVEY.md 8c V1-V6).
 // No compute happens here: bases go to HBM unmodified (1 byte per base) and the kernels do the rest.
 #include "host_io.h"
+#include "fasta.h"
 
 #include <fcntl.h>
 #include <sys/stat.h>
@@ -130,6 +131,27 @@ struct TextSource {
     }
 };
 }   // namespace
+
+// the whole text of a plain or gzip file into dst[0 .. cap); SkError("region") if it is longer
+static size_t read_text(const std::string &path, bool gz, uint8_t *dst, size_t cap, IoScratch &sc)
+{
+    FileCloser fc;
+    fc.fd = open(path.c_str(), O_RDONLY);
+    if (fc.fd < 0) throw SkError("cannot open " + path);
+    TextSource src(path, fc.fd, gz, sc);
+    size_t n = 0;
+    for (;;) {
+        if (n == cap) {
+            char probe;
+            if (src.fill(&probe, 1) != 0) throw SkError("region");
+            break;
+        }
+        const long k = src.fill(reinterpret_cast<char *>(dst) + n, cap - n);
+        if (k == 0) break;
+        n += (size_t)k;
+    }
+    return n;
+}
 
 void read_fasta(const std::string &path, HostGenome &g, uint8_t *region, size_t region_cap, IoScratch *scratch)
 {
@@ -327,7 +349,10 @@ class IoPool {
 };
 
 namespace {
-struct Slot { uint8_t *h = nullptr, *d = nullptr; size_t cap = 0; };
+struct Slot {
+    uint8_t *h = nullptr, *d = nullptr; size_t cap = 0;       // pinned host buffer + device copy (host parse: packed bases; device parse: FASTA text)
+    uint8_t *db = nullptr; size_t db_cap = 0;                  // device parse: the packed bases the kernel writes
+};
 struct StagingSet { Slot sl[2]; bool busy = false; };
 std::mutex g_staging_mu;
 StagingSet g_staging[64];          // per device
@@ -345,7 +370,7 @@ struct StagingLease {
     ~StagingLease()
     {
         if (set) { std::lock_guard<std::mutex> lk(g_staging_mu); set->busy = false; return; }
-        for (auto &s : own) { if (s.d) (void)hipFree(s.d); if (s.h) (void)hipHostFree(s.h); }
+        for (auto &s : own) { if (s.d) (void)hipFree(s.d); if (s.h) (void)hipHostFree(s.h); if (s.db) (void)hipFree(s.db); }
     }
 };
 }   // namespace
@@ -379,6 +404,91 @@ unsigned ingest_threads()
         return q ? std::min(t, q) : t;
     }();
     return n;
+}
+
+// N50 of a list of record lengths as util.py:686-724 computes it (all records; half = int(sum / 2); descending; first cumulative >= half)
+static uint64_t n50_of(std::vector<uint64_t> &all_len)
+{
+    std::sort(all_len.begin(), all_len.end());
+    uint64_t tot = 0;
+    for (uint64_t l : all_len) tot += l;
+    const uint64_t half = tot / 2;
+    uint64_t cum = 0, n50 = all_len[0];
+    for (size_t i = all_len.size(); i-- > 0;) {
+        cum += all_len[i];
+        if (cum >= half) { n50 = all_len[i]; break; }
+    }
+    return n50;
+}
+
+// The device stage of a batch whose pinned buffer holds FASTA TEXT (already on its way to d_text on the context's stream): the
+// kernel of fasta.hip builds the packed layout in d_bases and the record tables; the host adds what only it can (names from the
+// header lines, N50 from the length lists) and parses the files the kernel declined (blanks inside sequence lines, ...) itself.
+static void device_parse(skder_sketches *s, const uint8_t *h_text, const uint8_t *d_text, uint8_t *&d_bases, size_t &d_bases_cap,
+                         std::vector<FastaFile> &ff, uint64_t out_total, uint64_t table_total, std::vector<HostGenome> &gs,
+                         std::vector<uint64_t> &rec_off, std::vector<uint32_t> &rec_len, std::vector<uint32_t> &gbegin)
+{
+    hipStream_t st = s->ctx->stream;
+    const uint32_t nf = (uint32_t)ff.size();
+    if (out_total > d_bases_cap) {
+        if (d_bases) (void)hipFree(d_bases);
+        d_bases = nullptr;
+        d_bases_cap = out_total + out_total / 8;
+        HIPCHECK(hipMalloc(&d_bases, d_bases_cap));
+    }
+    DevBuf<FastaFile> d_ff;
+    DevBuf<FastaResult> d_res;
+    DevBuf<uint32_t> d_rel, d_len, d_all;
+    d_ff.resize(nf, st); d_res.resize(nf, st);
+    d_rel.resize(table_total + 1, st); d_len.resize(table_total + 1, st); d_all.resize(table_total + 1, st);
+    HIPCHECK(hipMemcpyAsync(d_ff.p, ff.data(), nf * sizeof(FastaFile), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemsetAsync(d_bases, 'A', 32, st));
+    fasta_parse_launch(d_text, d_ff.p, nf, d_bases, d_rel.p, d_len.p, d_all.p, d_res.p, st);
+    std::vector<FastaResult> res(nf);
+    std::vector<uint32_t> rel(table_total + 1), len(table_total + 1), all(table_total + 1);
+    HIPCHECK(hipMemcpyAsync(res.data(), d_res.p, nf * sizeof(FastaResult), hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipMemcpyAsync(rel.data(), d_rel.p, table_total * 4, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipMemcpyAsync(len.data(), d_len.p, table_total * 4, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipMemcpyAsync(all.data(), d_all.p, table_total * 4, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    rec_off.clear(); rec_len.clear(); gbegin.clear();
+    uint64_t last_end = 32;
+    for (uint32_t k = 0; k < nf; k++) {
+        const FastaFile &f = ff[k];
+        const FastaResult &r = res[k];
+        HostGenome &g = gs[k];
+        gbegin.push_back((uint32_t)rec_len.size());
+        if (r.flags) {
+            // the kernel declined: the host's reader, its layout copied into the file's region
+            HostGenome hg;
+            read_fasta(g.path, hg);
+            if (hg.packed_size > f.out_cap) throw SkError("internal error: host layout of " + g.path + " exceeds its region");
+            if (hg.packed_size) HIPCHECK(hipMemcpyAsync(d_bases + f.out_off, hg.own, hg.packed_size, hipMemcpyHostToDevice, st));
+            HIPCHECK(hipStreamSynchronize(st));
+            for (size_t q = 0; q < hg.rec_len.size(); q++) { rec_off.push_back(f.out_off + hg.rec_rel[q]); rec_len.push_back(hg.rec_len[q]); }
+            g.first_name = hg.first_name; g.n50 = hg.n50; g.packed_size = hg.packed_size;
+            last_end = f.out_off + hg.packed_size;
+            if (getenv("SKDER_AMD_DEBUG")) fprintf(stderr, "[skder_amd] %s: parsed on the host (device parser flags %u)\n", g.path.c_str(), r.flags);
+            continue;
+        }
+        if (r.n_lens == 0) throw SkError("no sequence in " + g.path);
+        if (getenv("SKDER_AMD_DEBUG_FASTA"))
+            fprintf(stderr, "[skder_amd] %s: text %u bytes, %u kept records, %u lengths, first header at %u, packed %u\n", g.path.c_str(), f.text_len, r.n_kept, r.n_lens, r.first_hdr, r.packed_size);
+        for (uint32_t q = 0; q < r.n_kept; q++) { rec_off.push_back(f.out_off + rel[f.table_off + q]); rec_len.push_back(len[f.table_off + q]); }
+        std::vector<uint64_t> al(all.begin() + f.table_off, all.begin() + f.table_off + r.n_lens);
+        g.n50 = n50_of(al);
+        g.first_name.clear();
+        if (r.n_kept) {
+            const uint8_t *p = h_text + f.text_off + r.first_hdr + 1, *e = h_text + f.text_off + f.text_len;
+            for (; p < e && *p != '\n'; p++) if (*p != '\r') g.first_name.push_back((char)*p);
+        }
+        g.packed_size = r.packed_size;
+        last_end = f.out_off + r.packed_size;
+    }
+    gbegin.push_back((uint32_t)rec_len.size());
+    // readable 'A's behind the last record (a tile's reads run past its record)
+    (void)last_end;
+    HIPCHECK(hipMemsetAsync(d_bases + (out_total - (SKDER_TILE + 64)), 'A', SKDER_TILE + 64, st));
 }
 
 void sketch_files(skder_sketches *s, const std::vector<std::string> &paths, GenomeNames &names, unsigned threads)
@@ -443,7 +553,12 @@ void sketch_files(skder_sketches *s, const std::vector<std::string> &paths, Geno
         std::vector<uint32_t> rec_len, gbegin;
         uint64_t total = 0;
         double ms = 0;
+        // device parse: the slot's pinned buffer holds FASTA text; the kernel of fasta.hip builds the layout
+        bool dev_parse = false;
+        std::vector<FastaFile> ff;
+        uint64_t out_total = 0, table_total = 0;
     };
+    const bool want_dev_parse = getenv("SKDER_AMD_HOST_PARSE") == nullptr;
     auto prepare = [&](size_t i0, size_t i1, int sl) {
         const double t0 = now();
         HIPCHECK(hipSetDevice(ctx->device));          // may run on a helper thread
@@ -465,6 +580,48 @@ void sketch_files(skder_sketches *s, const std::vector<std::string> &paths, Geno
         };
         bool direct = getenv("SKDER_AMD_IO_TWO_PHASE") == nullptr;
         for (size_t k = 0; k < ng; k++) direct = direct && info[i0 + k].trusted;
+        bool text_only = direct && want_dev_parse;
+        for (size_t k = 0; k < ng && text_only; k++) text_only = info[i0 + k].text < 0xF0000000ull;
+        if (text_only) {
+            // DEVICE PARSE: the host threads only read (or inflate) every file into the pinned buffer -- '\n' in front of each
+            // text and 128 bytes of '\n' behind it --; fasta_parse_kernel does the scan on the device
+            gs.clear(); gs.resize(ng);
+            P.ff.assign(ng, FastaFile());
+            uint64_t toff = 64, ooff = 32, tabs = 0;
+            for (size_t k = 0; k < ng; k++) {
+                FastaFile &f = P.ff[k];
+                f.text_off = toff; f.text_len = (uint32_t)info[i0 + k].text;      // (gzip: the trailer's figure; the true length follows)
+                toff += (info[i0 + k].text + 128u + 63u) & ~(uint64_t)63u;
+                f.out_off = ooff; f.out_cap = (uint32_t)bound(info[i0 + k].text);
+                ooff += f.out_cap;
+                f.rec_cap = (uint32_t)(info[i0 + k].text / 256u + 64u); f.table_off = (uint32_t)tabs;
+                tabs += f.rec_cap;
+            }
+            room(toff + 64);
+            std::atomic<bool> too_small(false);
+            pool.run(ng, [&](size_t k, IoScratch &sc) {
+                if (too_small.load()) return;
+                FastaFile &f = P.ff[k];
+                uint8_t *t = S.h + f.text_off;
+                try {
+                    const size_t n = read_text(paths[i0 + k], info[i0 + k].gz, t, info[i0 + k].text, sc);
+                    f.text_len = (uint32_t)n;
+                    memset(t - 64, '\n', 64);
+                    memset(t + n, '\n', (((size_t)info[i0 + k].text + 128u + 63u) & ~(size_t)63u) - n);
+                    gs[k].path = paths[i0 + k];
+                } catch (const SkError &e) {
+                    if (std::string(e.what()) != "region") throw;
+                    too_small.store(true);              // the text is longer than the file said: the whole batch again, on the host
+                }
+            });
+            if (!too_small.load()) {
+                P.dev_parse = true;
+                P.total = toff + 64; P.out_total = ooff + SKDER_TILE + 64; P.table_total = tabs;
+                P.ms = now() - t0;
+                return P;
+            }
+            direct = false;
+        }
         if (direct) {
             // every file straight into its region
             gs.clear(); gs.resize(ng);
@@ -536,11 +693,12 @@ void sketch_files(skder_sketches *s, const std::vector<std::string> &paths, Geno
         try {
             Slot &S = slot[cur.sl];
             HIPCHECK(hipMemcpyAsync(S.d, S.h, cur.total, hipMemcpyHostToDevice, st));
+            if (cur.dev_parse) device_parse(s, S.h, S.d, S.db, S.db_cap, cur.ff, cur.out_total, cur.table_total, cur.gs, cur.rec_off, cur.rec_len, cur.gbegin);
             skder_batch_t b;
             b.n_genomes = (uint32_t)cur.gs.size();
             b.n_records = (uint32_t)cur.rec_len.size();
             b.rec_off = cur.rec_off.data(); b.rec_len = cur.rec_len.data(); b.genome_rec_begin = cur.gbegin.data();
-            sketch_batch_impl(s, S.d, &b);
+            sketch_batch_impl(s, cur.dev_parse ? S.db : S.d, &b);
             HIPCHECK(hipStreamSynchronize(st));
         } catch (...) {
             if (more) { try { (void)next.get(); } catch (...) {} }

@@ -774,6 +774,76 @@ def test_gzip_inputs_direct_and_two_phase(gpu, tmp_path, monkeypatch):
     assert table("one", env="SKDER_AMD_IO_TWO_PHASE") == want
 
 
+def test_device_fasta_parser_equals_host_reader(gpu, tmp_path, monkeypatch):
+    """The ingest parses FASTA text ON THE DEVICE (skder_amd/csrc/fasta.hip): the host only reads or inflates.  Every formatting
+    case the host reader is tested with (tests/test_host_parser_asan.py: wrapped / unwrapped lines, CRLF, blank lines, text in front
+    of the first header, empty and tiny records, '>' inside a sequence line, no newline at the end, thousands of short records,
+    gzip) must give the N50 table and the edge table of the host reader (SKDER_AMD_HOST_PARSE=1), byte for byte; a file with
+    blanks inside sequence lines is declined by the kernel and parsed by the host -- same tables again."""
+    import skder_amd
+    rng = np.random.RandomState(11)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    anc = alpha[rng.randint(0, 4, 260000)]
+
+    def mutate(rate):
+        s = anc.copy()
+        idx = rng.randint(0, len(s), int(len(s) * rate))
+        s[idx] = alpha[rng.randint(0, 4, len(idx))]
+        return bytes(s)
+    wrap = lambda b, w, eol=b"\n": eol.join(b[i:i + w] for i in range(0, len(b), w)) + eol
+    files = {}
+    g = mutate(0.01)
+    files["wrapped.fa"] = b">r1 first record\n" + wrap(g[:150000], 80) + b">short\n" + wrap(g[150000:150300], 60) + b">r3\n" + wrap(g[150300:], 70)
+    g = mutate(0.012)
+    files["unwrapped.fa"] = b">one line per record\n" + g[:100000] + b"\n>second\n" + g[100000:] + b"\n"
+    g = mutate(0.02)
+    files["crlf.fa"] = b">r1 dos\r\n" + wrap(g[:200000], 60, b"\r\n") + b"\r\n>r2\r\n" + wrap(g[200000:200499], 60, b"\r\n") + b">r3\r\n" + wrap(g[200499:], 61, b"\r\n")
+    g = mutate(0.015)
+    files["pretext_noeol.fa"] = b"ACGTACGTAC\n\n>r1\n" + wrap(g[:130000], 100) + b"\n\n>empty\n>e2\n\n>tiny\nACG\n>t2\nA\n>r2 x>y\n" + wrap(g[130000:], 50)[:-1]
+    g = mutate(0.03)
+    body = wrap(g[:120000], 50)
+    files["gt_inside.fa"] = b">r1\n" + body[:5000] + b"AC>GT\n" + body[5000:] + b">r2\n" + g[120000:] + b"\n"
+    g = mutate(0.005)
+    lens = [500 + i % 37 for i in range(480)]
+    off, parts = 0, []
+    for i, l in enumerate(lens):
+        parts.append(b">c%d\n" % i + wrap(g[off:off + l], 61))
+        off += l
+    files["many.fa"] = b"".join(parts)
+    g = mutate(0.02)
+    files["blanks.fa"] = b">r1\n" + wrap(g[:100000], 50).replace(b"A", b"A ", 20) + b">r2\n  " + g[100000:] + b"  \n"
+    # the first kept record opens AND closes inside the parser's first 4 KB round (its name comes from a lane of the same
+    # round, not from the carry), behind a blank line / behind a record that is too short to keep
+    g = mutate(0.011)
+    files["early_a.fa"] = b"\n>e1 some description\n" + wrap(g[:1129], 70) + b">e2\n" + wrap(g[1129:], 70)
+    g = mutate(0.013)
+    files["early_b.fa"] = b"\n>s\nACGT\n>e1 kept\n" + wrap(g[:700], 60) + b">e2\n" + wrap(g[700:1300], 60) + b">e3\n" + wrap(g[1300:], 60)
+    for k in ("wrapped.fa", "many.fa", "crlf.fa"):
+        files[k + ".gz"] = gzip.compress(files[k], 1)
+    files["members.fa.gz"] = gzip.compress(files["unwrapped.fa"][:70000], 1) + gzip.compress(files["unwrapped.fa"][70000:], 6)
+    d = tmp_path / "fa"
+    d.mkdir()
+    for k, v in files.items():
+        (d / k).write_bytes(v)
+    listing = tmp_path / "listing.txt"
+    listing.write_text("".join(str(d / k) + "\n" for k in sorted(files)))
+
+    def run(tag, env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out, n50 = tmp_path / (tag + ".tsv"), tmp_path / (tag + "_n50.tsv")
+        skder_amd.runSkaniTriangle(str(listing), str(out), "-s 80", 0.0, "greedy", False, None, n50_file=str(n50))
+        for k in env:
+            monkeypatch.delenv(k)
+        return out.read_text(), n50.read_text()
+    host = run("host", {"SKDER_AMD_HOST_PARSE": "1"})
+    dev = run("dev", {})
+    assert dev[1] == host[1]                                 # N50 of every file
+    assert dev[0] == host[0] and dev[0].count("\n") == 1 + len(files) * (len(files) - 1) // 2
+    # small batches: files spread over several rounds of the double-buffered pipeline
+    assert run("dev_small", {"SKDER_AMD_IO_BATCH_MB": "1"}) == host
+
+
 def test_database_table_in_memory_equals_text(gpu, tmp_path):
     """the rows handed over in memory are the rows of the text table (same order, same
     orientation, same 2-decimal values), for a listing that is NOT in path order"""
