@@ -352,6 +352,18 @@ namespace {
 struct Slot {
     uint8_t *h = nullptr, *d = nullptr; size_t cap = 0;       // pinned host buffer + device copy (host parse: packed bases; device parse: FASTA text)
     uint8_t *db = nullptr; size_t db_cap = 0;                  // device parse: the packed bases the kernel writes
+    uint32_t *tab = nullptr; size_t tab_cap = 0;               // device parse: pinned landing area of the record tables
+    hipStream_t cs = nullptr; hipEvent_t ev = nullptr;         // the slot's copies run on a stream of their own: batch k+1 crosses PCIe while batch k is parsed and sketched
+    void release()
+    {
+        if (d) (void)hipFree(d);
+        if (h) (void)hipHostFree(h);
+        if (db) (void)hipFree(db);
+        if (tab) (void)hipHostFree(tab);
+        if (ev) (void)hipEventDestroy(ev);
+        if (cs) (void)hipStreamDestroy(cs);
+        h = d = db = nullptr; tab = nullptr; cs = nullptr; ev = nullptr; cap = db_cap = tab_cap = 0;
+    }
 };
 struct StagingSet { Slot sl[2]; bool busy = false; };
 std::mutex g_staging_mu;
@@ -370,7 +382,7 @@ struct StagingLease {
     ~StagingLease()
     {
         if (set) { std::lock_guard<std::mutex> lk(g_staging_mu); set->busy = false; return; }
-        for (auto &s : own) { if (s.d) (void)hipFree(s.d); if (s.h) (void)hipHostFree(s.h); if (s.db) (void)hipFree(s.db); }
+        for (auto &s : own) s.release();
     }
 };
 }   // namespace
@@ -424,18 +436,26 @@ static uint64_t n50_of(std::vector<uint64_t> &all_len)
 // The device stage of a batch whose pinned buffer holds FASTA TEXT (already on its way to d_text on the context's stream): the
 // kernel of fasta.hip builds the packed layout in d_bases and the record tables; the host adds what only it can (names from the
 // header lines, N50 from the length lists) and parses the files the kernel declined (blanks inside sequence lines, ...) itself.
-static void device_parse(skder_sketches *s, const uint8_t *h_text, const uint8_t *d_text, uint8_t *&d_bases, size_t &d_bases_cap,
+static void device_parse(skder_sketches *s, Slot &S,
                          std::vector<FastaFile> &ff, uint64_t out_total, uint64_t table_total, std::vector<HostGenome> &gs,
                          std::vector<uint64_t> &rec_off, std::vector<uint32_t> &rec_len, std::vector<uint32_t> &gbegin)
 {
     hipStream_t st = s->ctx->stream;
     const uint32_t nf = (uint32_t)ff.size();
-    if (out_total > d_bases_cap) {
-        if (d_bases) (void)hipFree(d_bases);
-        d_bases = nullptr;
-        d_bases_cap = out_total + out_total / 8;
-        HIPCHECK(hipMalloc(&d_bases, d_bases_cap));
+    const uint8_t *h_text = S.h, *d_text = S.d;
+    if (out_total > S.db_cap) {
+        if (S.db) (void)hipFree(S.db);
+        S.db = nullptr;
+        S.db_cap = out_total + out_total / 8;
+        HIPCHECK(hipMalloc(&S.db, S.db_cap));
     }
+    if (3 * (table_total + 1) > S.tab_cap) {
+        if (S.tab) (void)hipHostFree(S.tab);
+        S.tab = nullptr;
+        S.tab_cap = 3 * (table_total + 1) + (table_total + 1) / 2;
+        HIPCHECK(hipHostMalloc(&S.tab, S.tab_cap * sizeof(uint32_t)));
+    }
+    uint8_t *d_bases = S.db;
     DevBuf<FastaFile> d_ff;
     DevBuf<FastaResult> d_res;
     DevBuf<uint32_t> d_rel, d_len, d_all;
@@ -445,11 +465,11 @@ static void device_parse(skder_sketches *s, const uint8_t *h_text, const uint8_t
     HIPCHECK(hipMemsetAsync(d_bases, 'A', 32, st));
     fasta_parse_launch(d_text, d_ff.p, nf, d_bases, d_rel.p, d_len.p, d_all.p, d_res.p, st);
     std::vector<FastaResult> res(nf);
-    std::vector<uint32_t> rel(table_total + 1), len(table_total + 1), all(table_total + 1);
+    uint32_t *rel = S.tab, *len = S.tab + (table_total + 1), *all = S.tab + 2 * (table_total + 1);
     HIPCHECK(hipMemcpyAsync(res.data(), d_res.p, nf * sizeof(FastaResult), hipMemcpyDeviceToHost, st));
-    HIPCHECK(hipMemcpyAsync(rel.data(), d_rel.p, table_total * 4, hipMemcpyDeviceToHost, st));
-    HIPCHECK(hipMemcpyAsync(len.data(), d_len.p, table_total * 4, hipMemcpyDeviceToHost, st));
-    HIPCHECK(hipMemcpyAsync(all.data(), d_all.p, table_total * 4, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipMemcpyAsync(rel, d_rel.p, table_total * 4, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipMemcpyAsync(len, d_len.p, table_total * 4, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipMemcpyAsync(all, d_all.p, table_total * 4, hipMemcpyDeviceToHost, st));
     HIPCHECK(hipStreamSynchronize(st));
     rec_off.clear(); rec_len.clear(); gbegin.clear();
     uint64_t last_end = 32;
@@ -475,7 +495,7 @@ static void device_parse(skder_sketches *s, const uint8_t *h_text, const uint8_t
         if (getenv("SKDER_AMD_DEBUG_FASTA"))
             fprintf(stderr, "[skder_amd] %s: text %u bytes, %u kept records, %u lengths, first header at %u, packed %u\n", g.path.c_str(), f.text_len, r.n_kept, r.n_lens, r.first_hdr, r.packed_size);
         for (uint32_t q = 0; q < r.n_kept; q++) { rec_off.push_back(f.out_off + rel[f.table_off + q]); rec_len.push_back(len[f.table_off + q]); }
-        std::vector<uint64_t> al(all.begin() + f.table_off, all.begin() + f.table_off + r.n_lens);
+        std::vector<uint64_t> al(all + f.table_off, all + f.table_off + r.n_lens);
         g.n50 = n50_of(al);
         g.first_name.clear();
         if (r.n_kept) {
@@ -539,7 +559,8 @@ void sketch_files(skder_sketches *s, const std::vector<std::string> &paths, Geno
     auto batch_end = [&](size_t i0) {
         size_t i1 = i0;
         uint64_t est = 0;
-        while (i1 < paths.size() && (i1 == i0 || est < batch_bytes)) {
+        const uint64_t budget = i0 == 0 ? batch_bytes / 4 : batch_bytes;      // a short first batch: the device starts early
+        while (i1 < paths.size() && (i1 == i0 || est < budget)) {
             est += bound(info[i1].text);
             i1++;
         }
@@ -559,7 +580,7 @@ void sketch_files(skder_sketches *s, const std::vector<std::string> &paths, Geno
         uint64_t out_total = 0, table_total = 0;
     };
     const bool want_dev_parse = getenv("SKDER_AMD_HOST_PARSE") == nullptr;
-    auto prepare = [&](size_t i0, size_t i1, int sl) {
+    auto prepare_host = [&](size_t i0, size_t i1, int sl) {
         const double t0 = now();
         HIPCHECK(hipSetDevice(ctx->device));          // may run on a helper thread
         Prepared P;
@@ -571,6 +592,7 @@ void sketch_files(skder_sketches *s, const std::vector<std::string> &paths, Geno
         Slot &S = slot[sl];
         auto room = [&](uint64_t total) {            // regions: 32 readable bytes in front, SKDER_TILE + 64 behind
             if (total <= S.cap) return;
+            if (i1 - i0 < paths.size()) total = std::max<uint64_t>(total, batch_bytes + batch_bytes / 16);     // several batches: full size at once (the first batch is a short one)
             if (S.d) (void)hipFree(S.d);
             if (S.h) (void)hipHostFree(S.h);
             S.h = S.d = nullptr;
@@ -676,6 +698,17 @@ void sketch_files(skder_sketches *s, const std::vector<std::string> &paths, Geno
         P.ms = now() - t0;
         return P;
     };
+    // ... and its copy to the device, on the slot's own stream (the slot's buffers are free: the batch that used them two
+    // rounds ago was copied, parsed and sketched before this one was asked for)
+    auto prepare = [&](size_t i0, size_t i1, int sl) {
+        Prepared P = prepare_host(i0, i1, sl);
+        Slot &S = slot[sl];
+        if (!S.cs) HIPCHECK(hipStreamCreateWithFlags(&S.cs, hipStreamNonBlocking));
+        if (!S.ev) HIPCHECK(hipEventCreateWithFlags(&S.ev, hipEventDisableTiming));
+        HIPCHECK(hipMemcpyAsync(S.d, S.h, P.total, hipMemcpyHostToDevice, S.cs));
+        HIPCHECK(hipEventRecord(S.ev, S.cs));
+        return P;
+    };
     double t_parse = 0, t_dev = 0;
     if (paths.empty()) return;
     Prepared cur = prepare(0, batch_end(0), 0);
@@ -692,8 +725,8 @@ void sketch_files(skder_sketches *s, const std::vector<std::string> &paths, Geno
         t_parse += cur.ms;
         try {
             Slot &S = slot[cur.sl];
-            HIPCHECK(hipMemcpyAsync(S.d, S.h, cur.total, hipMemcpyHostToDevice, st));
-            if (cur.dev_parse) device_parse(s, S.h, S.d, S.db, S.db_cap, cur.ff, cur.out_total, cur.table_total, cur.gs, cur.rec_off, cur.rec_len, cur.gbegin);
+            HIPCHECK(hipStreamWaitEvent(st, S.ev, 0));
+            if (cur.dev_parse) device_parse(s, S, cur.ff, cur.out_total, cur.table_total, cur.gs, cur.rec_off, cur.rec_len, cur.gbegin);
             skder_batch_t b;
             b.n_genomes = (uint32_t)cur.gs.size();
             b.n_records = (uint32_t)cur.rec_len.size();
