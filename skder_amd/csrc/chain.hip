@@ -113,13 +113,14 @@ struct JoinGroup { uint32_t pair_begin, pair_end; };
 #ifndef JOIN_PROBE_N
 #define JOIN_PROBE_N 4       // bucket entries compared without a loop
 #endif
+#define JOIN_SLACK 64u       // readable entries behind the last remainder (the unconditional 8-entry compare; a group with an oversize bucket)
 #define JOIN_SMEM_MAX (155u * 1024u)   // dynamic LDS of a workgroup at most
 #define JOIN_SMEM_TWO (80u * 1024u)    // up to here two workgroups fit a CU
 
 // LDS bytes wanted for a whole-table pass over a genome with 2^bits buckets and n seeds
 static inline size_t join_need(uint32_t bits, uint32_t n)
 {
-    return (size_t)(1u << bits) + 64u + ((size_t)n + 8u) * (bits >= 14u ? 2u : 4u);      // one byte per bucket (group words), remainders
+    return (size_t)(1u << bits) + 64u + ((size_t)n + JOIN_SLACK) * (bits >= 14u ? 2u : 4u);      // one byte per bucket (group words), remainders
 }
 
 // the probe loop of one staged bucket range for all pairs of a group.  FP: remainder type (16 bits once
@@ -252,8 +253,128 @@ __device__ __forceinline__ void join_pass(const SetView &A, const SetView &B, co
     }
 }
 
+// The same pass for 16-bit remainders in LDS (every genome of 16 K seeds and more: the benchmark's), written for the
+// instruction count -- the kernel is issue-bound at two workgroups per CU:
+//  * a lane takes FOUR CONSECUTIVE seeds of the chunked genome: one 16-byte load of their k-mers and one 16-byte store of
+//    their hit words per trip (the hit words of a pair start at an entry congruent to the genome's seed offset mod 4, as
+//    run_extract_kernel relies on too), instead of four 4-byte accesses with a 64-bit address each;
+//  * the start of the bucket = the group's base + the sizes of the buckets below it in the group: ONE v_dot8_u32_u4 over
+//    the masked size nibbles;
+//  * EIGHT entries are compared without a loop, two halfwords per instruction: xor with the remainder in both halves,
+//    v_pk_min_u16 against 1 turns every half into "differs", three shift-ors and one shift gather the eight bits, one
+//    three-operand bit operation masks them with the bucket size -- count and first match are a population count and a
+//    find-first-bit.  (Per entry compares with a loop behind the fourth cost 27 instructions and, because some lane of a
+//    wavefront practically always has a fifth entry, a loop trip or two per wavefront: ~ 50 where this is 20.)  Buckets
+//    of more than eight entries and buckets marked "look it up in the global table" share one rare loop.
+__device__ __forceinline__ uint32_t halves_differ(uint32_t x)     // 1 in bit 0 / bit 16 where the half is not 0
+{
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(r) : "v"(x));      // (written out: the compiler turns min(half, 1) into a compare, a select and a permute per half)
+    return r;
+}
+
+template <bool WHOLE>
+__device__ __forceinline__ void join_pass16(const SetView &A, const SetView &B, const PairDesc *__restrict__ pairs, const JoinGroup g,
+                                            uint32_t *__restrict__ hits, uint4 *__restrict__ multi, uint32_t *__restrict__ pair_nmulti,
+                                            const uint16_t *s_fp, const uint32_t *s_grp, const uint32_t *__restrict__ rb,
+                                            const uint32_t *__restrict__ rg, uint32_t base, uint32_t bits, uint32_t bb0, uint32_t bb1,
+                                            uint32_t rrep, uint32_t tid)
+{
+    const uint32_t bsh = 30u - bits, rmask = (1u << bsh) - 1u;
+    for (uint32_t p = g.pair_begin; p < g.pair_end; p++) {
+        const PairDesc pd = pairs[p];
+        const SetView &QS = (pd.flags & 2u) ? B : A;
+        const GenomeMeta *Qm = QS.meta + pd.q;
+        const uint32_t nq = Qm->n_seeds, a = (uint32_t)(Qm->seed_off & 3u), nv = nq + a;
+        // virtual seed index v = s + a: v = 0 sits on a 16-byte boundary of both streams
+        const uint32_t *pk_al = QS.pkmer + (Qm->seed_off - a);
+        uint32_t *hit_al = hits + (pd.hit_base - a);
+        for (uint32_t v0 = 4u * tid; v0 < nv; v0 += 4u * JOIN_THREADS) {
+            const bool full = v0 >= a && v0 + 4u <= nv;
+            uint32_t kq[4], cntv[4], firstv[4], hv[4];
+            bool in[4], minev[4];
+            if (full) {
+                const uint4 k4 = *reinterpret_cast<const uint4 *>(pk_al + v0);
+                kq[0] = k4.x; kq[1] = k4.y; kq[2] = k4.z; kq[3] = k4.w;
+#pragma unroll
+                for (int u = 0; u < 4; u++) in[u] = true;
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    in[u] = v0 + u >= a && v0 + u < nv;
+                    kq[u] = in[u] ? pk_al[v0 + u] : 0u;
+                }
+            }
+            bool any_multi = false;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t mx = kmer_mix(kq[u] & SK_SEED_MASK);
+                const uint32_t b = mx >> bsh, rem = mx & rmask;
+                const bool mine = in[u] && (WHOLE || (b >= bb0 && b < bb1));      // else: this seed's bucket belongs to another pass
+                minev[u] = mine;
+                const uint32_t bi = WHOLE ? b : (mine ? b - bb0 : 0u);
+                // group word: first seed of the group | the four bucket sizes above it
+                const uint32_t w = s_grp[bi >> 2], sh = (bi & 3u) * 4u, sizes = w >> 16;
+                const uint32_t ne = (sizes >> sh) & 15u;
+                uint32_t lo = __builtin_amdgcn_udot8(sizes & ((1u << sh) - 1u), 0x11111111u, w & 0xFFFFu, false);
+                uint2 d0, d1;
+                __builtin_memcpy(&d0, s_fp + lo, 8);
+                __builtin_memcpy(&d1, s_fp + lo + 4, 8);
+                const uint32_t rem2 = rem | (rem << 16);
+                uint32_t t = halves_differ(d0.x ^ rem2);
+                t |= halves_differ(d0.y ^ rem2) << 2;
+                t |= halves_differ(d1.x ^ rem2) << 4;
+                t |= halves_differ(d1.y ^ rem2) << 6;                         // entry e differs: bit e (even e), bit 15 + e (odd e)
+                const uint32_t match = ~(t | (t >> 15)) & ((1u << ne) - 1u) & 0xFFu;
+                uint32_t cnt = (uint32_t)__popc(match), first = lo + (uint32_t)__builtin_ctz(match | 0x100u);
+                if (ne > 8u) {
+                    // a long bucket, or one whose bounds only the global table knows (15 seeds or more, or behind such a bucket)
+                    uint32_t e = lo + 8u, hi = lo + ne;
+                    if (ne == 15u) { e = rb[b] - base; hi = rb[b + 1] - base; cnt = 0; }
+                    for (; e < hi; e++)
+                        if (s_fp[e] == rem) { if (!cnt) first = e; cnt++; }
+                }
+                if (!mine || cnt > rrep) cnt = 0;
+                cntv[u] = cnt; firstv[u] = first;
+                any_multi |= cnt > 1;
+            }
+            // all position gathers in flight together: unconditional loads (seeds without a single hit read
+            // the genome's first entry, one broadcast address), combined only after the last one is issued
+            uint32_t gv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) gv[u] = rg[base + (cntv[u] == 1 ? firstv[u] : 0u)];
+#pragma unroll
+            for (int u = 0; u < 4; u++)      // bit 31 of a stag entry is the strand of the indexed k-mer: the hit is reversed when the two differ
+                hv[u] = cntv[u] == 1 ? (gv[u] ^ (kq[u] & USED_BIT)) : (cntv[u] > 4 ? HIT_MANY : HIT_NONE);
+            if (any_multi) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t cnt = cntv[u], first = firstv[u];
+                    if (cnt < 2 || cnt > 4) continue;
+                    const uint32_t slot = atomicAdd(&pair_nmulti[p], 1u);
+                    if (slot < pd.multi_cap) {
+                        uint32_t v[4] = {HIT_NONE, HIT_NONE, HIT_NONE, HIT_NONE};
+                        for (uint32_t w = 0; w < cnt; w++) v[w] = rg[base + first + w] ^ (kq[u] & USED_BIT);
+                        multi[pd.multi_base + slot] = make_uint4(v[0], v[1], v[2], v[3]);
+                        hv[u] = HIT_MULTI | slot;
+                    } else {
+                        hv[u] = HIT_MANY;
+                    }
+                }
+            }
+            if (WHOLE && full) {
+                *reinterpret_cast<uint4 *>(hit_al + v0) = make_uint4(hv[0], hv[1], hv[2], hv[3]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (minev[u]) hit_al[v0 + u] = hv[u];
+            }
+        }
+    }
+}
+
 // one bucket range of R after the other: stage, probe
-template <typename FP>
+template <typename FP, bool V2>
 __device__ __forceinline__ void join_group(const SetView &A, const SetView &B, const PairDesc *__restrict__ pairs, const JoinGroup g,
                                            uint32_t *__restrict__ hits, uint4 *__restrict__ multi, uint32_t *__restrict__ pair_nmulti,
                                            unsigned char *smem, uint32_t smem_bytes, const SetView &RS, const GenomeMeta *Rm, uint32_t tid)
@@ -265,11 +386,11 @@ __device__ __forceinline__ void join_group(const SetView &A, const SetView &B, c
     uint32_t *s_grp = reinterpret_cast<uint32_t *>(smem + 64);
     // whole table in one pass if it fits; else as many buckets as half of the space takes, at most 65535 seeds per pass
     const uint32_t whole_off = nbk + 64u;
-    const bool one = whole_off + ((size_t)Rm->n_seeds + 8u) * sizeof(FP) <= smem_bytes;
+    const bool one = whole_off + ((size_t)Rm->n_seeds + JOIN_SLACK) * sizeof(FP) <= smem_bytes;
     const uint32_t bcap = one ? nbk : ((smem_bytes / 2u - 64u) & ~3u);                   // buckets held per pass (a multiple of 4)
     const uint32_t fp_off = one ? whole_off : smem_bytes / 2u;
     FP *s_fp = reinterpret_cast<FP *>(smem + fp_off);
-    uint32_t kcap = (smem_bytes - fp_off) / (uint32_t)sizeof(FP) - 8u;                   // remainders held per pass
+    uint32_t kcap = (smem_bytes - fp_off) / (uint32_t)sizeof(FP) - JOIN_SLACK;                   // remainders held per pass
     kcap = kcap < 65535u ? kcap : 65535u;
     const uint32_t bsh = 30u - bits, rmask = (1u << bsh) - 1u;
 
@@ -303,11 +424,15 @@ __device__ __forceinline__ void join_group(const SetView &A, const SetView &B, c
                 s_grp[i] = (o0 - base) | ((v0 ? 15u : c0) << 16) | ((v1 ? 15u : c1) << 20) | ((v2 ? 15u : c2) << 24) | ((v3 ? 15u : c3) << 28);
             }
             for (uint32_t i = tid; i < nk; i += JOIN_THREADS) s_fp[i] = (FP)(kmer_mix(rk[base + i] & SK_SEED_MASK) & rmask);
-            if (tid < 8) s_fp[nk + tid] = (FP)0;
+            if (tid < JOIN_SLACK) s_fp[nk + tid] = (FP)0;
         }
         __syncthreads();
         const bool whole = bb0 == 0 && bb1 == nbk;
-        if (fits && whole) join_pass<FP, true, true>(A, B, pairs, g, hits, multi, pair_nmulti, s_fp, s_grp, rb, rk, rg, base, bits, bb0, bb1, rrep, tid);
+        if (V2 && sizeof(FP) == 2 && fits) {
+            if (whole) join_pass16<true>(A, B, pairs, g, hits, multi, pair_nmulti, reinterpret_cast<const uint16_t *>(s_fp), s_grp, rb, rg, base, bits, bb0, bb1, rrep, tid);
+            else join_pass16<false>(A, B, pairs, g, hits, multi, pair_nmulti, reinterpret_cast<const uint16_t *>(s_fp), s_grp, rb, rg, base, bits, bb0, bb1, rrep, tid);
+        }
+        else if (fits && whole) join_pass<FP, true, true>(A, B, pairs, g, hits, multi, pair_nmulti, s_fp, s_grp, rb, rk, rg, base, bits, bb0, bb1, rrep, tid);
         else if (fits) join_pass<FP, true, false>(A, B, pairs, g, hits, multi, pair_nmulti, s_fp, s_grp, rb, rk, rg, base, bits, bb0, bb1, rrep, tid);
         else join_pass<FP, false, false>(A, B, pairs, g, hits, multi, pair_nmulti, s_fp, s_grp, rb, rk, rg, base, bits, bb0, bb1, rrep, tid);
         bb0 = bb1;
@@ -317,6 +442,7 @@ __device__ __forceinline__ void join_group(const SetView &A, const SetView &B, c
 // (amdgpu_waves_per_eu(8): TWO of these 1024-thread workgroups per CU need 8 wavefronts per SIMD, i.e. at most 64 VGPRs and -- the
 // limit that was silently missed before -- at most 80 SGPRs per wavefront.  With the two SetViews in scalar registers the compiler
 // took 101, which admits 6 wavefronts per SIMD: ONE workgroup per CU, half the wavefronts this latency-bound kernel was designed for.)
+template <bool V2>
 __global__ __launch_bounds__(JOIN_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void join_probe_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs,
                                                                   const JoinGroup *__restrict__ groups,
                                                                   uint32_t *__restrict__ hits, uint4 *__restrict__ multi,
@@ -329,8 +455,8 @@ __global__ __launch_bounds__(JOIN_THREADS) __attribute__((amdgpu_waves_per_eu(8,
     const SetView &RS = (pd0.flags & 4u) ? B : A;
     const GenomeMeta *Rm = RS.meta + pd0.r;
     // 16-bit remainders identify a k-mer inside its bucket once there are 2^14 buckets (30 - bits <= 16)
-    if (Rm->bucket_bits >= 14u) join_group<uint16_t>(A, B, pairs, g, hits, multi, pair_nmulti, join_smem, smem_bytes, RS, Rm, tid);
-    else join_group<uint32_t>(A, B, pairs, g, hits, multi, pair_nmulti, join_smem, smem_bytes, RS, Rm, tid);
+    if (Rm->bucket_bits >= 14u) join_group<uint16_t, V2>(A, B, pairs, g, hits, multi, pair_nmulti, join_smem, smem_bytes, RS, Rm, tid);
+    else join_group<uint32_t, V2>(A, B, pairs, g, hits, multi, pair_nmulti, join_smem, smem_bytes, RS, Rm, tid);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2308,7 +2434,9 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
             S.groups.resize(hg.size() * 2, S.st_join);
             HIPCHECK(hipMemcpyAsync(S.groups.p, hg.data(), hg.size() * sizeof(JoinGroup), hipMemcpyHostToDevice, S.st_join));
             if (!ctx->chain_attr_set) {      // per context: the attribute belongs to the device, and a process may use several
-                HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(join_probe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(join_probe_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             JOIN_SMEM_MAX + 64));
+                HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(join_probe_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              JOIN_SMEM_MAX + 64));
                 HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(finalize_kernel_t<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              4096 * 35));
@@ -2322,14 +2450,15 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
                 const size_t w = join_need(R.bucket_bits, R.n_seeds);
                 want = w > want ? w : want;
             }
+            static const bool join_v1 = getenv("SKDER_AMD_JOIN_V1") != nullptr;      // the per-entry probe of round 2 (A/B; results identical)
             uint32_t join_smem = (uint32_t)(want < JOIN_SMEM_MAX ? want : JOIN_SMEM_MAX) / 64u * 64u + 64u;
             if (want <= JOIN_SMEM_TWO && join_smem > JOIN_SMEM_TWO) join_smem = JOIN_SMEM_TWO;
             if (getenv("SKDER_AMD_DEBUG")) {
                 int per_cu = 0;
-                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(join_probe_kernel), JOIN_THREADS, join_smem);
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(join_v1 ? join_probe_kernel<false> : join_probe_kernel<true>), JOIN_THREADS, join_smem);
                 fprintf(stderr, "[skder_amd] join: %zu workgroups of %u threads, %u bytes of LDS each: %d resident per CU (runtime's answer)\n", hg.size(), JOIN_THREADS, join_smem, per_cu);
             }
-            hipLaunchKernelGGL(join_probe_kernel, dim3((unsigned)hg.size()), dim3(JOIN_THREADS), join_smem, S.st_join, VA, VB, S.d_pairs.p,
+            hipLaunchKernelGGL(join_v1 ? join_probe_kernel<false> : join_probe_kernel<true>, dim3((unsigned)hg.size()), dim3(JOIN_THREADS), join_smem, S.st_join, VA, VB, S.d_pairs.p,
                                reinterpret_cast<const JoinGroup *>(S.groups.p), S.hits.p, S.multi.p, S.pair_nmulti.p, join_smem);
             HIPCHECK(hipGetLastError());
         }
