@@ -273,7 +273,8 @@ __device__ __forceinline__ uint32_t halves_differ(uint32_t x)     // 1 in bit 0 
     return r;
 }
 
-template <bool WHOLE>
+// JOIN_SUB: sub-trips (four consecutive seeds per lane each) between two drains of the memory queue
+template <bool WHOLE, int JOIN_SUB>
 __device__ __forceinline__ void join_pass16(const SetView &A, const SetView &B, const PairDesc *__restrict__ pairs, const JoinGroup g,
                                             uint32_t *__restrict__ hits, uint4 *__restrict__ multi, uint32_t *__restrict__ pair_nmulti,
                                             const uint16_t *s_fp, const uint32_t *s_grp, const uint32_t *__restrict__ rb,
@@ -289,92 +290,131 @@ __device__ __forceinline__ void join_pass16(const SetView &A, const SetView &B, 
         // virtual seed index v = s + a: v = 0 sits on a 16-byte boundary of both streams
         const uint32_t *pk_al = QS.pkmer + (Qm->seed_off - a);
         uint32_t *hit_al = hits + (pd.hit_base - a);
-        for (uint32_t v0 = 4u * tid; v0 < nv; v0 += 4u * JOIN_THREADS) {
-            const bool full = v0 >= a && v0 + 4u <= nv;
-            uint32_t kq[4], cntv[4], firstv[4], hv[4];
-            bool in[4], minev[4];
-            if (full) {
-                const uint4 k4 = *reinterpret_cast<const uint4 *>(pk_al + v0);
-                kq[0] = k4.x; kq[1] = k4.y; kq[2] = k4.z; kq[3] = k4.w;
+        const uint32_t last_vec = nv >= 4u ? (nv - 4u) & ~3u : 0u;      // the pair's last whole vector
+        // A trip = JOIN_SUB sub-trips with all k-mer loads at its start and all hit-word stores at its end (gfx9 counts loads and
+        // stores in one counter and they complete out of order with respect to each other: with a store pending, every wait for a
+        // load is a full drain of the queue).  Measured on one box (profiles/round3_join_probe.json): per-entry probe 20.1 ms per
+        // step, this probe with ONE sub-trip 18.45, with two 19.5 (a pair of 24 K seeds is three trips of 8 K then, the last one
+        // partly idle, and the extra registers spill in the prologue): one is shipped.  The same file holds what the kernel's time is
+        // made of: without its gathers 13.9 ms, without its stores 14.4, without both 13.1, without any global memory
+        // access 12.4 -- instruction issue + LDS and the 59 GB of HBM traffic (3.0 TB/s) each take about 13 ms and eight wavefronts
+        // per SIMD overlap them only partly.
+        for (uint32_t v0 = 4u * tid; v0 < nv; v0 += 4u * JOIN_THREADS * JOIN_SUB) {
+            uint32_t kq[JOIN_SUB][4], hv[JOIN_SUB][4];
+            bool in[JOIN_SUB][4], minev[JOIN_SUB][4], full[JOIN_SUB];
+            // unconditional 16-byte loads (no branch between them: they are issued together): a lane at or behind the pair's last
+            // whole vector re-reads that one; the one lane with the partial vector at the end reloads its seeds one by one
 #pragma unroll
-                for (int u = 0; u < 4; u++) in[u] = true;
-            } else {
+            for (int j = 0; j < JOIN_SUB; j++) {
+                const uint32_t vj = v0 + (uint32_t)j * 4u * JOIN_THREADS;
+                uint4 k4 = make_uint4(0u, 0u, 0u, 0u);
+                if (nv >= 4u) k4 = *reinterpret_cast<const uint4 *>(pk_al + (vj < last_vec ? vj : last_vec));      // (wave-uniform: a pair of fewer than four entries has no whole vector)
+                kq[j][0] = k4.x; kq[j][1] = k4.y; kq[j][2] = k4.z; kq[j][3] = k4.w;
+            }
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    in[u] = v0 + u >= a && v0 + u < nv;
-                    kq[u] = in[u] ? pk_al[v0 + u] : 0u;
+            for (int j = 0; j < JOIN_SUB; j++) {
+                const uint32_t vj = v0 + (uint32_t)j * 4u * JOIN_THREADS;
+                full[j] = vj >= a && vj + 4u <= nv;
+#pragma unroll
+                for (int u = 0; u < 4; u++) in[j][u] = vj + u >= a && vj + u < nv;
+                if (vj < nv && vj + 4u > nv) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) kq[j][u] = in[j][u] ? pk_al[vj + u] : 0u;
                 }
             }
-            bool any_multi = false;
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const uint32_t mx = kmer_mix(kq[u] & SK_SEED_MASK);
-                const uint32_t b = mx >> bsh, rem = mx & rmask;
-                const bool mine = in[u] && (WHOLE || (b >= bb0 && b < bb1));      // else: this seed's bucket belongs to another pass
-                minev[u] = mine;
-                const uint32_t bi = WHOLE ? b : (mine ? b - bb0 : 0u);
-                // group word: first seed of the group | the four bucket sizes above it
-                const uint32_t w = s_grp[bi >> 2], sh = (bi & 3u) * 4u, sizes = w >> 16;
-                const uint32_t ne = (sizes >> sh) & 15u;
-                uint32_t lo = __builtin_amdgcn_udot8(sizes & ((1u << sh) - 1u), 0x11111111u, w & 0xFFFFu, false);
-                uint2 d0, d1;
-                __builtin_memcpy(&d0, s_fp + lo, 8);
-                __builtin_memcpy(&d1, s_fp + lo + 4, 8);
-                const uint32_t rem2 = rem | (rem << 16);
-                uint32_t t = halves_differ(d0.x ^ rem2);
-                t |= halves_differ(d0.y ^ rem2) << 2;
-                t |= halves_differ(d1.x ^ rem2) << 4;
-                t |= halves_differ(d1.y ^ rem2) << 6;                         // entry e differs: bit e (even e), bit 15 + e (odd e)
-                const uint32_t match = ~(t | (t >> 15)) & ((1u << ne) - 1u) & 0xFFu;
-                uint32_t cnt = (uint32_t)__popc(match), first = lo + (uint32_t)__builtin_ctz(match | 0x100u);
-                if (ne > 8u) {
-                    // a long bucket, or one whose bounds only the global table knows (15 seeds or more, or behind such a bucket)
-                    uint32_t e = lo + 8u, hi = lo + ne;
-                    if (ne == 15u) { e = rb[b] - base; hi = rb[b + 1] - base; cnt = 0; }
-                    for (; e < hi; e++)
-                        if (s_fp[e] == rem) { if (!cnt) first = e; cnt++; }
-                }
-                if (!mine || cnt > rrep) cnt = 0;
-                cntv[u] = cnt; firstv[u] = first;
-                any_multi |= cnt > 1;
-            }
-            // all position gathers in flight together: unconditional loads (seeds without a single hit read
-            // the genome's first entry, one broadcast address), combined only after the last one is issued
-            uint32_t gv[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) gv[u] = rg[base + (cntv[u] == 1 ? firstv[u] : 0u)];
-#pragma unroll
-            for (int u = 0; u < 4; u++)      // bit 31 of a stag entry is the strand of the indexed k-mer: the hit is reversed when the two differ
-                hv[u] = cntv[u] == 1 ? (gv[u] ^ (kq[u] & USED_BIT)) : (cntv[u] > 4 ? HIT_MANY : HIT_NONE);
-            if (any_multi) {
+            for (int j = 0; j < JOIN_SUB; j++) {
+                // in phases, so that the LDS reads of the four seeds are in flight together: group words, bucket entries, compares
+                bool any_multi = false;
+                uint32_t wv[4], remv[4], lov[4], nev[4], cntv[4], firstv[4];
+                uint2 d0v[4], d1v[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
-                    const uint32_t cnt = cntv[u], first = firstv[u];
-                    if (cnt < 2 || cnt > 4) continue;
-                    const uint32_t slot = atomicAdd(&pair_nmulti[p], 1u);
-                    if (slot < pd.multi_cap) {
-                        uint32_t v[4] = {HIT_NONE, HIT_NONE, HIT_NONE, HIT_NONE};
-                        for (uint32_t w = 0; w < cnt; w++) v[w] = rg[base + first + w] ^ (kq[u] & USED_BIT);
-                        multi[pd.multi_base + slot] = make_uint4(v[0], v[1], v[2], v[3]);
-                        hv[u] = HIT_MULTI | slot;
-                    } else {
-                        hv[u] = HIT_MANY;
+                    const uint32_t mx = kmer_mix(kq[j][u] & SK_SEED_MASK);
+                    const uint32_t b = mx >> bsh;
+                    remv[u] = mx & rmask;
+                    minev[j][u] = in[j][u] && (WHOLE || (b >= bb0 && b < bb1));      // else: this seed's bucket belongs to another pass
+                    const uint32_t bi = WHOLE ? b : (minev[j][u] ? b - bb0 : 0u);
+                    wv[u] = s_grp[bi >> 2];                                           // group word: first seed of the group | the four bucket sizes above it
+                    lov[u] = (bi & 3u) * 4u;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t w = wv[u], sh = lov[u], sizes = w >> 16;
+                    const uint32_t ne = (sizes >> sh) & 15u;
+                    const uint32_t lo = __builtin_amdgcn_udot8(sizes & ((1u << sh) - 1u), 0x11111111u, w & 0xFFFFu, false);
+                    nev[u] = ne; lov[u] = lo;
+                    // (the second half only where the bucket has it: 2 % of the lanes)
+                    d1v[u] = make_uint2(0u, 0u);
+                    __builtin_memcpy(&d0v[u], s_fp + lo, 8);
+                    if (ne > 4u) __builtin_memcpy(&d1v[u], s_fp + lo + 4, 8);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t rem = remv[u], ne = nev[u], lo = lov[u];
+                    const uint32_t rem2 = rem | (rem << 16);
+                    uint32_t t = halves_differ(d0v[u].x ^ rem2);
+                    t |= halves_differ(d0v[u].y ^ rem2) << 2;
+                    t |= halves_differ(d1v[u].x ^ rem2) << 4;
+                    t |= halves_differ(d1v[u].y ^ rem2) << 6;                     // entry e differs: bit e (even e), bit 15 + e (odd e)
+                    const uint32_t match = ~(t | (t >> 15)) & ((1u << ne) - 1u) & 0xFFu;
+                    uint32_t cnt = (uint32_t)__popc(match), first = lo + (uint32_t)__builtin_ctz(match | 0x100u);
+                    if (ne > 8u) {
+                        // a long bucket, or one whose bounds only the global table knows (15 seeds or more, or behind such a bucket)
+                        uint32_t e = lo + 8u, hi = lo + ne;
+                        if (ne == 15u) {
+                            const uint32_t b = kmer_mix(kq[j][u] & SK_SEED_MASK) >> bsh;
+                            e = rb[b] - base; hi = rb[b + 1] - base; cnt = 0;
+                        }
+                        for (; e < hi; e++)
+                            if (s_fp[e] == rem) { if (!cnt) first = e; cnt++; }
+                    }
+                    if (!minev[j][u] || cnt > rrep) cnt = 0;
+                    cntv[u] = cnt; firstv[u] = first;
+                    any_multi |= cnt > 1;
+                }
+                // all position gathers in flight together: unconditional loads (seeds without a single hit read
+                // the genome's first entry, one broadcast address), combined only after the last one is issued
+                uint32_t gv[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) gv[u] = rg[base + (cntv[u] == 1 ? firstv[u] : 0u)];
+#pragma unroll
+                for (int u = 0; u < 4; u++)      // bit 31 of a stag entry is the strand of the indexed k-mer: the hit is reversed when the two differ
+                    hv[j][u] = cntv[u] == 1 ? (gv[u] ^ (kq[j][u] & USED_BIT)) : (cntv[u] > 4 ? HIT_MANY : HIT_NONE);
+                if (any_multi) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t cnt = cntv[u], first = firstv[u];
+                        if (cnt < 2 || cnt > 4) continue;
+                        const uint32_t slot = atomicAdd(&pair_nmulti[p], 1u);
+                        if (slot < pd.multi_cap) {
+                            uint32_t v[4] = {HIT_NONE, HIT_NONE, HIT_NONE, HIT_NONE};
+                            for (uint32_t w = 0; w < cnt; w++) v[w] = rg[base + first + w] ^ (kq[j][u] & USED_BIT);
+                            multi[pd.multi_base + slot] = make_uint4(v[0], v[1], v[2], v[3]);
+                            hv[j][u] = HIT_MULTI | slot;
+                        } else {
+                            hv[j][u] = HIT_MANY;
+                        }
                     }
                 }
             }
-            if (WHOLE && full) {
-                *reinterpret_cast<uint4 *>(hit_al + v0) = make_uint4(hv[0], hv[1], hv[2], hv[3]);
-            } else {
 #pragma unroll
-                for (int u = 0; u < 4; u++)
-                    if (minev[u]) hit_al[v0 + u] = hv[u];
+            for (int j = 0; j < JOIN_SUB; j++) {
+                const uint32_t vj = v0 + (uint32_t)j * 4u * JOIN_THREADS;
+                if (WHOLE && full[j]) {
+                    *reinterpret_cast<uint4 *>(hit_al + vj) = make_uint4(hv[j][0], hv[j][1], hv[j][2], hv[j][3]);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        if (minev[j][u]) hit_al[vj + u] = hv[j][u];
+                }
             }
         }
     }
 }
 
 // one bucket range of R after the other: stage, probe
-template <typename FP, bool V2>
+template <typename FP, int V2>
 __device__ __forceinline__ void join_group(const SetView &A, const SetView &B, const PairDesc *__restrict__ pairs, const JoinGroup g,
                                            uint32_t *__restrict__ hits, uint4 *__restrict__ multi, uint32_t *__restrict__ pair_nmulti,
                                            unsigned char *smem, uint32_t smem_bytes, const SetView &RS, const GenomeMeta *Rm, uint32_t tid)
@@ -428,9 +468,9 @@ __device__ __forceinline__ void join_group(const SetView &A, const SetView &B, c
         }
         __syncthreads();
         const bool whole = bb0 == 0 && bb1 == nbk;
-        if (V2 && sizeof(FP) == 2 && fits) {
-            if (whole) join_pass16<true>(A, B, pairs, g, hits, multi, pair_nmulti, reinterpret_cast<const uint16_t *>(s_fp), s_grp, rb, rg, base, bits, bb0, bb1, rrep, tid);
-            else join_pass16<false>(A, B, pairs, g, hits, multi, pair_nmulti, reinterpret_cast<const uint16_t *>(s_fp), s_grp, rb, rg, base, bits, bb0, bb1, rrep, tid);
+        if (V2 != 0 && sizeof(FP) == 2 && fits) {
+            if (whole) join_pass16<true, (V2 > 1 ? V2 : 1)>(A, B, pairs, g, hits, multi, pair_nmulti, reinterpret_cast<const uint16_t *>(s_fp), s_grp, rb, rg, base, bits, bb0, bb1, rrep, tid);
+            else join_pass16<false, 1>(A, B, pairs, g, hits, multi, pair_nmulti, reinterpret_cast<const uint16_t *>(s_fp), s_grp, rb, rg, base, bits, bb0, bb1, rrep, tid);
         }
         else if (fits && whole) join_pass<FP, true, true>(A, B, pairs, g, hits, multi, pair_nmulti, s_fp, s_grp, rb, rk, rg, base, bits, bb0, bb1, rrep, tid);
         else if (fits) join_pass<FP, true, false>(A, B, pairs, g, hits, multi, pair_nmulti, s_fp, s_grp, rb, rk, rg, base, bits, bb0, bb1, rrep, tid);
@@ -442,7 +482,8 @@ __device__ __forceinline__ void join_group(const SetView &A, const SetView &B, c
 // (amdgpu_waves_per_eu(8): TWO of these 1024-thread workgroups per CU need 8 wavefronts per SIMD, i.e. at most 64 VGPRs and -- the
 // limit that was silently missed before -- at most 80 SGPRs per wavefront.  With the two SetViews in scalar registers the compiler
 // took 101, which admits 6 wavefronts per SIMD: ONE workgroup per CU, half the wavefronts this latency-bound kernel was designed for.)
-template <bool V2>
+// V2: 0 = round 2's per-entry probe (SKDER_AMD_JOIN_V1), else the sub-trips per trip of join_pass16
+template <int V2>
 __global__ __launch_bounds__(JOIN_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void join_probe_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs,
                                                                   const JoinGroup *__restrict__ groups,
                                                                   uint32_t *__restrict__ hits, uint4 *__restrict__ multi,
@@ -2434,10 +2475,8 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
             S.groups.resize(hg.size() * 2, S.st_join);
             HIPCHECK(hipMemcpyAsync(S.groups.p, hg.data(), hg.size() * sizeof(JoinGroup), hipMemcpyHostToDevice, S.st_join));
             if (!ctx->chain_attr_set) {      // per context: the attribute belongs to the device, and a process may use several
-                HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(join_probe_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             JOIN_SMEM_MAX + 64));
-                HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(join_probe_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             JOIN_SMEM_MAX + 64));
+                for (const void *k : {reinterpret_cast<const void *>(join_probe_kernel<0>), reinterpret_cast<const void *>(join_probe_kernel<1>)})
+                    HIPCHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, JOIN_SMEM_MAX + 64));
                 HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(finalize_kernel_t<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              4096 * 35));
                 ctx->chain_attr_set = true;
@@ -2450,15 +2489,17 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
                 const size_t w = join_need(R.bucket_bits, R.n_seeds);
                 want = w > want ? w : want;
             }
-            static const bool join_v1 = getenv("SKDER_AMD_JOIN_V1") != nullptr;      // the per-entry probe of round 2 (A/B; results identical)
+            // SKDER_AMD_JOIN_V1: the per-entry probe of round 2 instead of the packed one (A/B; results identical)
+            static const bool join_v1 = getenv("SKDER_AMD_JOIN_V1") != nullptr;
+            auto join_kernel = join_v1 ? join_probe_kernel<0> : join_probe_kernel<1>;
             uint32_t join_smem = (uint32_t)(want < JOIN_SMEM_MAX ? want : JOIN_SMEM_MAX) / 64u * 64u + 64u;
             if (want <= JOIN_SMEM_TWO && join_smem > JOIN_SMEM_TWO) join_smem = JOIN_SMEM_TWO;
             if (getenv("SKDER_AMD_DEBUG")) {
                 int per_cu = 0;
-                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(join_v1 ? join_probe_kernel<false> : join_probe_kernel<true>), JOIN_THREADS, join_smem);
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(join_kernel), JOIN_THREADS, join_smem);
                 fprintf(stderr, "[skder_amd] join: %zu workgroups of %u threads, %u bytes of LDS each: %d resident per CU (runtime's answer)\n", hg.size(), JOIN_THREADS, join_smem, per_cu);
             }
-            hipLaunchKernelGGL(join_v1 ? join_probe_kernel<false> : join_probe_kernel<true>, dim3((unsigned)hg.size()), dim3(JOIN_THREADS), join_smem, S.st_join, VA, VB, S.d_pairs.p,
+            hipLaunchKernelGGL(join_kernel, dim3((unsigned)hg.size()), dim3(JOIN_THREADS), join_smem, S.st_join, VA, VB, S.d_pairs.p,
                                reinterpret_cast<const JoinGroup *>(S.groups.p), S.hits.p, S.multi.p, S.pair_nmulti.p, join_smem);
             HIPCHECK(hipGetLastError());
         }
