@@ -16,7 +16,7 @@ gz, _ = bench.gzip_sample_files(paths)
 res = {}
 for kind, ps in (("plain", paths), ("gz", gz)):
     open(os.path.join(tmp, kind + ".lst"), "w").write("\n".join(ps))
-    for mode, extra in (("device_parse", {}), ("host_parse", {"SKDER_AMD_HOST_PARSE": "1"})):
+    for mode, extra in (("device_parse", {}), ("host_parse", {"SKDER_AMD_HOST_PARSE": "1"})) + ((("device_parse_zlib", {"SKDER_AMD_ZLIB": "1"}),) if kind == "gz" else ()):
         env = dict(os.environ, SKDER_AMD_DEBUG="1", **extra)
         code = ("import sys,os; sys.path.insert(0,os.getcwd()); import bench\n"
                 "ps=open(%r).read().split()\n"

@@ -3,6 +3,7 @@
 // No compute happens here: bases go to HBM unmodified (1 byte per base) and the kernels do the rest.
 #include "host_io.h"
 #include "fasta.h"
+#include "gunzip.h"
 
 #include <fcntl.h>
 #include <sys/stat.h>
@@ -57,6 +58,7 @@ static bool looks_gzip(const std::string &path)
 struct IoScratch {
     std::vector<char> text;
     std::vector<unsigned char> zin;
+    std::vector<uint8_t> zfile;        // a whole compressed file (gunzip.cpp decodes from memory)
     z_stream strm;
     bool z_ready = false;
     IoScratch() : text(1u << 20), zin(256u << 10) { memset(&strm, 0, sizeof strm); }
@@ -138,6 +140,26 @@ static size_t read_text(const std::string &path, bool gz, uint8_t *dst, size_t c
     FileCloser fc;
     fc.fd = open(path.c_str(), O_RDONLY);
     if (fc.fd < 0) throw SkError("cannot open " + path);
+    static const bool use_zlib = getenv("SKDER_AMD_ZLIB") != nullptr;      // zlib's streaming inflate instead of gunzip.cpp (A/B; same text)
+    if (gz && !use_zlib) {
+        // the compressed file into memory, then decoded straight into the region
+        struct stat sb;
+        if (fstat(fc.fd, &sb) != 0) throw SkError("cannot open " + path);
+        const size_t zn = (size_t)sb.st_size;
+        if (sc.zfile.size() < zn) sc.zfile.resize(zn + zn / 4);
+        size_t got = 0;
+        while (got < zn) {
+            const long k = (long)read(fc.fd, sc.zfile.data() + got, zn - got);
+            if (k < 0) throw SkError("read error in " + path);
+            if (k == 0) break;
+            got += (size_t)k;
+        }
+        size_t n = 0;
+        const GunzipStatus st = gunzip_buffer(sc.zfile.data(), got, dst, cap, &n);
+        if (st == GUNZIP_OUTPUT_FULL) throw SkError("region");
+        if (st != GUNZIP_OK) throw SkError("truncated or corrupt gzip file " + path + ": " + gunzip_status_text(st));
+        return n;
+    }
     TextSource src(path, fc.fd, gz, sc);
     size_t n = 0;
     for (;;) {
