@@ -757,6 +757,7 @@ void sketch_files(skder_sketches *s, const std::vector<std::string> &paths, Geno
             HIPCHECK(hipStreamSynchronize(st));
         } catch (...) {
             if (more) { try { (void)next.get(); } catch (...) {} }
+            for (int k = 0; k < 2; k++) if (slot[k].cs) (void)hipStreamSynchronize(slot[k].cs);      // no copy of a slot in flight when its buffers go back
             throw;
         }
         t_dev += now() - t2;

@@ -844,6 +844,66 @@ def test_device_fasta_parser_equals_host_reader(gpu, tmp_path, monkeypatch):
     assert run("dev_small", {"SKDER_AMD_IO_BATCH_MB": "1"}) == host
 
 
+def test_device_fasta_parser_edges(gpu, tmp_path, monkeypatch):
+    """What the device parser hands back to the host or has to report: an empty file and a file of headers only (an error with
+    the host reader's message), a file of 20,000 records too short to keep (more record lengths than the kernel's table holds:
+    the kernel declines it, the host parses it), 1,500 tiny files in one listing (many files per batch, most regions a few
+    hundred bytes), a record that ends exactly at a 4 KB round of the kernel and one that ends at a 64-byte chunk of a lane --
+    N50 table and edge table equal the host reader's."""
+    import skder_amd
+    rng = np.random.RandomState(12)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    anc = alpha[rng.randint(0, 4, 150000)]
+
+    def mutate(rate):
+        s = anc.copy()
+        idx = rng.randint(0, len(s), int(len(s) * rate))
+        s[idx] = alpha[rng.randint(0, 4, len(idx))]
+        return bytes(s)
+    d = tmp_path / "fa"
+    d.mkdir()
+    files = {}
+    g = mutate(0.01)
+    hdr = b">r1\n"
+    # unwrapped first record: header + bases + newline = exactly 4096 bytes; the second one ends at byte 64 of a later round
+    files["round_edge.fa"] = hdr + g[:4096 - len(hdr) - 1] + b"\n>r2\n" + g[5000:5000 + 4096 + 64 - 5 - 1] + b"\n>r3\n" + g[20000:]
+    g = mutate(0.012)
+    files["short_records.fa"] = b"".join(b">s%d\n" % i + g[7 * i:7 * i + 40] + b"\n" for i in range(20000)) + b">long\n" + g + b"\n"
+    g = mutate(0.02)
+    files["plain.fa"] = b">p\n" + g + b"\n"
+    for i in range(1500):
+        files["tiny_%04d.fa" % i] = b">t%d\n" % i + g[50 * i:50 * i + 400 + (i % 200)] + b"\n"     # 400-599 bases: some kept, most not
+    for k, v in files.items():
+        (d / k).write_bytes(v)
+    listing = tmp_path / "listing.txt"
+    listing.write_text("".join(str(d / k) + "\n" for k in sorted(files)))
+
+    def run(tag, env, lst=listing):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out, n50 = tmp_path / (tag + ".tsv"), tmp_path / (tag + "_n50.tsv")
+        try:
+            skder_amd.runSkaniTriangle(str(lst), str(out), "-s 80", 0.0, "greedy", False, None, n50_file=str(n50))
+        finally:
+            for k in env:
+                monkeypatch.delenv(k)
+        return out.read_text(), n50.read_text()
+    host = run("host", {"SKDER_AMD_HOST_PARSE": "1"})
+    dev = run("dev", {})
+    assert dev == host and host[1].count("\n") == len(files)
+    assert run("dev_small", {"SKDER_AMD_IO_BATCH_MB": "1"}) == host
+    for name, content in (("empty.fa", b""), ("headers.fa", b">a\n>b\n\n>c\n")):
+        (d / name).write_bytes(content)
+        l2 = tmp_path / ("l_" + name + ".txt")
+        l2.write_text(str(d / "plain.fa") + "\n" + str(d / name) + "\n")
+        msgs = []
+        for env in ({"SKDER_AMD_HOST_PARSE": "1"}, {}):
+            with pytest.raises(Exception) as ei:
+                run("err", env, l2)
+            msgs.append(str(ei.value))
+        assert msgs[0] == msgs[1] and "no sequence in" in msgs[0] and name in msgs[0], msgs
+
+
 def test_database_table_in_memory_equals_text(gpu, tmp_path):
     """the rows handed over in memory are the rows of the text table (same order, same
     orientation, same 2-decimal values), for a listing that is NOT in path order"""
