@@ -1051,12 +1051,16 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, c
     bool done = !live || idx == 0xFFFFFFFFu || s1 <= s0;
     uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0, b0 = a0, b1 = a0;
     if (!done) { a0 = prec[2u * idx]; a1 = prec[2u * idx + 1u]; b0 = prec[2u * idx + 2u]; b1 = prec[2u * idx + 3u]; }   // a run record is never the last of its quarter
+    // One ANCHOR per round and lane: a record's first anchor -- or, for a seed with 2..4 occurrences on the other genome, one of
+    // its occurrences per round (pend = occurrences still to come; the lane keeps its record until they are through).  A loop
+    // over the occurrences inside the round made the whole wavefront repeat the look-back as often as its most repetitive seed
+    // asked: on real genome structure 29 % of the records are such seeds and 82 % of the rounds had one in some lane.
+    struct { uint32_t qi, q0, hw, q1, qi1, hw1, n, gsum; } rc;
+    rc.qi = 0; rc.q0 = 0; rc.hw = HIT_NONE; rc.hw1 = HIT_NONE; rc.q1 = 0; rc.qi1 = 0; rc.n = 0; rc.gsum = 0;
+    uint32_t pend = 0, g0 = HIT_NONE, g1 = HIT_NONE, g2 = HIT_NONE, g3 = HIT_NONE;
     for (;;) {
-        // one record per round
-        bool have = false;
-        struct { uint32_t qi, q0, hw, q1, qi1, hw1, n, gsum; } rc;
-        rc.qi = 0; rc.q0 = 0; rc.hw = HIT_NONE; rc.hw1 = HIT_NONE; rc.q1 = 0; rc.qi1 = 0; rc.n = 0; rc.gsum = 0;
-        if (!done) {
+        bool have = pend != 0u;
+        if (!done && !have) {
             if (a0.x == REC_LINK && s1 <= a0.z) done = true;       // the chunk ends with its quarter
             else if (a0.x == REC_LINK) {                  // the chunk goes on in the next quarter of the region
                 idx = a0.y;
@@ -1074,20 +1078,23 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, c
             }
         }
         if (have) do {
-            // ---- one record: its first anchor (all hits of a multi-occurrence seed) through the look-back
+            // ---- one anchor of the record (its first, or the next occurrence of a multi-occurrence seed) through the look-back
             const uint32_t s = rc.qi;
             const int32_t qp = (int32_t)rc.q0;
             const uint32_t hw = rc.hw;
-            if (hw == HIT_MANY) { cplx = true; cause = 2; break; }
-            uint32_t m = 1, g0 = hw, g1 = HIT_NONE, g2 = HIT_NONE, g3 = HIT_NONE;
-            if ((hw & 0xFF000000u) == HIT_MULTI) {   // 2..4 occurrences, ascending gpos
-                const uint4 mv = multi[pd.multi_base + (hw & 0x00FFFFFFu)];
-                g0 = mv.x; g1 = mv.y; g2 = mv.z; g3 = mv.w;
-                m = 2u + (g2 != HIT_NONE) + (g3 != HIT_NONE);
+            if (pend == 0u) {            // a new record
+                if (hw == HIT_MANY) { cplx = true; cause = 2; break; }
+                pend = 1u; g0 = hw; g1 = g2 = g3 = HIT_NONE;
+                if ((hw & 0xFF000000u) == HIT_MULTI) {   // 2..4 occurrences, ascending gpos
+                    const uint4 mv = multi[pd.multi_base + (hw & 0x00FFFFFFu)];
+                    g0 = mv.x; g1 = mv.y; g2 = mv.z; g3 = mv.w;
+                    pend = 2u + (g2 != HIT_NONE) + (g3 != HIT_NONE);
+                }
             }
-            for (uint32_t u = 0; u < m && !cplx; u++) {
+            {
                 const uint32_t rr = g0;
                 g0 = g1; g1 = g2; g2 = g3;
+                pend--;
                 const int32_t rp = (int32_t)(rr & HIT_POS_MASK);
                 const uint32_t rev = rr >> 31;
                 const uint32_t key = rr & HIT_KEY_MASK;     // strand + record tag
@@ -1141,41 +1148,40 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, c
     #undef SUMMARY_BLOCKS
                     if (!ok) { cplx = true; cause = 3; break; }
                 }
-                if (bj >= 0) {
-                    // bring the predecessor run to the front (it gets the newest anchor, or goes back: see below)
+                if (bj >= 0 && pgap == 0) {
+                    // same diagonal: the predecessor run comes to the front of the ring and grows
                     if (bj == 1) { const Run tr = r1; r1 = r0; r0 = tr; }
                     else if (bj == 2) { const Run tr = r2; r2 = r1; r1 = r0; r0 = tr; }
                     else if (bj == 3) { const Run tr = r3; r3 = r2; r2 = r1; r1 = r0; r0 = tr; }
                     if (r0.cnt & SUCC_BIT) { cplx = true; cause = 4; break; }   // two anchors chain to one predecessor
-                    if (pgap == 0) {
-                        // same diagonal: the run simply grows
-                        r0.pmax = r0.f > r0.pmax ? r0.f : r0.pmax;
-                        r0.f = best;
-                        r0.q_last = (uint32_t)qp; r0.rr_last = rr; r0.cnt += 1u;
-                        r0.qi_last = s; r0.idx_last = ia;
-                    } else {
-                        // an indel: new run on the same path; the old run's last anchor now has a successor
-                        Run e;
-                        e.q_last = (uint32_t)qp; e.rr_last = rr; e.f = best;
-                        e.cnt = (r0.cnt & ~SUCC_BIT) + 1u; e.first_qi = r0.first_qi; e.q_first = r0.q_first;
-                        e.r_pfirst = r0.r_pfirst;
-                        e.qi_last = s; e.idx_last = ia; e.pmax = r0.f > r0.pmax ? r0.f : r0.pmax;
-                        e.r_first = (uint32_t)rp; e.seg = pgap >= ANI_ANCHOR_SCORE ? ia : r0.seg; e.gs = 0;
-                        r0.cnt |= SUCC_BIT;
-                        // the predecessor run goes back to where it was: the ring is ordered by the LAST ANCHOR of
-                        // its runs (the look-back stops at the first run beyond a band and trusts that older ones,
-                        // in the ring and in the summaries, lie further back), and this run's last anchor did not move
-                        if (bj == 1) { const Run tr = r0; r0 = r1; r1 = tr; }
-                        else if (bj == 2) { const Run tr = r0; r0 = r1; r1 = r2; r2 = tr; }
-                        else if (bj == 3) { const Run tr = r0; r0 = r1; r1 = r2; r2 = r3; r3 = tr; }
-                        EVICT(r3);
-                        r3 = r2; r2 = r1; r1 = r0; r0 = e;
-                    }
+                    r0.pmax = r0.f > r0.pmax ? r0.f : r0.pmax;
+                    r0.f = best;
+                    r0.q_last = (uint32_t)qp; r0.rr_last = rr; r0.cnt += 1u;
+                    r0.qi_last = s; r0.idx_last = ia;
                 } else {
                     Run e;
                     e.q_last = (uint32_t)qp; e.rr_last = rr; e.f = best;
-                    e.cnt = 1; e.first_qi = s; e.q_first = (uint32_t)qp; e.r_pfirst = (uint32_t)rp;
-                    e.qi_last = s; e.idx_last = ia; e.pmax = NEG; e.r_first = (uint32_t)rp; e.seg = ia; e.gs = 0;
+                    e.qi_last = s; e.idx_last = ia; e.r_first = (uint32_t)rp; e.gs = 0;
+                    if (bj >= 0) {
+                        // an indel: new run on the same path; the old run's last anchor now has a successor.  The predecessor
+                        // run STAYS where it is: the ring is ordered by the LAST ANCHOR of its runs (the look-back stops at the
+                        // first run beyond a band and trusts that older ones, in the ring and in the summaries, lie further
+                        // back), and this run's last anchor did not move -- only its fields are read and its mark is set
+                        const uint32_t pc = bj == 0 ? r0.cnt : bj == 1 ? r1.cnt : bj == 2 ? r2.cnt : r3.cnt;
+                        if (pc & SUCC_BIT) { cplx = true; cause = 4; break; }   // two anchors chain to one predecessor
+                        const int32_t pf = bj == 0 ? r0.f : bj == 1 ? r1.f : bj == 2 ? r2.f : r3.f;
+                        const int32_t pp = bj == 0 ? r0.pmax : bj == 1 ? r1.pmax : bj == 2 ? r2.pmax : r3.pmax;
+                        e.cnt = pc + 1u;
+                        e.first_qi = bj == 0 ? r0.first_qi : bj == 1 ? r1.first_qi : bj == 2 ? r2.first_qi : r3.first_qi;
+                        e.q_first = bj == 0 ? r0.q_first : bj == 1 ? r1.q_first : bj == 2 ? r2.q_first : r3.q_first;
+                        e.r_pfirst = bj == 0 ? r0.r_pfirst : bj == 1 ? r1.r_pfirst : bj == 2 ? r2.r_pfirst : r3.r_pfirst;
+                        e.pmax = pf > pp ? pf : pp;
+                        e.seg = pgap >= ANI_ANCHOR_SCORE ? ia : (bj == 0 ? r0.seg : bj == 1 ? r1.seg : bj == 2 ? r2.seg : r3.seg);
+                        if (bj == 0) r0.cnt |= SUCC_BIT; else if (bj == 1) r1.cnt |= SUCC_BIT; else if (bj == 2) r2.cnt |= SUCC_BIT; else r3.cnt |= SUCC_BIT;
+                    } else {
+                        e.cnt = 1; e.first_qi = s; e.q_first = (uint32_t)qp; e.r_pfirst = (uint32_t)rp;
+                        e.pmax = NEG; e.seg = ia;
+                    }
                     EVICT(r3);
                     r3 = r2; r2 = r1; r1 = r0; r0 = e;
                 }
@@ -1183,7 +1189,7 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, c
                 runmax = best > runmax ? best : runmax;
             }
             if (cplx) break;
-            if (rc.n > 1u) {
+            if (pend == 0u && rc.n > 1u) {
                 // ---- the run's other anchors: extensions of r0 (which holds the anchor just placed) along the run,
                 // provided nothing else can offer its second anchor more than r0 does (header comment): every other
                 // run / summary is empty, of another record or strand, beyond the 2500-base band already at the first
@@ -1228,8 +1234,17 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, c
                 r0.gs += G;
             }
         } while (0);
-        if (cplx) done = true;
-        if (!__any(!done)) break;     // the whole wave is finished
+        if (cplx) { done = true; pend = 0u; }
+#ifdef SKDER_RUNS_STATS
+        {   // lanes with a record this round / lanes still at work, per wavefront round; rounds with a multi-occurrence seed
+            const unsigned long long hm = __ballot(have), lm = __ballot(!done);
+            const bool is_multi = have && (rc.hw & 0xFF000000u) == HIT_MULTI && rc.hw != HIT_MANY;
+            const unsigned long long mm = __ballot(is_multi);
+            if ((threadIdx.x & 63u) == 0) { atomicAdd(slow_count + 12, 1u); atomicAdd(slow_count + 13, (uint32_t)__popcll(hm)); atomicAdd(slow_count + 14, (uint32_t)__popcll(lm));
+                                            if (mm) atomicAdd(slow_count + 17, 1u); atomicAdd(slow_count + 18, (uint32_t)__popcll(mm)); }
+        }
+#endif
+        if (!__any(!done || pend != 0u)) break;     // the whole wave is finished
     }
     if (!cplx) EMIT_PATH(r3);
     if (!cplx) EMIT_PATH(r2);
@@ -2527,6 +2542,11 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         HIPCHECK(hipEventElapsedTime(&ms, S.ev[3], S.ev[4])); t_fin += ms;
 #ifdef SKDER_SIEVE_STATS
         fprintf(stderr, "[skder_amd] sieve: link %u, main-not-started-big %u, second-path %u, too-many-records %u, multi %u, third-stray %u, stray-near-main %u\n", S.h_cnt[24], S.h_cnt[25], S.h_cnt[26], S.h_cnt[28], S.h_cnt[29], S.h_cnt[30], S.h_cnt[31]);
+#endif
+#ifdef SKDER_RUNS_STATS
+        { uint32_t x[8]; HIPCHECK(hipMemcpy(x, S.counters.p + 16, 32, hipMemcpyDeviceToHost));
+          fprintf(stderr, "[skder_amd] run loop: %u chunks, %u wavefront rounds, %.1f lanes with a record per round, %.1f lanes not finished after it; %u rounds with a multi-occurrence seed (%u such lanes)\n",
+                  S.h_cnt[11], S.h_cnt[12], S.h_cnt[13] / (double)(S.h_cnt[12] ? S.h_cnt[12] : 1), S.h_cnt[14] / (double)(S.h_cnt[12] ? S.h_cnt[12] : 1), x[1], x[2]); }
 #endif
 #ifdef SKDER_SLOW_STATS
         fprintf(stderr, "[skder_amd] slow path: %u chunks, %u anchors, %u full look-backs, %u stretches, %u chain ends, %u ladder visits\n", S.h_cnt[29], S.h_cnt[24], S.h_cnt[25], S.h_cnt[26], S.h_cnt[27], S.h_cnt[28]);
