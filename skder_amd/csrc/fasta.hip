@@ -318,3 +318,375 @@ void fasta_parse_launch(const uint8_t *d_text, const FastaFile *d_files, uint32_
     hipLaunchKernelGGL(fasta_parse_kernel, dim3(n_files), dim3(64), 0, st, d_text, d_files, d_bases, d_kept_rel, d_kept_len, d_all_len, d_results);
     HIPCHECK(hipGetLastError());
 }
+
+// =============================================================================================================================
+// THE TILED PARSER.  One wavefront per file is as fast as the PCIe copy it follows only while a batch holds a few hundred files:
+// a wavefront walks its file 4 KB at a time (106 GB/s over a batch of 170 files, 0.8 GB/s for a single genome).  Here every 4 KB
+// TILE of every file is a wavefront of its own, in three kernels:
+//   A  fasta_tile_sum_kernel   per tile, WITHOUT knowing what came before it: does the tile contain a line start, and is the last
+//      one a header line; the bases in front of its first line start (they count only if the tile begins inside a sequence line);
+//      the bases in front of its first record start and behind its last one; the records that begin AND end inside the tile (how
+//      many are not empty, how many are kept, their padded size).  Everything else about a tile is fixed by its own bytes.
+//   B  fasta_tile_scan_kernel  per file, one wavefront over the tile summaries in order (64 loaded at a time, a few dozen
+//      instructions per tile): the state every tile starts in -- inside a header line or not, the record that is open, its length
+//      so far and where it starts in the output, how many table entries precede --, the table entries of the records that cross
+//      tiles, the end of the file.
+//   C  fasta_tile_write_kernel per tile again, now with that state: the bases to their places, the padding, the table entries
+//      of the records inside the tile.
+// The text is read twice (A and C), the bases are written once; the result is the one-wavefront-per-file kernel's, byte for byte
+// (same per-lane masks, same scans inside a tile: a tile is what a round is there).
+struct TileSum {
+    uint32_t flags;              // 1 has a line start, 2 the last one begins a header line, 4 blanks behind the first line start, 8 blanks in front of it, 16 has a record start
+    uint32_t p0;                 // bases in front of the first line start, if the tile begins inside a sequence line
+    uint32_t head_det;           // bases from the first line start to the first record start (to the end of the tile if there is none)
+    uint32_t tail;               // bases behind the last record start
+    uint32_t inner_nonempty, inner_kept, inner_pad;   // records opened and closed inside the tile: with bases; of >= 500; their padded sizes
+    uint32_t last_hdr_pos;       // text offset of the tile's last record start
+    uint32_t first_inner_kept_hdr;                     // ... of the record start that opens its first kept inner record
+    uint32_t pad[3];
+};
+struct TileCarry {
+    uint32_t flags;              // 1 begins inside a header line, 2 the open record began with a header
+    uint32_t open_len, open_start;                     // the record open at the tile's first byte: bases so far, start in the output
+    uint32_t rid;                // its number among the file's tile-crossing records (kept_flag[rid]); the record open at the tile's end: rid + 1 if the tile has a record start
+    uint32_t kept_base, lens_base;                     // table indices of the tile's first inner record
+    uint32_t pad[2];
+};
+#define TILE_BYTES FA_ROUND
+
+// the file of tile g: last file whose tile_off <= g (files without tiles share an offset with their successor: the LAST of equal offsets has the tiles)
+__device__ __forceinline__ uint32_t file_of_tile(const FastaFile *__restrict__ files, uint32_t n_files, uint32_t g)
+{
+    uint32_t lo = 0, hi = n_files;
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (files[mid].tile_off <= g) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+    return v;
+}
+
+// what kernels A and C share: the lane's masks and counts, given the state at the tile's first byte
+struct LaneView {
+    uint64_t NL, LOW, LS, H, INH, BASE, HEADM, TAILM, prefix;
+    uint32_t n_hdr, first_hdr_at, last_hdr_at, head, tail, n_tiny;
+    unsigned long long m_any;
+    bool in_hdr_out;             // state behind the lane's last byte
+};
+
+__device__ __forceinline__ void lane_view(LaneView &V, const uint32_t (&wd)[16], uint32_t n_valid, bool first_prev_nl, bool tile_in_hdr, uint32_t lane)
+{
+    uint64_t NL = chunk_mask(wd, [](uint32_t w) { return zero_bytes(w ^ 0x0A0A0A0Au); });
+    uint64_t GT = chunk_mask(wd, [](uint32_t w) { return zero_bytes(w ^ 0x3E3E3E3Eu); });
+    uint64_t LOW = chunk_mask(wd, [](uint32_t w) { return ~((w | 0x80808080u) - 0x21212121u) & ~w & 0x80808080u; });
+    if (n_valid < FA_CHUNK) {
+        const uint64_t valid = (1ull << n_valid) - 1ull;
+        NL |= ~valid; LOW |= ~valid; GT &= valid;
+    }
+    const uint32_t up_nl = (uint32_t)__shfl_up((int)(uint32_t)(NL >> 63), 1, 64);
+    const bool prev_nl = lane ? up_nl != 0u : first_prev_nl;
+    const uint64_t LS = (NL << 1) | (prev_nl ? 1ull : 0ull);
+    const uint64_t H = LS & GT;
+    const bool last_is_hdr = LS != 0ull && ((H >> (63 - __clzll((long long)LS))) & 1ull) != 0ull;
+    const unsigned long long m_any = __ballot(LS != 0ull), m_hdrline = __ballot(last_is_hdr);
+    const int pk = prev_set_below(m_any, lane);
+    const bool in_hdr = pk < 0 ? tile_in_hdr : ((m_hdrline >> pk) & 1ull) != 0ull;
+    const uint64_t P = ~LS, R = P + (H << 1) + (in_hdr ? 1ull : 0ull), flipped = R ^ P;
+    const uint64_t INH = (flipped >> 1) | H | (flipped & P & (1ull << 63));
+    V.NL = NL; V.LOW = LOW; V.LS = LS; V.H = H; V.INH = INH; V.BASE = ~INH & ~LOW; V.m_any = m_any;
+    V.in_hdr_out = (INH >> 63) != 0ull;
+    // bytes in front of the tile's first line start
+    V.prefix = pk < 0 ? (LS ? (LS & (0ull - LS)) - 1ull : ~0ull) : 0ull;
+    V.n_hdr = (uint32_t)__popcll(H);
+    V.first_hdr_at = V.n_hdr ? (uint32_t)__ffsll((long long)H) - 1u : 0u;
+    V.last_hdr_at = V.n_hdr ? 63u - (uint32_t)__clzll((long long)H) : 0u;
+    V.HEADM = V.n_hdr ? V.BASE & ((1ull << V.first_hdr_at) - 1ull) : V.BASE;
+    V.TAILM = V.n_hdr ? V.BASE & ~((2ull << V.last_hdr_at) - 1ull) : 0ull;
+    V.head = (uint32_t)__popcll(V.HEADM); V.tail = (uint32_t)__popcll(V.TAILM);
+    V.n_tiny = 0;
+    if (V.n_hdr > 1u) {
+        uint64_t hh = H & (H - 1ull);
+        uint32_t from = V.first_hdr_at;
+        while (hh) {
+            const uint32_t to = (uint32_t)__ffsll((long long)hh) - 1u;
+            if (V.BASE & ((1ull << to) - 1ull) & ~((2ull << from) - 1ull)) V.n_tiny++;
+            from = to; hh &= hh - 1ull;
+        }
+    }
+}
+
+// blanks and control bytes outside header lines that are not a '\r' in front of a line end (bit mask over the lane's bytes, header
+// lines NOT yet excluded: the caller knows which bytes are header bytes)
+__device__ __forceinline__ uint64_t odd_bytes(const LaneView &V, const uint32_t (&wd)[16], bool next_tile_nl, uint32_t lane)
+{
+    const uint64_t odd = V.LOW & ~V.NL;
+    if (!__any(odd != 0ull)) return 0ull;
+    const uint64_t CR = chunk_mask(wd, [](uint32_t w) { return zero_bytes(w ^ 0x0D0D0D0Du); });
+    const uint32_t down_nl = (uint32_t)__shfl_down((int)(uint32_t)(V.NL & 1ull), 1, 64);
+    const bool next_nl = lane == 63u ? next_tile_nl : down_nl != 0u;
+    const uint64_t nl_next = (V.NL >> 1) | (next_nl ? 1ull << 63 : 0ull);
+    return odd & ~(CR & nl_next);
+}
+
+__global__ __launch_bounds__(256) void fasta_tile_sum_kernel(const uint8_t *__restrict__ text, const FastaFile *__restrict__ files, uint32_t n_files,
+                                                             uint32_t total_tiles, TileSum *__restrict__ sums)
+{
+    const uint32_t lane = threadIdx.x & 63u, g = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (g >= total_tiles) return;
+    const FastaFile F = files[file_of_tile(files, n_files, g)];
+    const uint8_t *tx = text + F.text_off;
+    const uint64_t r0 = (uint64_t)(g - F.tile_off) * TILE_BYTES, c0 = r0 + (uint64_t)lane * FA_CHUNK;
+    const uint32_t n_valid = c0 >= F.text_len ? 0u : (F.text_len - c0 < FA_CHUNK ? (uint32_t)(F.text_len - c0) : FA_CHUNK);
+    uint32_t wd[16];
+    load_chunk(wd, tx, c0, F.text_len);
+    const bool first_prev_nl = tx[(int64_t)r0 - 1] == '\n';                                      // ('\n' in front of the file)
+    const bool next_tile_nl = r0 + TILE_BYTES >= F.text_len || tx[r0 + TILE_BYTES] == '\n';
+    LaneView V;
+    lane_view(V, wd, n_valid, first_prev_nl, true, lane);       // as if the tile began inside a header line: the bytes in front of its first line start count for nothing
+    const uint64_t odd = odd_bytes(V, wd, next_tile_nl, lane);
+    const bool bad_det = __any((odd & ~V.INH) != 0ull), bad_prefix = __any((odd & V.prefix) != 0ull);
+    const uint32_t p0 = wave_sum_u32((uint32_t)__popcll(~V.LOW & V.prefix));
+    const unsigned long long m_h = __ballot(V.n_hdr != 0u);
+    const uint32_t head_incl = wave_incl_scan_u32(V.head), head_excl = head_incl - V.head;
+    const uint32_t head_tot = (uint32_t)__shfl((int)head_incl, 63, 64);
+    // records opened and closed inside the tile: they close at a lane with a record start whose opener is a lane of the tile
+    const int opener = prev_set_below(m_h, lane);
+    const uint32_t op_tail = (uint32_t)__shfl((int)V.tail, opener < 0 ? 0 : opener, 64);
+    const uint32_t op_hexcl = (uint32_t)__shfl((int)head_excl, opener < 0 ? 0 : opener, 64);
+    const uint32_t op_head = (uint32_t)__shfl((int)V.head, opener < 0 ? 0 : opener, 64);
+    const bool inner = V.n_hdr != 0u && opener >= 0;
+    const uint32_t closed_len = inner ? op_tail + head_excl - op_hexcl - op_head + V.head : 0u;
+    const bool kept_inner = inner && closed_len >= (uint32_t)ANI_MIN_CONTIG;
+    const uint32_t inner_kept = wave_sum_u32(kept_inner ? 1u : 0u);
+    const uint32_t inner_pad = wave_sum_u32(kept_inner ? ((closed_len + 31u) & ~31u) : 0u);
+    const uint32_t inner_nonempty = wave_sum_u32((inner && closed_len != 0u ? 1u : 0u) + V.n_tiny);
+    const uint32_t my_last_hdr = (uint32_t)(c0 + V.last_hdr_at);
+    const uint32_t op_last = (uint32_t)__shfl((int)my_last_hdr, opener < 0 ? 0 : opener, 64);
+    const unsigned long long m_k = __ballot(kept_inner);
+    const uint32_t first_inner_kept_hdr = m_k ? (uint32_t)__shfl((int)op_last, __ffsll((long long)m_k) - 1, 64) : 0xFFFFFFFFu;
+    uint32_t head_det = head_tot, tail = 0u, last_hdr_pos = 0xFFFFFFFFu;
+    if (m_h) {
+        const int FL = __ffsll((long long)m_h) - 1, L = 63 - __clzll((long long)m_h);
+        head_det = (uint32_t)__shfl((int)head_incl, FL, 64);
+        const uint32_t l_tail = (uint32_t)__shfl((int)V.tail, L, 64), l_hexcl = (uint32_t)__shfl((int)head_excl, L, 64), l_head = (uint32_t)__shfl((int)V.head, L, 64);
+        tail = l_tail + head_tot - l_hexcl - l_head;
+        last_hdr_pos = (uint32_t)__shfl((int)my_last_hdr, L, 64);
+    }
+    const bool state_out = (bool)__shfl((int)V.in_hdr_out, 63, 64);
+    if (lane == 0) {
+        TileSum S;
+        S.flags = (V.m_any ? 1u : 0u) | (state_out ? 2u : 0u) | (bad_det ? 4u : 0u) | (bad_prefix ? 8u : 0u) | (m_h ? 16u : 0u);
+        S.p0 = p0; S.head_det = head_det; S.tail = tail;
+        S.inner_nonempty = inner_nonempty; S.inner_kept = inner_kept; S.inner_pad = inner_pad;
+        S.last_hdr_pos = last_hdr_pos; S.first_inner_kept_hdr = first_inner_kept_hdr;
+        S.pad[0] = S.pad[1] = S.pad[2] = 0;
+        sums[g] = S;
+    }
+}
+
+__global__ __launch_bounds__(64) void fasta_tile_scan_kernel(const FastaFile *__restrict__ files, const TileSum *__restrict__ sums,
+                                                             TileCarry *__restrict__ carries, uint8_t *__restrict__ kept_flag,
+                                                             uint8_t *__restrict__ bases, uint32_t *__restrict__ kept_rel, uint32_t *__restrict__ kept_len,
+                                                             uint32_t *__restrict__ all_len, FastaResult *__restrict__ results)
+{
+    const FastaFile F = files[blockIdx.x];
+    const uint32_t lane = threadIdx.x, nt = (uint32_t)(((uint64_t)F.text_len + TILE_BYTES - 1u) / TILE_BYTES);
+    uint32_t *k_rel = kept_rel + F.table_off, *k_len = kept_len + F.table_off, *a_len = all_len + F.table_off;
+    uint8_t *kf = kept_flag + F.tile_off + blockIdx.x;            // this file's records that cross tiles: at most one per tile, and the one open at the end
+    uint8_t *out = bases + F.out_off;
+    // wave-uniform state (every lane computes the same; lane 0 writes the tables)
+    bool in_hdr = false, open_real = false;
+    uint32_t open_len = 0, open_start = 0, open_hdr = 0xFFFFFFFFu, n_kept = 0, n_lens = 0, flags = 0, first_hdr = 0xFFFFFFFFu, rid = 0;
+    for (uint32_t b0 = 0; b0 < nt; b0 += 64u) {
+        const uint32_t nb = nt - b0 < 64u ? nt - b0 : 64u;
+        TileSum my;
+        if (lane < nb) my = sums[F.tile_off + b0 + lane];
+        else { my.flags = 0; my.p0 = my.head_det = my.tail = my.inner_nonempty = my.inner_kept = my.inner_pad = 0; my.last_hdr_pos = my.first_inner_kept_hdr = 0xFFFFFFFFu; }
+        TileCarry mine;
+        mine.flags = 0; mine.open_len = mine.open_start = mine.rid = mine.kept_base = mine.lens_base = 0; mine.pad[0] = mine.pad[1] = 0;
+        for (uint32_t j = 0; j < nb; j++) {
+            const uint32_t s_flags = (uint32_t)__shfl((int)my.flags, (int)j, 64), s_p0 = (uint32_t)__shfl((int)my.p0, (int)j, 64);
+            const uint32_t s_head = (uint32_t)__shfl((int)my.head_det, (int)j, 64);
+            if (lane == j) { mine.flags = (in_hdr ? 1u : 0u) | (open_real ? 2u : 0u); mine.open_len = open_len; mine.open_start = open_start; mine.rid = rid; }
+            const uint32_t head = s_head + (in_hdr ? 0u : s_p0);
+            if ((s_flags & 4u) || (!in_hdr && (s_flags & 8u))) flags |= 1u;
+            if (!(s_flags & 16u)) {
+                open_len += head;
+            } else {
+                const uint32_t s_tail = (uint32_t)__shfl((int)my.tail, (int)j, 64), s_ine = (uint32_t)__shfl((int)my.inner_nonempty, (int)j, 64);
+                const uint32_t s_ik = (uint32_t)__shfl((int)my.inner_kept, (int)j, 64), s_ip = (uint32_t)__shfl((int)my.inner_pad, (int)j, 64);
+                const uint32_t s_lh = (uint32_t)__shfl((int)my.last_hdr_pos, (int)j, 64), s_fk = (uint32_t)__shfl((int)my.first_inner_kept_hdr, (int)j, 64);
+                const uint32_t closed = open_len + head;
+                if (closed > 0x7FFFFFFFu) flags |= 2u;
+                if (closed) { if (lane == 0 && n_lens < F.rec_cap) a_len[n_lens] = closed; n_lens++; }
+                const bool kept = open_real && closed >= (uint32_t)ANI_MIN_CONTIG;
+                if (lane == 0) kf[rid] = kept ? 1 : 0;
+                if (kept) {
+                    if (lane == 0 && n_kept < F.rec_cap) { k_rel[n_kept] = open_start; k_len[n_kept] = closed; }
+                    if (first_hdr == 0xFFFFFFFFu) first_hdr = open_hdr;
+                    n_kept++;
+                    open_start += (closed + 31u) & ~31u;
+                }
+                if (lane == j) { mine.kept_base = n_kept; mine.lens_base = n_lens; }
+                if (first_hdr == 0xFFFFFFFFu && s_ik) first_hdr = s_fk;
+                n_kept += s_ik; n_lens += s_ine; open_start += s_ip;
+                rid++;
+                open_len = s_tail; open_real = true; open_hdr = s_lh;
+            }
+            if (open_len > 0x7FFFFFFFu) flags |= 2u;
+            if (s_flags & 1u) in_hdr = (s_flags & 2u) != 0u;
+        }
+        if (lane < nb) carries[F.tile_off + b0 + lane] = mine;
+    }
+    // ---- the end of the file closes the open record
+    if (lane == 0) {
+        if (open_len) { if (n_lens < F.rec_cap) a_len[n_lens] = open_len; n_lens++; }
+        uint32_t end = open_start;
+        const bool kept = open_real && open_len >= (uint32_t)ANI_MIN_CONTIG;
+        kf[rid] = kept ? 1 : 0;
+        if (kept) {
+            if (n_kept < F.rec_cap) { k_rel[n_kept] = open_start; k_len[n_kept] = open_len; }
+            if (first_hdr == 0xFFFFFFFFu) first_hdr = open_hdr;
+            n_kept++;
+            const uint32_t pad = (open_len + 31u) & ~31u;
+            if ((uint64_t)open_start + pad <= F.out_cap) for (uint32_t k = open_len; k < pad; k++) out[open_start + k] = 'A';
+            else flags |= 8u;
+            end = open_start + pad;
+        }
+        if (n_kept > F.rec_cap || n_lens > F.rec_cap) flags |= 4u;
+        FastaResult R;
+        R.n_kept = n_kept; R.n_lens = n_lens; R.flags = flags; R.packed_size = end; R.first_hdr = first_hdr;
+        R.pad[0] = R.pad[1] = R.pad[2] = 0;
+        results[blockIdx.x] = R;
+    }
+}
+
+__global__ __launch_bounds__(256) void fasta_tile_write_kernel(const uint8_t *__restrict__ text, const FastaFile *__restrict__ files, uint32_t n_files,
+                                                               uint32_t total_tiles, const TileCarry *__restrict__ carries,
+                                                               const uint8_t *__restrict__ kept_flag, uint8_t *__restrict__ bases,
+                                                               uint32_t *__restrict__ kept_rel, uint32_t *__restrict__ kept_len,
+                                                               uint32_t *__restrict__ all_len, FastaResult *__restrict__ results)
+{
+    const uint32_t lane = threadIdx.x & 63u, g = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (g >= total_tiles) return;
+    const uint32_t fi = file_of_tile(files, n_files, g);
+    const FastaFile F = files[fi];
+    const TileCarry T = carries[g];
+    const uint8_t *tx = text + F.text_off;
+    uint8_t *out = bases + F.out_off;
+    uint32_t *k_rel = kept_rel + F.table_off, *k_len = kept_len + F.table_off, *a_len = all_len + F.table_off;
+    const uint8_t *kf = kept_flag + F.tile_off + fi;
+    const uint64_t r0 = (uint64_t)(g - F.tile_off) * TILE_BYTES, c0 = r0 + (uint64_t)lane * FA_CHUNK;
+    const uint32_t n_valid = c0 >= F.text_len ? 0u : (F.text_len - c0 < FA_CHUNK ? (uint32_t)(F.text_len - c0) : FA_CHUNK);
+    uint32_t wd[16];
+    load_chunk(wd, tx, c0, F.text_len);
+    const bool first_prev_nl = tx[(int64_t)r0 - 1] == '\n';
+    LaneView V;
+    lane_view(V, wd, n_valid, first_prev_nl, (T.flags & 1u) != 0u, lane);
+    const bool open_real = (T.flags & 2u) != 0u;
+    const uint32_t open_len = T.open_len, open_start = T.open_start;
+    const uint32_t n_hdr = V.n_hdr, head = V.head, tail = V.tail;
+    const unsigned long long m_h = __ballot(n_hdr != 0u);
+    // ---- exactly the round of fasta_parse_kernel from here, with the carry read instead of kept
+    const uint32_t head_incl = wave_incl_scan_u32(head), head_excl = head_incl - head;
+    const int opener = prev_set_below(m_h, lane);
+    const uint32_t op_tail = (uint32_t)__shfl((int)tail, opener < 0 ? 0 : opener, 64);
+    const uint32_t op_hexcl = (uint32_t)__shfl((int)head_excl, opener < 0 ? 0 : opener, 64);
+    const uint32_t op_head = (uint32_t)__shfl((int)head, opener < 0 ? 0 : opener, 64);
+    const uint32_t before = opener < 0 ? open_len + head_excl : op_tail + head_excl - op_hexcl - op_head;
+    const bool op_real = opener < 0 ? open_real : true;
+    const uint32_t closed_len = before + head;
+    const bool closes_kept = n_hdr != 0u && op_real && closed_len >= (uint32_t)ANI_MIN_CONTIG;
+    const uint32_t pad = closes_kept ? ((closed_len + 31u) & ~31u) : 0u;
+    const uint32_t pad_incl = wave_incl_scan_u32(pad);
+    const uint32_t op_padincl = (uint32_t)__shfl((int)pad_incl, opener < 0 ? 0 : opener, 64);
+    const uint32_t rec_start = open_start + (opener < 0 ? 0u : op_padincl);
+    const int closer = next_set_from(m_h, lane);
+    const uint32_t cl_len = (uint32_t)__shfl((int)closed_len, closer < 0 ? 0 : closer, 64);
+    // a record that does not close inside the tile: the scan knows whether it is kept (the one open at the tile's start, or the
+    // one its last record start opens)
+    const bool keep_open = kf[T.rid] != 0, keep_tail = m_h ? kf[T.rid + 1u] != 0 : keep_open;
+    const bool write_head = closer < 0 ? (opener < 0 ? keep_open : keep_tail) : (op_real && cl_len >= (uint32_t)ANI_MIN_CONTIG);
+    const int closer2 = lane == 63u ? -1 : next_set_from(m_h, lane + 1u);
+    const uint32_t c2_hexcl = (uint32_t)__shfl((int)head_excl, closer2 < 0 ? 0 : closer2, 64);
+    const uint32_t c2_head = (uint32_t)__shfl((int)head, closer2 < 0 ? 0 : closer2, 64);
+    const uint32_t tail_total = closer2 < 0 ? 0u : tail + c2_hexcl - head_excl - head + c2_head;
+    const bool write_tail = n_hdr != 0u && (closer2 < 0 ? keep_tail : tail_total >= (uint32_t)ANI_MIN_CONTIG);
+    const uint32_t tail_start = open_start + pad_incl;
+    // ---- table entries of the records inside the tile (the one that closes at the tile's first record start is the scan's)
+    {
+        const bool inner = n_hdr != 0u && opener >= 0;
+        const uint32_t n_emit = (inner && closed_len != 0u ? 1u : 0u) + V.n_tiny;
+        const uint32_t e_incl = wave_incl_scan_u32(n_emit);
+        uint32_t at = T.lens_base + e_incl - n_emit;
+        if (inner && closed_len != 0u) { if (at < F.rec_cap) a_len[at] = closed_len; at++; }
+        if (V.n_tiny) {
+            uint64_t hh = V.H & (V.H - 1ull);
+            uint32_t from = V.first_hdr_at;
+            while (hh) {
+                const uint32_t to = (uint32_t)__ffsll((long long)hh) - 1u;
+                const uint32_t cnt = (uint32_t)__popcll(V.BASE & ((1ull << to) - 1ull) & ~((2ull << from) - 1ull));
+                if (cnt) { if (at < F.rec_cap) a_len[at] = cnt; at++; }
+                from = to; hh &= hh - 1ull;
+            }
+        }
+        const bool kept_inner = inner && closes_kept;
+        const uint32_t k_incl = wave_incl_scan_u32(kept_inner ? 1u : 0u);
+        if (kept_inner) {
+            const uint32_t ka = T.kept_base + k_incl - 1u;
+            if (ka < F.rec_cap) { k_rel[ka] = rec_start; k_len[ka] = closed_len; }
+        }
+    }
+    // ---- bases and padding
+    {
+        const uint64_t o_head = (uint64_t)rec_start + before, o_tail = tail_start;
+        bool over = false;
+        uint64_t Wh = write_head ? V.HEADM : 0ull, Wt = write_tail ? V.TAILM : 0ull;
+        if (Wh && o_head + head > F.out_cap) { over = true; Wh = 0ull; }
+        if (Wt && o_tail + tail > F.out_cap) { over = true; Wt = 0ull; }
+        const uint64_t W = Wh | Wt;
+        const uint32_t a_head = (uint32_t)o_head, a_tail = (uint32_t)o_tail - (uint32_t)__popcll(Wh);
+        const uint32_t split = n_hdr ? V.last_hdr_at : 64u;
+        const uint32_t w_lo = (uint32_t)W, w_hi = (uint32_t)(W >> 32);
+        uint32_t k = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < FA_CHUNK; i++) {
+            const uint32_t bit = ((i < 32u ? w_lo : w_hi) >> (i & 31u)) & 1u;
+            if (bit) out[(i < split ? a_head : a_tail) + k] = (uint8_t)(wd[i >> 2] >> (8u * (i & 3u)));
+            k += bit;
+        }
+        if (closes_kept) {
+            if ((uint64_t)rec_start + pad <= F.out_cap) for (uint32_t q = closed_len; q < pad; q++) out[rec_start + q] = 'A';
+            else over = true;
+        }
+        if (__any(over) && lane == 0) atomicOr(&results[fi].flags, 8u);
+    }
+}
+
+size_t fasta_tiles_work_bytes(uint32_t total_tiles, uint32_t n_files)
+{
+    return ((size_t)total_tiles + 1u) * (sizeof(TileSum) + sizeof(TileCarry)) + (((size_t)total_tiles + n_files + 1u + 15u) & ~(size_t)15u);
+}
+
+void fasta_parse_tiles_launch(const uint8_t *d_text, const FastaFile *d_files, uint32_t n_files, uint32_t total_tiles, void *d_work, uint8_t *d_bases,
+                              uint32_t *d_kept_rel, uint32_t *d_kept_len, uint32_t *d_all_len, FastaResult *d_results, hipStream_t st)
+{
+    if (!n_files) return;
+    TileSum *sums = static_cast<TileSum *>(d_work);
+    TileCarry *carries = reinterpret_cast<TileCarry *>(sums + total_tiles + 1u);
+    uint8_t *kept_flag = reinterpret_cast<uint8_t *>(carries + total_tiles + 1u);
+    if (total_tiles)
+        hipLaunchKernelGGL(fasta_tile_sum_kernel, dim3((total_tiles + 3u) / 4u), dim3(256), 0, st, d_text, d_files, n_files, total_tiles, sums);
+    hipLaunchKernelGGL(fasta_tile_scan_kernel, dim3(n_files), dim3(64), 0, st, d_files, sums, carries, kept_flag, d_bases, d_kept_rel, d_kept_len,
+                       d_all_len, d_results);
+    if (total_tiles)
+        hipLaunchKernelGGL(fasta_tile_write_kernel, dim3((total_tiles + 3u) / 4u), dim3(256), 0, st, d_text, d_files, n_files, total_tiles, carries,
+                           kept_flag, d_bases, d_kept_rel, d_kept_len, d_all_len, d_results);
+    HIPCHECK(hipGetLastError());
+}

@@ -485,7 +485,20 @@ static void device_parse(skder_sketches *s, Slot &S,
     d_rel.resize(table_total + 1, st); d_len.resize(table_total + 1, st); d_all.resize(table_total + 1, st);
     HIPCHECK(hipMemcpyAsync(d_ff.p, ff.data(), nf * sizeof(FastaFile), hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemsetAsync(d_bases, 'A', 32, st));
-    fasta_parse_launch(d_text, d_ff.p, nf, d_bases, d_rel.p, d_len.p, d_all.p, d_res.p, st);
+    // tiles of the files (a file without text has none), then the parser: tiled (three kernels, a wavefront per 4 KB of text), or
+    // one wavefront per file (SKDER_AMD_FASTA_WAVE=1: round 3's first device parser; same results)
+    static const bool wave_parser = getenv("SKDER_AMD_FASTA_WAVE") != nullptr;
+    DevBuf<uint8_t> d_work;
+    if (wave_parser) {
+        fasta_parse_launch(d_text, d_ff.p, nf, d_bases, d_rel.p, d_len.p, d_all.p, d_res.p, st);
+    } else {
+        uint64_t tiles = 0;
+        for (uint32_t k = 0; k < nf; k++) { ff[k].tile_off = (uint32_t)tiles; tiles += ((uint64_t)ff[k].text_len + 4095u) / 4096u; }
+        if (tiles > 0xFFFFFFF0ull) throw SkError("internal error: too many tiles in one ingest batch");
+        HIPCHECK(hipMemcpyAsync(d_ff.p, ff.data(), nf * sizeof(FastaFile), hipMemcpyHostToDevice, st));
+        d_work.resize(fasta_tiles_work_bytes((uint32_t)tiles, nf), st);
+        fasta_parse_tiles_launch(d_text, d_ff.p, nf, (uint32_t)tiles, d_work.p, d_bases, d_rel.p, d_len.p, d_all.p, d_res.p, st);
+    }
     std::vector<FastaResult> res(nf);
     uint32_t *rel = S.tab, *len = S.tab + (table_total + 1), *all = S.tab + 2 * (table_total + 1);
     HIPCHECK(hipMemcpyAsync(res.data(), d_res.p, nf * sizeof(FastaResult), hipMemcpyDeviceToHost, st));
