@@ -3,9 +3,10 @@
 // The ingest of the drop-in entry points (host_io.hip) used to scan every file on the host: find the lines, drop headers and
 // line ends, copy the bases of the records of >= 500 bases into the 32-byte-aligned layout sketch_tiles_kernel reads, count
 // record lengths for N50 (util.n50_calc, /root/reference/src/skDER/util.py:686-724).  Here the host only READS (or inflates)
-// the file into a pinned buffer; the text goes over PCIe as it is and this kernel does the rest at HBM speed:
+// the file into a pinned buffer; the text goes over PCIe as it is and the device does the rest.  Two parsers, same results:
+// the TILED one further down (three kernels, a wavefront per 4 KB of text: the one the ingest uses) and the one it grew out of:
 //
-//   one WAVEFRONT per file, 4 KB of text per round (64 bytes per lane), state carried from round to round in wave-uniform
+//   one WAVEFRONT per file (fasta_parse_kernel; SKDER_AMD_FASTA_WAVE=1), 4 KB of text per round (64 bytes per lane), state carried from round to round in wave-uniform
 //   registers.  Per round: every lane classifies its 64 bytes (line start / header / base / line end), the lanes agree through
 //   ballots and three wave scans on (a) whether a lane's chunk starts inside a header line, (b) how many bases of the record
 //   that is open at its chunk start precede the chunk, (c) where in the output the records begin -- a record is kept, padded
