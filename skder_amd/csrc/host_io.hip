@@ -550,7 +550,7 @@ void sketch_files(skder_sketches *s, const std::vector<std::string> &paths, Geno
 {
     skder_ctx *ctx = s->ctx;
     hipStream_t st = ctx->stream;
-    size_t batch_bytes = 512ull << 20;   // per batch of bases: enough files for every host thread, small enough that pinning the two staging buffers stays cheap
+    size_t batch_bytes = 256ull << 20;   // per batch: enough files for every host thread, small enough that pinning the two staging buffers stays cheap (1,024 files, first call of a process: 131 / 137 / 139 / 173 ms with 64 / 128 / 256 / 512 MB, later calls 111 / 103 / 95 / 89: profiles/run/r3_ingest_batch.py)
     if (const char *e = getenv("SKDER_AMD_IO_BATCH_MB")) batch_bytes = (size_t)std::max(1, atoi(e)) << 20;
     const bool dbg = getenv("SKDER_AMD_DEBUG") != nullptr;
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
