@@ -860,6 +860,7 @@ def test_device_fasta_parser_edges(gpu, tmp_path, monkeypatch):
         idx = rng.randint(0, len(s), int(len(s) * rate))
         s[idx] = alpha[rng.randint(0, 4, len(idx))]
         return bytes(s)
+    wrap = lambda b, w, eol=b"\n": eol.join(b[i:i + w] for i in range(0, len(b), w)) + eol
     d = tmp_path / "fa"
     d.mkdir()
     files = {}
@@ -871,6 +872,11 @@ def test_device_fasta_parser_edges(gpu, tmp_path, monkeypatch):
     files["short_records.fa"] = b"".join(b">s%d\n" % i + g[7 * i:7 * i + 40] + b"\n" for i in range(20000)) + b">long\n" + g + b"\n"
     g = mutate(0.02)
     files["plain.fa"] = b">p\n" + g + b"\n"
+    # header lines longer than a 4 KB tile (tiles that lie entirely inside a header line), one of them ending exactly on a tile
+    g = mutate(0.014)
+    h1 = b">long " + b"d" * 9000
+    h2 = b">second " + b"e" * (8192 - 9 - (len(h1) + 1 + 60000 + 1) % 4096)
+    files["long_headers.fa"] = h1 + b"\n" + g[:60000] + b"\n" + h2 + b"\n" + wrap(g[60000:], 80)
     for i in range(1500):
         files["tiny_%04d.fa" % i] = b">t%d\n" % i + g[50 * i:50 * i + 400 + (i % 200)] + b"\n"     # 400-599 bases: some kept, most not
     for k, v in files.items():
