@@ -74,6 +74,28 @@ def gzip_sample_files(paths):
     return [r[0] for r in res], sum(r[1] for r in res)
 
 
+def evict_from_page_cache(paths):
+    """the files written back and their pages dropped from the page cache (posix_fadvise DONTNEED: what an ordinary user can do);
+    returns the file system the directory lives on (a tmpfs keeps its pages: 'cold' means nothing there)"""
+    fstype = "unknown"
+    try:
+        d, best = os.path.realpath(os.path.dirname(paths[0])), ""
+        for line in open("/proc/mounts"):
+            f = line.split()
+            if len(f) >= 3 and (d == f[1] or d.startswith(f[1].rstrip("/") + "/")) and len(f[1]) >= len(best):
+                best, fstype = f[1], f[2]
+    except OSError:
+        pass
+    for q in paths:
+        fd = os.open(q, os.O_RDONLY)
+        try:
+            os.fsync(fd)
+            os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
+        finally:
+            os.close(fd)
+    return fstype
+
+
 def end_to_end_sample(tmp, paths, nbytes, device):
     """The file-based drop-in on a bounded sample (second clock): skder_amd_triangle runs
     listing -> ingest (read, parse, N50, PCIe copy) -> sketch -> index -> screen -> chain -> TSV on disk."""
@@ -816,6 +838,14 @@ def main():
                     e["extrapolated_full_workload_s"] = e["fixed_s"] + total_bases * 1.0125 / (e["marginal_MB_per_s"] * 1e6)
                 else:
                     e["extrapolated_full_workload_s"] = total_bases * 1.0125 / (e["fasta_bytes"] / e["seconds"]) + ms_per_step * 1e-3
+                try:
+                    # the same call with the files' pages dropped from the page cache first: what the storage of this box gives
+                    fs = evict_from_page_cache(all_paths)
+                    cold = end_to_end_sample(tmp, all_paths, sum(sizes), dev)
+                    e["cold_page_cache"] = {"seconds": cold["seconds"], "ingest_MB_per_s": cold["ingest_MB_per_s"], "file_system": fs,
+                                            "how": "fsync + posix_fadvise(DONTNEED) on every file, then the call once"}
+                except Exception as ex:
+                    e["cold_page_cache"] = {"error": repr(ex)}
                 e["sample"] = ("skder_amd_triangle_n50 on %d FASTA files written from the resident bases (page cache hot): read, PCIe copy, FASTA parse on the device, N50, "
                                "sketch, index, screen, chain, TSV. ingest_MB_per_s = bytes / seconds of the whole call; marginal_MB_per_s = the slope "
                                "between this sample and its first %d files (small_sample; both with the staging buffers of an earlier call), i.e. the ingest "
