@@ -456,7 +456,7 @@ static uint64_t n50_of(std::vector<uint64_t> &all_len)
 }
 
 // The device stage of a batch whose pinned buffer holds FASTA TEXT (already on its way to d_text on the context's stream): the
-// kernel of fasta.hip builds the packed layout in d_bases and the record tables; the host adds what only it can (names from the
+// kernels of fasta.hip build the packed layout in d_bases and the record tables; the host adds what only it can (names from the
 // header lines, N50 from the length lists) and parses the files the kernel declined (blanks inside sequence lines, ...) itself.
 static void device_parse(skder_sketches *s, Slot &S,
                          std::vector<FastaFile> &ff, uint64_t out_total, uint64_t table_total, std::vector<HostGenome> &gs,
@@ -483,13 +483,13 @@ static void device_parse(skder_sketches *s, Slot &S,
     DevBuf<uint32_t> d_rel, d_len, d_all;
     d_ff.resize(nf, st); d_res.resize(nf, st);
     d_rel.resize(table_total + 1, st); d_len.resize(table_total + 1, st); d_all.resize(table_total + 1, st);
-    HIPCHECK(hipMemcpyAsync(d_ff.p, ff.data(), nf * sizeof(FastaFile), hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemsetAsync(d_bases, 'A', 32, st));
     // tiles of the files (a file without text has none), then the parser: tiled (three kernels, a wavefront per 4 KB of text), or
     // one wavefront per file (SKDER_AMD_FASTA_WAVE=1: round 3's first device parser; same results)
     static const bool wave_parser = getenv("SKDER_AMD_FASTA_WAVE") != nullptr;
     DevBuf<uint8_t> d_work;
     if (wave_parser) {
+        HIPCHECK(hipMemcpyAsync(d_ff.p, ff.data(), nf * sizeof(FastaFile), hipMemcpyHostToDevice, st));
         fasta_parse_launch(d_text, d_ff.p, nf, d_bases, d_rel.p, d_len.p, d_all.p, d_res.p, st);
     } else {
         uint64_t tiles = 0;
@@ -507,7 +507,6 @@ static void device_parse(skder_sketches *s, Slot &S,
     HIPCHECK(hipMemcpyAsync(all, d_all.p, table_total * 4, hipMemcpyDeviceToHost, st));
     HIPCHECK(hipStreamSynchronize(st));
     rec_off.clear(); rec_len.clear(); gbegin.clear();
-    uint64_t last_end = 32;
     for (uint32_t k = 0; k < nf; k++) {
         const FastaFile &f = ff[k];
         const FastaResult &r = res[k];
@@ -522,7 +521,6 @@ static void device_parse(skder_sketches *s, Slot &S,
             HIPCHECK(hipStreamSynchronize(st));
             for (size_t q = 0; q < hg.rec_len.size(); q++) { rec_off.push_back(f.out_off + hg.rec_rel[q]); rec_len.push_back(hg.rec_len[q]); }
             g.first_name = hg.first_name; g.n50 = hg.n50; g.packed_size = hg.packed_size;
-            last_end = f.out_off + hg.packed_size;
             if (getenv("SKDER_AMD_DEBUG")) fprintf(stderr, "[skder_amd] %s: parsed on the host (device parser flags %u)\n", g.path.c_str(), r.flags);
             continue;
         }
@@ -538,11 +536,9 @@ static void device_parse(skder_sketches *s, Slot &S,
             for (; p < e && *p != '\n'; p++) if (*p != '\r') g.first_name.push_back((char)*p);
         }
         g.packed_size = r.packed_size;
-        last_end = f.out_off + r.packed_size;
     }
     gbegin.push_back((uint32_t)rec_len.size());
     // readable 'A's behind the last record (a tile's reads run past its record)
-    (void)last_end;
     HIPCHECK(hipMemsetAsync(d_bases + (out_total - (SKDER_TILE + 64)), 'A', SKDER_TILE + 64, st));
 }
 
