@@ -96,6 +96,19 @@ def evict_from_page_cache(paths):
     return fstype
 
 
+def granted_cpus():
+    """CPUs this process may actually use: the cgroup CPU quota if there is one (the MI355X boxes show 256 hardware threads and grant
+    16 CPUs' worth of time), else the CPU count"""
+    n = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def end_to_end_sample(tmp, paths, nbytes, device):
     """The file-based drop-in on a bounded sample (second clock): skder_amd_triangle runs
     listing -> ingest (read, parse, N50, PCIe copy) -> sketch -> index -> screen -> chain -> TSV on disk."""
@@ -864,12 +877,12 @@ def main():
                 eg["sample"] = ("the same files gzip-compressed (level 1, %.2f x): skder_amd_triangle_n50 from .fasta.gz; ingest_MB_per_s and marginal_MB_per_s count "
                                 "uncompressed FASTA bytes, gz_MB_per_s compressed ones; page cache hot" % (sum(sizes) / max(sum(gz_sizes), 1)))
                 out["end_to_end_gz"] = eg
-                threads = max(1, min(32, os.cpu_count() or 1))
-                sk = cpu_baseline_skani(tmp, paths, os.cpu_count() or 1)
+                threads = max(1, min(32, granted_cpus()))
+                sk = cpu_baseline_skani(tmp, paths, granted_cpus())
                 if sk is not None:
                     # the reference engine is on this box: it IS the baseline (kind "reference")
                     est = N * sk["per_genome"] + n_chained * sk["per_chained"]
-                    out["cpu_baseline"] = {"value": pairs / est, "unit": "genome-pairs/s", "cores": os.cpu_count() or 1, "kind": "reference",
+                    out["cpu_baseline"] = {"value": pairs / est, "unit": "genome-pairs/s", "cores": granted_cpus(), "kind": "reference",
                                            "skani_version": sk["version"],
                                            "sample": "%s on the same %d FASTA files, wall clock %.1f s (%.0f pairs/s on the sample itself, %d rows): "
                                                      "%.4f s/genome read+sketch (a -s 100 run), %.5f s per chained pair; extrapolated to %d genomes, "
