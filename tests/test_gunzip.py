@@ -88,6 +88,17 @@ def test_every_block_type_and_header_option_equals_zlib(harness):
         assert out.returncode == 0 and out.stdout.startswith("same"), (name, out.stdout, out.stderr[-500:])
 
 
+def test_the_reference_s_own_genome_files_decode_like_zlib(harness):
+    """the 34 real .fasta.gz assemblies of the reference's test run (tests/golden/genomes): NCBI's gzip, 3.5 x, 2.6 matches per literal"""
+    exe, _ = harness
+    gdir = os.path.join(ROOT, "tests", "golden", "genomes")
+    files = sorted(f for f in os.listdir(gdir) if f.endswith(".gz"))
+    assert len(files) >= 30
+    for f in files:
+        out = _run(exe, "check", os.path.join(gdir, f))
+        assert out.returncode == 0 and out.stdout.startswith("same"), (f, out.stdout, out.stderr[-300:])
+
+
 def test_output_buffer_too_small_is_reported_not_overrun(harness):
     exe, d = harness
     files, texts = _corpus()
