@@ -910,6 +910,58 @@ def test_device_fasta_parser_edges(gpu, tmp_path, monkeypatch):
         assert msgs[0] == msgs[1] and "no sequence in" in msgs[0] and name in msgs[0], msgs
 
 
+def test_device_fasta_parsers_on_large_files(gpu, tmp_path, monkeypatch):
+    """Two 30 Mb genomes (7,500 tiles each: the tiled parser's per-file scan runs over 118 loads of 64 tile summaries) of 300 records
+    with lengths from 200 to 400,000 bases, one wrapped at 60 columns, one unwrapped and gzip-compressed: the tiled parser, the
+    one-wavefront-per-file parser and the host reader give the same N50 table and edge table."""
+    import skder_amd
+    rng = np.random.RandomState(13)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    anc = alpha[rng.randint(0, 4, 30_000_000)]
+    lens = np.concatenate([rng.randint(200, 700, 150), rng.randint(100_000, 400_000, 150)])
+    rng.shuffle(lens)
+    cuts = np.minimum(np.cumsum(lens), len(anc))
+    d = tmp_path / "fa"
+    d.mkdir()
+
+    def genome(rate, wrap_at):
+        s = anc.copy()
+        idx = rng.randint(0, len(s), int(len(s) * rate))
+        s[idx] = alpha[rng.randint(0, 4, len(idx))]
+        parts, a = [], 0
+        for i, b in enumerate(cuts):
+            if b <= a:
+                break
+            body = s[a:b]
+            parts.append(b">rec%d len=%d\n" % (i, b - a))
+            if wrap_at:
+                full = (len(body) // wrap_at) * wrap_at
+                parts.append(np.concatenate([body[:full].reshape(-1, wrap_at), np.full((full // wrap_at, 1), 10, np.uint8)], axis=1).tobytes())
+                if len(body) > full:
+                    parts.append(body[full:].tobytes() + b"\n")
+            else:
+                parts.append(body.tobytes() + b"\n")
+            a = b
+        return b"".join(parts)
+    (d / "wrapped.fa").write_bytes(genome(0.01, 60))
+    (d / "unwrapped.fa.gz").write_bytes(gzip.compress(genome(0.012, 0), 1))
+    listing = tmp_path / "listing.txt"
+    listing.write_text(str(d / "unwrapped.fa.gz") + "\n" + str(d / "wrapped.fa") + "\n")
+
+    def run(tag, env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out, n50 = tmp_path / (tag + ".tsv"), tmp_path / (tag + "_n50.tsv")
+        skder_amd.runSkaniTriangle(str(listing), str(out), "-s 80", 0.0, "greedy", False, None, n50_file=str(n50))
+        for k in env:
+            monkeypatch.delenv(k)
+        return out.read_text(), n50.read_text()
+    host = run("host", {"SKDER_AMD_HOST_PARSE": "1"})
+    assert host[0].count("\n") == 2
+    assert run("tiles", {}) == host
+    assert run("wave", {"SKDER_AMD_FASTA_WAVE": "1"}) == host
+
+
 def test_database_table_in_memory_equals_text(gpu, tmp_path):
     """the rows handed over in memory are the rows of the text table (same order, same
     orientation, same 2-decimal values), for a listing that is NOT in path order"""
