@@ -239,6 +239,27 @@ skder_db_t *skder_amd_db_from_sketches(skder_sketches_t *s, int device, const ch
 int skder_amd_db_triangle(skder_db_t *db, double min_af_pct, double screen_pct, const char *out_tsv,
                           const skder_edge_t **edges, uint64_t *n_edges, char *err, size_t errlen);
 
+/* 8f-1  representative selection ON the edge rows (host code, select.cpp): the counterparts of skDERsum + `sort -k 2 -gr` + the
+ * greedy loop (/root/reference/src/skDER/skDERsum.cpp:60-165, skder.py:136-165), of skDERcore (skDERcore.cpp:60-224, the rule the
+ * code implements) and of determineClusters (skder.py:168-277), byte-identical with the files the reference writes from the same
+ * table.  rows: ref/query = indices into paths (the array skder_amd_db_triangle hands over, in the table's row order -- member
+ * lists and the clustering table follow it); values are rounded to the table's two decimals here.  n50: listing order.
+ * display_names (may be NULL = paths): the names written into skDER_Results.txt / skDER_Clustering.txt, i.e. the reference's
+ * mge_proc_to_unproc_mapping (skder.py:76-92, 160-163, 236-253).  Output file names may be NULL (not written); reps (room for
+ * n_genomes) receives the representatives in the order of skDER_Results.txt. */
+int skder_amd_select_greedy(const skder_edge_t *rows, uint64_t n_rows, uint32_t n_genomes, const char *const *paths, const uint64_t *n50,
+                            const char *const *display_names, double min_ani_pct, double min_af_pct,
+                            const char *info_txt /* Genome_Information_for_Greedy_Clustering.txt */, const char *sorted_txt /* ....sorted.txt */,
+                            const char *results_txt /* skDER_Results.txt */, uint32_t *reps, uint32_t *n_reps, char *err, size_t errlen);
+int skder_amd_select_dynamic(const skder_edge_t *rows, uint64_t n_rows, uint32_t n_genomes, const char *const *paths, const uint64_t *n50,
+                             const char *const *display_names, double min_ani_pct, double min_af_pct, double max_af_diff_pct,
+                             const char *results_txt, uint32_t *reps, uint32_t *n_reps, char *err, size_t errlen);
+int skder_amd_select_clusters(const skder_edge_t *rows, uint64_t n_rows, uint32_t n_genomes, const char *const *paths,
+                              const char *const *display_names, const uint32_t *reps, uint32_t n_reps, double af_cutoff_pct,
+                              double ani_cutoff_pct, const char *clustering_txt /* skDER_Clustering.txt */, char *err, size_t errlen);
+/* hundredths of a percent as `%.2f` prints (double)((float)fraction * 100.0f): the rounding the table writer and the selection share */
+int64_t skder_amd_pct2_cents(float fraction);
+
 /* 8f-3  speculative batch of `skani search` calls (skder.py:116-133 evaluates one representative
  * at a time): the rows of n_queries candidates are computed in one pass.  Rows come grouped by
  * query in the order given, references by ANI descending, `query` = index into query_paths.

@@ -65,6 +65,15 @@ SYMBOLS = {
                                       C.POINTER(C.c_uint64)]),
     "skder_amd_copy_d2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "skder_amd_last_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "skder_amd_select_greedy": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.POINTER(C.c_char_p),
+                                         C.c_double, C.c_double, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                         C.c_char_p, C.c_size_t]),
+    "skder_amd_select_dynamic": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.POINTER(C.c_char_p),
+                                          C.c_double, C.c_double, C.c_double, C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                          C.c_char_p, C.c_size_t]),
+    "skder_amd_select_clusters": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_uint32),
+                                           C.c_uint32, C.c_double, C.c_double, C.c_char_p, C.c_char_p, C.c_size_t]),
+    "skder_amd_pct2_cents": (C.c_int64, [C.c_float]),
     "skder_amd_last_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "skder_amd_last_index_ms": (C.c_double, [C.c_void_p]),
     "skder_amd_last_runs_ms": (C.c_double, [C.c_void_p]),

@@ -13,7 +13,6 @@ written because it is one of skDER's outputs) and, with --store, the sketches ar
 later run over the same listing skips ingest (8f-4).
 """
 import argparse
-import gzip
 import json
 import os
 import shutil
@@ -24,29 +23,6 @@ from . import selection
 from .skder import Database, lowMemGreedyDerep, parse_skani_params, runSkaniDist
 
 ACCEPTED_SUFFICES = ("fasta", "fas", "fna", "fa")      # util.py:21
-
-
-def n50_of_fasta(path: str) -> int:
-    """util.py:686-724: all records, half = int(sum/2), lengths descending, first cumulative >= half"""
-    op = gzip.open if path.endswith(".gz") else open
-    lens, cur = [], None
-    with op(path, "rt") as f:
-        for line in f:
-            if line.startswith(">"):
-                if cur is not None:
-                    lens.append(cur)
-                cur = 0
-            elif cur is not None:
-                cur += len(line.strip())
-    if cur is not None:
-        lens.append(cur)
-    lens.sort(reverse=True)
-    half, cum = int(sum(lens) / 2), 0
-    for l in lens:
-        cum += l
-        if cum >= half:
-            return l
-    return 0
 
 
 def list_genomes(inputs):
@@ -117,7 +93,7 @@ def open_database(listing, genomes, n50_file, store=None, devices=None):
 
 
 def run(genomes, outdir, mode="greedy", ani=99.5, af=50.0, max_af_dist=10.0, clusters=False, params="-s X", store=None,
-        symlink=False, devices=None):
+        symlink=False, devices=None, name_map=None):
     outdir = os.path.abspath(outdir) + "/"
     os.makedirs(outdir, exist_ok=True)
     if params == "-s X":                          # bin/skder:199-201
@@ -132,13 +108,16 @@ def run(genomes, outdir, mode="greedy", ani=99.5, af=50.0, max_af_dist=10.0, clu
     n50_file = outdir + "Concatenated_N50.txt"
     db = open_database(listing, genomes, n50_file, store, devices)
     try:
-        return _run(db, genomes, outdir, mode, ani, af, af_tri, max_af_dist, clusters, params, listing, n50_file, symlink)
+        return _run(db, genomes, outdir, mode, ani, af, af_tri, max_af_dist, clusters, params, listing, n50_file, symlink, name_map)
     finally:
         db.close()
 
 
-def _run(db, genomes, outdir, mode, ani, af, af_tri, max_af_dist, clusters, params, listing, n50_file, symlink=False):
+def _run(db, genomes, outdir, mode, ani, af, af_tri, max_af_dist, clusters, params, listing, n50_file, symlink=False, name_map=None):
     n50 = OrderedDict(zip(db.paths, db.n50))
+    # name_map: the reference's mge_proc_to_unproc_mapping (skder.py:76-92, 127-129, 160-163, 236-253) -- the genomes were
+    # pre-processed (MGE regions cut out: out of scope here) and the result files name the originals
+    shown = [name_map[p] for p in db.paths] if name_map else None
     result_file = outdir + "skDER_Results.txt"
     edge_file = outdir + "Skani_Triangle_Edge_Output.txt"
     if mode == "low_mem_greedy":
@@ -151,31 +130,31 @@ def _run(db, genomes, outdir, mode, ani, af, af_tri, max_af_dist, clusters, para
             edge_file = outdir + "Skani_Dist_Output.txt"
             runSkaniDist(cdir, result_file, listing, edge_file, params, af, mode, False, None)
         reps = [l.strip() for l in open(result_file)]
+        if shown is not None:                      # skder.py:130-132: the names written are the mapped ones; the flow goes on with the listing's
+            with open(result_file, "w") as f:
+                f.write("".join(name_map[r] + "\n" for r in reps))
     else:
+        # the edge rows reach the selection in memory; the selection itself is native (skder_amd/csrc/select.cpp): no per-edge Python
         rows = db.triangle(af_tri, parse_skani_params(params), out_tsv=edge_file)
-        edges = selection.edges_from_engine(rows, db.paths)
+        n50v = [n50[p] for p in db.paths]
         if mode == "greedy":
-            info = selection.genome_information(edges, n50, ani, af)
-            with open(outdir + "Genome_Information_for_Greedy_Clustering.txt", "w") as f:
-                f.write("".join(l + "\n" for l in info))
-            srt = selection.sort_like_coreutils(info)
-            with open(outdir + "Genome_Information_for_Greedy_Clustering.sorted.txt", "w") as f:
-                f.write("".join(l + "\n" for l in srt))
-            reps = selection.greedy(srt)
+            rep_idx = selection.native_greedy(rows, db.paths, n50v, ani, af, outdir + "Genome_Information_for_Greedy_Clustering.txt",
+                                              outdir + "Genome_Information_for_Greedy_Clustering.sorted.txt", result_file, display=shown)
         elif mode == "dynamic":
-            reps = selection.dynamic(edges, n50, ani, af, max_af_dist)
+            rep_idx = selection.native_dynamic(rows, db.paths, n50v, ani, af, max_af_dist, result_file, display=shown)
         else:
             raise ValueError("unknown dereplication mode " + mode)
-        with open(result_file, "w") as f:
-            f.write("".join(r + "\n" for r in reps))
+        reps = [db.paths[i] for i in rep_idx]
     if clusters:
         if mode == "low_mem_greedy":
-            edges = selection.edges_from_table(edge_file)
-        with open(outdir + "skDER_Clustering.txt", "w") as f:
-            f.write("".join(l + "\n" for l in selection.determine_clusters(reps, edges, af, ani)))
+            rows = selection.rows_from_table(edge_file, db.paths)
+            idx = {p: i for i, p in enumerate(db.paths)}
+            rep_idx = [idx[r] for r in reps]
+        selection.native_clusters(rows, db.paths, rep_idx, af, ani, outdir + "skDER_Clustering.txt", display=shown)
     rep_dir = outdir + "Dereplicated_Representative_Genomes/"
     os.makedirs(rep_dir, exist_ok=True)
     for r in reps:                                  # util.py:411-427: copies unless -l / --symlink was given
+        r = name_map[r] if name_map else r          # (the originals, as the result file names them)
         dst = rep_dir + os.path.basename(r)
         if os.path.lexists(dst):
             continue
@@ -202,13 +181,19 @@ def main(argv=None):
     ap.add_argument("-p", "--skani-triangle-parameters", default="-s X")
     ap.add_argument("-n", "--determine-clusters", action="store_true")
     ap.add_argument("-l", "--symlink", action="store_true", help="symlink the representatives instead of copying them (bin/skder:106)")
+    ap.add_argument("--name-map", default=None, help="TSV `listed path<TAB>name to report`: the reference's mge_proc_to_unproc_mapping "
+                                                     "(genomes pre-processed elsewhere; result files and the representatives' directory use the originals)")
     ap.add_argument("--store", default=None, help="sketch store file: loaded if present and still describing these files, written otherwise")
     ap.add_argument("--devices", default=None, help="comma-separated GPU indices (default: $SKDER_AMD_DEVICE or 0): with several, the genomes "
                                                     "are sketched in shares, the sketches exchanged between the GPUs and the pair matrix dealt out by rows")
     a = ap.parse_args(argv)
+    name_map = None
+    if a.name_map:
+        with open(a.name_map) as f:
+            name_map = dict(l.rstrip("\n").split("\t")[:2] for l in f if l.strip())
     reps = run(list_genomes(a.genomes), a.output_directory, a.dereplication_mode, a.percent_identity_cutoff,
                a.aligned_fraction_cutoff, a.max_af_distance_cutoff, a.determine_clusters, a.skani_triangle_parameters, a.store,
-               a.symlink, [int(x) for x in a.devices.split(",")] if a.devices else None)
+               a.symlink, [int(x) for x in a.devices.split(",")] if a.devices else None, name_map)
     print("%d representative genomes -> %s" % (len(reps), os.path.join(a.output_directory, "skDER_Results.txt")))
 
 

@@ -10,7 +10,12 @@ reference's exact text conventions so that outputs can be compared file for file
   determine_clusters()  ~ src/skDER/skder.py:168-277      (non-MGE branch)
 
 Edges are (ref, query, ani, af_ref, af_query) with the values ROUNDED TO TWO DECIMALS, i.e. what the
-reference would have parsed from skani's text table (both C++ programs `stod` the text)."""
+reference would have parsed from skani's text table (both C++ programs `stod` the text).
+
+This module is the READABLE STATEMENT of the rules.  The product path is native: `native_greedy`, `native_dynamic`,
+`native_clusters` at the end of the file call skder_amd/csrc/select.cpp through the C ABI on the engine's edge RECORDS (no
+per-edge Python, no text round trip); tests/test_selection.py holds the two byte-identical with each other and with the
+reference's own binaries."""
 from collections import OrderedDict
 from typing import Dict, Iterable, List, Sequence, Tuple
 
@@ -166,3 +171,97 @@ def read_n50(path: str) -> "OrderedDict[str, int]":
                 g, n = line.split("\t")
                 d[g] = int(float(n))
     return d
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# native selection (skder_amd/csrc/select.cpp) on engine edge records
+
+def _c_strings(names):
+    import ctypes as C
+    return (C.c_char_p * max(len(names), 1))(*[n.encode() for n in names])
+
+
+def _native_args(rows, paths, display):
+    import ctypes as C
+    import numpy as np
+    from .engine import EDGE_DTYPE
+    rows = np.ascontiguousarray(rows, dtype=EDGE_DTYPE)
+    if display is not None and len(display) != len(paths):
+        raise ValueError("display names: one per genome")
+    return rows, rows.ctypes.data_as(C.c_void_p), _c_strings(paths), (_c_strings(display) if display is not None else None)
+
+
+def _enc(x):
+    return x.encode() if x else None
+
+
+def native_greedy(rows, paths: Sequence[str], n50: Sequence[int], min_ani: float, min_af: float, info_txt=None, sorted_txt=None,
+                  results_txt=None, display: Sequence[str] = None) -> List[int]:
+    """skDERsum + `sort -k 2 -gr` + the greedy loop on edge records; returns the representatives' indices in result-file order"""
+    import ctypes as C
+    import numpy as np
+    from . import _lib
+    if len(n50) != len(paths):
+        raise ValueError("N50 table: one value per genome")
+    rows, prow, cpaths, cdisp = _native_args(rows, paths, display)
+    n50a = np.ascontiguousarray(n50, dtype=np.uint64)
+    reps = np.zeros(max(len(paths), 1), np.uint32)
+    nr = C.c_uint32(0)
+    err = C.create_string_buffer(_lib.ERRLEN)
+    rc = _lib.lib().skder_amd_select_greedy(prow, len(rows), len(paths), cpaths, n50a.ctypes.data_as(C.POINTER(C.c_uint64)), cdisp,
+                                            float(min_ani), float(min_af), _enc(info_txt), _enc(sorted_txt), _enc(results_txt),
+                                            reps.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(nr), err, _lib.ERRLEN)
+    if rc != 0:
+        raise RuntimeError("skder_amd_select_greedy: " + err.value.decode())
+    return [int(x) for x in reps[:nr.value]]
+
+
+def native_dynamic(rows, paths: Sequence[str], n50: Sequence[int], min_ani: float, min_af: float, max_af_diff: float, results_txt=None,
+                   display: Sequence[str] = None) -> List[int]:
+    """skDERcore on edge records; representatives in N50-file (listing) order"""
+    import ctypes as C
+    import numpy as np
+    from . import _lib
+    if len(n50) != len(paths):
+        raise ValueError("N50 table: one value per genome")
+    rows, prow, cpaths, cdisp = _native_args(rows, paths, display)
+    n50a = np.ascontiguousarray(n50, dtype=np.uint64)
+    reps = np.zeros(max(len(paths), 1), np.uint32)
+    nr = C.c_uint32(0)
+    err = C.create_string_buffer(_lib.ERRLEN)
+    rc = _lib.lib().skder_amd_select_dynamic(prow, len(rows), len(paths), cpaths, n50a.ctypes.data_as(C.POINTER(C.c_uint64)), cdisp,
+                                             float(min_ani), float(min_af), float(max_af_diff), _enc(results_txt),
+                                             reps.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(nr), err, _lib.ERRLEN)
+    if rc != 0:
+        raise RuntimeError("skder_amd_select_dynamic: " + err.value.decode())
+    return [int(x) for x in reps[:nr.value]]
+
+
+def native_clusters(rows, paths: Sequence[str], reps: Sequence[int], af_cutoff: float, ani_cutoff: float, clustering_txt: str,
+                    display: Sequence[str] = None) -> None:
+    """determineClusters on edge records -> skDER_Clustering.txt"""
+    import ctypes as C
+    import numpy as np
+    from . import _lib
+    rows, prow, cpaths, cdisp = _native_args(rows, paths, display)
+    ra = np.ascontiguousarray(reps, dtype=np.uint32)
+    err = C.create_string_buffer(_lib.ERRLEN)
+    rc = _lib.lib().skder_amd_select_clusters(prow, len(rows), len(paths), cpaths, cdisp, ra.ctypes.data_as(C.POINTER(C.c_uint32)), len(ra),
+                                              float(af_cutoff), float(ani_cutoff), clustering_txt.encode(), err, _lib.ERRLEN)
+    if rc != 0:
+        raise RuntimeError("skder_amd_select_clusters: " + err.value.decode())
+
+
+def rows_from_table(path: str, paths: Sequence[str]):
+    """a text table (Skani_Dist_Output.txt of the low_mem_greedy flow, or a golden table) as edge records for the native functions:
+    values as fractions whose single-precision percentage prints back to the table's two decimals"""
+    import numpy as np
+    from .engine import EDGE_DTYPE
+    idx = {p: i for i, p in enumerate(paths)}
+    ed = edges_from_table(path)
+    rows = np.zeros(len(ed), EDGE_DTYPE)
+    for k, (r, q, ani, afr, afq) in enumerate(ed):
+        rows[k]["ref"] = idx[r]; rows[k]["query"] = idx[q]
+        rows[k]["ani"] = np.float32(ani) / np.float32(100); rows[k]["af_ref"] = np.float32(afr) / np.float32(100)
+        rows[k]["af_query"] = np.float32(afq) / np.float32(100)
+    return rows

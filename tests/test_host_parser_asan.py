@@ -28,7 +28,7 @@ def _n50(lens):
 def test_parser_under_sanitizers(tmp_path):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     subprocess.check_call(["make", "-C", CSRC, "-j8"], stdout=subprocess.DEVNULL)
-    objs = [os.path.join(CSRC, o) for o in ("pool.o", "fasta.o", "gunzip.o", "sketch.o", "scan.o", "index.o", "screen.o", "chain.o", "api.o")]
+    objs = [os.path.join(CSRC, o) for o in ("pool.o", "fasta.o", "gunzip.o", "sketch.o", "scan.o", "index.o", "screen.o", "chain.o", "chain_join.o", "chain_extract.o", "chain_runs.o", "chain_rows.o", "chain_slow.o", "chain_finalize.o", "select.o", "api.o")]
     exe = str(tmp_path / "harness")
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O1", "-g", "-Xarch_host", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",   # host code only
                            "-std=c++17", "-I" + CSRC, "-x", "hip", os.path.join(ROOT, "tests", "host_parser_harness.cpp"),

@@ -16,7 +16,7 @@ CSRC = os.path.join(ROOT, "skder_amd", "csrc")
 def _build(tmp_path, sanitize):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     subprocess.check_call(["make", "-C", CSRC, "-j8"], stdout=subprocess.DEVNULL)
-    objs = [os.path.join(CSRC, o) for o in ("pool.o", "fasta.o", "gunzip.o", "sketch.o", "scan.o", "index.o", "screen.o", "chain.o", "api.o")]
+    objs = [os.path.join(CSRC, o) for o in ("pool.o", "fasta.o", "gunzip.o", "sketch.o", "scan.o", "index.o", "screen.o", "chain.o", "chain_join.o", "chain_extract.o", "chain_runs.o", "chain_rows.o", "chain_slow.o", "chain_finalize.o", "select.o", "api.o")]
     exe = str(tmp_path / ("writer_harness" + ("_san" if sanitize else "")))
     flags = ["-O1", "-g", "-Xarch_host", "-fsanitize=address,undefined", "-fno-omit-frame-pointer"] if sanitize else ["-O3"]
     subprocess.check_call([hipcc, "--offload-arch=gfx950"] + flags + ["-std=c++17", "-I" + CSRC, "-x", "hip",
