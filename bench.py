@@ -530,6 +530,90 @@ def low_mem_greedy_scale(engine, ctx, torch, synth, n, genome_len, device):
     return out
 
 
+def one_species_database(engine, ctx, torch, synth, n, device, keep_bases=None):
+    """n genomes of ONE species with real genome structure, sketched: the reference's 34 real C. granulosum assemblies and descendants
+    of them generated on the device (skder_amd/csrc/descend.hip: substitutions 0.02 - 3 %, short indels, inversions / translocations /
+    deletions, the assembly's own contigs).  Returns (sketch set, paths, n50, seconds).  keep_bases(batch_index, device tensor, layout):
+    called per batch before it is dropped (the file-based variant writes FASTA from it)."""
+    gold = os.path.join(ROOT, "tests", "golden", "genomes")
+    names = sorted(os.listdir(gold))
+    recs = [_read_fasta_records(os.path.join(gold, x)) for x in names]
+    anc_layout = engine.BatchLayout([r[0] for r in recs])
+    d_anc = torch.from_numpy(anc_layout.pack_host([r[1] for r in recs])).cuda()
+    per = max((n - len(recs) + len(recs) - 1) // len(recs), 0)
+    plan = synth.real_family_plan([r[0] for r in recs], per)
+    # descendant k of every assembly before descendant k + 1 of any: a prefix of the plan is a balanced family
+    order = np.argsort(np.arange(len(plan)) % max(per, 1), kind="stable")
+    plan = plan[order][:max(n - len(recs), 0)]
+    sk = engine.Sketches(ctx)
+    sk.reserve(n * 18000, n * 2300)
+    t0 = time.perf_counter()
+    sk.sketch_batch(d_anc.data_ptr(), anc_layout)
+    paths = ["/one_species/%s" % x for x in names]
+    n50 = [n50_of_lengths(r[0]) for r in recs]
+    if keep_bases:
+        keep_bases(0, d_anc, anc_layout)
+    step = 1000
+    for b0 in range(0, len(plan), step):
+        part = plan[b0:b0 + step]
+        d, lay = ctx.descendants(d_anc.data_ptr(), anc_layout, part, torch)
+        sk.sketch_batch(d.data_ptr(), lay)
+        for g in range(len(part)):
+            a, b = int(lay.genome_rec_begin[g]), int(lay.genome_rec_begin[g + 1])
+            n50.append(n50_of_lengths(lay.rec_len[a:b]))
+            paths.append("/one_species/%s.descendant%05d.fasta" % (names[int(part[g]["parent"])].split(".")[0], b0 + g))
+        if keep_bases:
+            keep_bases(1 + b0 // step, d, lay)
+        del d
+    torch.cuda.synchronize()
+    return sk, paths, n50, time.perf_counter() - t0
+
+
+def low_mem_greedy_one_species(engine, ctx, torch, synth, n, device):
+    """The reference's published workload in its REAL SHAPE (README.md:27: `skder -d low_mem_greedy` on > 20,000 genomes of one genus,
+    mostly one species, 2.25 h on 20 threads): lowMemGreedyDerep -i 99.5 -f 50 (skder.py:95-134) over n genomes of ONE species with
+    real genome structure -- nearly every `search` passes the screen against thousands of genomes and chains them all, unlike the
+    200-species synthetic leg where a search chains ~100 pairs."""
+    import shutil
+    import tempfile
+    from skder_amd.skder import Database, lowMemGreedyDerep
+    t_all = time.perf_counter()
+    sk, paths, n50, t_sketch = one_species_database(engine, ctx, torch, synth, n, device)
+    tmp = tempfile.mkdtemp(prefix="skder_amd_onesp_")
+    try:
+        listing, n50_file = os.path.join(tmp, "listing.txt"), os.path.join(tmp, "Concatenated_N50.txt")
+        open(listing, "w").write("".join(p + "\n" for p in paths))
+        open(n50_file, "w").write("".join("%s\t%d\n" % kv for kv in zip(paths, n50)))
+        t0 = time.perf_counter()
+        db = Database.from_sketches(sk, paths, n50, device=device)
+        t_db = time.perf_counter() - t0
+        sk.close()
+
+        def run(width, tag):
+            ws = os.path.join(tmp, "ws_" + tag) + "/"
+            os.makedirs(ws, exist_ok=True)
+            res = os.path.join(ws, "skDER_Results.txt")
+            t0 = time.perf_counter()
+            lowMemGreedyDerep(listing, ws, n50_file, res, ws, 99.5, 50.0, None, search_batch=width, database=db)
+            return time.perf_counter() - t0, open(res).read(), dict(getattr(lowMemGreedyDerep, "last_stats", {}))
+        t_spec, reps_spec, st = run(0, "spec")
+        t_seq, reps_seq, _ = run(1, "seq")
+        db.close()
+        nrep = len(reps_spec.split())
+        return {"genomes": len(paths), "representatives": nrep, "seconds_speculative_batches": t_spec, "seconds_one_search_per_representative": t_seq,
+                "listings_identical": reps_spec == reps_seq, "searches": st.get("searches"), "search_batches": st.get("batches"),
+                "rows_per_search": (st.get("rows", 0) / max(st.get("searches", 1), 1)), "rows_total": st.get("rows"),
+                "sketching_s_incl_generating_the_bases": t_sketch, "database_from_resident_sketches_s": t_db,
+                "reference_published": {"seconds": 2.25 * 3600, "what": "README.md:27: low_mem_greedy on > 20,000 Staphylococcus genomes (GTDB R220), 20 threads, machine "
+                                        "unspecified; other genomes, other hardware, FASTA ingest and skani's own arithmetic included there -- quoted, not compared"},
+                "total_s_of_this_leg": time.perf_counter() - t_all,
+                "workload": "%d genomes of ONE species: the reference's 34 real C. granulosum assemblies + descendants generated on the device (0.02-3 %% substitutions, "
+                            "short indels, inversions / translocations / deletions, the assemblies' own contigs); lowMemGreedyDerep -i 99.5 -f 50 on one MI355X, sketches resident"
+                            % len(paths)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def cpu_baseline_files(tmp, paths, threads):
     """oracle (CPU restatement, OpenMP) on the sample files, wall clock on `threads` host threads:
       per genome   : read + sketch, from a triangle whose 101 % screen lets no pair through;
@@ -564,8 +648,11 @@ def cpu_baseline_files(tmp, paths, threads):
     t_screen = (time.perf_counter() - t0) / max(npair, 1)
     per_pair = t_screen / threads
     per_genome = t_load / n
-    per_chained = max(t_full - t_load, 0.0) / max(chained, 1)
-    return per_genome, per_pair, per_chained, chained, t_load + t_full + t_screen * npair
+    # the full triangle's time beyond read + sketch is the screen of every pair plus the chaining of those that pass
+    per_chained = max(t_full - t_load - per_pair * (n * (n - 1) // 2), 0.0) / max(chained, 1)
+    measured = {"files": n, "pairs": n * (n - 1) // 2, "chained_pairs": chained, "wall_s": t_full, "pairs_per_s": (n * (n - 1) // 2) / t_full,
+                "what": "one `triangle` of the oracle over the sample files, every pair screened, every screened pair chained: MEASURED wall clock"}
+    return per_genome, per_pair, per_chained, chained, t_load + t_full + t_screen * npair, measured
 
 
 def cpu_baseline_skani(tmp, paths, threads):
@@ -604,6 +691,8 @@ def main():
     ap.add_argument("--indel-genomes", type=int, default=48, help="genomes of the host-generated indel family")
     ap.add_argument("--mixed-genomes", type=int, default=5000, help="genomes of the mixed 1-8 Mb extra workload (0: skip)")
     ap.add_argument("--real-derived", type=int, default=30, help="descendants per real assembly in the real-structure workload (34 x this many genomes; 0: skip)")
+    ap.add_argument("--one-species-genomes", type=int, default=5000, help="genomes of the one-species low_mem_greedy leg (README.md:27's workload in its real shape; "
+                                                                            "profiles/run/r4_one_species.py runs 20000; 0: skip)")
     ap.add_argument("--low-mem-genomes", type=int, default=20000, help="genomes of the low_mem_greedy leg (README.md:27's workload shape: 20000; 0: skip)")
     args = ap.parse_args()
 
@@ -645,7 +734,8 @@ def main():
     total_bases = sum(l.total_bases for l, _ in batches)
     torch.cuda.synchronize()
 
-    wall = {"sketch": 0.0, "exchange": 0.0, "triangle": 0.0}
+    wall = {"sketch": 0.0, "exchange": 0.0, "triangle": 0.0, "gather": 0.0}
+    stage = {}          # N > 1: this rank's wall time per stage of the sharded triangle, summed over the timed steps
 
     def step():
         tm = np.zeros(8)
@@ -676,7 +766,11 @@ def main():
         step.runs_ms = ctx.runs_ms()
         step.counters = ctx.counters()
         if dist_on:
+            t5 = time.perf_counter()
             edges = multigpu.gather_edges(edges)
+            wall["gather"] += time.perf_counter() - t5
+            for k, v in getattr(multigpu.triangle_sharded, "last_stage_ms", {}).items():
+                stage[k] = stage.get(k, 0.0) + v
         sk.close()
         return edges, tm
 
@@ -688,6 +782,9 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    for k in wall:
+        wall[k] = 0.0
+    stage.clear()
     t0 = time.perf_counter()
     tms = []
     for _ in range(args.steps):
@@ -700,6 +797,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
+    # every rank's wall time per stage and step (N > 1: so that the first scaling curve can be read: which stage does not shrink)
+    my_stages = {"sketch": 1e3 * wall["sketch"] / args.steps, "exchange": 1e3 * wall["exchange"] / args.steps}
+    my_stages.update({k: v / args.steps for k, v in stage.items()})
+    my_stages["gather"] = 1e3 * wall["gather"] / args.steps
+    per_rank = [my_stages]
+    if dist_on:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, my_stages)
     pairs = N * (N - 1) // 2
     tm = np.mean(tms, axis=0)
     # In the timed region the chaining batches alternate between two queues and overlap, so the event bracket
@@ -813,7 +918,8 @@ def main():
                                            "alternate between two queues and overlap, and their event brackets (kernel_ms_two_queues) "
                                            "include the wait for the other queue's share of the chip",
                          "kernel_ms_two_queues": overlapped, "ms_per_step_one_queue": one_queue_ms,
-                         "host_wall_ms": {k: 1e3 * v / (args.steps + args.warmup) for k, v in wall.items()},
+                         "host_wall_ms": {k: 1e3 * v / args.steps for k, v in wall.items()},
+                         "per_rank_stage_ms": per_rank,
                          "kernel_GBs": {k: float(v[1] / (v[0] * 1e-3) / 1e9) if v[0] > 0 else 0.0 for k, v in cand.items()},
                          "other_ms": {"sketch_post": float(tm[1]), "index_beside_screen": float(step.index_ms), "screen": float(tm[2]), "chain_slow_path": float(tm[4]),
                                       "finalize": float(tm[5])}},
@@ -841,7 +947,10 @@ def main():
                     if len(big_paths) <= len(small_paths):
                         return a
                     b = min((end_to_end_sample(tmp, big_paths, big_bytes, dev) for _ in range(2)), key=lambda r: r["seconds"])
-                    slope = (b["fasta_bytes"] - a["fasta_bytes"]) / max(b["seconds"] - a["seconds"], 1e-9)
+                    if b["seconds"] <= a["seconds"]:         # the big sample was not slower (noise): no slope to extrapolate from
+                        b["small_sample"] = a
+                        return a if a["seconds"] < b["seconds"] else b
+                    slope = (b["fasta_bytes"] - a["fasta_bytes"]) / (b["seconds"] - a["seconds"])
                     b["small_sample"] = a
                     b["marginal_MB_per_s"] = slope / 1e6
                     b["fixed_s"] = max(a["seconds"] - a["fasta_bytes"] / slope, 0.0) + max(cold["seconds"] - a["seconds"], 0.0)
@@ -889,14 +998,19 @@ def main():
                                                      "%d chained pairs" % (sk["command"], len(paths), sk["seconds"], sk["sample_pairs_per_s"], sk["chained"],
                                                                            sk["per_genome"], sk["per_chained"], N, int(n_chained))}
                 else:
-                    pg, pp, pc, chained, spent = cpu_baseline_files(tmp, paths, threads)
+                    # MEASURED on the large sample (1,024 files of the workload: 523,776 pairs, every screened pair chained), and the
+                    # extrapolation to the full workload from its three measured rates beside it
+                    pg, pp, pc, chained, spent, measured = cpu_baseline_files(tmp, all_paths, threads)
                     est = N * pg + pairs * pp + n_chained * pc
-                    out["cpu_baseline"] = {"value": pairs / est, "unit": "genome-pairs/s", "cores": threads, "kind": "port",
+                    out["cpu_baseline"] = {"value": pairs / est, "unit": "genome-pairs/s", "cores": threads, "kind": "port", "measured_on_sample": measured,
+                                           "value_is": "the extrapolation to the full workload (genomes x read+sketch + pairs x screen + chained pairs x chaining, all three rates "
+                                                       "measured on the sample); measured_on_sample.pairs_per_s is the sample's own wall-clock rate (it has %.1f x the full workload's share of chained pairs)"
+                                                       % ((measured["chained_pairs"] / max(measured["pairs"], 1)) / max(n_chained / max(pairs, 1), 1e-12)),
                                            "skani": "unavailable on this host (oracle/skani_ref.py looked for it on PATH): the repo's own CPU restatement is timed instead",
                                            "sample": "oracle (CPU restatement, OpenMP, %d threads, wall clock) on the same %d FASTA files: "
                                                      "%.4f s/genome read+sketch, %.2e s/pair marker screen, %.5f s/chained pair (%d pairs); "
                                                      "%.1f s of wall time spent; extrapolated to %d genomes, %d pairs, %d chained pairs"
-                                                     % (threads, len(paths), pg, pp, pc, chained, spent, N, pairs, int(n_chained))}
+                                                     % (threads, len(all_paths), pg, pp, pc, chained, spent, N, pairs, int(n_chained))}
             finally:
                 shutil.rmtree(tmp, ignore_errors=True)
         if world == 1 and not args.no_realistic and not args.no_cpu_baseline:
@@ -908,6 +1022,12 @@ def main():
                     out["realistic"]["low_mem_greedy_%d" % args.low_mem_genomes] = low_mem_greedy_scale(engine, ctx, torch, synth, args.low_mem_genomes, 2_800_000, dev)
                 except Exception as ex:
                     out["realistic"]["low_mem_greedy_%d" % args.low_mem_genomes] = {"error": str(ex)}
+            if args.one_species_genomes > 0:
+                try:
+                    torch.cuda.empty_cache()
+                    out["realistic"]["low_mem_greedy_one_species"] = low_mem_greedy_one_species(engine, ctx, torch, synth, args.one_species_genomes, dev)
+                except Exception as ex:
+                    out["realistic"]["low_mem_greedy_one_species"] = {"error": repr(ex)}
         print(json.dumps(out))
     ctx.close()
     if dist_on:

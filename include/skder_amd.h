@@ -200,12 +200,38 @@ double skder_amd_last_runs_ms(skder_ctx_t *ctx);
 /* counters of the last triangle_rows/rectangle call: [0] chunks processed, [1] chunks that needed the
  * unabridged (slow) chaining path */
 int skder_amd_last_counters(skder_ctx_t *ctx, uint64_t *out4);
+/* Memory the library keeps between calls on a device -- the ingest's pinned staging buffers with their device copies (about 0.6 GB of
+ * pinned host memory and 1.2 GB of HBM at the default batch size) and the device allocator's cached blocks -- handed back to the
+ * driver.  For long-lived host applications; 0: released, 1: the staging set is in use by a running call (the rest was released). */
+int skder_amd_release_cached_buffers(int device);
+/* multi-GPU calls of one process (skder_amd_triangle_multi, skder_amd_sketch_multi): ordered device pairs found WITHOUT peer access so
+ * far -- their copies are staged through host memory by the runtime (correct, an order of magnitude slower than xGMI).  0 on a healthy node. */
+uint32_t skder_amd_peer_fallbacks(void);
 
 /* synthetic genomes generated ON the device (SURVEY 8d recipe; bench.py / tests):
  * fills d_bases for one batch from (seed, species, strain, isolate) lineage ids. See synth.h. */
 int skder_amd_synth_fill(skder_ctx_t *ctx, uint8_t *d_bases, const skder_batch_t *batch,
                          const uint64_t *genome_lineage /* 3 per genome: species,strain,isolate seeds */,
                          const uint32_t *genome_params /* 4 per genome, see synth.h */);
+
+/* descendants of REAL assemblies generated ON the device (descend.hip; bench.py / tests): a descendant keeps its parent's records;
+ * per record at most one structural event (three per genome), then short indels and substitutions at the given rates, everything a
+ * pure function of (seed, record, position).  Two calls, no state between them: _lengths computes every record's length (the caller
+ * lays the batch out: records of 500 bases and more, 32-byte aligned), _fill writes the bases.  rec_len_out / rec_out_off: one entry
+ * per record of every descendant's parent, in order; rec_out_off = ~0 drops a record. */
+typedef struct {
+    uint32_t parent;               /* genome index in the ancestors' batch */
+    uint32_t sub_ppm, indel_ppm;   /* substitutions / short-indel events per million positions */
+    uint32_t n_events;             /* structural events, 0..3, no two in one record */
+    uint64_t seed;
+    struct { uint32_t rec, type, s, n, b; } ev[3];   /* rec: record inside the parent; type 0 inversion of [s, s+n), 1 [s, s+n) moved to
+                                                        position b of the record without it, 2 deletion of [s, s+n) */
+    uint32_t pad;
+} skder_descendant_t;
+int skder_amd_descend_lengths(skder_ctx_t *ctx, const uint8_t *d_anc_bases, const skder_batch_t *anc, const skder_descendant_t *desc,
+                              uint32_t n_desc, uint32_t *rec_len_out, uint32_t n_rec_out);
+int skder_amd_descend_fill(skder_ctx_t *ctx, const uint8_t *d_anc_bases, const skder_batch_t *anc, const skder_descendant_t *desc,
+                           uint32_t n_desc, uint8_t *d_out_bases, const uint64_t *rec_out_off, uint32_t n_rec_out);
 
 /* ======================================================================================
  * C. the callers either side of the path: all work on the resident database
@@ -229,8 +255,8 @@ uint64_t skder_amd_db_n50(skder_db_t *db, uint32_t i);
  * (device to device) into a database of their own on `device` and indexed; `s` stays the caller's.  paths / first_names:
  * n strings each (the Ref_file / Ref_name columns; first_names may be NULL: empty names), n50 may be NULL (zeros).
  * A query path that equals one of `paths` is served from the resident sketch, as with skder_amd_sketch. */
-skder_db_t *skder_amd_db_from_sketches(skder_sketches_t *s, int device, const char *const *paths, const char *const *first_names,
-                                       const uint64_t *n50, char *err, size_t errlen);
+skder_db_t *skder_amd_db_from_sketches(skder_sketches_t *s, int device, uint32_t n /* entries of the three arrays: must equal the set's genome count */,
+                                       const char *const *paths, const char *const *first_names, const uint64_t *n50, char *err, size_t errlen);
 
 /* 8f-1  edge list handed over IN MEMORY.  All-pairs table of the resident database: the rows of
  * `skani triangle` (Ref = the genome whose path sorts first, skani's row order, --min-af applied),
@@ -257,6 +283,9 @@ int skder_amd_select_dynamic(const skder_edge_t *rows, uint64_t n_rows, uint32_t
 int skder_amd_select_clusters(const skder_edge_t *rows, uint64_t n_rows, uint32_t n_genomes, const char *const *paths,
                               const char *const *display_names, const uint32_t *reps, uint32_t n_reps, double af_cutoff_pct,
                               double ani_cutoff_pct, const char *clustering_txt /* skDER_Clustering.txt */, char *err, size_t errlen);
+/* rows whose table TEXT passes: ANI >= ani_cut and column af_column (4: Align_fraction_ref, 5: Align_fraction_query) >= af_cut -- the test
+ * of skder.py:127-129 on a `skani search` table, on edge records; pass[i] = 0 / 1 */
+int skder_amd_rows_pass(const skder_edge_t *rows, uint64_t n_rows, double ani_cut_pct, double af_cut_pct, int af_column, uint8_t *pass);
 /* hundredths of a percent as `%.2f` prints (double)((float)fraction * 100.0f): the rounding the table writer and the selection share */
 int64_t skder_amd_pct2_cents(float fraction);
 

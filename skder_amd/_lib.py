@@ -73,7 +73,12 @@ SYMBOLS = {
                                           C.c_char_p, C.c_size_t]),
     "skder_amd_select_clusters": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_uint32),
                                            C.c_uint32, C.c_double, C.c_double, C.c_char_p, C.c_char_p, C.c_size_t]),
+    "skder_amd_rows_pass": (C.c_int, [C.c_void_p, C.c_uint64, C.c_double, C.c_double, C.c_int, C.c_void_p]),
     "skder_amd_pct2_cents": (C.c_int64, [C.c_float]),
+    "skder_amd_descend_lengths": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]),
+    "skder_amd_descend_fill": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32]),
+    "skder_amd_peer_fallbacks": (C.c_uint32, []),
+    "skder_amd_release_cached_buffers": (C.c_int, [C.c_int]),
     "skder_amd_last_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "skder_amd_last_index_ms": (C.c_double, [C.c_void_p]),
     "skder_amd_last_runs_ms": (C.c_double, [C.c_void_p]),
@@ -84,7 +89,7 @@ SYMBOLS = {
     "skder_amd_triangle_multi": (C.c_int, [C.c_char_p, C.c_double, C.c_double, C.POINTER(C.c_int), C.c_int, C.c_char_p, C.c_char_p,
                                            C.c_char_p, C.c_size_t]),
     "skder_amd_sketch_multi": (C.c_void_p, [C.c_char_p, C.POINTER(C.c_int), C.c_int, C.c_char_p, C.c_char_p, C.c_size_t]),
-    "skder_amd_db_from_sketches": (C.c_void_p, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_void_p, C.c_char_p,
+    "skder_amd_db_from_sketches": (C.c_void_p, [C.c_void_p, C.c_int, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_void_p, C.c_char_p,
                                                C.c_size_t]),
     "skder_amd_db_size": (C.c_uint32, [C.c_void_p]),
     "skder_amd_db_path": (C.c_char_p, [C.c_void_p, C.c_uint32]),

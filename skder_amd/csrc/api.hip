@@ -6,6 +6,7 @@
 
 #include "device_utils.h"
 #include "engine.h"
+#include <atomic>
 #include "host_io.h"
 #include "screen.h"
 #include "synth.h"
@@ -82,6 +83,18 @@ extern "C" int skder_amd_copy_d2d(skder_ctx_t *ctx, void *dst, const void *src, 
     HIPCHECK(hipStreamSynchronize(ctx->stream));
     return 0;
     API_CATCH_CTX(ctx, 2)
+}
+
+// memory the library keeps between calls (the ingest's pinned staging buffers and their device copies, the device
+// allocator's cached blocks): handed back to the driver.  Buffers in use by a running call stay.
+extern "C" int skder_amd_release_cached_buffers(int device)
+{
+    try {
+        HIPCHECK(hipSetDevice(device));
+        const bool ok = staging_release(device);
+        pool_trim();
+        return ok ? 0 : 1;
+    } catch (const std::exception &) { return 2; }
 }
 
 extern "C" double skder_amd_last_index_ms(skder_ctx_t *ctx) { return ctx ? ctx->timing_index : 0.0; }
@@ -582,10 +595,11 @@ extern "C" skder_db_t *skder_amd_sketch_n50(const char *listing, int device, con
     }
 }
 
-extern "C" skder_db_t *skder_amd_db_from_sketches(skder_sketches_t *src, int device, const char *const *paths, const char *const *first_names,
-                                                  const uint64_t *n50, char *err, size_t errlen)
+extern "C" skder_db_t *skder_amd_db_from_sketches(skder_sketches_t *src, int device, uint32_t n_names, const char *const *paths,
+                                                  const char *const *first_names, const uint64_t *n50, char *err, size_t errlen)
 {
     if (!src || !paths) { set_err(err, errlen, "null argument"); return nullptr; }
+    if (n_names != src->n_genomes) { set_err(err, errlen, "paths / first_names / n50 must hold one entry per genome of the sketch set"); return nullptr; }
     skder_ctx *ctx = skder_amd_ctx_create(device, err, errlen);
     if (!ctx) return nullptr;
     skder_db *db = new skder_db();
@@ -616,6 +630,8 @@ extern "C" skder_db_t *skder_amd_db_from_sketches(skder_sketches_t *src, int dev
 // Peer access from `dev` to every other device of the list (once per process and pair): with it a copy between two GPUs goes
 // over their xGMI link directly; without it the runtime stages it through host memory (still correct, an order of magnitude
 // slower) -- said on stderr under SKDER_AMD_DEBUG, never silently.
+static std::atomic<uint32_t> g_peer_fallbacks{0};      // device pairs (ordered) whose copies go through host memory
+extern "C" uint32_t skder_amd_peer_fallbacks() { return g_peer_fallbacks.load(); }
 static void enable_peer_access(int dev, const std::vector<int> &devices)
 {
     HIPCHECK(hipSetDevice(dev));
@@ -628,6 +644,7 @@ static void enable_peer_access(int dev, const std::vector<int> &devices)
             if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) can = 0;
             (void)hipGetLastError();
         }
+        if (!can) g_peer_fallbacks++;
         if (!can && getenv("SKDER_AMD_DEBUG"))
             fprintf(stderr, "[skder_amd] GPU %d has no peer access to GPU %d: sketches from there are copied through host memory\n", dev, other);
     }

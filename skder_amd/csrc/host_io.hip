@@ -409,6 +409,18 @@ struct StagingLease {
 };
 }   // namespace
 
+// the cached staging set of a device (pinned text buffer, its device copy, bases buffer, pinned tables: ~0.6 GB of pinned host memory
+// and ~1.2 GB of HBM at the default batch size) handed back; a set that is in use stays.  A long-lived host application calls this
+// (skder_amd_release_cached_buffers) when it is done with a device for a while.
+bool staging_release(int device)
+{
+    if (device < 0 || device >= 64) return false;
+    std::lock_guard<std::mutex> lk(g_staging_mu);
+    if (g_staging[device].busy) return false;
+    for (auto &sl : g_staging[device].sl) sl.release();
+    return true;
+}
+
 // Host threads of the ingest: one per file in flight -- as many as the process may actually RUN at once.  A container is
 // often given fewer CPUs than the machine shows (cgroup CPU quota: the MI355X boxes this was measured on show 256 hardware
 // threads and grant 16 CPUs' worth of time); threads beyond the quota only get throttled, and the ingest was slower with 128
@@ -634,7 +646,7 @@ void sketch_files(skder_sketches *s, const std::vector<std::string> &paths, Geno
         bool direct = getenv("SKDER_AMD_IO_TWO_PHASE") == nullptr;
         for (size_t k = 0; k < ng; k++) direct = direct && info[i0 + k].trusted;
         bool text_only = direct && want_dev_parse;
-        for (size_t k = 0; k < ng && text_only; k++) text_only = info[i0 + k].text < 0xF0000000ull;
+        for (size_t k = 0; k < ng && text_only; k++) text_only = bound(info[i0 + k].text) <= 0xFFFFFFFFull;       // (its output region is addressed in 32 bits)
         if (text_only) {
             // DEVICE PARSE: the host threads only read (or inflate) every file into the pinned buffer -- '\n' in front of each
             // text and 128 bytes of '\n' behind it --; fasta_parse_kernel does the scan on the device
@@ -1022,6 +1034,9 @@ void write_rows_tsv(const std::string &out, const skder_edge_t *rows, size_t n, 
     std::vector<char> known(nblocks + 1, 0);
     std::mutex mu;
     std::condition_variable cv;
+    bool aborted = false;          // a block failed: nobody waits for an offset that will never be published (host_parallel_for
+                                   // stops dealing out blocks after a failure, so the block in front of a waiter may never run)
+    auto abort_all = [&]() { { std::lock_guard<std::mutex> lk(mu); aborted = true; } cv.notify_all(); };
     start[0] = hdr; known[0] = 1;
     host_parallel_for(nblocks, ingest_threads(), [&](size_t b) {
         std::string text, failure;
@@ -1036,16 +1051,17 @@ void write_rows_tsv(const std::string &out, const skder_edge_t *rows, size_t n, 
         uint64_t at;
         {
             std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&]() { return known[b] != 0; });          // blocks are dealt out in ascending order: b - 1 is being written or done
+            cv.wait(lk, [&]() { return known[b] != 0 || aborted; });          // blocks are dealt out in ascending order: b - 1 is being written or done
+            if (!known[b]) throw SkError("edge table: another block failed");
             at = start[b];
             start[b + 1] = at + text.size(); known[b + 1] = 1;     // published whatever happens to this block: nobody waits for ever
         }
         cv.notify_all();
-        if (!failure.empty()) throw SkError("edge table: " + failure);
+        if (!failure.empty()) { abort_all(); throw SkError("edge table: " + failure); }
         size_t done = 0;
         while (done < text.size()) {
             const ssize_t w = pwrite(fd, text.data() + done, text.size() - done, (off_t)(at + done));
-            if (w <= 0) throw SkError("write error on " + out);
+            if (w <= 0) { abort_all(); throw SkError("write error on " + out); }
             done += (size_t)w;
         }
     });

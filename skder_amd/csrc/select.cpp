@@ -349,5 +349,18 @@ extern "C" int skder_amd_select_clusters(const skder_edge_t *rows, uint64_t n_ro
     SEL_CATCH
 }
 
+// rows whose TABLE TEXT passes two cut-offs: ani >= ani_cut and column `af_column` (4: Align_fraction_ref, 5: Align_fraction_query) >= af_cut,
+// compared as the reference compares the parsed two-decimal text (skder.py:127-129 on a `skani search` table)
+extern "C" int skder_amd_rows_pass(const skder_edge_t *rows, uint64_t n_rows, double ani_cut_pct, double af_cut_pct, int af_column, uint8_t *pass)
+{
+    if ((!rows && n_rows) || !pass || (af_column != 4 && af_column != 5)) return 1;
+    const int32_t c_ani = cents_at_least(ani_cut_pct), c_af = cents_at_least(af_cut_pct);
+    parallel_ranges(n_rows, [&](unsigned, size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; i++)
+            pass[i] = pct2_cents((float)rows[i].ani) >= c_ani && pct2_cents((float)(af_column == 4 ? rows[i].af_ref : rows[i].af_query)) >= c_af;
+    });
+    return 0;
+}
+
 // the rounding rule by itself, for the tests (exhaustive comparison with printf)
 extern "C" int64_t skder_amd_pct2_cents(float fraction) { return pct2_cents(fraction); }

@@ -2,6 +2,11 @@
 // -> one seed bit and one marker bit per position.  In a header of its own so that profiles/calib/sketch_body_bench.hip
 // times exactly the code the kernel runs.
 #pragma once
+// The canonical 21-mer is taken with ONE v_min_f64 on 42-bit integers read as (denormal) doubles: correct only while f64 denormals
+// are preserved.  A fast-math build would flush every marker k-mer to zero without any error.
+#ifdef __FAST_MATH__
+#error "sketch_body.h orders 42-bit integers as f64 denormals (v_min_f64): do not build with -ffast-math / -Ofast"
+#endif
 #include "common.h"
 
 // mm_hash64 (include/skder_amd_spec.h): key = ~(key + (key << 21)); key ^= key >> 24; key *= 265; key ^= key >> 14; key *= 21;

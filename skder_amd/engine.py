@@ -14,6 +14,10 @@ EDGE_DTYPE = np.dtype([("ref", "<u4"), ("query", "<u4"), ("ani", "<f8"), ("af_re
                        ("n_chains", "<u4"), ("n_anchors", "<u4"), ("aligned_bases", "<u8"),
                        ("sum_anchors", "<u8"), ("sum_seeds", "<u8"), ("cell_seeds", "<u8"), ("ani_raw", "<f8")])
 assert EDGE_DTYPE.itemsize == C.sizeof(Edge)
+# skder_descendant_t (include/skder_amd.h): a descendant of a real assembly for the device generator
+DESCENDANT_DTYPE = np.dtype([("parent", "<u4"), ("sub_ppm", "<u4"), ("indel_ppm", "<u4"), ("n_events", "<u4"), ("seed", "<u8"),
+                             ("ev", [("rec", "<u4"), ("type", "<u4"), ("s", "<u4"), ("n", "<u4"), ("b", "<u4")], (3,)), ("pad", "<u4")])
+assert DESCENDANT_DTYPE.itemsize == 88
 
 
 class BatchLayout:
@@ -115,6 +119,39 @@ class Context:
         b = layout.c_batch()
         self.check(_lib.lib().skder_amd_synth_fill(self.h, d_bases_ptr, C.byref(b), lineage.ctypes.data,
                                                    params.ctypes.data), "synth_fill")
+
+
+    # ---- descendants of real assemblies, generated on the device (skder_amd/csrc/descend.hip)
+    def descend_lengths(self, d_anc_ptr: int, anc_layout: BatchLayout, desc: np.ndarray) -> np.ndarray:
+        """length of every record of every descendant (one entry per record of its parent, in order)"""
+        desc = np.ascontiguousarray(desc, DESCENDANT_DTYPE)
+        nrec = int(sum(int(anc_layout.genome_rec_begin[p + 1] - anc_layout.genome_rec_begin[p]) for p in desc["parent"]))
+        out = np.zeros(max(nrec, 1), np.uint32)
+        b = anc_layout.c_batch()
+        self.check(_lib.lib().skder_amd_descend_lengths(self.h, d_anc_ptr, C.byref(b), desc.ctypes.data, len(desc), out.ctypes.data, nrec), "descend_lengths")
+        return out[:nrec]
+
+    def descend_fill(self, d_anc_ptr: int, anc_layout: BatchLayout, desc: np.ndarray, d_out_ptr: int, rec_out_off: np.ndarray):
+        """the bases; rec_out_off: where each record goes in the output buffer (2^64 - 1: dropped)"""
+        desc = np.ascontiguousarray(desc, DESCENDANT_DTYPE)
+        off = np.ascontiguousarray(rec_out_off, np.uint64)
+        b = anc_layout.c_batch()
+        self.check(_lib.lib().skder_amd_descend_fill(self.h, d_anc_ptr, C.byref(b), desc.ctypes.data, len(desc), d_out_ptr, off.ctypes.data, len(off)), "descend_fill")
+
+    def descendants(self, d_anc_ptr: int, anc_layout: BatchLayout, desc: np.ndarray, torch):
+        """lengths, layout (records of 500 bases and more), bases: -> (device tensor, BatchLayout of the descendants)"""
+        lens = self.descend_lengths(d_anc_ptr, anc_layout, desc)
+        per, at = [], 0
+        for p in desc["parent"]:
+            k = int(anc_layout.genome_rec_begin[p + 1] - anc_layout.genome_rec_begin[p])
+            per.append(lens[at:at + k])
+            at += k
+        layout = BatchLayout([l[l >= 500] for l in per])
+        off = np.full(len(lens), np.uint64(0xFFFFFFFFFFFFFFFF), np.uint64)
+        off[lens >= 500] = layout.rec_off
+        d = torch.full((layout.total_bytes,), ord("A"), dtype=torch.uint8, device="cuda:%d" % self.device)
+        self.descend_fill(d_anc_ptr, anc_layout, desc, d.data_ptr(), off)
+        return d, layout
 
 
 def _np_from(ptr, n, dtype):

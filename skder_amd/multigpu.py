@@ -9,8 +9,9 @@ with torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" i
   * the marker screen is dealt out by rows (i = r, r + world, ...: row i has N-1-i entries);
   * every candidate pair goes to the rank that owns the genome it PROBES, which chains it;
   * edge records are gathered on rank 0.
-Collectives: the sketch all-gather (the only large one), the repetitive-cut-off table (4 B per genome), the candidate
-pair lists (8 B per pair) and the edge gather."""
+Collectives: the sketch all-gather (the only large one: one padded collective of everything a rank has, behind a 40-byte header),
+the repetitive-cut-off table (4 B per genome), the candidate pairs (8 B per pair, all_to_all_single: each pair to its owner only)
+and the edge gather."""
 from typing import Dict, List
 
 import numpy as np
@@ -24,50 +25,48 @@ def partition(n: int, world: int) -> List[range]:
     return [range(cuts[r], cuts[r + 1]) for r in range(world)]
 
 
-def _allgather_var(t: torch.Tensor, counts: List[int], group=None) -> torch.Tensor:
-    """all-gather of a 1-D tensor whose length differs per rank: padded to the maximum, then trimmed"""
-    world = len(counts)
-    mx = max(max(counts), 1)
-    if t.numel() == mx:
-        pad = t.contiguous()
-    else:
-        pad = torch.empty(mx, dtype=t.dtype, device=t.device)
-        pad[: t.numel()] = t
-    buf = torch.empty(world * mx, dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(buf, pad, group=group)
-    if all(c == mx for c in counts):
-        return buf
-    return torch.cat([buf[r * mx: r * mx + counts[r]] for r in range(world)])
-
-
 def exchange_raw(raw: Dict, group=None, staging: str = None) -> Dict:
     """raw: dict with torch tensors seed_kmer/seed_gpos (int32 views of u32) and markers
     (int64 view of u64) of THIS rank's genomes, and numpy metadata seed_off, marker_off, genome_len,
     genome_nrec, rec_goff.  Returns the same dict for the concatenation of all ranks' genomes.
-    staging="cpu": move device tensors through host memory (gloo backend)."""
+    TWO collectives: a 40-byte header per rank (the section sizes), then ONE padded all-gather of everything a rank has --
+    its per-genome tables, seed k-mers, seed positions and markers packed into one int64 buffer on the device (RCCL moves
+    it over xGMI; only the few KB of tables come back to the host).
+    staging="cpu": the buffer travels through host memory (gloo backend)."""
     world = dist.get_world_size(group)
-    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-    # per-genome tables of every rank: a fixed-size header, then one padded all-gather of the tables packed
-    # as int64 (no pickling, two small collectives)
+    nccl = dist.get_backend(group) == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
     ng = int(raw["n_genomes"])
     tabs = [np.asarray(raw["seed_off"], np.uint64), np.asarray(raw["marker_off"], np.uint64),
             np.asarray(raw["genome_len"], np.uint64), np.asarray(raw["genome_nrec"], np.uint64),
             np.asarray(raw["rec_goff"], np.uint64)]
     blob = np.concatenate(tabs).astype(np.int64)
-    hdr = torch.tensor([ng, int(raw["seed_kmer"].numel()), int(raw["markers"].numel()), len(tabs[4]), len(blob)], dtype=torch.int64, device=dev)
+    ns, nm = int(raw["seed_kmer"].numel()), int(raw["markers"].numel())
+    hdr = torch.tensor([ng, ns, nm, len(tabs[4]), len(blob)], dtype=torch.int64, device=dev)
     hdrs = torch.empty(world * 5, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(hdrs, hdr, group=group)
     H = hdrs.cpu().numpy().reshape(world, 5)
-    mxb = max(int(H[:, 4].max()), 1)
-    pad = torch.zeros(mxb, dtype=torch.int64, device=dev)
-    pad[: len(blob)] = torch.from_numpy(blob).to(dev)
-    blobs = torch.empty(world * mxb, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(blobs, pad, group=group)
-    B = blobs.cpu().numpy().reshape(world, mxb)
-    metas = []
+    # sections of a rank's buffer, in int64 words: tables | seed k-mers (two per word) | seed positions | markers
+    words = lambda h: (int(h[4]), (int(h[1]) + 1) // 2, (int(h[1]) + 1) // 2, int(h[2]))
+    mx = max(max(sum(words(H[r])) for r in range(world)), 1)
+    wdev = raw["seed_kmer"].device if (nccl or staging != "cpu") else torch.device("cpu")
+    mine = torch.zeros(mx, dtype=torch.int64, device=wdev)
+    w = words(H[dist.get_rank(group)])
+    o = 0
+    mine[o:o + w[0]] = torch.from_numpy(blob).to(wdev); o += w[0]
+    for key in ("seed_kmer", "seed_gpos"):
+        mine[o:o + w[1]].view(torch.int32)[:ns] = raw[key].to(wdev); o += w[1]
+    mine[o:o + w[3]] = raw["markers"].to(wdev)
+    if not nccl:
+        mine = mine.cpu()
+    allb = torch.empty(world * mx, dtype=torch.int64, device=mine.device)
+    dist.all_gather_into_tensor(allb, mine, group=group)
+    metas, parts = [], {"seed_kmer": [], "seed_gpos": [], "markers": []}
     for r in range(world):
         g, nr = int(H[r, 0]), int(H[r, 3])
-        b = B[r].view(np.uint64)
+        wr = words(H[r])
+        base = r * mx
+        b = allb[base:base + wr[0]].cpu().numpy().view(np.uint64)
         o = 0
         m = dict(n_genomes=g, n_seeds=int(H[r, 1]), n_markers=int(H[r, 2]))
         for key, ln, dt in (("seed_off", g + 1, np.uint64), ("marker_off", g + 1, np.uint64), ("genome_len", g, np.uint64),
@@ -75,14 +74,14 @@ def exchange_raw(raw: Dict, group=None, staging: str = None) -> Dict:
             m[key] = b[o:o + ln].astype(dt)
             o += ln
         metas.append(m)
+        o = base + wr[0]
+        parts["seed_kmer"].append(allb[o:o + wr[1]].view(torch.int32)[:m["n_seeds"]]); o += wr[1]
+        parts["seed_gpos"].append(allb[o:o + wr[2]].view(torch.int32)[:m["n_seeds"]]); o += wr[2]
+        parts["markers"].append(allb[o:o + wr[3]])
     out = dict(n_genomes=sum(m["n_genomes"] for m in metas))
     # the record index of a seed follows from its position and the record table: it is not exchanged
-    for key, cnt in (("seed_kmer", "n_seeds"), ("seed_gpos", "n_seeds"), ("markers", "n_markers")):
-        src = raw[key]
-        if staging == "cpu" and src.is_cuda:      # gloo functional runs: exchange through host memory
-            out[key] = _allgather_var(src.cpu(), [m[cnt] for m in metas], group).to(src.device)
-        else:
-            out[key] = _allgather_var(src, [m[cnt] for m in metas], group)
+    for key in parts:
+        out[key] = torch.cat(parts[key]).to(raw[key].device)
     so, mo = [np.zeros(1, np.uint64)], [np.zeros(1, np.uint64)]
     sbase = mbase = np.uint64(0)
     for m in metas:
@@ -178,20 +177,23 @@ def sketches_from_raw(ctx, raw: Dict):
 
 
 def route_pairs(ref: np.ndarray, query: np.ndarray, probed: np.ndarray, world: int, rank: int, group=None):
-    """all ranks' candidate pairs, each kept by the rank that owns the genome it probes (owner = genome mod world).
-    The lists are small (8 B per pair): one padded all-gather of (ref << 32 | query, probed) instead of an all-to-all."""
+    """every candidate pair to the rank that owns the genome it probes (owner = genome mod world): the pairs are ordered by
+    destination on the device, the ranks exchange their counts, then ONE all_to_all_single moves each pair (8 bytes) to its owner --
+    nobody receives a pair it does not chain.  Received pairs come grouped by sender, each sender's in its own order."""
     nccl = dist.get_backend(group) == "nccl"
     dev = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
-    packed = np.empty(2 * len(ref), np.int64)
-    packed[0::2] = (ref.astype(np.int64) << 32) | query.astype(np.int64)
-    packed[1::2] = probed.astype(np.int64)
-    n = torch.tensor([len(packed)], dtype=torch.int64, device=dev)
-    sizes = torch.empty(world, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(sizes, n, group=group)
-    allp = _allgather_var(torch.from_numpy(packed).to(dev), [int(x) for x in sizes.cpu().tolist()], group).cpu().numpy()
-    pr, pb = allp[0::2], allp[1::2]
-    mine = (pb % world) == rank
-    return (pr[mine] >> 32).astype(np.uint32), (pr[mine] & 0xFFFFFFFF).astype(np.uint32)
+    packed = torch.from_numpy((ref.astype(np.int64) << 32) | query.astype(np.int64)).to(dev)
+    dest = torch.from_numpy((probed.astype(np.int64) % world)).to(dev)
+    order = torch.argsort(dest, stable=True)
+    send = packed[order].contiguous()
+    counts = torch.bincount(dest, minlength=world).to(torch.int64)
+    incoming = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_to_all_single(incoming, counts, group=group)
+    n_in, n_out = [int(x) for x in incoming.cpu().tolist()], [int(x) for x in counts.cpu().tolist()]
+    recv = torch.empty(sum(n_in), dtype=torch.int64, device=dev)
+    dist.all_to_all_single(recv, send, output_split_sizes=n_in, input_split_sizes=n_out, group=group)
+    got = recv.cpu().numpy()
+    return (got >> 32).astype(np.uint32), (got & 0xFFFFFFFF).astype(np.uint32)
 
 
 def triangle_sharded(sk, rank: int, world: int, screen_pct: float, group=None, copy: bool = True) -> np.ndarray:
@@ -203,8 +205,7 @@ def triangle_sharded(sk, rank: int, world: int, screen_pct: float, group=None, c
     t = [time.perf_counter()]
 
     def lap():
-        if dbg:
-            t.append(time.perf_counter())
+        t.append(time.perf_counter())
 
     n = sk.view()["n_genomes"]
     owned = (np.arange(n) % world == rank).astype(np.uint8)
@@ -224,7 +225,8 @@ def triangle_sharded(sk, rank: int, world: int, screen_pct: float, group=None, c
     lap()
     edges = sk.chain_pairs(ref, query, copy=copy)
     lap()
+    names = ("index_enqueue", "screen", "index_wait_rep_cuts", "route", "chain")
+    triangle_sharded.last_stage_ms = {k: 1e3 * (t[i + 1] - t[i]) for i, k in enumerate(names)}      # (bench.py --gpus N reports them per rank)
     if dbg and rank == 0:
-        names = ("index_part (enqueue)", "screen_rows", "index wait + rep_cuts", "route_pairs", "chain_pairs")
-        print("[skder_amd] triangle_sharded: " + ", ".join("%s %.2f ms" % (k, 1e3 * (t[i + 1] - t[i])) for i, k in enumerate(names)), file=sys.stderr)
+        print("[skder_amd] triangle_sharded: " + ", ".join("%s %.2f ms" % kv for kv in triangle_sharded.last_stage_ms.items()), file=sys.stderr)
     return edges

@@ -148,11 +148,13 @@ class Database:
         a database of their own; `sketches` stays the caller's (include/skder_amd.h, skder_amd_db_from_sketches)"""
         import numpy as np
         k = len(paths)
+        if (first_names is not None and len(first_names) != k) or (n50 is not None and len(n50) != k):
+            raise ValueError("paths, first_names and n50 must have one entry per genome")
         ps = (C.c_char_p * max(k, 1))(*[p.encode() for p in paths])
         fn = (C.c_char_p * max(k, 1))(*[f.encode() for f in first_names]) if first_names is not None else None
         n50a = np.ascontiguousarray(n50, np.uint64) if n50 is not None else None
         err = C.create_string_buffer(_lib.ERRLEN)
-        h = _lib.lib().skder_amd_db_from_sketches(sketches.h, _device() if device is None else device, ps, fn,
+        h = _lib.lib().skder_amd_db_from_sketches(sketches.h, _device() if device is None else device, k, ps, fn,
                                                   n50a.ctypes.data if n50a is not None else None, err, _lib.ERRLEN)
         if not h:
             raise RuntimeError('Had an issue running: skder_amd_db_from_sketches: %s' % err.value.decode())
@@ -267,35 +269,45 @@ def lowMemGreedyDerep(all_genomes_listing_file, skder_lm_workspace, concat_n50_r
                 accounted_genomes |= _accounted_by_search_table(skani_search_result, ani_cutoff, af_cutoff)
                 emit(gn[0])
         else:
+            # rows are tested in bulk by the native code (the table's two-decimal text, skder.py:127-129) and applied with numpy:
+            # one species with 20,000 genomes returns ~20,000 rows per search, and per-row Python was the loop's time
+            import numpy as np
+            index_of = {p: i for i, p in enumerate(db.paths)}
+            acc = np.zeros(len(db.paths), bool)
+            extra = set()                                         # (genomes of the N50 table that are not in the database: cannot be accounted for)
+            is_acc = lambda g: acc[index_of[g]] if g in index_of else g in extra
             width = search_batch if search_batch > 1 else 4       # 0: adaptive, starting at 4
             pos = 0
+            stats = {"searches": 0, "rows": 0, "batches": 0}
             while pos < len(order):
                 batch = []
                 while pos < len(order) and len(batch) < width:
-                    if order[pos][0] not in accounted_genomes:
+                    if not is_acc(order[pos][0]):
                         batch.append(order[pos][0])
                     pos += 1
                 if not batch:
                     break
                 rows = db.search_batch(batch)
-                lo, kept = 0, 0
+                ok = np.zeros(len(rows), np.uint8)
+                if len(rows):
+                    _lib.lib().skder_amd_rows_pass(rows.ctypes.data, len(rows), float(ani_cutoff), float(af_cutoff), 5, ok.ctypes.data)
+                bounds = np.searchsorted(rows['query'], np.arange(len(batch) + 1))          # rows come grouped by query, in order
+                stats["batches"] += 1
+                kept = 0
                 for k, genome in enumerate(batch):
-                    hi = lo
-                    while hi < len(rows) and rows[hi]['query'] == k:
-                        hi += 1
-                    if genome not in accounted_genomes:
-                        for e in rows[lo:hi]:
-                            # column 5 of the table (Align_fraction_query), as skder.py:126-128 reads it
-                            if text_value(e['ani']) >= ani_cutoff and text_value(e['af_query']) >= af_cutoff:
-                                accounted_genomes.add(db.paths[int(e['ref'])])
+                    if not is_acc(genome):
+                        lo, hi = int(bounds[k]), int(bounds[k + 1])
+                        acc[rows['ref'][lo:hi][ok[lo:hi] != 0]] = True
                         emit(genome)
                         kept += 1
-                    lo = hi
+                        stats["searches"] += 1
+                        stats["rows"] += hi - lo
                 if search_batch == 0:
                     if kept == len(batch):
                         width = min(width * 2, 64)
                     elif kept * 2 < len(batch):
                         width = max(width // 2, 1)
+            lowMemGreedyDerep.last_stats = stats
         skder_result_handle.close()
     finally:
         if database is None:

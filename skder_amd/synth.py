@@ -178,3 +178,33 @@ def ani_vs_truth(edges, truth: np.ndarray, bins=((99.5, 100.0), (98.0, 99.5), (9
                                    "raw_bias": float(r.mean()) if len(r) else None, "raw_rms": float(np.sqrt((r ** 2).mean())) if len(r) else None,
                                    "model_bias": float(m.mean()) if len(m) else None, "model_rms": float(np.sqrt((m ** 2).mean())) if len(m) else None}
     return out
+
+
+def real_family_plan(anc_rec_lens, per_ancestor: int, seed: int = 4, sub_log10=(-3.7, -1.5), max_events: int = 3):
+    """descendants of real assemblies for skder_amd/csrc/descend.hip (engine.Context.descendants): `per_ancestor` descendants of every
+    ancestor (anc_rec_lens: the record lengths of each), with the rates of bench._real_descendant -- substitutions log-uniform
+    0.02 - 3 %, one short indel per ~12 substitutions, 0 - 3 structural events (inversion / translocation / deletion of 0.5 - 20 kb,
+    each inside one record of at least 60 kb, no two in one record).  Returns an array of engine.DESCENDANT_DTYPE."""
+    from .engine import DESCENDANT_DTYPE
+    rng = np.random.RandomState(seed)
+    n_anc = len(anc_rec_lens)
+    out = np.zeros(n_anc * per_ancestor, DESCENDANT_DTYPE)
+    k = 0
+    for a in range(n_anc):
+        lens = np.asarray(anc_rec_lens[a], np.int64)
+        big = np.flatnonzero(lens >= 60000)
+        for d in range(per_ancestor):
+            sub = 10 ** rng.uniform(*sub_log10)
+            out[k]["parent"] = a
+            out[k]["sub_ppm"] = int(sub * 1e6)
+            out[k]["indel_ppm"] = int(sub * 1e6 / 12.0)
+            out[k]["seed"] = (np.uint64(seed) << np.uint64(40)) ^ (np.uint64(a) << np.uint64(20)) ^ np.uint64(d) ^ np.uint64(0x9E3779B97F4A7C15)
+            ne = min(int(rng.randint(0, max_events + 1)), len(big))
+            recs = rng.choice(big, ne, replace=False) if ne else []
+            for e, r in enumerate(recs):
+                n = int(rng.randint(500, 20000))
+                s = int(rng.randint(0, lens[r] - n))
+                out[k]["ev"][e] = (int(r), int(rng.randint(0, 3)), s, n, int(rng.randint(0, lens[r] - n + 1)))
+            out[k]["n_events"] = ne
+            k += 1
+    return out

@@ -24,6 +24,18 @@ def oracle():
 
 
 @pytest.fixture(scope="session")
+def ref_bins():
+    """the reference's own skDERsum / skDERcore (oracle/_ref), compiled from the sources under /root/reference by oracle/build_ref.sh
+    when that tree exists; None where it does not (the GPU box) -- tests then use committed outputs / digests of these binaries"""
+    import subprocess
+    d = os.path.join(ROOT, "oracle", "_ref")
+    have = lambda: all(os.path.isfile(os.path.join(d, b)) for b in ("skDERsum", "skDERcore"))
+    if not have() and os.path.isdir("/root/reference"):
+        subprocess.check_call(["bash", os.path.join(ROOT, "oracle", "build_ref.sh")], stdout=subprocess.DEVNULL)
+    return {b: os.path.join(d, b) for b in ("skDERsum", "skDERcore")} if have() else None
+
+
+@pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
 

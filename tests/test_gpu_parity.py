@@ -397,6 +397,8 @@ def test_several_gpus_in_one_process(gpu, tmp_path):
     assert _lib.lib().skder_amd_triangle_multi(str(listing).encode(), 10.0, 89.5, devs, len(ids), str(many).encode(), str(n3).encode(), err, 2048) == 0, err.value
     assert one.read_text() == many.read_text() and len(one.read_text().splitlines()) == 1 + 14 * 13 // 2
     assert n1.read_text() == n3.read_text()
+    if ndev > 1:        # distinct GPUs: the sketches must have crossed over xGMI, not through host memory
+        assert _lib.lib().skder_amd_peer_fallbacks() == 0, "a GPU pair has no peer access: copies were staged through host memory"
     # search on a database spread over the "GPUs": same tables as the one-GPU database, batch and single
     db1 = skder.Database.from_listing(str(listing), devices=[0])
     db3 = skder.Database.from_listing(str(listing), devices=ids)
@@ -1668,7 +1670,7 @@ def test_config4_low_mem_greedy_at_scale(gpu, oracle, tmp_path):
             assert got.read_text() == want.read_text() and got.read_text().count("\n") > 50
 
 
-def test_driver_greedy_and_dynamic_on_1000_genomes(gpu, oracle, tmp_path):
+def test_driver_greedy_and_dynamic_on_1000_genomes(gpu, oracle, ref_bins, tmp_path):
     """BASELINE.json configs[1] / [2] by their own words -- greedy and dynamic selection over >= 1,000 genomes -- through
     the whole flow of bin/skder (skder_amd.driver.run: FASTA files -> N50 table -> edge table on the GPU -> selection):
     1,000 synthetic 2.8 Mb genomes = 10 species x 10 strains x 10 isolates.  At -i 98.5 -f 50 the table's edges join exactly
@@ -1698,12 +1700,33 @@ def test_driver_greedy_and_dynamic_on_1000_genomes(gpu, oracle, tmp_path):
     hdr, rows = load_table(str(table))
     assert len(rows) == 10 * (100 * 99 // 2)                                # every within-species pair, nothing across species
     n50_file = tmp_path / "greedy" / "Concatenated_N50.txt"
-    ref_dir = os.path.join(ROOT, "oracle", "_ref")
-    if os.path.isfile(os.path.join(ref_dir, "skDERsum")) and os.path.isfile(os.path.join(ref_dir, "skDERcore")):
-        out = subprocess.run([os.path.join(ref_dir, "skDERsum"), str(table), str(n50_file), "98.5", "50.0"], capture_output=True, text=True, check=True).stdout
-        assert out == (tmp_path / "greedy" / "Genome_Information_for_Greedy_Clustering.txt").read_text()
-        out = subprocess.run([os.path.join(ref_dir, "skDERcore"), str(table), str(n50_file), "98.5", "50.0", "10.0"], capture_output=True, text=True, check=True).stdout
+    # the reference's own binaries on this table.  Where they exist (oracle/_ref, built from /root/reference by conftest) they run here;
+    # where they cannot (the GPU box has no /root/reference) their outputs are pinned by DIGESTS generated in the build container
+    # (tests/golden/make_n1000_fixture.py: the same table with the scratch directory replaced by /G/).  Never a silent pass:
+    # a table the fixture does not describe fails the test.
+    import hashlib
+    import json
+    norm = lambda text: text.replace(str(fdir) + "/", "/G/")
+    sha = lambda text: hashlib.sha256(text.encode()).hexdigest()
+    info_txt = (tmp_path / "greedy" / "Genome_Information_for_Greedy_Clustering.txt").read_text()
+    dump = os.environ.get("SKDER_AMD_DUMP_N1000")          # (fixture generation: the normalised table and N50 file for the reference binaries)
+    if dump:
+        os.makedirs(dump, exist_ok=True)
+        open(os.path.join(dump, "table.tsv"), "w").write(norm(table.read_text()))
+        open(os.path.join(dump, "n50.txt"), "w").write(norm(n50_file.read_text()))
+    if ref_bins:
+        out = subprocess.run([ref_bins["skDERsum"], str(table), str(n50_file), "98.5", "50.0"], capture_output=True, text=True, check=True).stdout
+        assert out == info_txt
+        out = subprocess.run([ref_bins["skDERcore"], str(table), str(n50_file), "98.5", "50.0", "10.0"], capture_output=True, text=True, check=True).stdout
         assert out.split() == reps_d
+    fx_path = os.path.join(GOLDEN, "downstream", "n1000_reference_digests.json")
+    if os.path.isfile(fx_path):
+        fx = json.load(open(fx_path))
+        assert sha(norm(table.read_text())) == fx["table_sha256"], "the 1,000-genome table differs from the one the reference binaries were run on"
+        assert sha(norm(info_txt)) == fx["skDERsum_98.5_50_sha256"]
+        assert sha(norm("".join(r + "\n" for r in reps_d))) == fx["skDERcore_98.5_50_10_sha256"]
+    else:
+        assert ref_bins, "neither oracle/_ref nor tests/golden/downstream/n1000_reference_digests.json: nothing to hold the selection against"
     # sampled rows against the oracle: two strains of species 3 and one of species 7 (30 genomes, 435 pairs of which 390 within a species)
     pick = [p for p in paths if strain_of[p] in ((3, 0), (3, 7), (7, 4))]
     sub = tmp_path / "sub.txt"
@@ -1715,6 +1738,136 @@ def test_driver_greedy_and_dynamic_on_1000_genomes(gpu, oracle, tmp_path):
     assert len(orows) == 20 * 19 // 2 + 10 * 9 // 2
     for r in orows:
         assert big[(r[0], r[1])] == r, r[:2]
+
+
+def test_device_descendants_of_real_assemblies(gpu, oracle):
+    """descend.hip, the generator behind the real-structure benchmark workloads: descendants of two real assemblies built ON the device.
+    Hand-checkable cases against numpy (no edit: the parent itself; one inversion / translocation / deletion alone), the two passes
+    agree (lengths = bases written, padding untouched), a descendant does not depend on the batch it is generated in, and the family
+    -- substitutions, short indels, structural events on real contig structure -- through sketch + triangle is bit-equal with the oracle."""
+    from skder_amd import synth
+    from skder_amd.engine import DESCENDANT_DTYPE
+    engine, ctx, torch = gpu
+    recs = [_read_records(os.path.join(GOLDEN, "genomes", n)) for n in (GENOMES[0], GENOMES[5])]
+    anc_layout = engine.BatchLayout([r[0] for r in recs])
+    d_anc = torch.from_numpy(anc_layout.pack_host([r[1] for r in recs])).cuda()
+    lens0 = recs[0][0].astype(np.int64)
+    big = int(np.argmax(lens0))
+    assert lens0[big] > 100000
+    plan = np.zeros(4, DESCENDANT_DTYPE)
+    plan["parent"] = 0
+    plan["seed"] = [11, 12, 13, 14]
+    for k, (typ, s_, n_, b_) in enumerate([(None, 0, 0, 0), (0, 5000, 7001, 0), (1, 20000, 3000, 61234), (2, 40000, 12345, 0)]):
+        if typ is not None:
+            plan[k]["n_events"] = 1
+            plan[k]["ev"][0] = (big, typ, s_, n_, b_)
+    d_out, lay = ctx.descendants(d_anc.data_ptr(), anc_layout, plan, torch)
+    host = d_out.cpu().numpy()
+    comp = np.zeros(256, np.uint8)
+    for a, b in zip(b"ACGTacgtNn", b"TGCAtgcaNn"):
+        comp[a] = b
+    off0 = np.concatenate([[0], np.cumsum(lens0)])
+    parent_rec = recs[0][1][off0[big]:off0[big + 1]]
+
+    def rec_of(g, r):
+        i = int(lay.genome_rec_begin[g]) + r
+        return host[int(lay.rec_off[i]):int(lay.rec_off[i]) + int(lay.rec_len[i])]
+    assert all((rec_of(0, r) == recs[0][1][off0[r]:off0[r + 1]]).all() for r in range(len(lens0)))       # no edits: the parent
+    want = parent_rec.copy(); want[5000:12001] = comp[parent_rec[5000:12001][::-1]]
+    assert (rec_of(1, big) == want).all()                                                                  # inversion
+    rest = np.concatenate([parent_rec[:20000], parent_rec[23000:]])
+    assert (rec_of(2, big) == np.concatenate([rest[:61234], parent_rec[20000:23000], rest[61234:]])).all()  # translocation
+    assert (rec_of(3, big) == np.concatenate([parent_rec[:40000], parent_rec[52345:]])).all()              # deletion
+    for g in (1, 2, 3):                                                                                    # the other records: untouched
+        assert all((rec_of(g, r) == recs[0][1][off0[r]:off0[r + 1]]).all() for r in range(len(lens0)) if r != big)
+    # a random family: two passes agree, padding untouched, batch-independent
+    fam = synth.real_family_plan([r[0] for r in recs], 3, seed=9)
+    assert len(fam) == 6 and fam["sub_ppm"].min() > 0
+    d_fam, lay_f = ctx.descendants(d_anc.data_ptr(), anc_layout, fam, torch)
+    hf = d_fam.cpu().numpy()
+    used = np.zeros(len(hf), bool)
+    for o, l in zip(lay_f.rec_off, lay_f.rec_len):
+        used[int(o):int(o) + int(l)] = True
+    assert (hf[~used] == ord("A")).all() and np.isin(hf[used], np.frombuffer(b"ACGTNacgtn", np.uint8)).all()
+    alone, lay_a = ctx.descendants(d_anc.data_ptr(), anc_layout, fam[4:5], torch)
+    ha = alone.cpu().numpy()
+    i0, i1 = int(lay_f.genome_rec_begin[4]), int(lay_f.genome_rec_begin[5])
+    assert (lay_a.rec_len == lay_f.rec_len[i0:i1]).all()
+    for k in range(i1 - i0):
+        assert (ha[int(lay_a.rec_off[k]):int(lay_a.rec_off[k]) + int(lay_a.rec_len[k])] ==
+                hf[int(lay_f.rec_off[i0 + k]):int(lay_f.rec_off[i0 + k]) + int(lay_f.rec_len[i0 + k])]).all()
+    # the edits are what they say: a descendant differs from its parent by about its rates
+    g0 = np.concatenate([hf[int(o):int(o) + int(l)] for o, l in zip(lay_f.rec_off[:int(lay_f.genome_rec_begin[1])], lay_f.rec_len[:int(lay_f.genome_rec_begin[1])])])
+    assert abs(len(g0) - len(recs[0][1])) < 0.02 * len(recs[0][1]) + 25000
+    # parity of the whole family (and the two parents) with the oracle
+    p = oracle.default_params()
+    s = engine.Sketches(ctx)
+    s.sketch_batch(d_anc.data_ptr(), anc_layout)
+    s.sketch_batch(d_fam.data_ptr(), lay_f)
+    og = [oracle.Genome.from_bases(r[1], r[0], p) for r in recs]
+    for g in range(6):
+        a, b = int(lay_f.genome_rec_begin[g]), int(lay_f.genome_rec_begin[g + 1])
+        bases = np.concatenate([hf[int(lay_f.rec_off[i]):int(lay_f.rec_off[i]) + int(lay_f.rec_len[i])] for i in range(a, b)])
+        og.append(oracle.Genome.from_bases(bases, lay_f.rec_len[a:b], p))
+    edges = s.triangle_rows(0, 1, 80.0)
+    want = _oracle_edges(oracle, og, p, 80.0)
+    assert len(want) == 28
+    _check_edges(edges, want)
+    s.close()
+
+
+def test_tc_grid_through_the_gpu_dropin(gpu, tmp_path):
+    """The reference's `-tc` sweep (bin/skder:331-407: 6 ANI x 5 AF cut-offs over ONE table, `--min-af 10 -s 89.5`) through the GPU
+    drop-in and the native selection, against the 30 golden listings of test_case/skder_gtdb_results/skDER_Result/.  A FLOOR, with
+    the reason for every listing that differs on record: ANI / AF come from the stand-in for skani's learned model (DESIGN.md section
+    2), so an edge whose golden value and ours lie on different sides of a cut-off can move a representative.
+      * every listing at the cut-offs skDER is run with (-i 99.0, 99.5; all five AF cut-offs) is identical, order included;
+      * at least 19 of the 30 are identical;
+      * every other listing differs by at most one representative AND is explained: some pair that involves a genome of the
+        difference (or one of its neighbours at the cut-off) passes the cut-offs in one table and not in the other."""
+    import json
+    from skder_amd import selection as S
+    from skder_amd.skder import Database
+    from test_selection import ANI_CUTS, AF_CUTS, D
+    names = sorted(os.listdir(os.path.join(GOLDEN, "genomes")))
+    listing = tmp_path / "l.txt"
+    listing.write_text("".join(os.path.join(GOLDEN, "genomes", n) + "\n" for n in names))
+    n50g = S.read_n50(os.path.join(D, "skder_gtdb_results__Concatenated_N50.txt"))           # keys: file names, the golden listing's order
+    with Database.from_listing(str(listing), str(tmp_path / "n50.txt")) as db:
+        rows = db.triangle(10.0, 89.5, out_tsv=str(tmp_path / "tri.tsv"))
+        base = [os.path.basename(p) for p in db.paths]
+        assert [n50g[b] for b in base] == list(db.n50)                                        # the N50 table of the ingest pass = the golden one
+        order = [base.index(k) for k in n50g]                                                 # the golden run listed the genomes in another order:
+        inv = {g: i for i, g in enumerate(order)}                                             # selection walks the N50 file, so re-index to it
+        r2 = rows.copy()
+        r2["ref"] = [inv[int(x)] for x in rows["ref"]]
+        r2["query"] = [inv[int(x)] for x in rows["query"]]
+        paths2 = [base[g] for g in order]
+        n502 = [n50g[b] for b in paths2]
+        ours = {(a, f): [paths2[i] for i in S.native_greedy(r2, paths2, n502, a, f)] for a in ANI_CUTS for f in AF_CUTS}
+    gold_edges = {(os.path.basename(a), os.path.basename(b)): (x, y, z) for a, b, x, y, z in S.edges_from_table(os.path.join(GOLDEN, "G5_triangle_minaf10_s89.5.tsv"))}
+    our_edges = {(os.path.basename(a), os.path.basename(b)): (x, y, z) for a, b, x, y, z in S.edges_from_table(str(tmp_path / "tri.tsv"))}
+    assert set(gold_edges) == set(our_edges)
+    same, record = 0, []
+    for a in ANI_CUTS:
+        for f in AF_CUTS:
+            want = [l.rstrip("\n") for l in open(os.path.join(D, "tc", "skDER_Results_ANI%s_AF%s.txt" % (a, f)))]
+            got = ours[(a, f)]
+            if got == want:
+                same += 1
+                continue
+            assert a < 99.0, (a, f)                                                           # the cut-offs skDER runs with: identical
+            diff = set(got) ^ set(want)
+            assert abs(len(got) - len(want)) <= 1 and len(diff) <= 2, (a, f, sorted(diff))
+            passes = lambda e: e[0] >= a and (e[1] >= f or e[2] >= f)
+            flips = [k for k in gold_edges if passes(gold_edges[k]) != passes(our_edges[k])]
+            assert flips, "listing at -i %s -f %s differs without any edge changing sides of the cut-offs" % (a, f)
+            near = [k for k in flips if k[0] in diff or k[1] in diff]
+            record.append({"ani": a, "af": f, "only_ours": sorted(set(got) - set(want)), "only_golden": sorted(set(want) - set(got)),
+                           "edges_on_the_other_side": len(flips),
+                           "deciding": [{"pair": k, "golden": gold_edges[k], "ours": our_edges[k]} for k in (near or flips)[:3]]})
+    print(json.dumps({"identical": same, "of": 30, "differing": record}))
+    assert same >= 19, same
 
 
 def test_config5_mixed_sizes_with_the_af_filter(gpu, oracle, tmp_path):
@@ -1734,6 +1887,73 @@ def test_config5_mixed_sizes_with_the_af_filter(gpu, oracle, tmp_path):
     assert got.read_text() == want.read_text()
     rows = got.read_text().splitlines()
     assert len(rows) == 1 + 3 * (8 * 7 // 2)                                              # every within-species pair, none across
+
+
+def test_config5_shape_at_3000_genomes(gpu, oracle, tmp_path):
+    """BASELINE.json configs[4]'s shape at a size the oracle cannot cross-check pair by pair: 3,000 genomes of 1 - 8 Mb in 30 species,
+    `--min-af` filter on, through the database calls the driver uses (sketches streamed batch by batch -- the bases are never resident
+    together --, skder_amd_db_triangle, the in-place row order, the parallel writer).  Size-independent properties:
+      * the unfiltered table holds exactly the within-species pairs, Ref < Query by path, and two runs are bit-identical;
+      * the AF filter at a boundary that cuts the table in half keeps exactly the rows with max(AF_ref, AF_query) >= cut-off on the
+        unrounded single-precision values (SURVEY V4), in the unfiltered table's order, and the text table has those rows;
+      * same-strain pairs are closer than different strains; AF within (0, 1];
+      * sampled rows (one pair of 8 Mb genomes, one of 1 Mb genomes, one across strains) equal the oracle's bit for bit;
+      * the native greedy selection on the rows returns at least one representative per species and never two of one strain at -i 98.5."""
+    from skder_amd import synth, selection as S
+    from skder_amd.skder import Database
+    engine, ctx, torch = gpu
+    n, nsp = 3000, 30
+    rec = synth.make_recipe(n, len_range=(1_000_000, 8_000_000), n_species=nsp, seed=505)
+    sk = engine.Sketches(ctx)
+    for b0 in range(0, n, 250):                       # streamed: a batch's bases are dropped before the next is generated
+        gs = range(b0, min(b0 + 250, n))
+        layout = engine.BatchLayout([rec.rec_lens[g] for g in gs])
+        d = torch.empty(layout.total_bytes, dtype=torch.uint8, device="cuda")
+        ctx.synth_fill(d.data_ptr(), layout, rec.lineage[gs.start:gs.stop], rec.params[gs.start:gs.stop])
+        sk.sketch_batch(d.data_ptr(), layout)
+        del d
+    paths = ["/mixed/species%02d/g%05d.fasta" % (int(rec.species[g]), g) for g in range(n)]
+    n50 = [int(sorted(rec.rec_lens[g])[len(rec.rec_lens[g]) // 2]) for g in range(n)]
+    with Database.from_sketches(sk, paths, n50) as db:
+        sk.close()
+        e0 = db.triangle(0.0, 80.0)
+        e1 = db.triangle(0.0, 80.0)
+        assert np.array_equal(e0, e1)                                               # bit-identical reruns, row order included
+        per = n // nsp
+        pairs = {(int(a), int(b)) for a, b in zip(e0["ref"], e0["query"])}
+        assert len(pairs) == len(e0) == nsp * (per * (per - 1) // 2)
+        assert all(a < b and a // per == b // per for a, b in pairs)               # (paths sort like indices here)
+        mx = np.maximum(e0["af_ref"].astype(np.float32), e0["af_query"].astype(np.float32)).astype(np.float64) * 100.0
+        cut = float(np.median(mx))
+        out = tmp_path / "filtered.tsv"
+        ef = db.triangle(cut, 80.0, out_tsv=str(out))
+        keep = mx >= cut
+        assert 0.3 < keep.mean() < 0.7 and np.array_equal(ef, e0[keep])             # the rule on unrounded values, order preserved
+        with open(out) as f:
+            assert sum(1 for _ in f) == 1 + int(keep.sum())
+        strain = lambda g: (g % per) % 10
+        same = np.array([strain(int(a)) == strain(int(b)) for a, b in zip(e0["ref"], e0["query"])])
+        assert e0["ani"][same].min() > e0["ani"][~same].max() and e0["ani"][same].min() > 0.98
+        assert (e0["af_ref"] > 0).all() and (e0["af_ref"] <= 1).all() and (e0["af_query"] > 0).all() and (e0["af_query"] <= 1).all()
+        # sampled rows against the oracle: the species with the longest and the shortest genomes
+        tl = np.array([rec.total_len(g) for g in range(n)])
+        p = oracle.default_params()
+        got = {(int(e["ref"]), int(e["query"])): e for e in e0}
+        for sp in (int(rec.species[int(np.argmax(tl))]), int(rec.species[int(np.argmin(tl))])):
+            g0 = sp * per
+            trio = [g0, g0 + 10, g0 + 1]                                            # same strain (0, 10), another strain (1)
+            og = [oracle.Genome.from_bases(synth.bases_numpy(rec, g), rec.rec_lens[g], p) for g in trio]
+            for i in range(3):
+                for j in range(i + 1, 3):
+                    a, b = sorted((trio[i], trio[j]))
+                    r = oracle.pair(og[i], og[j], p) if trio[i] < trio[j] else oracle.pair(og[j], og[i], p)
+                    e = got[(a, b)]
+                    assert int(e["n_anchors"]) == r.n_anchors and int(e["n_chains"]) == r.n_chains and int(e["aligned_bases"]) == r.aligned_bases, (a, b)
+                    assert float(e["ani"]) == r.ani and float(e["af_ref"]) == r.af_ref and float(e["af_query"]) == r.af_query, (a, b)
+        assert tl.max() > 7_000_000 and tl.min() < 1_500_000
+        reps = S.native_greedy(e0, paths, n50, 98.5, 50.0)
+        assert {r // per for r in reps} == set(range(nsp))
+        assert len({(r // per, strain(r)) for r in reps}) == len(reps)
 
 
 def _fuzz_repeats_module():

@@ -153,9 +153,10 @@ def test_native_equals_the_python_statement_on_random_tables(tmp_path):
                 assert _lines(clu) == mapped
 
 
-@pytest.mark.skipif(not os.path.isfile(os.path.join(ROOT, "oracle", "_ref", "skDERcore")), reason="oracle/_ref is built only where /root/reference exists")
-def test_native_against_the_reference_binaries(tmp_path):
+def test_native_against_the_reference_binaries(ref_bins, tmp_path):
     """skDERsum / skDERcore compiled from the reference's sources, on the golden tables: identical output"""
+    if not ref_bins:
+        pytest.skip("the reference's binaries need /root/reference (absent on this box); the golden files they wrote are tested above")
     for tag in TABLES:
         S, rows, paths, n50, _, _ = _load(tag)
         tp, nf = os.path.join(GOLDEN, TABLES[tag][0]), os.path.join(D, TABLES[tag][1])
