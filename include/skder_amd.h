@@ -233,6 +233,14 @@ int skder_amd_descend_lengths(skder_ctx_t *ctx, const uint8_t *d_anc_bases, cons
 int skder_amd_descend_fill(skder_ctx_t *ctx, const uint8_t *d_anc_bases, const skder_batch_t *anc, const skder_descendant_t *desc,
                            uint32_t n_desc, uint8_t *d_out_bases, const uint64_t *rec_out_off, uint32_t n_rec_out);
 
+/* DEFLATE on the device (ginflate.hip): n raw DEFLATE streams resident in HBM (the bytes behind a gzip header; the host parses header
+ * and trailer) -> their text, one wavefront per stream; then the CRC-32 of every text.  jobs / results are host arrays.
+ * status: 0 ok, 2 corrupt, 3 truncated, 4 the text is longer than out_cap.  kernel_ms (may be NULL): [0] inflate, [1] CRC. */
+typedef struct { uint64_t in_off; uint32_t in_len, pad; uint64_t out_off, out_cap; } skder_gz_job_t;
+typedef struct { uint32_t status, crc, in_used, pad; uint64_t out_len; } skder_gz_result_t;
+int skder_amd_inflate_device(skder_ctx_t *ctx, const uint8_t *d_in, const skder_gz_job_t *jobs, uint32_t n, uint8_t *d_out,
+                             skder_gz_result_t *results, float *kernel_ms);
+
 /* ======================================================================================
  * C. the callers either side of the path: all work on the resident database
  * ====================================================================================== */
