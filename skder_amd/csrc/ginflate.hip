@@ -6,7 +6,8 @@
 //
 // One wavefront decodes one stream, every lane holding the SAME decoder state (bit buffer, positions): table look-ups are
 // broadcast LDS reads, the instruction stream is uniform, and the 64 lanes are used where the work is wide --
-//   * input: 512 bytes at a time from HBM into an LDS ring (coalesced 8-byte loads), the bit buffer refills from LDS;
+//   * input: 256 bytes of the stream sit IN REGISTERS (lane k holds word k; the next 256 are requested a block ahead), the bit
+//     buffer refills by a cross-lane read -- no memory access on the decoder's critical path;
 //   * Huffman tables in LDS (9-bit root for literals / lengths, 6-bit for distances, second-level tables behind them: the
 //     sizes zlib proves sufficient, 852 + 592 entries), built per block with the entry fills spread over the lanes;
 //   * the 32 KB window in LDS: a match is ONE cooperative copy (lane k moves byte k; overlapping matches read modulo the
@@ -24,7 +25,6 @@
 #define GI_DIST_ROOT 6u
 #define GI_LIT_N 852u          // zlib: ENOUGH_LENS for a 9-bit root and 286 symbols
 #define GI_DIST_N 592u         // zlib: ENOUGH_DISTS for a 6-bit root and 30 symbols
-#define GI_RING 1024u          // input ring, bytes (two halves of 512)
 
 enum : uint32_t { GK_LITERAL = 0, GK_MATCH = 1, GK_END = 2, GK_SUB = 3, GK_INVALID = 4 };
 // table entry: [31:16] value, [15:12] kind, [11:8] extra bits (or index bits of a second-level table), [7:0] bits consumed
@@ -41,8 +41,8 @@ struct __attribute__((aligned(16))) GiLds {
     uint32_t lit[GI_LIT_N];
     uint32_t dist[GI_DIST_N];
     union {
-        struct { uint32_t ring[GI_RING / 4]; uint32_t pre[128]; } in;          // while bits are read
-        struct { uint8_t sub_bits[512]; uint16_t sub_start[512]; } build;      // while a table is built (the ring is re-staged afterwards)
+        struct { uint32_t pre[128]; } in;                                       // the code-length code's table, while a block's code lengths are read
+        struct { uint8_t sub_bits[512]; uint16_t sub_start[512]; } build;      // while the literal / distance tables are built
     } u;
     uint8_t lens[352];        // fixed code: 288 + 32; dynamic: the 19 lengths of the code-length code in front, the others from 32 on
     uint32_t count[16];
@@ -50,6 +50,7 @@ struct __attribute__((aligned(16))) GiLds {
 };
 static_assert(sizeof(GiLds) <= 40960, "four wavefronts per CU");
 
+#define GI_UNI(X) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(X)))      // a value that is the same in every lane, as a scalar
 #define GI_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
 struct GiIn {
@@ -58,28 +59,37 @@ struct GiIn {
     uint64_t bb;             // bit buffer, next bit of the stream in bit 0
     uint32_t nb;             // valid bits
     uint32_t ipos;           // next input byte that enters the bit buffer (a multiple of 4)
-    uint32_t staged;         // the ring holds input bytes [staged - 1024, staged), staged a multiple of 512
+    uint32_t cur, nxt;       // input IN REGISTERS: lane k holds word k of the 256-byte block that contains ipos (cur) and of the one behind it (nxt,
+                             // requested a block ahead: its latency is hidden behind ~700 bytes of decoded text)
 };
 
-// the next 512 input bytes into their half of the ring (bytes behind the end of the stream read as zero)
-__device__ __forceinline__ void gi_stage(GiLds &L, GiIn &I, uint32_t lane)
+// word `lane` of the 256-byte block b of the stream (bytes behind its end read as zero)
+__device__ __forceinline__ uint32_t gi_load_word(const GiIn &I, uint32_t block, uint32_t lane)
 {
-    const uint32_t at = I.staged + lane * 8u;
-    uint64_t v = 0;
-    if (at + 8u <= I.len) __builtin_memcpy(&v, I.src + at, 8);
-    else for (uint32_t k = 0; k < 8u; k++) if (at + k < I.len) v |= (uint64_t)I.src[at + k] << (8u * k);
-    const uint32_t w = ((I.staged & (GI_RING - 1u)) >> 2) + lane * 2u;
-    L.u.in.ring[w] = (uint32_t)v; L.u.in.ring[w + 1u] = (uint32_t)(v >> 32);
-    I.staged += 512u;
-    GI_SYNC();
+    const uint64_t at = (uint64_t)block * 256u + lane * 4u;
+    uint32_t v = 0;
+    if (at + 4u <= I.len) __builtin_memcpy(&v, I.src + at, 4);
+    else for (uint32_t k = 0; k < 4u; k++) if (at + k < I.len) v |= (uint32_t)I.src[at + k] << (8u * k);
+    return v;
 }
-// at least 33 valid bits
-__device__ __forceinline__ void gi_refill(GiLds &L, GiIn &I, uint32_t lane)
+__device__ __forceinline__ void gi_start(GiIn &I, uint32_t lane)
+{
+    I.bb = 0; I.nb = 0; I.ipos = 0;
+    I.cur = gi_load_word(I, 0u, lane);
+    I.nxt = gi_load_word(I, 1u, lane);
+}
+// at least 33 valid bits: 32 more from the register block (a cross-lane read: no memory access on the decoder's critical path)
+__device__ __forceinline__ void gi_refill(GiIn &I, uint32_t lane)
 {
     while (I.nb <= 32u) {
-        if (I.ipos + 4u > I.staged) gi_stage(L, I, lane);
-        I.bb |= (uint64_t)L.u.in.ring[(I.ipos & (GI_RING - 1u)) >> 2] << I.nb;
+        const uint32_t wsel = (uint32_t)__builtin_amdgcn_readfirstlane((int)((I.ipos >> 2) & 63u));
+        const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)I.cur, (int)wsel);
+        I.bb |= (uint64_t)word << I.nb;
         I.nb += 32u; I.ipos += 4u;
+        if ((I.ipos & 255u) == 0u) {                 // into the next block: it is here already; request the one behind it
+            I.cur = I.nxt;
+            I.nxt = gi_load_word(I, (I.ipos >> 8) + 1u, lane);
+        }
     }
 }
 __device__ __forceinline__ uint32_t gi_take(GiIn &I, uint32_t n)
@@ -88,8 +98,6 @@ __device__ __forceinline__ uint32_t gi_take(GiIn &I, uint32_t n)
     I.bb >>= n; I.nb -= n;
     return v;
 }
-// after a table build (which used the ring's memory): forget what was staged; the next refill stages again
-__device__ __forceinline__ void gi_restage(GiIn &I) { I.staged = I.ipos & ~511u; }
 
 __device__ __forceinline__ uint32_t gi_symbol_entry(int tk, uint32_t sym, uint32_t len)
 {
@@ -115,19 +123,19 @@ __device__ bool gi_build(GiLds &L, int tk, const uint8_t *lens, uint32_t n, uint
     for (uint32_t i = lane; i < n; i += 64u) atomicAdd(&L.count[lens[i]], 1u);
     GI_SYNC();
     uint32_t max_len = 15u;
-    while (max_len > 0u && L.count[max_len] == 0u) max_len--;
+    while (max_len > 0u && GI_UNI(L.count[max_len]) == 0u) max_len--;
     const uint32_t root_size = 1u << root;
     for (uint32_t i = lane; i < root_size; i += 64u) table[i] = GI_ENTRY(0, GK_INVALID, 0, 1);
     GI_SYNC();
     if (max_len == 0u) return tk != 0;
     int left = 1;
-    for (uint32_t len = 1; len <= 15u; len++) { left = left * 2 - (int)L.count[len]; if (left < 0) return false; }
+    for (uint32_t len = 1; len <= 15u; len++) { left = left * 2 - (int)GI_UNI(L.count[len]); if (left < 0) return false; }
     if (left > 0 && (tk == 0 || max_len != 1u)) return false;
     {
         uint32_t code = 0, prev = 0;
         for (uint32_t len = 1; len <= 15u; len++) {
             code = (code + prev) << 1;
-            prev = L.count[len];
+            prev = GI_UNI(L.count[len]);
             if (lane == 0u) L.nc[len] = code;
         }
         GI_SYNC();
@@ -140,9 +148,9 @@ __device__ bool gi_build(GiLds &L, int tk, const uint8_t *lens, uint32_t n, uint
         if (lane < 16u) L.count[lane] = L.nc[lane];
         GI_SYNC();
         for (uint32_t s = 0; s < n; s++) {
-            const uint32_t len = lens[s];
+            const uint32_t len = GI_UNI(lens[s]);
             if (!len) continue;
-            const uint32_t code = L.count[len];
+            const uint32_t code = GI_UNI(L.count[len]);
             GI_SYNC();
             if (lane == 0u) {
                 L.count[len] = code + 1u;
@@ -155,7 +163,7 @@ __device__ bool gi_build(GiLds &L, int tk, const uint8_t *lens, uint32_t n, uint
         }
         uint32_t next = root_size;
         for (uint32_t pfx = 0; pfx < root_size; pfx++) {
-            const uint32_t sb = L.u.build.sub_bits[pfx];
+            const uint32_t sb = GI_UNI(L.u.build.sub_bits[pfx]);
             if (!sb) continue;
             const uint32_t size = 1u << sb;
             if (next + size > table_size) return false;
@@ -166,9 +174,9 @@ __device__ bool gi_build(GiLds &L, int tk, const uint8_t *lens, uint32_t n, uint
         GI_SYNC();
     }
     for (uint32_t s = 0; s < n; s++) {
-        const uint32_t len = lens[s];
+        const uint32_t len = GI_UNI(lens[s]);
         if (!len) continue;
-        const uint32_t code = L.nc[len];
+        const uint32_t code = GI_UNI(L.nc[len]);
         GI_SYNC();
         if (lane == 0u) L.nc[len] = code + 1u;
         const uint32_t rev = __brev(code) >> (32u - len);
@@ -176,7 +184,7 @@ __device__ bool gi_build(GiLds &L, int tk, const uint8_t *lens, uint32_t n, uint
             const uint32_t e = gi_symbol_entry(tk, s, len);
             for (uint32_t k = lane; k < (1u << (root - len)); k += 64u) table[rev + (k << len)] = e;
         } else {
-            const uint32_t pfx = rev & (root_size - 1u), sb = L.u.build.sub_bits[pfx], st = L.u.build.sub_start[pfx];
+            const uint32_t pfx = rev & (root_size - 1u), sb = GI_UNI(L.u.build.sub_bits[pfx]), st = GI_UNI(L.u.build.sub_start[pfx]);
             const uint32_t e = gi_symbol_entry(tk, s, len - root);
             for (uint32_t k = lane; k < (1u << (sb - (len - root))); k += 64u) table[st + (rev >> root) + (k << (len - root))] = e;
         }
@@ -202,20 +210,21 @@ __global__ __launch_bounds__(64) void ginflate_kernel(const uint8_t *__restrict_
     const GiJob J = jobs[blockIdx.x];
     uint8_t *o = out + J.out_off;
     GiIn I;
-    I.src = in + J.in_off; I.len = J.in_len; I.bb = 0; I.nb = 0; I.ipos = 0; I.staged = 0;
+    I.src = in + J.in_off; I.len = J.in_len;
+    gi_start(I, lane);
     uint64_t w = 0, flushed = 0;          // bytes of text produced; bytes of it in HBM (a multiple of 4096 until the end)
     uint32_t status = GI_OK;
     for (;;) {
-        gi_refill(L, I, lane);
+        gi_refill(I, lane);
         const uint32_t last = gi_take(I, 1), type = gi_take(I, 2);
         if (type == 0u) {
             gi_take(I, I.nb & 7u);
-            gi_refill(L, I, lane);
+            gi_refill(I, lane);
             const uint32_t len = gi_take(I, 16), nlen = gi_take(I, 16);
             if ((len ^ 0xFFFFu) != nlen) { status = GI_CORRUPT; break; }
             if (w + len > J.out_cap) { status = GI_OUTPUT_FULL; break; }
             for (uint32_t i = 0; i < len; i++) {
-                gi_refill(L, I, lane);
+                gi_refill(I, lane);
                 const uint32_t b = gi_take(I, 8);
                 if (lane == 0u) L.win[(uint32_t)w & (GI_WIN - 1u)] = (uint8_t)b;
                 w++;
@@ -234,14 +243,13 @@ __global__ __launch_bounds__(64) void ginflate_kernel(const uint8_t *__restrict_
                 GI_SYNC();
                 bool clob = false;
                 if (!gi_build(L, 1, L.lens, 288u, GI_LIT_ROOT, L.lit, GI_LIT_N, lane, clob) || !gi_build(L, 2, L.lens + 288, 32u, GI_DIST_ROOT, L.dist, GI_DIST_N, lane, clob)) { status = GI_CORRUPT; break; }
-                if (clob) gi_restage(I);
             } else {
                 const uint32_t nlit = gi_take(I, 5) + 257u, ndist = gi_take(I, 5) + 1u, npre = gi_take(I, 4) + 4u;
                 if (nlit > 286u || ndist > 30u) { status = GI_CORRUPT; break; }
                 if (lane < 19u) L.lens[lane] = 0;
                 GI_SYNC();
                 for (uint32_t i = 0; i < npre; i++) {
-                    gi_refill(L, I, lane);
+                    gi_refill(I, lane);
                     const uint32_t v = gi_take(I, 3);
                     if (lane == 0u) L.lens[GI_PRE_ORDER[i]] = (uint8_t)v;
                 }
@@ -255,14 +263,14 @@ __global__ __launch_bounds__(64) void ginflate_kernel(const uint8_t *__restrict_
                 uint32_t i = 0;
                 bool bad = false;
                 while (i < nlit + ndist) {
-                    gi_refill(L, I, lane);
-                    const uint32_t e = L.u.in.pre[(uint32_t)I.bb & 127u];
+                    gi_refill(I, lane);
+                    const uint32_t e = GI_UNI(L.u.in.pre[(uint32_t)I.bb & 127u]);
                     if (((e >> 12) & 15u) != GK_LITERAL) { bad = true; break; }
                     gi_take(I, e & 255u);
                     const uint32_t sym = e >> 16;
                     if (sym < 16u) { if (lane == 0u) L.lens[32u + i] = (uint8_t)sym; i++; GI_SYNC(); continue; }
                     uint32_t rep, val = 0;
-                    if (sym == 16u) { if (i == 0u) { bad = true; break; } rep = 3u + gi_take(I, 2); val = L.lens[32u + i - 1u]; }
+                    if (sym == 16u) { if (i == 0u) { bad = true; break; } rep = 3u + gi_take(I, 2); val = GI_UNI(L.lens[32u + i - 1u]); }
                     else if (sym == 17u) rep = 3u + gi_take(I, 3);
                     else rep = 11u + gi_take(I, 7);
                     if (i + rep > nlit + ndist) { bad = true; break; }
@@ -274,13 +282,18 @@ __global__ __launch_bounds__(64) void ginflate_kernel(const uint8_t *__restrict_
                 // (the code lengths sit at lens[32 ..]: the 19 lengths of the code-length code kept the front)
                 bool clob = false;
                 if (!gi_build(L, 1, L.lens + 32, nlit, GI_LIT_ROOT, L.lit, GI_LIT_N, lane, clob) || !gi_build(L, 2, L.lens + 32 + nlit, ndist, GI_DIST_ROOT, L.dist, GI_DIST_N, lane, clob)) { status = GI_CORRUPT; break; }
-                if (clob) gi_restage(I);
             }
             // ---- literals, lengths and distances of the block
+            uint32_t e_ahead = 0;
+            bool ahead = false;
             for (;;) {
-                gi_refill(L, I, lane);
-                uint32_t e = L.lit[(uint32_t)I.bb & ((1u << GI_LIT_ROOT) - 1u)];
-                if (((e >> 12) & 15u) == GK_SUB) { gi_take(I, GI_LIT_ROOT); const uint32_t ix = (e >> 16) + ((uint32_t)I.bb & ((1u << ((e >> 8) & 15u)) - 1u)); e = L.lit[ix < GI_LIT_N ? ix : 0u]; }
+                if (I.nb < 20u) gi_refill(I, lane);                       // a literal / length code and its extra bits: 15 + 5
+                // (every table entry goes through readfirstlane: the decoder's state is the same in all lanes, and saying so puts the whole
+                // serial part -- bit buffer, fields, positions -- on the SCALAR unit, which runs dependent integer code faster than the
+                // vector unit's four-cycle cadence)
+                uint32_t e = GI_UNI(ahead ? e_ahead : L.lit[(uint32_t)I.bb & ((1u << GI_LIT_ROOT) - 1u)]);
+                ahead = false;
+                if (((e >> 12) & 15u) == GK_SUB) { gi_take(I, GI_LIT_ROOT); const uint32_t ix = (e >> 16) + ((uint32_t)I.bb & ((1u << ((e >> 8) & 15u)) - 1u)); e = GI_UNI(L.lit[ix < GI_LIT_N ? ix : 0u]); }
                 gi_take(I, e & 255u);
                 const uint32_t kind = (e >> 12) & 15u;
                 if (kind == GK_LITERAL) {
@@ -289,15 +302,19 @@ __global__ __launch_bounds__(64) void ginflate_kernel(const uint8_t *__restrict_
                     w++;
                 } else if (kind == GK_MATCH) {
                     const uint32_t len = (e >> 16) + gi_take(I, (e >> 8) & 15u);
-                    gi_refill(L, I, lane);
-                    uint32_t d = L.dist[(uint32_t)I.bb & ((1u << GI_DIST_ROOT) - 1u)];
-                    if (((d >> 12) & 15u) == GK_SUB) { gi_take(I, GI_DIST_ROOT); const uint32_t ix = (d >> 16) + ((uint32_t)I.bb & ((1u << ((d >> 8) & 15u)) - 1u)); d = L.dist[ix < GI_DIST_N ? ix : 0u]; }
+                    if (I.nb < 28u) gi_refill(I, lane);                   // a distance code and its extra bits: 15 + 13
+                    uint32_t d = GI_UNI(L.dist[(uint32_t)I.bb & ((1u << GI_DIST_ROOT) - 1u)]);
+                    if (((d >> 12) & 15u) == GK_SUB) { gi_take(I, GI_DIST_ROOT); const uint32_t ix = (d >> 16) + ((uint32_t)I.bb & ((1u << ((d >> 8) & 15u)) - 1u)); d = GI_UNI(L.dist[ix < GI_DIST_N ? ix : 0u]); }
                     if (((d >> 12) & 15u) != GK_MATCH) { status = GI_CORRUPT; break; }
                     gi_take(I, d & 255u);
                     const uint32_t dist = (d >> 16) + gi_take(I, (d >> 8) & 15u);
                     if ((uint64_t)dist > w) { status = GI_CORRUPT; break; }
                     if (w + len > J.out_cap) { status = GI_OUTPUT_FULL; break; }
                     GI_SYNC();
+                    // the next symbol's table entry is requested BEFORE the copy: it depends on the bit buffer only, and the copy's
+                    // read-then-write round trip through LDS is the longest wait of a match
+                    e_ahead = L.lit[(uint32_t)I.bb & ((1u << GI_LIT_ROOT) - 1u)];
+                    ahead = I.nb >= 20u;
                     const uint32_t from = (uint32_t)(w - dist), to = (uint32_t)w;
                     if (dist >= len) {
                         for (uint32_t k = lane; k < len; k += 64u) L.win[(to + k) & (GI_WIN - 1u)] = L.win[(from + k) & (GI_WIN - 1u)];
