@@ -408,11 +408,21 @@ __global__ __launch_bounds__(64) void crc32_kernel(const uint8_t *__restrict__ o
     }
 }
 
+// n streams resident in d_in -> their texts in d_out and the CRC-32 of each, on `st` (asynchronous: the results are in d_results when the
+// stream reaches that point).  d_jobs / d_results: device arrays of n entries.
+void ginflate_enqueue(hipStream_t st, const uint8_t *d_in, const skder_gz_job_t *d_jobs, uint32_t n, uint8_t *d_out, skder_gz_result_t *d_results)
+{
+    static_assert(sizeof(GiJob) == sizeof(skder_gz_job_t) && sizeof(GiResult) == sizeof(skder_gz_result_t), "job / result layout");
+    if (!n) return;
+    hipLaunchKernelGGL(ginflate_kernel, dim3(n), dim3(64), 0, st, d_in, reinterpret_cast<const GiJob *>(d_jobs), d_out, reinterpret_cast<GiResult *>(d_results));
+    hipLaunchKernelGGL(crc32_kernel, dim3(n), dim3(64), 0, st, d_out, reinterpret_cast<const GiJob *>(d_jobs), reinterpret_cast<GiResult *>(d_results));
+    HIPCHECK(hipGetLastError());
+}
+
 // jobs / results: host arrays.  d_in: the DEFLATE streams (raw: behind the gzip header), d_out: the text regions
 extern "C" int skder_amd_inflate_device(skder_ctx_t *ctx, const uint8_t *d_in, const skder_gz_job_t *jobs, uint32_t n, uint8_t *d_out,
                                         skder_gz_result_t *results, float *kernel_ms)
 {
-    static_assert(sizeof(GiJob) == sizeof(skder_gz_job_t) && sizeof(GiResult) == sizeof(skder_gz_result_t), "job / result layout");
     if (!ctx || !d_in || !jobs || !d_out || !results) return 1;
     try {
         HIPCHECK(hipSetDevice(ctx->device));
@@ -423,11 +433,9 @@ extern "C" int skder_amd_inflate_device(skder_ctx_t *ctx, const uint8_t *d_in, c
         HIPCHECK(hipMemcpyAsync(dj.p, jobs, (size_t)n * sizeof(GiJob), hipMemcpyHostToDevice, st));
         HIPCHECK(hipMemsetAsync(dr.p, 0, (size_t)n * sizeof(GiResult), st));
         HIPCHECK(hipEventRecord(ctx->ev[11], st));
-        if (n) {
-            hipLaunchKernelGGL(ginflate_kernel, dim3(n), dim3(64), 0, st, d_in, dj.p, d_out, dr.p);
-            HIPCHECK(hipEventRecord(ctx->ev[12], st));
-            hipLaunchKernelGGL(crc32_kernel, dim3(n), dim3(64), 0, st, d_out, dj.p, dr.p);
-        } else HIPCHECK(hipEventRecord(ctx->ev[12], st));
+        if (n) hipLaunchKernelGGL(ginflate_kernel, dim3(n), dim3(64), 0, st, d_in, dj.p, d_out, dr.p);
+        HIPCHECK(hipEventRecord(ctx->ev[12], st));
+        if (n) hipLaunchKernelGGL(crc32_kernel, dim3(n), dim3(64), 0, st, d_out, dj.p, dr.p);
         HIPCHECK(hipEventRecord(ctx->ev[13], st));
         HIPCHECK(hipGetLastError());
         HIPCHECK(hipMemcpyAsync(results, dr.p, (size_t)n * sizeof(GiResult), hipMemcpyDeviceToHost, st));

@@ -71,3 +71,5 @@ void write_n50_tsv(const std::string &out, const GenomeNames &names);
 void store_save(const std::string &out, skder_sketches *s, const GenomeNames &names);
 void store_load(const std::string &path, skder_sketches *s, GenomeNames &names);
 bool staging_release(int device);      // free the device's cached ingest buffers (false: in use)
+// DEFLATE on the device (ginflate.hip), asynchronous on `st`: d_jobs / d_results are device arrays
+void ginflate_enqueue(hipStream_t st, const uint8_t *d_in, const skder_gz_job_t *d_jobs, uint32_t n, uint8_t *d_out, skder_gz_result_t *d_results);

@@ -1816,6 +1816,40 @@ def test_device_descendants_of_real_assemblies(gpu, oracle):
     s.close()
 
 
+@pytest.mark.parametrize("share", [100, 50])
+def test_gzip_ingest_with_streams_inflated_on_the_device(gpu, tmp_path, monkeypatch, share):
+    """the opt-in ingest path (SKDER_AMD_GPU_INFLATE): a share of the .fasta.gz files is only READ by the host, inflated by ginflate.hip in
+    HBM and checked against its trailer there; files the device does not confirm (several members, data behind the member) fall back to
+    the host decoder, a text longer than its trailer says sends the batch back to the host's two-phase layout.  Tables, N50 values
+    and names must equal the host path's byte for byte."""
+    import ctypes as C
+    from skder_amd import _lib
+    gdir = os.path.join(GOLDEN, "genomes")
+    names = sorted(os.listdir(gdir))
+    paths = [os.path.join(gdir, n) for n in names[:12]]
+    texts = [gzip.open(p, "rb").read() for p in paths[:4]]
+    odd = tmp_path / "odd"
+    odd.mkdir()
+    (odd / "two_members.fasta.gz").write_bytes(gzip.compress(texts[0][:700000], 6) + gzip.compress(texts[0][700000:], 6))
+    (odd / "many_members.fasta.gz").write_bytes(b"".join(gzip.compress(texts[1][i:i + 50000], 1) for i in range(0, len(texts[1]), 50000)))
+    (odd / "trailing_bytes.fasta.gz").write_bytes(gzip.compress(texts[2], 9) + b"\0" * 40)
+    (odd / "stored.fasta.gz").write_bytes(gzip.compress(texts[3], 0))
+    (odd / "long_header.fasta.gz").write_bytes(gzip.compress(b">" + b"x" * 3000 + b" a very long header line\n" + texts[3][texts[3].index(b"\n") + 1:], 6))
+    paths += [str(odd / n) for n in sorted(os.listdir(odd))]
+    listing = tmp_path / "l.txt"
+    listing.write_text("".join(p + "\n" for p in paths))
+    err = C.create_string_buffer(2048)
+    out = {}
+    for tag, env in (("host", {"SKDER_AMD_GPU_INFLATE": "0"}), ("device", {"SKDER_AMD_GPU_INFLATE": str(share), "SKDER_AMD_GPU_INFLATE_MIN": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        t, n = tmp_path / (tag + ".tsv"), tmp_path / (tag + "_n50.tsv")
+        assert _lib.lib().skder_amd_triangle_n50(str(listing).encode(), 10.0, 89.5, 0, str(t).encode(), str(n).encode(), err, 2048) == 0, err.value
+        out[tag] = (t.read_text(), n.read_text())
+    assert out["host"] == out["device"]
+    assert out["host"][0].count("\n") == 1 + len(paths) * (len(paths) - 1) // 2
+
+
 def test_tc_grid_through_the_gpu_dropin(gpu, tmp_path):
     """The reference's `-tc` sweep (bin/skder:331-407: 6 ANI x 5 AF cut-offs over ONE table, `--min-af 10 -s 89.5`) through the GPU
     drop-in and the native selection, against the 30 golden listings of test_case/skder_gtdb_results/skDER_Result/.  A FLOOR, with
