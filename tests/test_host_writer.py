@@ -3,6 +3,7 @@ established in place, parallel sort of search tables, blocks of text formatted i
 each against the simple single-threaded statement, under AddressSanitizer + UBSan (tests/host_writer_harness.cpp)."""
 import json
 import os
+import re
 import shutil
 import subprocess
 
@@ -16,7 +17,10 @@ CSRC = os.path.join(ROOT, "skder_amd", "csrc")
 def _build(tmp_path, sanitize):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     subprocess.check_call(["make", "-C", CSRC, "-j8"], stdout=subprocess.DEVNULL)
-    objs = [os.path.join(CSRC, o) for o in ("pool.o", "fasta.o", "gunzip.o", "sketch.o", "scan.o", "index.o", "screen.o", "chain.o", "chain_join.o", "chain_extract.o", "chain_runs.o", "chain_rows.o", "chain_slow.o", "chain_finalize.o", "select.o", "api.o")]
+    # every object of the library except host_io.o, which the harness compiles from source under the sanitizers (list: csrc/Makefile)
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    srcs = re.search(r"^SRC = (.*)$", mk, re.M).group(1).split()
+    objs = [os.path.join(CSRC, f[:-4] + ".o") for f in srcs if f != "host_io.hip"] + [os.path.join(CSRC, o) for o in ("gunzip.o", "select.o")]
     exe = str(tmp_path / ("writer_harness" + ("_san" if sanitize else "")))
     flags = ["-O1", "-g", "-Xarch_host", "-fsanitize=address,undefined", "-fno-omit-frame-pointer"] if sanitize else ["-O3"]
     subprocess.check_call([hipcc, "--offload-arch=gfx950"] + flags + ["-std=c++17", "-I" + CSRC, "-x", "hip",
