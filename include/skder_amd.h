@@ -207,6 +207,12 @@ int skder_amd_release_cached_buffers(int device);
 /* multi-GPU calls of one process (skder_amd_triangle_multi, skder_amd_sketch_multi): ordered device pairs found WITHOUT peer access so
  * far -- their copies are staged through host memory by the runtime (correct, an order of magnitude slower than xGMI).  0 on a healthy node. */
 uint32_t skder_amd_peer_fallbacks(void);
+/* Which ANI the edge records, and every table written from them, carry (process-wide; returns the previous setting, -1 for an invalid
+ * argument): 0 = after the learned-ANI stand-in of skder_amd_spec.h (default; what `skani` prints by default), 1 = the raw chunk-level
+ * k-mer estimate (A/N)^(1/15), the counterpart of skani's `--no-learned-ani`.  The stand-in is fitted to skani's output on real genomes,
+ * whose changes cluster; on simulated genomes with independent substitutions it reads 1.24 x the true divergence and the raw estimate is
+ * the unbiased one.  skder_edge_t.ani_raw holds the raw estimate under either setting. */
+int skder_amd_set_ani_output(int raw);
 
 /* synthetic genomes generated ON the device (SURVEY 8d recipe; bench.py / tests):
  * fills d_bases for one batch from (seed, species, strain, isolate) lineage ids. See synth.h. */

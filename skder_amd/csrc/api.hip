@@ -632,6 +632,13 @@ extern "C" skder_db_t *skder_amd_db_from_sketches(skder_sketches_t *src, int dev
 // slower) -- said on stderr under SKDER_AMD_DEBUG, never silently.
 static std::atomic<uint32_t> g_peer_fallbacks{0};      // device pairs (ordered) whose copies go through host memory
 extern "C" uint32_t skder_amd_peer_fallbacks() { return g_peer_fallbacks.load(); }
+
+extern std::atomic<int> g_ani_output_raw;      // chain.hip
+extern "C" int skder_amd_set_ani_output(int raw)
+{
+    if (raw != 0 && raw != 1) return -1;
+    return g_ani_output_raw.exchange(raw);
+}
 static void enable_peer_access(int dev, const std::vector<int> &devices)
 {
     HIPCHECK(hipSetDevice(dev));

@@ -97,7 +97,13 @@ void launch_chain_rows(hipStream_t st, unsigned grid, SetView A, SetView B, cons
 void launch_chain_runs(hipStream_t st, unsigned grid, SetView A, SetView B, const PairDesc *pairs, uint32_t npairs, const uint32_t *gen_list,
                        const uint32_t *gen_cnt, uint32_t gen_cap, const RunRec *recs, const uint32_t *chunk_rec0, const uint4 *multi,
                        ChainRec *fast_chains, uint32_t *chunk_state, uint32_t *slow_list, uint32_t *slow_count, uint32_t *pair_na,
-                       const uint32_t *chunk_pair);
+                       const uint32_t *chunk_pair, uint32_t *decl_list, uint32_t *decl_count);
+
+// ---- the run DP in row form (chain_rruns.hip): what the run loop gives up, or everything the sieve leaves
+void launch_chain_rruns(hipStream_t st, unsigned grid, SetView A, SetView B, const PairDesc *pairs, const uint32_t *list, const uint32_t *n_ptr,
+                        const uint32_t *gen_list, const uint32_t *gen_cnt, uint32_t gen_cap, const RunRec *recs, const uint32_t *chunk_rec0,
+                        const uint4 *multi, ChainRec *fast_chains, uint32_t *chunk_state, ChainRec *chains, uint32_t *pair_nch, uint32_t *pair_na,
+                        uint32_t *next_list, uint32_t *next_count, uint32_t *stats, uint32_t *flags, const uint32_t *chunk_pair);
 
 // ---- the join (chain_join.hip)
 struct JoinGroup { uint32_t pair_begin, pair_end; };

@@ -14,6 +14,11 @@
 #include <chrono>
 #include <thread>
 #include <type_traits>
+#include <atomic>
+
+// which ANI the edge records (and the tables written from them) carry: 0 = after the learned-ANI stand-in (default), 1 = the raw k-mer
+// estimate -- skani's `--no-learned-ani` (skder_amd_set_ani_output, api.hip)
+std::atomic<int> g_ani_output_raw{0};
 
 #include "chain.h"
 
@@ -53,7 +58,7 @@ struct ChainSlot {
     DevBuf<uint32_t> hits, pair_nmulti, groups, over_list, flags;
     DevBuf<uint4> multi;
     DevBuf<RunRec> recs;
-    DevBuf<uint32_t> pair_over, chunk_rec0, wg_pair, gen_list, gen_cnt, chunk_pair, rows_next;
+    DevBuf<uint32_t> pair_over, chunk_rec0, wg_pair, gen_list, gen_cnt, chunk_pair, rows_next, rr_list;
     std::vector<uint32_t> h_wg_pair;
     DevBuf<ChainRec> fast_chains, chains;
     DevBuf<PairOut> d_out;
@@ -214,8 +219,27 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
             launch_chain_single(S.st, nwg, VA, VB, S.d_pairs.p, nb, (uint32_t)S.nchunks, S.recs.p,
                                S.pair_over.p, S.chunk_rec0.p, S.wg_pair.p, S.multi.p, S.fast_chains.p, S.chunk_state.p, S.slow_list.p, S.counters.p,
                                S.gen_list.p, S.gen_cnt.p, gen_cap, S.pair_na.p, xcd_remap, S.chunk_pair.p);
-            launch_chain_runs(S.st, nwg < 4096u ? nwg : 4096u, VA, VB, S.d_pairs.p, nb, S.gen_list.p, S.gen_cnt.p, gen_cap, S.recs.p, S.chunk_rec0.p, S.multi.p,
-                              S.fast_chains.p, S.chunk_state.p, S.slow_list.p, S.counters.p, S.pair_na.p, S.chunk_pair.p);
+            // what the sieve left: the run loop (one lane per chunk, a ring of four runs); what it gives up goes to the general kernel.
+            // SKDER_AMD_RRUNS=1 puts the run DP in ROW form in between (one 16-lane row per chunk, all runs resident: chain_rruns.hip),
+            // =2 lets it take everything the sieve left instead of the run loop.  It settles 72 % of what the run loop gives up (3.6 %
+            // of the real-structure set's chunks reach the general kernel instead of 12.6 %) and is bit-equal with the oracle -- and
+            // costs 5.4 ns per chunk where the general kernel takes 4: measured slower, so it is not the default
+            const int rruns = getenv("SKDER_AMD_RRUNS") ? atoi(getenv("SKDER_AMD_RRUNS")) : 0;
+            const uint64_t wantq = (S.nchunks + 7) / 8;
+            const unsigned rr_grid = (unsigned)(wantq < 8192 ? wantq : 8192);
+            if (rruns == 2) {
+                launch_chain_rruns(S.st, rr_grid, VA, VB, S.d_pairs.p, nullptr, nullptr, S.gen_list.p, S.gen_cnt.p, gen_cap, S.recs.p, S.chunk_rec0.p,
+                                   S.multi.p, S.fast_chains.p, S.chunk_state.p, S.chains.p, S.pair_nch.p, S.pair_na.p, S.slow_list.p, S.counters.p,
+                                   S.counters.p + 40, S.flags.p, S.chunk_pair.p);
+            } else {
+                launch_chain_runs(S.st, nwg < 4096u ? nwg : 4096u, VA, VB, S.d_pairs.p, nb, S.gen_list.p, S.gen_cnt.p, gen_cap, S.recs.p, S.chunk_rec0.p, S.multi.p,
+                                  S.fast_chains.p, S.chunk_state.p, S.slow_list.p, S.counters.p, S.pair_na.p, S.chunk_pair.p,
+                                  rruns ? S.rr_list.p : S.slow_list.p, rruns ? S.counters.p + 39 : S.counters.p);
+                if (rruns)
+                    launch_chain_rruns(S.st, rr_grid, VA, VB, S.d_pairs.p, S.rr_list.p, S.counters.p + 39, nullptr, nullptr, 0, S.recs.p, S.chunk_rec0.p,
+                                       S.multi.p, S.fast_chains.p, S.chunk_state.p, S.chains.p, S.pair_nch.p, S.pair_na.p, S.slow_list.p, S.counters.p,
+                                       S.counters.p + 40, S.flags.p, S.chunk_pair.p);
+            }
         } else {
             HIPCHECK(hipEventRecord(S.ev[6], S.st));
         }
@@ -319,7 +343,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         grow(S.d_pairs, nb);
         grow(S.chunk_state, nchunks + 1); grow(S.chunk_mark, nchunks + 1); grow(S.slow_list, nchunks + 1); grow(S.over_list, nchunks + 1); grow(S.chunk_pair, nchunks + 1);
         grow(S.fast_chains, nchunks * FAST_SLOTS + 1);
-        grow(S.counters, 64); grow(S.flags, 16); grow(S.rows_next, nchunks + 1);
+        grow(S.counters, 64); grow(S.flags, 16); grow(S.rows_next, nchunks + 1); grow(S.rr_list, nchunks + 1);
         grow(S.pair_na, nb); grow(S.pair_nch, nb); grow(S.pair_nmulti, nb);
         grow(S.hits, nhits + 64); grow(S.multi, nmulti + 1);
         grow(S.recs, nrecs + 8); grow(S.pair_over, nb + 1); grow(S.chunk_rec0, nchunks + 1); grow(S.gen_list, nchunks + 256ull * GEN_LISTS + 1); grow(S.gen_cnt, GEN_LISTS);
@@ -446,6 +470,12 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
 #ifdef SKDER_SIEVE_STATS
         fprintf(stderr, "[skder_amd] sieve: link %u, main-not-started-big %u, second-path %u, too-many-records %u, multi %u, third-stray %u, stray-near-main %u\n", S.h_cnt[24], S.h_cnt[25], S.h_cnt[26], S.h_cnt[28], S.h_cnt[29], S.h_cnt[30], S.h_cnt[31]);
 #endif
+        if (getenv("SKDER_AMD_DEBUG")) {
+            uint32_t x[12]; HIPCHECK(hipMemcpy(x, S.counters.p + 39, 48, hipMemcpyDeviceToHost));
+            if (x[0] || x[1])
+                fprintf(stderr, "[skder_amd] run DP in rows: %u chunks from the run loop, %u settled; on to the general kernel: many-hits %u, runs %u, anchors %u, interior %u, run-not-dominant %u\n",
+                        x[0], x[1], x[3], x[4], x[7], x[8], x[10]);
+        }
 #ifdef SKDER_RUNS_STATS
         { uint32_t x[8]; HIPCHECK(hipMemcpy(x, S.counters.p + 16, 32, hipMemcpyDeviceToHost));
           fprintf(stderr, "[skder_amd] run loop: %u chunks, %u wavefront rounds, %.1f lanes with a record per round, %.1f lanes not finished after it; %u rounds with a multi-occurrence seed (%u such lanes)\n",
@@ -561,7 +591,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
             const bool cq = S.hp[i].flags & 1u;
             skder_edge_t e;
             e.ref = pref[jobs[S.p0 + i].orig]; e.query = pquery[jobs[S.p0 + i].orig];
-            e.ani = o.ani;
+            e.ani = g_ani_output_raw.load(std::memory_order_relaxed) ? o.ani_raw : o.ani;
             e.af_query = cq ? o.af_q : o.af_r;
             e.af_ref = cq ? o.af_r : o.af_q;
             e.n_chains = o.n_chains; e.n_anchors = o.n_anchors;

@@ -41,7 +41,8 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, c
                                                          const uint32_t *__restrict__ chunk_rec0, const uint4 *__restrict__ multi,
                                                          ChainRec *__restrict__ fast_chains, uint32_t *__restrict__ chunk_state,
                                                          uint32_t *__restrict__ slow_list, uint32_t *__restrict__ slow_count,
-                                                         uint32_t *__restrict__ pair_na, const uint32_t *__restrict__ chunk_pair)
+                                                         uint32_t *__restrict__ pair_na, const uint32_t *__restrict__ chunk_pair,
+                                                         uint32_t *__restrict__ decl_list, uint32_t *__restrict__ decl_count)
 {
     // the chunks chain_single_kernel could not settle, one per lane; their number is only known on the device: a fixed
     // grid strides over the GEN_LISTS lists laid end to end (offsets by a scan of the 256 counts, in LDS)
@@ -364,9 +365,9 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, c
         if (dm) {
             const uint32_t ln = threadIdx.x & 63u, leader = (uint32_t)__ffsll((long long)dm) - 1u;
             uint32_t base = 0;
-            if (ln == leader) base = atomicAdd(slow_count, (uint32_t)__popcll(dm));
+            if (ln == leader) base = atomicAdd(decl_count, (uint32_t)__popcll(dm));
             base = (uint32_t)__shfl((int)base, (int)leader, 64);
-            if (decl) { chunk_state[t] = CHUNK_SLOW; slow_list[base + (uint32_t)__popcll(dm & ((1ull << ln) - 1ull))] = t; }
+            if (decl) { chunk_state[t] = CHUNK_SLOW; decl_list[base + (uint32_t)__popcll(dm & ((1ull << ln) - 1ull))] = t; }
             for (uint32_t cz = 1; cz <= 10u; cz++) {
                 const unsigned long long cm = __ballot(decl && cause == cz);
                 if (cm && ln == 0) atomicAdd(slow_count + 1 + cz, (uint32_t)__popcll(cm));
@@ -384,8 +385,8 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, c
 void launch_chain_runs(hipStream_t st, unsigned grid, SetView A, SetView B, const PairDesc *pairs, uint32_t npairs, const uint32_t *gen_list,
                        const uint32_t *gen_cnt, uint32_t gen_cap, const RunRec *recs, const uint32_t *chunk_rec0, const uint4 *multi,
                        ChainRec *fast_chains, uint32_t *chunk_state, uint32_t *slow_list, uint32_t *slow_count, uint32_t *pair_na,
-                       const uint32_t *chunk_pair)
+                       const uint32_t *chunk_pair, uint32_t *decl_list, uint32_t *decl_count)
 {
     hipLaunchKernelGGL(chain_runs_kernel, dim3(grid), dim3(256), 0, st, A, B, pairs, npairs, gen_list, gen_cnt, gen_cap, recs, chunk_rec0, multi,
-                       fast_chains, chunk_state, slow_list, slow_count, pair_na, chunk_pair);
+                       fast_chains, chunk_state, slow_list, slow_count, pair_na, chunk_pair, decl_list, decl_count);
 }

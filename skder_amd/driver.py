@@ -186,7 +186,14 @@ def main(argv=None):
     ap.add_argument("--store", default=None, help="sketch store file: loaded if present and still describing these files, written otherwise")
     ap.add_argument("--devices", default=None, help="comma-separated GPU indices (default: $SKDER_AMD_DEVICE or 0): with several, the genomes "
                                                     "are sketched in shares, the sketches exchanged between the GPUs and the pair matrix dealt out by rows")
+    ap.add_argument("--ani", choices=("model", "raw"), default="model",
+                    help="which ANI the tables carry and the selection reads: `model` = after the learned-ANI stand-in (what skani prints by default), "
+                         "`raw` = the chunk-level k-mer estimate, skani's --no-learned-ani (for simulated genomes with independent substitutions, "
+                         "where the stand-in reads 1.24 x the true divergence: DESIGN.md section 2)")
     a = ap.parse_args(argv)
+    from . import _lib
+    if _lib.lib().skder_amd_set_ani_output(1 if a.ani == "raw" else 0) < 0:
+        raise RuntimeError("skder_amd_set_ani_output failed")
     name_map = None
     if a.name_map:
         with open(a.name_map) as f:

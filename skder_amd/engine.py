@@ -319,6 +319,22 @@ def download(ptr: int, n: int, dtype, ctx=None) -> np.ndarray:
     return t.cpu().numpy().view(dtype)
 
 
+class _DeviceArray:
+    """a raw device pointer dressed for torch.as_tensor (the CUDA array interface, which torch's HIP build reads too)"""
+
+    def __init__(self, ptr: int, n: int, typestr: str):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2, "strides": None}
+
+
+def device_view(ptr: int, n: int, torch_dtype):
+    """n elements at a raw device pointer as a torch tensor WITHOUT a copy; the memory stays the owner's (keep it alive while the view is used)"""
+    import torch
+    if n <= 0 or not ptr:
+        return torch.empty(0, dtype=torch_dtype, device="cuda")
+    typestr = {torch.int32: "<i4", torch.int64: "<i8", torch.uint8: "|u1"}[torch_dtype]
+    return torch.as_tensor(_DeviceArray(ptr, n, typestr), device="cuda")
+
+
 def download_tensor(ptr: int, n: int, torch_dtype, ctx=None):
     """copy n elements from a raw device pointer into a new torch tensor on the current device"""
     import torch

@@ -25,14 +25,16 @@ def partition(n: int, world: int) -> List[range]:
     return [range(cuts[r], cuts[r + 1]) for r in range(world)]
 
 
-def exchange_raw(raw: Dict, group=None, staging: str = None) -> Dict:
+def exchange_raw(raw: Dict, group=None, staging: str = None, parts: bool = False) -> Dict:
     """raw: dict with torch tensors seed_kmer/seed_gpos (int32 views of u32) and markers
     (int64 view of u64) of THIS rank's genomes, and numpy metadata seed_off, marker_off, genome_len,
     genome_nrec, rec_goff.  Returns the same dict for the concatenation of all ranks' genomes.
     TWO collectives: a 40-byte header per rank (the section sizes), then ONE padded all-gather of everything a rank has --
     its per-genome tables, seed k-mers, seed positions and markers packed into one int64 buffer on the device (RCCL moves
     it over xGMI; only the few KB of tables come back to the host).
-    staging="cpu": the buffer travels through host memory (gloo backend)."""
+    staging="cpu": the buffer travels through host memory (gloo backend).
+    parts=True: the result also carries "parts", one raw dict per rank whose tensors are VIEWS of the gathered buffer (for
+    sketches_from_raw: no concatenation copy); the concatenated tensors are then left out."""
     world = dist.get_world_size(group)
     nccl = dist.get_backend(group) == "nccl"
     dev = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
@@ -50,18 +52,21 @@ def exchange_raw(raw: Dict, group=None, staging: str = None) -> Dict:
     words = lambda h: (int(h[4]), (int(h[1]) + 1) // 2, (int(h[1]) + 1) // 2, int(h[2]))
     mx = max(max(sum(words(H[r])) for r in range(world)), 1)
     wdev = raw["seed_kmer"].device if (nccl or staging != "cpu") else torch.device("cpu")
-    mine = torch.zeros(mx, dtype=torch.int64, device=wdev)
+    mine = torch.empty(mx, dtype=torch.int64, device=wdev)
     w = words(H[dist.get_rank(group)])
     o = 0
     mine[o:o + w[0]] = torch.from_numpy(blob).to(wdev); o += w[0]
     for key in ("seed_kmer", "seed_gpos"):
+        if ns & 1:
+            mine[o + w[1] - 1] = 0                # the odd half word
         mine[o:o + w[1]].view(torch.int32)[:ns] = raw[key].to(wdev); o += w[1]
-    mine[o:o + w[3]] = raw["markers"].to(wdev)
+    mine[o:o + w[3]] = raw["markers"].to(wdev); o += w[3]
+    mine[o:].zero_()                               # padding up to the longest rank's buffer
     if not nccl:
         mine = mine.cpu()
     allb = torch.empty(world * mx, dtype=torch.int64, device=mine.device)
     dist.all_gather_into_tensor(allb, mine, group=group)
-    metas, parts = [], {"seed_kmer": [], "seed_gpos": [], "markers": []}
+    metas, parts_t = [], {"seed_kmer": [], "seed_gpos": [], "markers": []}
     for r in range(world):
         g, nr = int(H[r, 0]), int(H[r, 3])
         wr = words(H[r])
@@ -75,13 +80,20 @@ def exchange_raw(raw: Dict, group=None, staging: str = None) -> Dict:
             o += ln
         metas.append(m)
         o = base + wr[0]
-        parts["seed_kmer"].append(allb[o:o + wr[1]].view(torch.int32)[:m["n_seeds"]]); o += wr[1]
-        parts["seed_gpos"].append(allb[o:o + wr[2]].view(torch.int32)[:m["n_seeds"]]); o += wr[2]
-        parts["markers"].append(allb[o:o + wr[3]])
+        parts_t["seed_kmer"].append(allb[o:o + wr[1]].view(torch.int32)[:m["n_seeds"]]); o += wr[1]
+        parts_t["seed_gpos"].append(allb[o:o + wr[2]].view(torch.int32)[:m["n_seeds"]]); o += wr[2]
+        parts_t["markers"].append(allb[o:o + wr[3]])
     out = dict(n_genomes=sum(m["n_genomes"] for m in metas))
     # the record index of a seed follows from its position and the record table: it is not exchanged
-    for key in parts:
-        out[key] = torch.cat(parts[key]).to(raw[key].device)
+    tens = parts_t
+    if parts:
+        out["parts"] = [dict(n_genomes=m["n_genomes"], seed_kmer=tens["seed_kmer"][r].to(raw["seed_kmer"].device),
+                             seed_gpos=tens["seed_gpos"][r].to(raw["seed_kmer"].device), markers=tens["markers"][r].to(raw["seed_kmer"].device),
+                             seed_off=m["seed_off"], marker_off=m["marker_off"], genome_len=m["genome_len"], genome_nrec=m["genome_nrec"],
+                             rec_goff=m["rec_goff"]) for r, m in enumerate(metas)]
+    else:
+        for key in tens:
+            out[key] = torch.cat(tens[key]).to(raw[key].device)
     so, mo = [np.zeros(1, np.uint64)], [np.zeros(1, np.uint64)]
     sbase = mbase = np.uint64(0)
     for m in metas:
@@ -109,9 +121,10 @@ def _pinned(nbytes: int) -> torch.Tensor:
     return t[:nbytes]
 
 
-def gather_edges(edges: np.ndarray, group=None) -> np.ndarray:
+def gather_edges(edges: np.ndarray, group=None, copy: bool = True) -> np.ndarray:
     """edge records of all ranks on rank 0 (others get an empty array).  The records travel as raw bytes:
-    one padded gather to rank 0 (device tensors under RCCL, host tensors under gloo), rank order kept."""
+    one padded gather to rank 0 (device tensors under RCCL, host tensors under gloo), rank order kept.
+    copy=False (RCCL): the result is a view of this module's page-locked buffer, valid until the next call."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     nccl = dist.get_backend(group) == "nccl"
@@ -131,9 +144,9 @@ def gather_edges(edges: np.ndarray, group=None) -> np.ndarray:
     if rank != 0:
         return edges[:0].copy()
     total = sum(counts) * item
-    res = np.empty(sum(counts), dtype=edges.dtype)
     if total == 0:
-        return res
+        return np.empty(0, dtype=edges.dtype)
+    res = np.empty(sum(counts), dtype=edges.dtype) if (copy or not nccl) else None
     if nccl:
         host = _pinned(total)
         o = 0
@@ -142,6 +155,8 @@ def gather_edges(edges: np.ndarray, group=None) -> np.ndarray:
             host[o:o + k].copy_(out[r][:k], non_blocking=True)
             o += k
         torch.cuda.synchronize()
+        if not copy:
+            return host.numpy().view(edges.dtype)
         res.view(np.uint8).reshape(-1)[:] = host.numpy()
     else:
         o = 0
@@ -153,26 +168,35 @@ def gather_edges(edges: np.ndarray, group=None) -> np.ndarray:
     return res
 
 
-def raw_from_sketches(sk) -> Dict:
-    """wrap a Sketches object's raw arrays as torch tensors on the current device (one D2D copy)"""
-    from .engine import download_tensor
+def raw_from_sketches(sk, copy: bool = False) -> Dict:
+    """a Sketches object's raw arrays as torch tensors on the current device: views of the set's own memory (no copy; valid while the set
+    lives and is not appended to), or copies with copy=True"""
+    from .engine import device_view, download_tensor
     v = sk.view()
+    torch.cuda.synchronize()          # the set's arrays were written on the library's stream, torch reads them on its own
+    get = (lambda p, n, dt: download_tensor(p, n, dt, sk.ctx)) if copy else device_view
     return dict(n_genomes=v["n_genomes"],
-                seed_kmer=download_tensor(v["d_seed_kmer"], v["n_seeds"], torch.int32, sk.ctx),
-                seed_gpos=download_tensor(v["d_seed_gpos"], v["n_seeds"], torch.int32, sk.ctx),
-                markers=download_tensor(v["d_markers"], v["n_markers"], torch.int64, sk.ctx),
+                seed_kmer=get(v["d_seed_kmer"], v["n_seeds"], torch.int32),
+                seed_gpos=get(v["d_seed_gpos"], v["n_seeds"], torch.int32),
+                markers=get(v["d_markers"], v["n_markers"], torch.int64),
                 seed_off=v["seed_off"], marker_off=v["marker_off"], genome_len=v["genome_len"],
                 genome_nrec=v["genome_nrec"], rec_goff=v["rec_goff"])
 
 
 def sketches_from_raw(ctx, raw: Dict):
-    """a new Sketches object holding the genomes described by `raw` (tensors on ctx's device)"""
+    """a new Sketches object holding the genomes described by `raw` (tensors on ctx's device).  A dict from exchange_raw(parts=True) is
+    appended rank by rank straight out of the gathered buffer (one copy into the set, none in between)."""
     from .engine import Sketches
     s = Sketches(ctx)
     torch.cuda.synchronize()
-    s.append_raw(raw["n_genomes"], raw["seed_kmer"].data_ptr(), raw["seed_gpos"].data_ptr(), None,
-                 raw["markers"].data_ptr(), raw["seed_off"], raw["marker_off"], raw["genome_len"], raw["genome_nrec"],
-                 raw["rec_goff"])
+    parts = raw.get("parts") or [raw]
+    if len(parts) > 1:
+        s.reserve(sum(int(p["seed_kmer"].numel()) for p in parts), sum(int(p["markers"].numel()) for p in parts))
+    for p in parts:
+        if int(p["n_genomes"]) == 0:
+            continue
+        s.append_raw(p["n_genomes"], p["seed_kmer"].data_ptr(), p["seed_gpos"].data_ptr(), None,
+                     p["markers"].data_ptr(), p["seed_off"], p["marker_off"], p["genome_len"], p["genome_nrec"], p["rec_goff"])
     return s
 
 

@@ -153,6 +153,36 @@ def true_identity_matrix(recipe: Recipe) -> np.ndarray:
     return out + out.T + np.eye(recipe.n)
 
 
+CLUSTERED_RATES_PCT = (0.0, 0.25, 0.5, 1.0, 1.5, 2.5, 4.0)
+
+
+def clustered_truth_family(genome_len: int = 2_000_000, rates_pct=CLUSTERED_RATES_PCT, shape: float = 0.3, window: int = 1000, seed: int = SEED):
+    """Genomes whose substitutions CLUSTER, with the truth known -- the other side of truth_recipe's iid substitutions.  One random
+    ancestor; descendant i carries substitutions at a mean rate of rates_pct[i] percent, the rate of every `window`-base stretch
+    multiplied by a Gamma(shape, 1/shape) factor (mean 1; shape 0.3: a third of the windows carry 90 % of the changes, the pattern
+    recombination leaves in real genomes and the reason a k-mer estimate reads their identity too high).  No indels, one record:
+    the true identity of a pair is the fraction of equal bases.  Returns (list of ASCII base arrays, truth matrix).  Host numpy:
+    test / bench input, not a device generator."""
+    rng = np.random.RandomState(seed & 0x7FFFFFFF)
+    anc = rng.randint(0, 4, genome_len).astype(np.uint8)
+    nwin = (genome_len + window - 1) // window
+    codes = []
+    for r in rates_pct:
+        mult = rng.gamma(shape, 1.0 / shape, nwin)
+        rate = np.minimum(0.6, np.repeat(mult, window)[:genome_len] * (float(r) / 100.0))
+        hit = rng.random_sample(genome_len) < rate
+        c = anc.copy()
+        c[hit] = (c[hit] + rng.randint(1, 4, int(hit.sum())).astype(np.uint8)) & 3
+        codes.append(c)
+    n = len(codes)
+    truth = np.eye(n)
+    for a in range(n):
+        for b in range(a + 1, n):
+            truth[a, b] = truth[b, a] = float((codes[a] == codes[b]).mean())
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    return [lut[c] for c in codes], truth
+
+
 def ani_vs_truth(edges, truth: np.ndarray, bins=((99.5, 100.0), (98.0, 99.5), (95.0, 98.0), (90.0, 95.0), (85.0, 90.0))) -> dict:
     """bias / rms (percentage points) of the engine's two ANI figures against the generator's truth, by true-ANI bin:
     `raw` = the chunk-level k-mer estimate (A/N)^(1/15) (skder_edge_t.ani_raw), `model` = what the table prints (after the

@@ -282,6 +282,43 @@ def test_ani_against_generator_truth(gpu):
             assert float(e["af_ref"]) >= 0.95 and float(e["af_query"]) >= 0.95, (e, t)
 
 
+def test_ani_against_clustered_truth_and_raw_output(gpu, oracle, tmp_path):
+    """The truth pin from the other side (tests/test_oracle_golden.py::test_estimator_against_clustered_truth has the reasoning): genomes
+    whose substitutions cluster per 1 kb window, truth known.  The device's records equal the oracle's bit for bit; the raw k-mer estimate
+    reads the identity too high there, the table's ANI (learned-ANI stand-in) lands 0.94-1.20 x the true divergence with exponential
+    window rates and below the truth with strongly clustered ones -- iid substitutions (1.24 x) and these bracket real genomes.
+    Then skder_amd_set_ani_output(1), skani's --no-learned-ani: records and tables carry the raw estimate."""
+    engine, ctx, torch = gpu
+    from skder_amd import synth, _lib
+    p = oracle.default_params()
+    for shape, lo, hi in ((1.0, 0.94, 1.20), (0.3, 0.60, 1.13)):
+        bases, truth = synth.clustered_truth_family(2_000_000, shape=shape)
+        lens = [np.array([len(b)], np.uint32) for b in bases]
+        sk, _ = _sketch(gpu, lens, bases)
+        edges = sk.triangle_rows(0, 1, 80.0)
+        og = [oracle.Genome.from_bases(b, [len(b)], p) for b in bases]
+        _check_edges(edges, _oracle_edges(oracle, og, p, 80.0))
+        assert len(edges) == len(bases) * (len(bases) - 1) // 2
+        for e in edges:
+            t = 100.0 * (1.0 - truth[int(e["ref"]), int(e["query"])])
+            assert 100.0 * (1.0 - float(e["ani_raw"])) / t < 1.0, (shape, e, t)
+            assert lo <= 100.0 * (1.0 - float(e["ani"])) / t <= hi, (shape, e, t)
+        if shape == 1.0:
+            lib = _lib.lib()
+            assert lib.skder_amd_set_ani_output(1) == 0
+            try:
+                raw_edges = sk.triangle_rows(0, 1, 80.0)
+            finally:
+                assert lib.skder_amd_set_ani_output(0) == 1
+            a = {(int(e["ref"]), int(e["query"])): e for e in edges}
+            assert len(raw_edges) == len(edges)
+            for e in raw_edges:
+                m = a[(int(e["ref"]), int(e["query"]))]
+                assert float(e["ani"]) == float(m["ani_raw"]) == float(e["ani_raw"]) and float(e["ani"]) > float(m["ani"])
+                assert float(e["af_ref"]) == float(m["af_ref"]) and int(e["n_chains"]) == int(m["n_chains"])
+        sk.close()
+
+
 def test_dropin_tables_match_oracle_and_golden(gpu, oracle, tmp_path):
     """file in, TSV out through the reference-shaped functions; text-identical with the oracle's
     drivers, and within the oracle's measured tolerance of the reference's golden table G1"""
@@ -454,6 +491,17 @@ def test_driver_end_to_end_listings(gpu, tmp_path):
     assert 0 < len(reps_d) <= len(reps_g)                          # dynamic is the more concise mode (README)
     assert 0 < len(reps_l) <= len(genomes) and os.path.isfile(tmp_path / "l" / "Skani_Dist_Output.txt")
     assert set(reps_l) <= set(genomes)
+    # --ani raw (skani's --no-learned-ani): the table carries the k-mer estimate, which reads most real pairs' identity higher than the
+    # stand-in does (the stand-in is 0.53 x the cell divergence + 0.71 x the span divergence: lower only where the two differ widely)
+    from skder_amd import _lib
+    try:
+        driver.main(["-g"] + genomes + ["-o", str(tmp_path / "raw"), "-d", "greedy", "-i", "99.5", "-f", "50.0", "--ani", "raw"])
+    finally:
+        assert _lib.lib().skder_amd_set_ani_output(0) == 1
+    rows = lambda d: {tuple(c[:2]): float(c[2]) for c in (l.split("\t") for l in list(open(tmp_path / d / "Skani_Triangle_Edge_Output.txt"))[1:])}
+    raw, model = rows("raw"), rows("g")
+    assert set(raw) == set(model) and sum(raw[k] > model[k] for k in raw) > 0.8 * len(raw) and any(raw[k] != model[k] for k in raw)
+    assert 0 < len(list(open(tmp_path / "raw" / "skDER_Results.txt"))) <= len(genomes)
 
 
 def _custom_recipe(lens_species, per_species, seed=11):
@@ -1283,6 +1331,42 @@ def test_structural_variants_randomized(gpu, oracle, realistic):
         slow += int(c[1])
         s.close()
     assert (slow < 0.15 * chunks) if realistic else (slow > 0.3 * chunks)
+
+
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_run_dp_in_row_form(gpu, oracle, monkeypatch, mode):
+    """chain_rruns.hip -- the run DP with a chunk's runs held across the 16 lanes of a DPP row (opt-in: SKDER_AMD_RRUNS): behind the run
+    loop (1) or instead of it (2), bit-equal with the oracle on structural-variant families (both kinds) and on real assemblies, and
+    with fewer chunks left for the general kernel than the run loop alone leaves (branching chains, dead tails, look-backs beyond
+    the ring of four and any number of chains are settled on the runs)."""
+    engine, ctx, torch = gpu
+    p = oracle.default_params()
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+
+    def family(seed, realistic):
+        rng = np.random.RandomState(seed)
+        anc = alpha[rng.randint(0, 4, rng.randint(300000, 700000))]
+        fam = [_structural_variant(rng, anc, realistic) for _ in range(4)]
+        return [g[1] for g in fam], [g[0] for g in fam]
+
+    sets = [family(2000, True), family(2001, True), family(7, False), family(309, False)]
+    names = GENOMES[:6]
+    recs = [_read_records(os.path.join(GOLDEN, "genomes", n)) for n in names]
+    sets.append(([r[0] for r in recs], [r[1] for r in recs]))
+    general = {}
+    for setting in ("0", mode):
+        monkeypatch.setenv("SKDER_AMD_RRUNS", setting)
+        tot = 0
+        for lens, bases in sets:
+            s, _ = _sketch(gpu, lens, bases)
+            og = [oracle.Genome.from_bases(b, l, p) for b, l in zip(bases, lens)]
+            edges = s.triangle_rows(0, 1, 0.0)
+            _check_edges(edges, _oracle_edges(oracle, og, p, 0.0))
+            tot += int(ctx.counters()[1])
+            s.close()
+        general[setting] = tot
+    monkeypatch.delenv("SKDER_AMD_RRUNS")
+    assert general[mode] < 0.6 * general["0"], general
 
 
 def test_real_derived_family_sampled_against_oracle(gpu, oracle):

@@ -40,6 +40,16 @@ def _worker(rank, world, port, q, empty=-1):
     from skder_amd import engine, multigpu
     raw = _fake_raw(rank, empty)
     merged = multigpu.exchange_raw(raw)
+    # parts=True: one raw dict per rank, views of the gathered buffer -- their concatenation is the merged form, their tables the senders'
+    mp = multigpu.exchange_raw(raw, parts=True)
+    assert len(mp["parts"]) == world and "seed_kmer" not in mp
+    for key in ("seed_kmer", "seed_gpos", "markers"):
+        assert torch.equal(torch.cat([p[key] for p in mp["parts"]]), merged[key]), key
+    for r, p in enumerate(mp["parts"]):
+        want = _fake_raw(r, empty)
+        assert p["n_genomes"] == want["n_genomes"]
+        for key in ("seed_off", "marker_off", "genome_len", "genome_nrec", "rec_goff"):
+            assert np.array_equal(p[key], want[key]), (r, key)
     edges = np.zeros(0 if rank == empty else 2 + rank, engine.EDGE_DTYPE)
     edges["ref"] = rank
     edges["query"] = np.arange(len(edges)) + 10 * rank
