@@ -310,6 +310,13 @@ int64_t skder_amd_pct2_cents(float fraction);
 int skder_amd_search_batch(skder_db_t *db, const char *const *query_paths, uint32_t n_queries, double min_af_pct,
                            double screen_pct, const char *const *out_tsvs, const skder_edge_t **edges,
                            uint64_t *n_edges, char *err, size_t errlen);
+/* The same with the database genomes a caller still cares about: live[i] != 0 (skder_amd_db_size entries; NULL: all).  Candidate pairs
+ * of the other genomes are screened but not chained and have no rows.  lowMemGreedyDerep (skder.py:116-133) only ever ADDS the Ref of a
+ * row to its set of accounted genomes, so rows of genomes that are accounted for already, or were representatives earlier in the order,
+ * cannot change its result: with those masked out the listing is the same and the chaining shrinks with the live set. */
+int skder_amd_search_batch_live(skder_db_t *db, const char *const *query_paths, uint32_t n_queries, double min_af_pct,
+                                double screen_pct, const char *const *out_tsvs, const uint8_t *live, const skder_edge_t **edges,
+                                uint64_t *n_edges, char *err, size_t errlen);
 
 /* 8f-4  sketch store on disk (the counterpart of the directory `skani sketch -o` creates,
  * skder.py:102-104): one file holding the raw sketches, record tables, names, paths and N50s of a

@@ -101,6 +101,9 @@ SYMBOLS = {
     "skder_amd_search_batch": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.c_uint32, C.c_double, C.c_double,
                                          C.POINTER(C.c_char_p), C.POINTER(C.POINTER(Edge)), C.POINTER(C.c_uint64),
                                          C.c_char_p, C.c_size_t]),
+    "skder_amd_search_batch_live": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.c_uint32, C.c_double, C.c_double,
+                                              C.POINTER(C.c_char_p), C.c_void_p, C.POINTER(C.POINTER(Edge)), C.POINTER(C.c_uint64),
+                                              C.c_char_p, C.c_size_t]),
     "skder_amd_db_save": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]),
     "skder_amd_db_load": (C.c_void_p, [C.c_char_p, C.c_int, C.c_char_p, C.c_size_t]),
     "skder_amd_debug_genome": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),

@@ -907,6 +907,13 @@ extern "C" int skder_amd_search_batch(skder_db_t *db, const char *const *query_p
                                       double screen_pct, const char *const *out_tsvs, const skder_edge_t **edges,
                                       uint64_t *n_edges, char *err, size_t errlen)
 {
+    return skder_amd_search_batch_live(db, query_paths, n_queries, min_af_pct, screen_pct, out_tsvs, nullptr, edges, n_edges, err, errlen);
+}
+
+extern "C" int skder_amd_search_batch_live(skder_db_t *db, const char *const *query_paths, uint32_t n_queries, double min_af_pct,
+                                           double screen_pct, const char *const *out_tsvs, const uint8_t *live, const skder_edge_t **edges,
+                                           uint64_t *n_edges, char *err, size_t errlen)
+{
     if (!db || !query_paths) { set_err(err, errlen, "null argument"); return 1; }
     skder_sketches *q = nullptr;
     int rc = 0;
@@ -929,7 +936,7 @@ extern "C" int skder_amd_search_batch(skder_db_t *db, const char *const *query_p
         }
         db->rows.clear();
         if (n_queries && db->more.empty()) {
-            rectangle_impl(db->refs, q, screen_pct);
+            rectangle_impl(db->refs, q, screen_pct, live);
             db->rows.swap(db->ctx->edges);
             rect_rows_order_inplace(db->rows, min_af_pct);
         } else if (n_queries) {
@@ -956,7 +963,9 @@ extern "C" int skder_amd_search_batch(skder_db_t *db, const char *const *query_p
                     if (!rows.empty()) screen_pairs(refs, qs[d], rows, false, screen_pct, squery[d], sref[d]);
                 });
                 std::vector<uint32_t> ref, query;
-                for (uint32_t d = 0; d < n; d++) { ref.insert(ref.end(), sref[d].begin(), sref[d].end()); query.insert(query.end(), squery[d].begin(), squery[d].end()); }
+                for (uint32_t d = 0; d < n; d++)
+                    for (size_t k = 0; k < sref[d].size(); k++)
+                        if (!live || live[sref[d][k]]) { ref.push_back(sref[d][k]); query.push_back(squery[d][k]); }
                 route_by_probed(db->refs, q, ref, query, n, true, oref, oquery);
                 per_gpu(n, [&](uint32_t d) {
                     skder_sketches *refs = db_refs(db, d);

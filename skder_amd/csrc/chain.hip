@@ -706,7 +706,7 @@ void triangle_rows_impl(skder_sketches *s, uint32_t row_begin, uint32_t row_stri
     }
 }
 
-void rectangle_impl(skder_sketches *refs, skder_sketches *queries, double screen_pct)
+void rectangle_impl(skder_sketches *refs, skder_sketches *queries, double screen_pct, const uint8_t *live_refs)
 {
     skder_ctx *ctx = refs->ctx;
     if (!queries->indexed) index_impl(queries);
@@ -727,6 +727,12 @@ void rectangle_impl(skder_sketches *refs, skder_sketches *queries, double screen
         float ms;
         HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[9], ctx->ev[10]));
         ctx->timing[2] += ms;
+        if (live_refs) {      // the caller has no use for rows of the other reference genomes: their candidate pairs are not chained
+            size_t w = 0;
+            for (size_t k = 0; k < ppart.size(); k++)
+                if (live_refs[ppart[k]]) { ppart[w] = ppart[k]; prow[w] = prow[k]; w++; }
+            ppart.resize(w); prow.resize(w);
+        }
         index_impl(refs);
         ensure_probed_indexed(refs, queries, ppart, prow);
         // rows are queries, partners are references

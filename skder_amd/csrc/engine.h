@@ -70,7 +70,7 @@ void index_promote(skder_sketches *s, const std::vector<uint32_t> &genomes);    
 void index_set_rep_cuts(skder_sketches *s, const uint32_t *in, const uint8_t *mask);
 void index_finish(skder_sketches *s);                    // wait for it, fetch the per-genome results
 void triangle_rows_impl(skder_sketches *s, uint32_t row_begin, uint32_t row_stride, double screen_pct);
-void rectangle_impl(skder_sketches *refs, skder_sketches *queries, double screen_pct);
+void rectangle_impl(skder_sketches *refs, skder_sketches *queries, double screen_pct, const uint8_t *live_refs = nullptr);   // live_refs: per genome of refs, 0 = leave its pairs out
 void screen_rows_impl(skder_sketches *s, uint32_t row_begin, uint32_t row_stride, double screen_pct,
                       std::vector<uint32_t> &pref, std::vector<uint32_t> &pquery);
 void pairs_probed_impl(skder_sketches *SA, skder_sketches *SB, const uint32_t *ref, const uint32_t *query, uint64_t n, uint32_t *probed,

@@ -191,8 +191,9 @@ class Database:
             raise RuntimeError('Had an issue running: skder_amd_db_triangle: %s' % err.value.decode())
         return self._rows(p, n)
 
-    def search_batch(self, queries, min_af=SKANI_DEFAULT_MIN_AF, screen=SKANI_DEFAULT_SCREEN, out_tsvs=None):
-        """rows of `skani search` for several queries at once; `query` = position in `queries`"""
+    def search_batch(self, queries, min_af=SKANI_DEFAULT_MIN_AF, screen=SKANI_DEFAULT_SCREEN, out_tsvs=None, live=None):
+        """rows of `skani search` for several queries at once; `query` = position in `queries`.  live: one flag per database genome
+        (uint8 / bool array), 0 = the caller has no use for rows of that genome (they are not computed)"""
         k = len(queries)
         qs = (C.c_char_p * max(k, 1))(*[q.encode() for q in queries])
         outs = None
@@ -200,8 +201,14 @@ class Database:
             outs = (C.c_char_p * max(k, 1))(*[o.encode() if o else None for o in out_tsvs])
         p, n = C.POINTER(_lib.Edge)(), C.c_uint64()
         err = C.create_string_buffer(_lib.ERRLEN)
-        rc = _lib.lib().skder_amd_search_batch(self._h, qs, k, float(min_af), float(screen), outs, C.byref(p), C.byref(n),
-                                               err, _lib.ERRLEN)
+        mask = None
+        if live is not None:
+            import numpy as np
+            mask = np.ascontiguousarray(live, np.uint8)
+            if len(mask) != len(self.paths):
+                raise ValueError("live: one flag per database genome")
+        rc = _lib.lib().skder_amd_search_batch_live(self._h, qs, k, float(min_af), float(screen), outs,
+                                                    mask.ctypes.data if mask is not None else None, C.byref(p), C.byref(n), err, _lib.ERRLEN)
         if rc != 0:
             raise RuntimeError('Had an issue running: skder_amd_search_batch: %s' % err.value.decode())
         return self._rows(p, n)
@@ -240,7 +247,10 @@ def lowMemGreedyDerep(all_genomes_listing_file, skder_lm_workspace, concat_n50_r
     which is parsed by the reference's code).  Otherwise (default) the rows of the
     next few unaccounted candidates are computed speculatively in one pass and applied in order;
     rows of candidates that an earlier member of the batch accounted for are discarded, so the
-    result equals the sequential loop's."""
+    result equals the sequential loop's.  The speculative searches also leave out what cannot change the result: the
+    reference's loop only ever ADDS the Ref of a row to `accounted_genomes` (skder.py:127-129), so rows of genomes that are
+    accounted for already, or that were handled earlier in the order, are never computed (Database.search_batch(live=...));
+    SKDER_AMD_SEARCH_ALL=1 computes them anyway (A/B; the listing is the same)."""
     if search_batch is None:
         search_batch = int(os.environ.get('SKDER_AMD_SEARCH_BATCH', '0'))
     db = database if database is not None else Database.from_listing(all_genomes_listing_file)
@@ -274,6 +284,8 @@ def lowMemGreedyDerep(all_genomes_listing_file, skder_lm_workspace, concat_n50_r
             import numpy as np
             index_of = {p: i for i, p in enumerate(db.paths)}
             acc = np.zeros(len(db.paths), bool)
+            handled = np.zeros(len(db.paths), bool)                # candidates whose turn has come (representative or not)
+            live_only = os.environ.get('SKDER_AMD_SEARCH_ALL') != '1'
             extra = set()                                         # (genomes of the N50 table that are not in the database: cannot be accounted for)
             is_acc = lambda g: acc[index_of[g]] if g in index_of else g in extra
             width = search_batch if search_batch > 1 else 4       # 0: adaptive, starting at 4
@@ -287,7 +299,10 @@ def lowMemGreedyDerep(all_genomes_listing_file, skder_lm_workspace, concat_n50_r
                     pos += 1
                 if not batch:
                     break
-                rows = db.search_batch(batch)
+                rows = db.search_batch(batch, live=~(acc | handled) if live_only else None)
+                for genome in batch:
+                    if genome in index_of:
+                        handled[index_of[genome]] = True
                 ok = np.zeros(len(rows), np.uint8)
                 if len(rows):
                     _lib.lib().skder_amd_rows_pass(rows.ctypes.data, len(rows), float(ani_cutoff), float(af_cutoff), 5, ok.ctypes.data)

@@ -1032,7 +1032,7 @@ def test_database_table_in_memory_equals_text(gpu, tmp_path):
     assert all(r[0] < r[1] for r in trows)                   # Ref = the path that sorts first
 
 
-def test_speculative_search_batches_equal_the_sequential_loop(gpu, tmp_path):
+def test_speculative_search_batches_equal_the_sequential_loop(gpu, tmp_path, monkeypatch):
     """low_mem_greedy with speculative batches of searches gives the listing of the one-search-
     per-representative loop (skder.py:116-133), for every batch width; a batch's per-query tables are the
     single searches' tables"""
@@ -1052,6 +1052,19 @@ def test_speculative_search_batches_equal_the_sequential_loop(gpu, tmp_path):
             results[(ani, width)] = res.read_text()
         assert len(set(results[(ani, w)] for w in (1, 0, 2, 5, 64))) == 1
         assert 0 < results[(ani, 1)].count("\n") < len(paths)
+        # the speculative searches leave out the database genomes that cannot change the result (accounted for already, or handled
+        # earlier in the order: skder.py:127-129 only ever adds a row's Ref to the accounted set); with every row computed the listing
+        # is the same and the searches return more rows
+        rows = {}
+        for every in ("0", "1"):
+            monkeypatch.setenv("SKDER_AMD_SEARCH_ALL", every)
+            ws = tmp_path / ("ws_all%s_%s" % (every, ani))
+            ws.mkdir()
+            skder_amd.lowMemGreedyDerep(listing, str(ws) + "/", str(n50_file), str(ws / "res.txt"), str(ws) + "/", ani, 50.0, None, search_batch=2)
+            assert (ws / "res.txt").read_text() == results[(ani, 1)]
+            rows[every] = skder_amd.lowMemGreedyDerep.last_stats["rows"]
+        monkeypatch.delenv("SKDER_AMD_SEARCH_ALL")
+        assert rows["0"] < rows["1"], rows
     assert results[(99.5, 1)] != results[(98.0, 1)]
     with Database.from_listing(listing) as db:
         qs = [paths[3], paths[20], paths[3], paths[11]]
