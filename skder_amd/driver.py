@@ -113,6 +113,58 @@ def run(genomes, outdir, mode="greedy", ani=99.5, af=50.0, max_af_dist=10.0, clu
         db.close()
 
 
+PRESELECTED_ANI_CUTOFFS = [90.0, 95.0, 97.0, 98.0, 99.0, 99.5]         # bin/skder:54-55
+PRESELECTED_AF_CUTOFFS = [10.0, 25.0, 50.0, 75.0, 90.0]
+
+
+def run_test_cutoffs(genomes, outdir, mode="greedy", max_af_dist=10.0, params="-s X", ani=99.5, store=None, devices=None, name_map=None):
+    """bin/skder -tc (bin/skder:331-401): ONE edge table at --min-af 10 (0 for the dynamic mode: skder.py:19-25), then the selection at every
+    pre-selected (ANI, AF) cut-off pair: skDER_Result/skDER_Results_ANI<a>_AF<f>.txt and the counts the reference prints and plots
+    (Parameter_Impacts_Overview.tsv here; the PDF heat map is the control plane's).  The table is computed once and stays in memory;
+    low_mem_greedy runs its searches per cut-off pair on the resident database, as the reference does on its sketch directory.
+    Returns {(ani, af): number of representatives}."""
+    outdir = os.path.abspath(outdir) + "/"
+    os.makedirs(outdir + "skDER_Result/", exist_ok=True)
+    if params == "-s X":
+        params = "-s %s" % max(ani - 10.0, 0.0)
+    listing = outdir + "All_Genomes_Listing.txt"
+    with open(listing, "w") as f:
+        f.write("".join(g + "\n" for g in genomes))
+    n50_file = outdir + "Concatenated_N50.txt"
+    db = open_database(listing, genomes, n50_file, store, devices)
+    counts = OrderedDict()
+    try:
+        shown = [name_map[p] for p in db.paths] if name_map else None
+        rows = None
+        if mode in ("greedy", "dynamic"):
+            min_af = 10.0 if mode == "greedy" else 0.0
+            rows = db.triangle(min_af, parse_skani_params(params), out_tsv=outdir + "Skani_Triangle_Edge_Output.txt")
+        elif mode != "low_mem_greedy":
+            raise ValueError("unknown dereplication mode " + mode)
+        n50v = list(db.n50)
+        for a in PRESELECTED_ANI_CUTOFFS:
+            for f_ in PRESELECTED_AF_CUTOFFS:
+                res = outdir + "skDER_Result/skDER_Results_ANI%s_AF%s.txt" % (a, f_)
+                if mode == "greedy":
+                    n = len(selection.native_greedy(rows, db.paths, n50v, a, f_, outdir + "Genome_Information_for_Greedy_Clustering.txt",
+                                                    outdir + "Genome_Information_for_Greedy_Clustering.sorted.txt", res, display=shown))
+                elif mode == "dynamic":
+                    n = len(selection.native_dynamic(rows, db.paths, n50v, a, f_, max_af_dist, res, display=shown))
+                else:
+                    ws = outdir + "skDER_iterative_greedy_workspace/"
+                    os.makedirs(ws, exist_ok=True)
+                    lowMemGreedyDerep(listing, ws, n50_file, res, outdir, a, f_, None, mge_proc_to_unproc_mapping=name_map, database=db)
+                    n = sum(1 for _ in open(res))
+                counts[(a, f_)] = n
+        with open(outdir + "Parameter_Impacts_Overview.tsv", "w") as f:
+            f.write("ANI/AF\t" + "\t".join(str(x) for x in PRESELECTED_AF_CUTOFFS) + "\n")
+            for a in PRESELECTED_ANI_CUTOFFS:
+                f.write(str(a) + "\t" + "\t".join(str(counts[(a, x)]) for x in PRESELECTED_AF_CUTOFFS) + "\n")
+    finally:
+        db.close()
+    return counts
+
+
 def _run(db, genomes, outdir, mode, ani, af, af_tri, max_af_dist, clusters, params, listing, n50_file, symlink=False, name_map=None):
     n50 = OrderedDict(zip(db.paths, db.n50))
     # name_map: the reference's mge_proc_to_unproc_mapping (skder.py:76-92, 127-129, 160-163, 236-253) -- the genomes were
@@ -186,6 +238,7 @@ def main(argv=None):
     ap.add_argument("--store", default=None, help="sketch store file: loaded if present and still describing these files, written otherwise")
     ap.add_argument("--devices", default=None, help="comma-separated GPU indices (default: $SKDER_AMD_DEVICE or 0): with several, the genomes "
                                                     "are sketched in shares, the sketches exchanged between the GPUs and the pair matrix dealt out by rows")
+    ap.add_argument("-tc", "--test-cutoffs", action="store_true", help="one edge table, the selection at every pre-selected cut-off pair (bin/skder:99)")
     ap.add_argument("--ani", choices=("model", "raw"), default="model",
                     help="which ANI the tables carry and the selection reads: `model` = after the learned-ANI stand-in (what skani prints by default), "
                          "`raw` = the chunk-level k-mer estimate, skani's --no-learned-ani (for simulated genomes with independent substitutions, "
@@ -198,6 +251,13 @@ def main(argv=None):
     if a.name_map:
         with open(a.name_map) as f:
             name_map = dict(l.rstrip("\n").split("\t")[:2] for l in f if l.strip())
+    if a.test_cutoffs:
+        counts = run_test_cutoffs(list_genomes(a.genomes), a.output_directory, a.dereplication_mode, a.max_af_distance_cutoff,
+                                  a.skani_triangle_parameters, a.percent_identity_cutoff, a.store,
+                                  [int(x) for x in a.devices.split(",")] if a.devices else None, name_map)
+        print("Number of representative genomes selected:")
+        print(open(os.path.join(a.output_directory, "Parameter_Impacts_Overview.tsv")).read())
+        return counts
     reps = run(list_genomes(a.genomes), a.output_directory, a.dereplication_mode, a.percent_identity_cutoff,
                a.aligned_fraction_cutoff, a.max_af_distance_cutoff, a.determine_clusters, a.skani_triangle_parameters, a.store,
                a.symlink, [int(x) for x in a.devices.split(",")] if a.devices else None, name_map)

@@ -1947,6 +1947,33 @@ def test_gzip_ingest_with_streams_inflated_on_the_device(gpu, tmp_path, monkeypa
     assert out["host"][0].count("\n") == 1 + len(paths) * (len(paths) - 1) // 2
 
 
+def test_driver_test_cutoffs_mode(gpu, tmp_path):
+    """`python -m skder_amd.driver -tc` (bin/skder:99,331-401): one edge table at --min-af 10, then the selection at all 30 pre-selected
+    cut-off pairs -- the 30 files of the reference's own -tc run: identical at the cut-offs skDER is run with (-i 99.0 / 99.5), at least 19
+    of 30 overall (the floor of test_tc_grid_through_the_gpu_dropin), and the counts table equals the files.  The low_mem_greedy form of
+    the sweep runs its searches on one resident database and agrees with the greedy form wherever both are defined by the same edges."""
+    from skder_amd import driver
+    gdir = os.path.join(GOLDEN, "genomes")
+    n50_gold = [l.split("\t")[0] for l in open(os.path.join(GOLDEN, "downstream", "skder_gtdb_results__Concatenated_N50.txt"))]
+    genomes = [os.path.join(gdir, n) for n in n50_gold]           # the reference run's listing order
+    counts = driver.run_test_cutoffs(genomes, str(tmp_path / "tc"), "greedy", params="-s 89.5")
+    assert list(counts) == [(a, f) for a in driver.PRESELECTED_ANI_CUTOFFS for f in driver.PRESELECTED_AF_CUTOFFS]
+    same = 0
+    for (a, f), n in counts.items():
+        got = [os.path.basename(l.strip()) for l in open(tmp_path / "tc" / "skDER_Result" / ("skDER_Results_ANI%s_AF%s.txt" % (a, f)))]
+        want = [l.strip() for l in open(os.path.join(GOLDEN, "downstream", "tc", "skDER_Results_ANI%s_AF%s.txt" % (a, f)))]
+        assert n == len(got)
+        same += got == want
+        assert got == want or a < 99.0, (a, f)
+    assert same >= 19, same
+    table = [l.rstrip("\n").split("\t") for l in open(tmp_path / "tc" / "Parameter_Impacts_Overview.tsv")]
+    assert table[0] == ["ANI/AF"] + [str(x) for x in driver.PRESELECTED_AF_CUTOFFS] and len(table) == 7
+    assert [int(x) for x in table[6][1:]] == [counts[(99.5, f)] for f in driver.PRESELECTED_AF_CUTOFFS]
+    low = driver.run_test_cutoffs(genomes, str(tmp_path / "tcl"), "low_mem_greedy", params="-s 89.5")
+    assert set(low) == set(counts) and all(0 < n <= len(genomes) for n in low.values())
+    assert low[(99.5, 50.0)] == sum(1 for _ in open(tmp_path / "tcl" / "skDER_Result" / "skDER_Results_ANI99.5_AF50.0.txt"))
+
+
 def test_tc_grid_through_the_gpu_dropin(gpu, tmp_path):
     """The reference's `-tc` sweep (bin/skder:331-407: 6 ANI x 5 AF cut-offs over ONE table, `--min-af 10 -s 89.5`) through the GPU
     drop-in and the native selection, against the 30 golden listings of test_case/skder_gtdb_results/skDER_Result/.  A FLOOR, with
