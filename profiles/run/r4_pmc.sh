@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4: SQ counters of the chaining kernels on the real-structure workload (34 assemblies x D descendants), separate passes.
-# TAG names the output; extra environment (SKDER_AMD_RUNS_V1=1 ...) selects the variant
+# TAG names the output; extra environment (SKDER_AMD_RRUNS=1, SKDER_AMD_NO_ROWS=1 ...) selects a variant
 export TMPDIR=/tmp D=${D:-8}
 TAG=${TAG:-r4}
 OUT=gpurun_out/r4pmc/$TAG

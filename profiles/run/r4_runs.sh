@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 4: the predicated run loop -- parity (normal mix, and every chunk with hits through the run loop), A/B timing on the real-structure set
+# (historical: the variant this script selected was measured and removed -- DESIGN.md section 8; it documents how the number was taken and no longer switches anything)
 mkdir -p gpurun_out/r4b
 K="not config4 and not config5 and not 1000_genomes and not properties_at_scale and not ranks_share and not rccl"
 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "$K" > gpurun_out/r4b/pytest.log 2>&1; echo "rc=$?" >> gpurun_out/r4b/pytest.log

@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 4: run loop A/B on the real-structure set (lists per record-count class): branching (v1) against predicated (v2), then round statistics
+# (historical: the variant this script selected was measured and removed -- DESIGN.md section 8; it documents how the number was taken and no longer switches anything)
 for v in v1 v2; do
   unset SKDER_AMD_RUNS_V1
   if [ $v = v1 ]; then export SKDER_AMD_RUNS_V1=1; fi
