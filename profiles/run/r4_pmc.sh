@@ -17,7 +17,7 @@ tot=collections.defaultdict(lambda: collections.defaultdict(float))
 for f in glob.glob(out+'/p*/**/*counter_collection.csv',recursive=True):
     for r in csv.DictReader(open(f)):
         k=r['Kernel_Name'].split('(')[0].replace('void ','')
-        for name in ("chain_runs_kernel",'chain_rows_kernel','slow_wave_kernel','chain_single_kernel','finalize_kernel','run_extract_kernel','join_probe_kernel'):
+        for name in ("chain_runs_kernel",'chain_rruns_kernel','chain_rows_kernel','slow_wave_kernel','chain_single_kernel','finalize_kernel','run_extract_kernel','join_probe_kernel'):
             if name in k: tot[name][r['Counter_Name']]+=float(r['Counter_Value'])
 for k,v in tot.items():
     print(k, {c: '%.4g' % x for c,x in sorted(v.items())})
