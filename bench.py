@@ -27,6 +27,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0
+PMC_TRAFFIC = os.path.join("profiles", "round4_pmc_traffic.json")     # rocprofv3 --pmc passes of THIS build (profiles/collect.sh)
+ONE_QUEUE_STEPS = 3
 
 
 def write_sample_files(batches, n_sample):
@@ -678,6 +680,36 @@ def cpu_baseline_files(tmp, paths, threads):
     return per_genome, per_pair, per_chained, chained, t_load + t_full + t_screen * npair, measured
 
 
+def parity_sample(recipe, edges, n_pairs, seed=5):
+    """The headline's own output against the oracle, at the metric's own size: n_pairs random edge records of the last step
+    -- integer sums and doubles -- against oracle_py.pair on the same two genomes (bases regenerated on the host by the numpy
+    statement of the generator).  After the timed region; the oracle is the checker here, never the thing measured."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py
+    from skder_amd import synth
+    rng = np.random.RandomState(seed)
+    pick = rng.choice(len(edges), size=min(n_pairs, len(edges)), replace=False) if len(edges) else []
+    p = oracle_py.default_params()
+    cache, bad, t0 = {}, [], time.perf_counter()
+
+    def genome(g):
+        if g not in cache:
+            cache[g] = oracle_py.Genome.from_bases(synth.bases_numpy(recipe, g), recipe.rec_lens[g], p)
+        return cache[g]
+    for i in pick:
+        e = edges[int(i)]
+        a, b = int(e["ref"]), int(e["query"])
+        r = oracle_py.pair(genome(a), genome(b), p)
+        same = (int(e["sum_anchors"]) == r.sum_anchors and int(e["sum_seeds"]) == r.sum_seeds and int(e["cell_seeds"]) == r.cell_seeds
+                and int(e["aligned_bases"]) == r.aligned_bases and float(e["ani"]) == r.ani and float(e["ani_raw"]) == r.ani_raw
+                and float(e["af_ref"]) == r.af_ref and float(e["af_query"]) == r.af_query)
+        if not same:
+            bad.append([a, b])
+    return {"pairs": int(len(pick)), "mismatches": len(bad), "mismatched_pairs": bad[:5], "seconds": time.perf_counter() - t0,
+            "what": "random edge records of the headline's last step (the shipped two-queue path) against oracle_py.pair on the same genomes: "
+                    "anchors, seeds, cell seeds, aligned bases, ANI (raw and model) and both aligned fractions, bit for bit"}
+
+
 def cpu_baseline_skani(tmp, paths, threads):
     """The reference engine itself, when the box has it (oracle/skani_ref.py): `skani triangle -t threads`
     on the sample files, wall-clocked, next to a run whose screen lets nothing through but identical genomes (-s 100),
@@ -716,6 +748,7 @@ def main():
     ap.add_argument("--real-derived", type=int, default=30, help="descendants per real assembly in the real-structure workload (34 x this many genomes; 0: skip)")
     ap.add_argument("--one-species-genomes", type=int, default=5000, help="genomes of the one-species low_mem_greedy leg (README.md:27's workload in its real shape; "
                                                                             "profiles/run/r4_one_species.py runs 20000; 0: skip)")
+    ap.add_argument("--parity-pairs", type=int, default=20, help="edges of the headline's last step checked against the CPU oracle after the timed region (0: skip)")
     ap.add_argument("--low-mem-genomes", type=int, default=20000, help="genomes of the low_mem_greedy leg (README.md:27's workload shape: 20000; 0: skip)")
     args = ap.parse_args()
 
@@ -820,6 +853,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
+    host_wall_ms = {k: 1e3 * v / args.steps for k, v in wall.items()}      # of the timed steps only (the extra steps below add to wall[])
     # every rank's wall time per stage and step (N > 1: so that the first scaling curve can be read: which stage does not shrink)
     my_stages = {"sketch": 1e3 * wall["sketch"] / args.steps, "exchange": 1e3 * wall["exchange"] / args.steps}
     my_stages.update({k: v / args.steps for k, v in stage.items()})
@@ -836,18 +870,27 @@ def main():
     # kernel (the longest, never overlapped) keeps the timed region's figure.
     overlapped = {"join_probe_kernel": float(step.counters[2]) / 1000.0, "run_extract_kernel": float(step.runs_ms),
                   "chain_single_kernel+chain_runs_kernel": float(tm[3]), "chain_slow_path": float(tm[4]), "finalize": float(tm[5])}
-    one_queue_ms = None
+    one_queue_ms, one_queue_steps_ms = None, None
     if not dist_on and os.environ.get("SKDER_AMD_QUEUES") is None:
+        # one discarded step after the queue count changes (the work buffers are laid out again), then ONE_QUEUE_STEPS steps timed one
+        # by one; the figures are those of the fastest step, and every step's time is in the line so that an outlier can be seen
         os.environ["SKDER_AMD_QUEUES"] = "1"
-        t1q = time.perf_counter()
-        tq = []
-        for _ in range(2):
-            _, t_ = step()
-            tq.append(t_)
+        step()
         torch.cuda.synchronize()
-        one_queue_ms = (time.perf_counter() - t1q) / 2 * 1e3
+        tq, one_queue_steps_ms = [], []
+        for _ in range(ONE_QUEUE_STEPS):
+            t1q = time.perf_counter()
+            _, t_ = step()
+            torch.cuda.synchronize()
+            one_queue_steps_ms.append((time.perf_counter() - t1q) * 1e3)
+            tq.append((t_, np.array(step.counters, copy=True), step.runs_ms, step.index_ms))
         del os.environ["SKDER_AMD_QUEUES"]
-        tm[2:6] = np.mean(tq, axis=0)[2:6]
+        fastest = int(np.argmin(one_queue_steps_ms))
+        one_queue_ms = one_queue_steps_ms[fastest]
+        tm[2:6] = tq[fastest][0][2:6]
+        edges, _ = step()          # back on the shipped two queues: the edges checked below are those of the shipped path
+        torch.cuda.synchronize()
+        _, step.counters, step.runs_ms, step.index_ms = tq[fastest]       # per-kernel figures: the fastest one-queue step's
     n_chained_all = float(tm[6])
     if dist_on:
         t = torch.tensor([tm[6]], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
@@ -906,12 +949,14 @@ def main():
         traffic, traffic_source = None, None
         try:
             if N == 5000 and world == 1 and args.len_range is None and args.genome_len == 3_000_000:
-                src = os.path.join("profiles", "round3_pmc_traffic.json")
+                src = PMC_TRAFFIC
+                if not os.path.isfile(os.path.join(ROOT, src)):
+                    raise RuntimeError("%s is missing: roofline.traffic has no source (collect it with profiles/collect.sh)" % src)
                 pm = json.load(open(os.path.join(ROOT, src)))[dom.split("+")[0]]
                 # counter values corrected by the calibration of profiles/calib (profiles/summarise.py)
                 traffic = sum(pm[c].get("corrected_bytes", pm[c]["sum_counter_kb"] * 1024.0) for c in ("FETCH_SIZE", "WRITE_SIZE"))
                 traffic_source = src + " (static: rocprofv3 --pmc passes of this build, not measured in this run)"
-        except Exception:
+        except (KeyError, ValueError):
             traffic = None
         out = {
             "metric": "genome-pairs ANI/sec on 5k x 3Mb synthetic", "value": pairs / (ms_per_step * 1e-3),
@@ -940,14 +985,18 @@ def main():
                                            "durations of two extra steps with all batches on ONE queue; in the timed region the batches "
                                            "alternate between two queues and overlap, and their event brackets (kernel_ms_two_queues) "
                                            "include the wait for the other queue's share of the chip",
-                         "kernel_ms_two_queues": overlapped, "ms_per_step_one_queue": one_queue_ms,
-                         "host_wall_ms": {k: 1e3 * v / args.steps for k, v in wall.items()},
+                         "kernel_ms_two_queues": overlapped, "ms_per_step_one_queue": one_queue_ms, "one_queue_steps_ms": one_queue_steps_ms,
+                         "host_wall_ms": host_wall_ms,
                          "per_rank_stage_ms": per_rank,
                          "kernel_GBs": {k: float(v[1] / (v[0] * 1e-3) / 1e9) if v[0] > 0 else 0.0 for k, v in cand.items()},
                          "other_ms": {"sketch_post": float(tm[1]), "index_beside_screen": float(step.index_ms), "screen": float(tm[2]), "chain_slow_path": float(tm[4]),
                                       "finalize": float(tm[5])}},
         }
         out["config"]["us_per_chained_pair"] = 1e3 * (join_ms + step.runs_ms + tm[3] + tm[4] + tm[5]) / max(n_chained, 1.0)
+        if world == 1 and not args.no_cpu_baseline and args.parity_pairs > 0:
+            out["parity_sample"] = parity_sample(recipe, edges, args.parity_pairs)
+            out["config"]["parity_sample_pairs"] = out["parity_sample"]["pairs"]
+            out["config"]["parity_sample_mismatches"] = out["parity_sample"]["mismatches"]
         if world == 1 and not args.no_cpu_baseline:
             out["parity_vs_skani"] = golden_parity(dev)
         if world == 1 and not args.no_cpu_baseline and args.e2e_genomes > 0:

@@ -19,6 +19,19 @@
  * err[0..errlen) -- the Python shim raises RuntimeError from it, as util.runCmd does (util.py:652).
  * There is NO CPU fallback anywhere behind this header: without a gfx950 device every compute entry
  * point fails with an error.
+ *
+ * ENVIRONMENT SWITCHES read by the library (all of them; none is needed for normal use; results are identical under every one):
+ *   SKDER_AMD_DEBUG=1|2        per-batch counters (chunks per path, decline causes) and host timings on stderr; 2: one line per ingested file
+ *   SKDER_AMD_QUEUES=n         HIP queues the chaining batches alternate between (default 2; 1 = batch after batch: per-kernel timings)
+ *   SKDER_AMD_CHUNK_BUDGET=n   chunks per chaining batch (default 6 M);  SKDER_AMD_PAIR_BUDGET=n  candidate pairs per screening block (2^31);
+ *   SKDER_AMD_REC_DIV=n        seeds per run-record slot (default 4)                       -- the three are exercised by the parity tests
+ *   SKDER_AMD_FORCE_SLOW=1     every chunk through the general (unabridged) chaining kernel;  SKDER_AMD_NO_SIEVE=1  none settled by the sieve;
+ *   SKDER_AMD_NO_ROWS=1        declined chunks to the one-wavefront-per-chunk kernel instead of the rows kernel  -- parity A/B of the chaining paths
+ *   SKDER_AMD_IO_THREADS=n     reader threads of the ingest (default: the cgroup's CPUs, at most 128);  SKDER_AMD_IO_BATCH_MB=n  pinned staging batch (256)
+ *   SKDER_AMD_IO_TWO_PHASE=1   .gz files through memory of their own instead of straight into the staging buffer
+ *   SKDER_AMD_HOST_PARSE=1     FASTA parsed by the host reader instead of the device;  SKDER_AMD_FASTA_WAVE=1  by the one-wavefront-per-file kernel
+ * Read by the Python host mirror (skder_amd/skder.py): SKDER_AMD_DEVICE, SKDER_AMD_DEVICES (device list of the drop-in entry points),
+ * SKDER_AMD_SEARCH_BATCH, SKDER_AMD_SEARCH_ALL (lowMemGreedyDerep's speculative batches); by bench.py: SKDER_AMD_FORCE_DIST, SKDER_AMD_DIST_BACKEND.
  */
 #ifndef SKDER_AMD_H
 #define SKDER_AMD_H
@@ -238,14 +251,6 @@ int skder_amd_descend_lengths(skder_ctx_t *ctx, const uint8_t *d_anc_bases, cons
                               uint32_t n_desc, uint32_t *rec_len_out, uint32_t n_rec_out);
 int skder_amd_descend_fill(skder_ctx_t *ctx, const uint8_t *d_anc_bases, const skder_batch_t *anc, const skder_descendant_t *desc,
                            uint32_t n_desc, uint8_t *d_out_bases, const uint64_t *rec_out_off, uint32_t n_rec_out);
-
-/* DEFLATE on the device (ginflate.hip): n raw DEFLATE streams resident in HBM (the bytes behind a gzip header; the host parses header
- * and trailer) -> their text, one wavefront per stream; then the CRC-32 of every text.  jobs / results are host arrays.
- * status: 0 ok, 2 corrupt, 3 truncated, 4 the text is longer than out_cap.  kernel_ms (may be NULL): [0] inflate, [1] CRC. */
-typedef struct { uint64_t in_off; uint32_t in_len, pad; uint64_t out_off, out_cap; } skder_gz_job_t;
-typedef struct { uint32_t status, crc, in_used, pad; uint64_t out_len; } skder_gz_result_t;
-int skder_amd_inflate_device(skder_ctx_t *ctx, const uint8_t *d_in, const skder_gz_job_t *jobs, uint32_t n, uint8_t *d_out,
-                             skder_gz_result_t *results, float *kernel_ms);
 
 /* ======================================================================================
  * C. the callers either side of the path: all work on the resident database

@@ -13,6 +13,7 @@
 
 #define ANI_K              15      /* seed k-mer length */
 #define ANI_C              125     /* seed FracMinHash compression: keep if hash < 2^64/125 */
+#define ANI_SAMPLE_WINDOW  0       /* 0: sample hash < 2^64/c; 1: sample (hash ^ 2^63) < 2^64/c */
 #define ANI_MARKER_K       21      /* marker k-mer length */
 #define ANI_MARKER_C       1000    /* marker compression */
 #define ANI_MIN_CONTIG     500     /* FASTA records shorter than this are ignored */

@@ -52,6 +52,9 @@ void oracle_default_params(oracle_params_t *p)
     p->small_pass = ANI_SMALL_PASS;
     p->rep_floor = ANI_REP_FLOOR;
     p->learned = 1;
+    p->sample_window = ANI_SAMPLE_WINDOW;
+    p->hash_first_step = 0;
+    p->quarters = 0;
 }
 
 /* ------------------------------------------------------------------ hashing */
@@ -59,6 +62,17 @@ void oracle_default_params(oracle_params_t *p)
 /* minimap2's invertible 64-bit mix (Thomas Wang), which skani uses for FracMinHash sampling
  * (SURVEY R1), with the first step as skani's Rust source spells it:
  * `key = !key.wrapping_add(key << 21)` == ~(key + (key << 21)) -- see include/skder_amd_spec.h. */
+static inline uint64_t mm_hash64_v(uint64_t key, int first_step)
+{
+    key = first_step ? ~key + (key << 21) : ~(key + (key << 21));
+    key = key ^ (key >> 24);
+    key = (key + (key << 3)) + (key << 8);
+    key = key ^ (key >> 14);
+    key = (key + (key << 2)) + (key << 4);
+    key = key ^ (key >> 28);
+    key = key + (key << 31);
+    return key;
+}
 uint64_t oracle_mm_hash64(uint64_t key)
 {
     key = ~(key + (key << 21));
@@ -127,9 +141,12 @@ typedef struct {
 
 /* FracMinHash over one kept record.  pos is the index of the k-mer's LAST base; the first
  * marker_k-1 positions only warm the rolling registers up (seed and marker k-mers are both
- * examined from i = marker_k-1 on), following skani's seeding loop structure. */
-static void sketch_contig(const uint8_t *s, uint32_t len, uint32_t ctg, uint32_t goff,
-                          const oracle_params_t *p, sketch_acc *acc)
+ * examined from i = marker_k-1 on), following skani's seeding loop structure.
+ * A k-mer is sampled when (hash ^ window) < 2^64 / c as unsigned numbers: window = 0 keeps the
+ * hashes [0, T); window = 2^63 keeps [2^63, 2^63 + T), which is what a SIGNED 64-bit compare of the
+ * hash against i64::MIN + T keeps (p->sample_window; oracle/sample_hypotheses.py). */
+static void sketch_range(const uint8_t *s, uint32_t from, uint32_t to, uint32_t first_pos, uint32_t ctg,
+                         uint32_t goff, const oracle_params_t *p, sketch_acc *acc)
 {
     const int k = p->k, mk = p->marker_k;
     const uint64_t smask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
@@ -137,25 +154,50 @@ static void sketch_contig(const uint8_t *s, uint32_t len, uint32_t ctg, uint32_t
     const int sshift = 2 * (k - 1), mshift = 2 * (mk - 1);
     const uint64_t sthr = UINT64_MAX / (uint64_t)p->c;
     const uint64_t mthr = UINT64_MAX / (uint64_t)p->marker_c;
+    const uint64_t win = p->sample_window ? 0x8000000000000000ULL : 0;
+    const int fst = p->hash_first_step;
     uint64_t fs = 0, rs = 0, fm = 0, rm = 0;
-    if (len < (uint32_t)mk) return;
-    for (uint32_t i = 0; i < len; i++) {
+    const int enc = p->rule[7] & 1, cmax = (p->rule[7] >> 1) & 1;   /* hypotheses: A,C,T,G = 0..3; canonical = larger */
+    for (uint32_t i = from; i < to; i++) {
         uint64_t nf = base_code(s[i]), nr = 3 - nf;
+        if (enc) { nf = (nf == 2) ? 3 : (nf == 3) ? 2 : nf; nr = nf ^ 2; }
         fs = ((fs << 2) | nf) & smask;
         rs = (rs >> 2) | (nr << sshift);
         fm = ((fm << 2) | nf) & mmask;
         rm = (rm >> 2) | (nr << mshift);
-        if (i + 1 < (uint32_t)mk) continue;
-        int fwd = fs < rs;
+        if (i < first_pos) continue;
+        int fwd = cmax ? fs > rs : fs < rs;
         uint64_t cs = fwd ? fs : rs;
-        if (oracle_mm_hash64(cs) < sthr) {
+        if ((mm_hash64_v(cs, fst) ^ win) < sthr) {
             VPUSH(acc->kmer, uint64_t, cs);
             VPUSH(acc->gpos, uint32_t, goff + i);
             VPUSH(acc->ctg, uint32_t, ctg);
             VPUSH(acc->fwd, uint8_t, (uint8_t)fwd);
         }
-        uint64_t cm = fm < rm ? fm : rm;
-        if (oracle_mm_hash64(cm) < mthr) VPUSH(acc->markers, uint64_t, cm);
+        uint64_t cm = (cmax ? fm > rm : fm < rm) ? fm : rm;
+        if ((mm_hash64_v(cm, fst) ^ win) < mthr) VPUSH(acc->markers, uint64_t, cm);
+    }
+}
+
+static void sketch_contig(const uint8_t *s, uint32_t len, uint32_t ctg, uint32_t goff,
+                          const oracle_params_t *p, sketch_acc *acc)
+{
+    const uint32_t mk = (uint32_t)p->marker_k;
+    if (len < mk) return;
+    if (p->quarters == 1) {
+        /* hypothesis: four SIMD lanes take the k-mers of a record in four equal runs; the last
+         * (number of k-mers) mod 4 k-mers are not examined */
+        uint32_t q = (len - mk + 1) / 4;
+        for (uint32_t j = 0; j < 4; j++)
+            sketch_range(s, j * q, (j + 1) * q + mk - 1, j * q + mk - 1, ctg, goff, p, acc);
+    } else if (p->quarters == 2) {
+        /* hypothesis: four disjoint quarters of len / 4 bases, each warmed up on its own */
+        uint32_t q = len / 4;
+        if (q < mk) return;
+        for (uint32_t j = 0; j < 4; j++)
+            sketch_range(s, j * q, (j + 1) * q, j * q + mk - 1, ctg, goff, p, acc);
+    } else {
+        sketch_range(s, 0, len, mk - 1, ctg, goff, p, acc);
     }
 }
 
@@ -411,8 +453,16 @@ typedef struct {
 /* Which genome is cut into chunks?  The one with the smaller T * (T / n_contigs) (shorter and
  * more fragmented); ties: fewer seeds, then fewer markers, then the `query` argument.
  * Returns 1 to chunk `query`. */
-static int chunk_query(const oracle_genome_t *ref, const oracle_genome_t *query)
+static int chunk_query(const oracle_genome_t *ref, const oracle_genome_t *query, const oracle_params_t *p)
 {
+    switch (p->rule[0]) {
+    case 1: if (query->total_len != ref->total_len) return query->total_len < ref->total_len; break;
+    case 2: if (query->n_seeds != ref->n_seeds) return query->n_seeds < ref->n_seeds; break;
+    case 3: if (query->total_len != ref->total_len) return query->total_len > ref->total_len; break;
+    case 4: return 1;
+    case 5: return 0;
+    default: break;
+    }
     double tq = (double)query->total_len, tr = (double)ref->total_len;
     double sq = tq * (tq / (double)(query->n_contigs ? query->n_contigs : 1));
     double sr = tr * (tr / (double)(ref->n_contigs ? ref->n_contigs : 1));
@@ -462,7 +512,7 @@ int oracle_pair(const oracle_genome_t *ref, const oracle_genome_t *query, const 
                 oracle_pair_t *out, oracle_chain_t *chains_out, uint32_t chain_cap)
 {
     memset(out, 0, sizeof(*out));
-    int cq = chunk_query(ref, query);
+    int cq = chunk_query(ref, query, p);
     const oracle_genome_t *Q = cq ? query : ref;   /* chunked genome */
     const oracle_genome_t *R = cq ? ref : query;
     out->chunked_query = cq;
@@ -505,6 +555,9 @@ int oracle_pair(const oracle_genome_t *ref, const oracle_genome_t *query, const 
         uint32_t qc = Q->s_ctg[A[s].qi];
         uint32_t ck = (A[s].qpos - Q->ctg_off[qc]) / (uint32_t)p->chunk_len;
         size_t e = s;
+        if (p->rule[1] == 1) {          /* hypothesis: a chunk begins at an anchor and holds the next chunk_len bases */
+            while (e < na && Q->s_ctg[A[e].qi] == qc && A[e].qpos - A[s].qpos <= (uint32_t)p->chunk_len) e++;
+        } else
         while (e < na && Q->s_ctg[A[e].qi] == qc &&
                (A[e].qpos - Q->ctg_off[qc]) / (uint32_t)p->chunk_len == ck) e++;
         /* 3. banded chaining inside [s, e): f[i] = max(score, max_j f[j] + score - |dq - dr|),
@@ -547,7 +600,15 @@ int oracle_pair(const oracle_genome_t *ref, const oracle_genome_t *query, const 
                 if (A[cur].rpos > rmax) rmax = A[cur].rpos;
                 cur = bp[cur];
             }
-            if (n < (uint32_t)p->min_anchors) continue;
+            if (p->rule[3] && cur >= 0) continue;      /* hypothesis: a chain that runs into a taken anchor is no chain */
+            if (n < (uint32_t)p->min_anchors) {
+                if (p->rule[2]) {                      /* hypothesis: its anchors are spent all the same */
+                    cur = (int32_t)endi;
+                    while (cur >= 0 && !used[cur]) { int32_t nx = bp[cur]; used[cur] = 1; cur = nx; }
+                }
+                continue;
+            }
+            if (p->rule[6] && t > 0 && nch > 0 && C[nch - 1].chunk == n_chunks) break;  /* hypothesis: one chain per chunk */
             cur = (int32_t)endi;
             while (cur >= 0 && !used[cur]) { int32_t nx = bp[cur]; used[cur] = 1; cur = nx; }
             if (nch == chcap) { chcap *= 2; C = (oracle_chain_t *)realloc(C, chcap * sizeof(oracle_chain_t)); }
@@ -587,7 +648,9 @@ int oracle_pair(const oracle_genome_t *ref, const oracle_genome_t *query, const 
             if (!C[j].kept || C[j].rctg != C[i].rctg) continue;
             uint32_t lo = C[i].r0 > C[j].r0 ? C[i].r0 : C[j].r0;
             uint32_t hi = C[i].r1 < C[j].r1 ? C[i].r1 : C[j].r1;
-            if (hi > lo && (uint64_t)ANI_REF_OVERLAP_DEN * (hi - lo) > (uint64_t)ANI_REF_OVERLAP_NUM * li) {
+            if (p->rule[4] == 1) break;                /* hypothesis: no overlap filter */
+            if (p->rule[4] == 3 ? hi > lo :
+                hi > lo && (uint64_t)ANI_REF_OVERLAP_DEN * (hi - lo) > (uint64_t)ANI_REF_OVERLAP_NUM * li) {
                 C[i].kept = 0;
                 break;
             }
@@ -602,7 +665,7 @@ int oracle_pair(const oracle_genome_t *ref, const oracle_genome_t *query, const 
             if (!C[i].kept) continue;
             out->sum_seeds += C[i].n_seeds;
             out->sum_anchors += C[i].n_anchors;
-            out->sum_span += (uint64_t)(C[i].q1 - C[i].q0);
+            out->sum_span += p->rule[5] ? (uint64_t)(C[i].r1 - C[i].r0) : (uint64_t)(C[i].q1 - C[i].q0);
             out->n_chains++;
             if (!cell_used[C[i].chunk]) { cell_used[C[i].chunk] = 1; out->cell_seeds += cell_seeds[C[i].chunk]; }
         }

@@ -12,7 +12,8 @@ _LIB = None
 class Params(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "k", "c", "marker_k", "marker_c", "min_contig", "chunk_len", "band", "bp_band", "max_gap",
-        "max_lin", "anchor_score", "min_anchors", "pad", "small_pass", "rep_floor", "learned")]
+        "max_lin", "anchor_score", "min_anchors", "pad", "small_pass", "rep_floor", "learned",
+        "sample_window", "hash_first_step", "quarters")] + [("rule", C.c_int32 * 8)]
 
 
 class Chain(C.Structure):

@@ -79,7 +79,6 @@ SYMBOLS = {
     "skder_amd_descend_fill": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32]),
     "skder_amd_peer_fallbacks": (C.c_uint32, []),
     "skder_amd_set_ani_output": (C.c_int, [C.c_int]),
-    "skder_amd_inflate_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "skder_amd_release_cached_buffers": (C.c_int, [C.c_int]),
     "skder_amd_last_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "skder_amd_last_index_ms": (C.c_double, [C.c_void_p]),

@@ -49,7 +49,10 @@ struct PairOut {
 #define USED_BIT 0x80000000u
 #define FIN_LDS_CHAINS 2048
 #define FIN_BINS 1024
-#define FAST_SLOTS 3
+#ifndef FAST_SLOTS
+#define FAST_SLOTS 6         // chain slots per chunk of the two fast kernels (the run loop declines a chunk with more chains)
+#endif
+#define SIEVE_PATHS 3        // paths the sieve follows (its own limit; its chains use the first slots)
 #ifndef CF_OCC
 #define CF_OCC 3           // wavefronts per SIMD chain_fast_kernel is compiled for
 #endif
@@ -97,13 +100,10 @@ void launch_chain_rows(hipStream_t st, unsigned grid, SetView A, SetView B, cons
 void launch_chain_runs(hipStream_t st, unsigned grid, SetView A, SetView B, const PairDesc *pairs, uint32_t npairs, const uint32_t *gen_list,
                        const uint32_t *gen_cnt, uint32_t gen_cap, const RunRec *recs, const uint32_t *chunk_rec0, const uint4 *multi,
                        ChainRec *fast_chains, uint32_t *chunk_state, uint32_t *slow_list, uint32_t *slow_count, uint32_t *pair_na,
-                       const uint32_t *chunk_pair, uint32_t *decl_list, uint32_t *decl_count);
-
-// ---- the run DP in row form (chain_rruns.hip): what the run loop gives up, or everything the sieve leaves
-void launch_chain_rruns(hipStream_t st, unsigned grid, SetView A, SetView B, const PairDesc *pairs, const uint32_t *list, const uint32_t *n_ptr,
-                        const uint32_t *gen_list, const uint32_t *gen_cnt, uint32_t gen_cap, const RunRec *recs, const uint32_t *chunk_rec0,
-                        const uint4 *multi, ChainRec *fast_chains, uint32_t *chunk_state, ChainRec *chains, uint32_t *pair_nch, uint32_t *pair_na,
-                        uint32_t *next_list, uint32_t *next_count, uint32_t *stats, uint32_t *flags, const uint32_t *chunk_pair);
+                       const uint32_t *chunk_pair, uint32_t *decl_list, uint32_t *decl_count, uint32_t *work_next);
+#define RUNS_DRAW 512u          // items a wavefront takes from the shared counter at a time
+#define RUNS_DECL_FLUSH 64u     // declined chunks a wavefront collects before it appends them to the shared list
+#define RUNS_REFILL_MIN 24u     // lanes of a wavefront that must be free before finished chunks are written out and new ones handed over
 
 // ---- the join (chain_join.hip)
 struct JoinGroup { uint32_t pair_begin, pair_end; };

@@ -58,7 +58,7 @@ struct ChainSlot {
     DevBuf<uint32_t> hits, pair_nmulti, groups, over_list, flags;
     DevBuf<uint4> multi;
     DevBuf<RunRec> recs;
-    DevBuf<uint32_t> pair_over, chunk_rec0, wg_pair, gen_list, gen_cnt, chunk_pair, rows_next, rr_list;
+    DevBuf<uint32_t> pair_over, chunk_rec0, wg_pair, gen_list, gen_cnt, chunk_pair, rows_next;
     std::vector<uint32_t> h_wg_pair;
     DevBuf<ChainRec> fast_chains, chains;
     DevBuf<PairOut> d_out;
@@ -185,14 +185,13 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
     size_t budget = 6u << 20;   // chunks (work items) per batch
     int nqueues = 1;
     uint32_t join_group_max = 8;       // pairs per join workgroup (8: 24.6 ms per step of the benchmark; 16: 25.9; 4: 24.7; 32: 28.8)
-    if (const char *e = getenv("SKDER_AMD_JOIN_GROUP")) join_group_max = (uint32_t)atoi(e);
     hipStream_t queues[3] = {st, st, st};
     if (const char *e = getenv("SKDER_AMD_CHUNK_BUDGET")) budget = strtoull(e, nullptr, 10);
     ChainWork &W = *chain_work(ctx);
     const SetView VA = view_of(SA), VB = view_of(SB);
-    // debugging switches: SKDER_AMD_NO_XCD keeps the join's groups in launch order; SKDER_AMD_FORCE_SLOW sends every chunk down the slow path;
+    // debugging switches: SKDER_AMD_FORCE_SLOW sends every chunk down the slow path;
     // SKDER_AMD_NO_SIEVE hands every chunk with hits to chain_runs_kernel (to tell the two fast kernels apart behind a parity failure)
-    int xcd_remap = (getenv("SKDER_AMD_NO_XCD") ? 0 : 1) | (getenv("SKDER_AMD_FORCE_SLOW") ? 2 : 0);
+    int xcd_remap = 1 | (getenv("SKDER_AMD_FORCE_SLOW") ? 2 : 0);
     if (const char *e = getenv("SKDER_AMD_NO_SIEVE")) xcd_remap |= atoi(e) ? 1024 : 0;
     double t_fast = 0, t_slow = 0, t_fin = 0, t_join = 0, t_runs = 0;
     uint64_t tot_anchors = 0, tot_slow = 0, tot_chunks = 0, tot_over = 0;
@@ -220,26 +219,9 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
                                S.pair_over.p, S.chunk_rec0.p, S.wg_pair.p, S.multi.p, S.fast_chains.p, S.chunk_state.p, S.slow_list.p, S.counters.p,
                                S.gen_list.p, S.gen_cnt.p, gen_cap, S.pair_na.p, xcd_remap, S.chunk_pair.p);
             // what the sieve left: the run loop (one lane per chunk, a ring of four runs); what it gives up goes to the general kernel.
-            // SKDER_AMD_RRUNS=1 puts the run DP in ROW form in between (one 16-lane row per chunk, all runs resident: chain_rruns.hip),
-            // =2 lets it take everything the sieve left instead of the run loop.  It settles 72 % of what the run loop gives up (3.6 %
-            // of the real-structure set's chunks reach the general kernel instead of 12.6 %) and is bit-equal with the oracle -- and
-            // costs 5.4 ns per chunk where the general kernel takes 4: measured slower, so it is not the default
-            const int rruns = getenv("SKDER_AMD_RRUNS") ? atoi(getenv("SKDER_AMD_RRUNS")) : 0;
-            const uint64_t wantq = (S.nchunks + 7) / 8;
-            const unsigned rr_grid = (unsigned)(wantq < 8192 ? wantq : 8192);
-            if (rruns == 2) {
-                launch_chain_rruns(S.st, rr_grid, VA, VB, S.d_pairs.p, nullptr, nullptr, S.gen_list.p, S.gen_cnt.p, gen_cap, S.recs.p, S.chunk_rec0.p,
-                                   S.multi.p, S.fast_chains.p, S.chunk_state.p, S.chains.p, S.pair_nch.p, S.pair_na.p, S.slow_list.p, S.counters.p,
-                                   S.counters.p + 40, S.flags.p, S.chunk_pair.p);
-            } else {
-                launch_chain_runs(S.st, nwg < 4096u ? nwg : 4096u, VA, VB, S.d_pairs.p, nb, S.gen_list.p, S.gen_cnt.p, gen_cap, S.recs.p, S.chunk_rec0.p, S.multi.p,
-                                  S.fast_chains.p, S.chunk_state.p, S.slow_list.p, S.counters.p, S.pair_na.p, S.chunk_pair.p,
-                                  rruns ? S.rr_list.p : S.slow_list.p, rruns ? S.counters.p + 39 : S.counters.p);
-                if (rruns)
-                    launch_chain_rruns(S.st, rr_grid, VA, VB, S.d_pairs.p, S.rr_list.p, S.counters.p + 39, nullptr, nullptr, 0, S.recs.p, S.chunk_rec0.p,
-                                       S.multi.p, S.fast_chains.p, S.chunk_state.p, S.chains.p, S.pair_nch.p, S.pair_na.p, S.slow_list.p, S.counters.p,
-                                       S.counters.p + 40, S.flags.p, S.chunk_pair.p);
-            }
+            launch_chain_runs(S.st, nwg < 1024u ? nwg : 1024u, VA, VB, S.d_pairs.p, nb, S.gen_list.p, S.gen_cnt.p, gen_cap, S.recs.p, S.chunk_rec0.p, S.multi.p,
+                              S.fast_chains.p, S.chunk_state.p, S.slow_list.p, S.counters.p, S.pair_na.p, S.chunk_pair.p, S.slow_list.p, S.counters.p,
+                              S.counters.p + 40);
         } else {
             HIPCHECK(hipEventRecord(S.ev[6], S.st));
         }
@@ -268,7 +250,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         uint32_t max_chunks = 0;
         for (const PairDesc &d : S.hp) max_chunks = d.n_chunks > max_chunks ? d.n_chunks : max_chunks;
         uint32_t lds_cap = 512;
-        while (lds_cap < FAST_SLOTS * max_chunks / 2 + 128 && lds_cap < 4096) lds_cap <<= 1;   // retried with more if a pair needs it
+        while (lds_cap < 3u * max_chunks / 2 + 128 && lds_cap < 4096) lds_cap <<= 1;   // retried with more if a pair needs it
         S.lds_cap = lds_cap;
         if (nb)
             launch_finalize(S.st, nb, lds_cap, VA, VB, S.d_pairs.p, S.fast_chains.p, S.chunk_state.p, S.chains.p, S.pair_nch.p, S.pair_na.p, S.d_out.p,
@@ -343,7 +325,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         grow(S.d_pairs, nb);
         grow(S.chunk_state, nchunks + 1); grow(S.chunk_mark, nchunks + 1); grow(S.slow_list, nchunks + 1); grow(S.over_list, nchunks + 1); grow(S.chunk_pair, nchunks + 1);
         grow(S.fast_chains, nchunks * FAST_SLOTS + 1);
-        grow(S.counters, 64); grow(S.flags, 16); grow(S.rows_next, nchunks + 1); grow(S.rr_list, nchunks + 1);
+        grow(S.counters, 64); grow(S.flags, 16); grow(S.rows_next, nchunks + 1);
         grow(S.pair_na, nb); grow(S.pair_nch, nb); grow(S.pair_nmulti, nb);
         grow(S.hits, nhits + 64); grow(S.multi, nmulti + 1);
         grow(S.recs, nrecs + 8); grow(S.pair_over, nb + 1); grow(S.chunk_rec0, nchunks + 1); grow(S.gen_list, nchunks + 256ull * GEN_LISTS + 1); grow(S.gen_cnt, GEN_LISTS);
@@ -470,12 +452,6 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
 #ifdef SKDER_SIEVE_STATS
         fprintf(stderr, "[skder_amd] sieve: link %u, main-not-started-big %u, second-path %u, too-many-records %u, multi %u, third-stray %u, stray-near-main %u\n", S.h_cnt[24], S.h_cnt[25], S.h_cnt[26], S.h_cnt[28], S.h_cnt[29], S.h_cnt[30], S.h_cnt[31]);
 #endif
-        if (getenv("SKDER_AMD_DEBUG")) {
-            uint32_t x[12]; HIPCHECK(hipMemcpy(x, S.counters.p + 39, 48, hipMemcpyDeviceToHost));
-            if (x[0] || x[1])
-                fprintf(stderr, "[skder_amd] run DP in rows: %u chunks from the run loop, %u settled; on to the general kernel: many-hits %u, runs %u, anchors %u, interior %u, run-not-dominant %u\n",
-                        x[0], x[1], x[3], x[4], x[7], x[8], x[10]);
-        }
 #ifdef SKDER_RUNS_STATS
         { uint32_t x[8]; HIPCHECK(hipMemcpy(x, S.counters.p + 16, 32, hipMemcpyDeviceToHost));
           fprintf(stderr, "[skder_amd] run loop: %u chunks, %u wavefront rounds, %.1f lanes with a record per round, %.1f lanes not finished after it; %u rounds with a multi-occurrence seed (%u such lanes)\n",

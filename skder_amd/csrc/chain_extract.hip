@@ -267,9 +267,9 @@ __global__ __launch_bounds__(256) void chain_single_kernel(SetView A, SetView B,
             uint32_t n = 0, G = 0, nstray = 0, anchors = 0, nfin = 0, npath = 0;
             uint32_t m_qi = 0, m_q0 = 0, m_hw = 0, l_q = 0, l_hw = 0, l_qi = 0;     // current path: first anchor; last anchor
             uint32_t st_hw0 = 0, st_q0 = 0, st_hw1 = 0, st_q1 = 0;                  // the strays
-            uint32_t p_hw[FAST_SLOTS] = {0, 0, 0}, p_G[FAST_SLOTS] = {0, 0, 0};     // closed and current paths: key, first diagonal, steps
-            int32_t p_D[FAST_SLOTS] = {0, 0, 0};
-            uint32_t p_lq[FAST_SLOTS] = {0, 0, 0};                                   // ... and the position of their last anchor
+            uint32_t p_hw[SIEVE_PATHS] = {0, 0, 0}, p_G[SIEVE_PATHS] = {0, 0, 0};     // closed and current paths: key, first diagonal, steps
+            int32_t p_D[SIEVE_PATHS] = {0, 0, 0};
+            uint32_t p_lq[SIEVE_PATHS] = {0, 0, 0};                                   // ... and the position of their last anchor
             ChainRec *slots = fast_chains + (uint64_t)t * FAST_SLOTS;
             // the current path ends: its chain, and what the strays have to be checked against
 #define CLOSE_PATH()                                                                                                  \
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void chain_single_kernel(SetView A, SetView B,
                             // a new path: of a record / strand no path of the chunk had so far, or more than the 2500-base band
                             // behind the last anchor of every path that had it (nothing can chain across)
                             if (main_on) {
-                                if (npath + 1u >= FAST_SLOTS) { fail = true; SIEVE_WHY(10); break; }
+                                if (npath + 1u >= SIEVE_PATHS) { fail = true; SIEVE_WHY(10); break; }
                                 CLOSE_PATH();
                                 bool clash = false;
                                 for (uint32_t x = 0; x < npath; x++) clash |= !((p_hw[x] ^ a0.z) & HIT_KEY_MASK) && a0.y - p_lq[x] <= (uint32_t)ANI_BP_BAND;

@@ -92,11 +92,12 @@ __global__ __launch_bounds__(256) void finalize_kernel_t(SetView A, SetView B, c
         const uint32_t st = chunk_state[pd.chunk_base + ck];
         if (st == CHUNK_SLOW || st == 0u) continue;
         const ChainRec *fc = fast_chains + (uint64_t)(pd.chunk_base + ck) * FAST_SLOTS;
-        ChainRec c[FAST_SLOTS];
+        ChainRec c[3];        // the first three at once (nearly every chunk has no more), the rest one by one
 #pragma unroll
-        for (uint32_t k = 0; k < FAST_SLOTS; k++) if (k < st) c[k] = fc[k];
+        for (uint32_t k = 0; k < 3u; k++) if (k < st) c[k] = fc[k];
 #pragma unroll
-        for (uint32_t k = 0; k < FAST_SLOTS; k++) if (k < st) put(c[k]);
+        for (uint32_t k = 0; k < 3u; k++) if (k < st) put(c[k]);
+        for (uint32_t k = 3u; k < st && k < FAST_SLOTS; k++) put(fc[k]);
     }
     for (uint32_t i = tid; i < nslow; i += 256) put(chains[pd.c_base + i]);
     __syncthreads();

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64 * ROWS_WAVES) void chain_rows_kernel(SetView A, 
                                                                     ChainRec *__restrict__ chains, uint32_t *__restrict__ pair_nch,
                                                                     uint32_t *__restrict__ pair_na, uint32_t *__restrict__ next_list,
                                                                     uint32_t *__restrict__ next_count, uint32_t *__restrict__ flags,
-                                                                    const uint32_t *__restrict__ chunk_pair, int dbg_stop)
+                                                                    const uint32_t *__restrict__ chunk_pair)
 {
     __shared__ RowLds lds[ROWS_WAVES * 4];
     const uint32_t lane = threadIdx.x & 63u, rl = lane & 15u, row = lane >> 4, wv = threadIdx.x >> 6;
@@ -175,7 +175,6 @@ __global__ __launch_bounds__(64 * ROWS_WAVES) void chain_rows_kernel(SetView A, 
 #else
 #define ROWS_STAT(X)
 #endif
-        if (dbg_stop == 1) continue;          // (timing only: SKDER_AMD_ROWS_STOP)
         if (rl < ROWS_MAXA / 32 + 2) L.marks[rl] = 0u;          // (one word more than the anchors fill: the 32-bit window behind the last anchor)
         ROW_SYNC();
 
@@ -192,7 +191,6 @@ __global__ __launch_bounds__(64 * ROWS_WAVES) void chain_rows_kernel(SetView A, 
             if (rl == 0) reinterpret_cast<uint16_t *>(L.marks)[b0 >> 4] = (uint16_t)(m >> (row * 16u));
         }
         ROW_SYNC();
-        if (dbg_stop == 2) continue;
 
         // ---- C. banded DP
         {
@@ -260,7 +258,6 @@ __global__ __launch_bounds__(64 * ROWS_WAVES) void chain_rows_kernel(SetView A, 
                 }
             }
         }
-        if (dbg_stop == 3) continue;
 
         // ---- D. chains: best end first (ties: lowest index); back-track until the start or a used anchor
         const uint32_t c_base = pdp->c_base, c_cap = pdp->c_cap;
@@ -339,7 +336,6 @@ void launch_chain_rows(hipStream_t st, unsigned grid, SetView A, SetView B, cons
                        const uint32_t *hits, const uint4 *multi, ChainRec *chains, uint32_t *pair_nch, uint32_t *pair_na, uint32_t *next_list,
                        uint32_t *next_count, uint32_t *flags, const uint32_t *chunk_pair)
 {
-    static const int dbg_stop = getenv("SKDER_AMD_ROWS_STOP") ? atoi(getenv("SKDER_AMD_ROWS_STOP")) : 0;      // timing only: stop after phase A / B / C
     hipLaunchKernelGGL(chain_rows_kernel, dim3(grid), dim3(64 * ROWS_WAVES), 0, st, A, B, pairs, list, n_ptr, hits, multi, chains, pair_nch, pair_na,
-                       next_list, next_count, flags, chunk_pair, dbg_stop);
+                       next_list, next_count, flags, chunk_pair);
 }

@@ -42,11 +42,18 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, c
                                                          ChainRec *__restrict__ fast_chains, uint32_t *__restrict__ chunk_state,
                                                          uint32_t *__restrict__ slow_list, uint32_t *__restrict__ slow_count,
                                                          uint32_t *__restrict__ pair_na, const uint32_t *__restrict__ chunk_pair,
-                                                         uint32_t *__restrict__ decl_list, uint32_t *__restrict__ decl_count)
+                                                         uint32_t *__restrict__ decl_list, uint32_t *__restrict__ decl_count,
+                                                         uint32_t *__restrict__ work_next, uint32_t refill_min)
 {
-    // the chunks chain_single_kernel could not settle, one per lane; their number is only known on the device: a fixed
-    // grid strides over the GEN_LISTS lists laid end to end (offsets by a scan of the 256 counts, in LDS)
+    // the chunks chain_single_kernel could not settle, one per lane; their number is only known on the device: the GEN_LISTS
+    // lists are laid end to end (offsets by a scan of the 256 counts, in LDS) and the wavefronts of a fixed grid DRAW their chunks
+    // from one counter.  A lane keeps its chunk for as many rounds as the chunk has anchors to place, and chunks differ (3 to 60
+    // records; a declined chunk stops at once): with 64 chunks handed out together a wavefront ran until its longest chunk was
+    // through, 11 - 23 of its lanes at work per round (round 4's counters: 12 of 64 lanes per VALU instruction).  Now lanes whose
+    // chunk is finished wait until `refill_min` of them are free; then the wavefront writes their results and hands them new chunks
+    // in one pass (the service block below), so that the rounds run with at least 64 - refill_min lanes at work until the lists run dry.
     __shared__ uint32_t g_off[GEN_LISTS + 1], g_ws[4];
+    __shared__ uint32_t dbuf_all[4][RUNS_DECL_FLUSH + 64];
     {
         uint32_t total;
         const uint32_t ex = block_excl_scan_256(gen_cnt[threadIdx.x], g_ws, total);
@@ -56,35 +63,18 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, c
     }
     const uint32_t n_items = g_off[GEN_LISTS];
     if (blockIdx.x == 0 && threadIdx.x == 0) slow_count[11] = n_items;      // for the host's statistics
-    for (uint32_t w0 = blockIdx.x * 256u; w0 < n_items; w0 += gridDim.x * 256u) {
-    const uint32_t w = w0 + threadIdx.x;
-    const bool live = w < n_items;
-    uint32_t t = 0;
-    if (live) {
-        uint32_t lo = 0, hi = GEN_LISTS;              // the list that holds item w: last offset <= w
-        while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (g_off[mid] <= w) lo = mid; else hi = mid; }
-        t = gen_list[(uint64_t)lo * gen_cap + (w - g_off[lo])];
-    }
-    const uint32_t pi = live ? chunk_pair[t] : 0u;        // (chain_single_kernel left it there: a binary search over the pairs is 15 dependent loads)
-    const PairDesc pd = pairs[pi];
-    const uint32_t idx0 = chunk_rec0[t];
-    const uint32_t c = t - pd.chunk_base;
-    const SetView &QS = (pd.flags & 2u) ? B : A;
-    const uint32_t s0 = QS.chunk_start[pd.q_chunk_off + c], s1 = QS.chunk_start[pd.q_chunk_off + c + 1];
-    bool cplx = false;
-    uint32_t cause = 0u;
-
+    const uint32_t ln = threadIdx.x & 63u;
     const int32_t NEG = -0x40000000;
+    // ---- a lane's chunk (valid while busy)
+    bool busy = false, done = true, cplx = false, exhausted = false;
+    uint32_t w_cur = 0, w_end = 0;             // the wavefront's range of the item list (wave-uniform)
+    uint32_t cause_acc = 0;                    // lane cz: chunks this wavefront declined for cause cz
+    uint32_t *dbuf = dbuf_all[threadIdx.x >> 6];
+    uint32_t dn = 0;                           // declined chunks waiting in dbuf (wave-uniform)
+    uint32_t t = 0, pi = 0, c = 0, s1 = 0, multi_base = 0, cause = 0u;
+    const uint4 *prec = nullptr;
+    ChainRec *slots = nullptr;
     Run r0, r1, r2, r3;
-    r0.cnt = r1.cnt = r2.cnt = r3.cnt = 0;          // cnt == 0: empty ring position
-    r0.f = r1.f = r2.f = r3.f = NEG;
-    r0.q_last = r1.q_last = r2.q_last = r3.q_last = 0; r0.rr_last = r1.rr_last = r2.rr_last = r3.rr_last = 0;
-    r0.first_qi = r1.first_qi = r2.first_qi = r3.first_qi = 0; r0.q_first = r1.q_first = r2.q_first = r3.q_first = 0;
-    r0.r_pfirst = r1.r_pfirst = r2.r_pfirst = r3.r_pfirst = 0;
-    r0.qi_last = r1.qi_last = r2.qi_last = r3.qi_last = 0; r0.idx_last = r1.idx_last = r2.idx_last = r3.idx_last = 0;
-    r0.pmax = r1.pmax = r2.pmax = r3.pmax = NEG; r0.r_first = r1.r_first = r2.r_first = r3.r_first = 0;
-    r0.seg = r1.seg = r2.seg = r3.seg = 0;
-    r0.gs = r1.gs = r2.gs = r3.gs = 0;
     uint32_t ia = 0, nfin = 0, nevict = 0;
     int32_t runmax = NEG;
     // summaries of runs that left the ring: the most recent segment, plus one conservative scalar
@@ -93,7 +83,27 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, c
     // the keyless summary keeps TWO diagonal intervals (empty: lo > hi): the remnants of the main path and a
     // stray single hit far off its diagonal would otherwise merge into one interval that covers everything in between
     int32_t lost2_dlo = 1, lost2_dhi = 0;
-    ChainRec *slots = fast_chains + (uint64_t)t * FAST_SLOTS;
+    // record cursor: the chunk's records follow one another in the pair's region, from chunk_rec0 on, in seed order; the
+    // record BEHIND a run closes it (a link or the terminator at the end of a quarter), so two records are held and
+    // the third is on its way while the first is worked on
+    uint32_t idx = 0;
+    uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0, b0 = a0, b1 = a0;
+    // One ANCHOR per round and lane: a record's first anchor -- or, for a seed with 2..4 occurrences on the other genome, one of
+    // its occurrences per round (pend = occurrences still to come; the lane keeps its record until they are through).  A loop
+    // over the occurrences inside the round made the whole wavefront repeat the look-back as often as its most repetitive seed
+    // asked: on real genome structure 29 % of the records are such seeds and 82 % of the rounds had one in some lane.
+    struct { uint32_t qi, q0, hw, q1, qi1, hw1, n, gsum; } rc;
+    rc.qi = 0; rc.q0 = 0; rc.hw = HIT_NONE; rc.hw1 = HIT_NONE; rc.q1 = 0; rc.qi1 = 0; rc.n = 0; rc.gsum = 0;
+    uint32_t pend = 0, g0 = HIT_NONE, g1 = HIT_NONE, g2 = HIT_NONE, g3 = HIT_NONE;
+    r0.cnt = r1.cnt = r2.cnt = r3.cnt = 0;
+    r0.f = r1.f = r2.f = r3.f = NEG;
+    r0.q_last = r1.q_last = r2.q_last = r3.q_last = 0; r0.rr_last = r1.rr_last = r2.rr_last = r3.rr_last = 0;
+    r0.first_qi = r1.first_qi = r2.first_qi = r3.first_qi = 0; r0.q_first = r1.q_first = r2.q_first = r3.q_first = 0;
+    r0.r_pfirst = r1.r_pfirst = r2.r_pfirst = r3.r_pfirst = 0;
+    r0.qi_last = r1.qi_last = r2.qi_last = r3.qi_last = 0; r0.idx_last = r1.idx_last = r2.idx_last = r3.idx_last = 0;
+    r0.pmax = r1.pmax = r2.pmax = r3.pmax = NEG; r0.r_first = r1.r_first = r2.r_first = r3.r_first = 0;
+    r0.seg = r1.seg = r2.seg = r3.seg = 0;
+    r0.gs = r1.gs = r2.gs = r3.gs = 0;
 
 #define EMIT_PATH(E)                                                                         \
     do {                                                                                     \
@@ -147,22 +157,99 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, c
         }                                                                                    \
     } while (0)
 
-    // record cursor: the chunk's records follow one another in the pair's region, from chunk_rec0 on, in seed order; the
-    // record BEHIND a run closes it (a link or the terminator at the end of a quarter), so two records are held and
-    // the third is on its way while the first is worked on
-    const uint4 *prec = reinterpret_cast<const uint4 *>(recs + pd.rec_base);
-    uint32_t idx = idx0;
-    bool done = !live || idx == 0xFFFFFFFFu || s1 <= s0;
-    uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0, b0 = a0, b1 = a0;
-    if (!done) { a0 = prec[2u * idx]; a1 = prec[2u * idx + 1u]; b0 = prec[2u * idx + 2u]; b1 = prec[2u * idx + 3u]; }   // a run record is never the last of its quarter
-    // One ANCHOR per round and lane: a record's first anchor -- or, for a seed with 2..4 occurrences on the other genome, one of
-    // its occurrences per round (pend = occurrences still to come; the lane keeps its record until they are through).  A loop
-    // over the occurrences inside the round made the whole wavefront repeat the look-back as often as its most repetitive seed
-    // asked: on real genome structure 29 % of the records are such seeds and 82 % of the rounds had one in some lane.
-    struct { uint32_t qi, q0, hw, q1, qi1, hw1, n, gsum; } rc;
-    rc.qi = 0; rc.q0 = 0; rc.hw = HIT_NONE; rc.hw1 = HIT_NONE; rc.q1 = 0; rc.qi1 = 0; rc.n = 0; rc.gsum = 0;
-    uint32_t pend = 0, g0 = HIT_NONE, g1 = HIT_NONE, g2 = HIT_NONE, g3 = HIT_NONE;
+    // (a wavefront's LDS writes are seen by its own later reads: DS operations of a wavefront complete in order)
+#define FLUSH_DECLINED()                                                                     \
+    do {                                                                                     \
+        uint32_t base_ = 0;                                                                  \
+        if (ln == 0) base_ = atomicAdd(decl_count, dn);                                      \
+        base_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)base_);                        \
+        for (uint32_t i_ = ln; i_ < dn; i_ += 64u) decl_list[base_ + i_] = dbuf[i_];          \
+        dn = 0;                                                                              \
+    } while (0)
+
     for (;;) {
+        // ---- service: results of finished chunks out, new chunks in -- when enough lanes are free, or nothing else is left to do
+        {
+            const bool fin = busy && done && pend == 0u;
+            const unsigned long long finm = __ballot(fin), idlem = __ballot(!busy);
+            const bool none_active = (finm | idlem) == ~0ull;
+            const uint32_t n_free = (uint32_t)__popcll(finm | idlem);
+            if (none_active || (finm && (uint32_t)__popcll(finm) >= refill_min) || (!exhausted && n_free >= refill_min)) {
+                if (fin && !cplx) EMIT_PATH(r3);
+                if (fin && !cplx) EMIT_PATH(r2);
+                if (fin && !cplx) EMIT_PATH(r1);
+                if (fin && !cplx) EMIT_PATH(r0);
+                // declined chunks: ONE atomic per wavefront and service for the list (a counter shared by the whole device takes an
+                // atomic every ~10 ns: a million lanes adding one each were the kernel's time), the lanes take consecutive places;
+                // the per-cause statistics likewise
+                const bool decl = fin && cplx;
+                const unsigned long long dm = __ballot(decl);
+                if (dm) {
+                    // declined chunks collect in the wavefront's LDS buffer and go to the shared list RUNS_DECL_FLUSH or more at a time:
+                    // ONE atomic on the list's counter per flush (a counter shared by the whole device takes an atomic every ~10 ns,
+                    // serialised: one per chunk -- round 3 -- or per service made the counter the kernel's time)
+                    if (decl) { chunk_state[t] = CHUNK_SLOW; dbuf[dn + (uint32_t)__popcll(dm & ((1ull << ln) - 1ull))] = t; }
+                    dn += (uint32_t)__popcll(dm);
+                    // per-cause statistics: lane cz keeps the wavefront's count of cause cz and adds it to the shared counters ONCE, when the
+                    // wavefront is through (the counters share one cache line with decl_count)
+                    for (uint32_t cz = 1; cz <= 10u; cz++) {
+                        const unsigned long long cm = __ballot(decl && cause == cz);
+                        if (ln == cz) cause_acc += (uint32_t)__popcll(cm);
+                    }
+                    if (dn >= RUNS_DECL_FLUSH) { FLUSH_DECLINED(); }
+                }
+                if (fin && !cplx) {
+                    chunk_state[t] = nfin;
+                    if (ia) atomicAdd(&pair_na[pi], ia);
+                }
+                if (fin) busy = false;
+                if (!exhausted) {
+                    // the wavefront draws its chunks from a range of its own, RUNS_DRAW items at a time: ONE atomic on the shared counter
+                    // per range (a device-wide counter takes an atomic every ~10 ns, serialised: one per service made the counter the
+                    // kernel's time -- 15.5 ms at refill_min 16 where 64 took 7.8, measured)
+                    const unsigned long long freem = __ballot(!busy);
+                    const uint32_t nfree = (uint32_t)__popcll(freem);
+                    if (w_cur >= w_end) {
+                        uint32_t base = 0;
+                        if (ln == 0) base = atomicAdd(work_next, RUNS_DRAW);
+                        w_cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                        w_end = w_cur + RUNS_DRAW < n_items ? w_cur + RUNS_DRAW : n_items;
+                        if (w_cur >= n_items) { exhausted = true; w_cur = w_end = n_items; }
+                    }
+                    const uint32_t w = w_cur + (uint32_t)__popcll(freem & ((1ull << ln) - 1ull));
+                    const uint32_t w_lim = w_end;
+                    w_cur = w_cur + nfree < w_end ? w_cur + nfree : w_end;
+                    if (!busy && w < w_lim) {
+                        uint32_t lo = 0, hi = GEN_LISTS;              // the list that holds item w: last offset <= w
+                        while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (g_off[mid] <= w) lo = mid; else hi = mid; }
+                        t = gen_list[(uint64_t)lo * gen_cap + (w - g_off[lo])];
+                        pi = chunk_pair[t];        // (chain_single_kernel left it there: a binary search over the pairs is 15 dependent loads)
+                        const PairDesc pd = pairs[pi];
+                        idx = chunk_rec0[t];
+                        c = t - pd.chunk_base;
+                        const uint32_t *cs = ((pd.flags & 2u) ? B.chunk_start : A.chunk_start) + pd.q_chunk_off + c;
+                        const uint32_t s0 = cs[0];
+                        s1 = cs[1];
+                        multi_base = pd.multi_base;
+                        prec = reinterpret_cast<const uint4 *>(recs + pd.rec_base);
+                        slots = fast_chains + (uint64_t)t * FAST_SLOTS;
+                        busy = true; cplx = false; cause = 0u;
+                        done = idx == 0xFFFFFFFFu || s1 <= s0;
+                        if (!done) { a0 = prec[2u * idx]; a1 = prec[2u * idx + 1u]; b0 = prec[2u * idx + 2u]; b1 = prec[2u * idx + 3u]; }   // a run record is never the last of its quarter
+                        r0.cnt = r1.cnt = r2.cnt = r3.cnt = 0;          // cnt == 0: empty ring position
+                        r0.f = r1.f = r2.f = r3.f = NEG;
+                        r0.pmax = r1.pmax = r2.pmax = r3.pmax = NEG;
+                        r0.gs = r1.gs = r2.gs = r3.gs = 0;
+                        ia = nfin = nevict = 0; runmax = NEG;
+                        s0_seg = 0xFFFFFFFFu; s0_key = 0; s0_q = 0; lost_q = 0;
+                        s0_f = NEG; lost_f = NEG; s0_dlo = s0_dhi = lost_dlo = lost_dhi = 0;
+                        lost2_dlo = 1; lost2_dhi = 0;
+                        pend = 0u; g0 = g1 = g2 = g3 = HIT_NONE;
+                    }
+                }
+                if (!__any(busy)) break;
+            }
+        }
         bool have = pend != 0u;
         if (!done && !have) {
             if (a0.x == REC_LINK && s1 <= a0.z) done = true;       // the chunk ends with its quarter
@@ -190,7 +277,7 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, c
                 if (hw == HIT_MANY) { cplx = true; cause = 2; break; }
                 pend = 1u; g0 = hw; g1 = g2 = g3 = HIT_NONE;
                 if ((hw & 0xFF000000u) == HIT_MULTI) {   // 2..4 occurrences, ascending gpos
-                    const uint4 mv = multi[pd.multi_base + (hw & 0x00FFFFFFu)];
+                    const uint4 mv = multi[multi_base + (hw & 0x00FFFFFFu)];
                     g0 = mv.x; g1 = mv.y; g2 = mv.z; g3 = mv.w;
                     pend = 2u + (g2 != HIT_NONE) + (g3 != HIT_NONE);
                 }
@@ -348,45 +435,22 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, c
                                             if (mm) atomicAdd(slow_count + 17, 1u); atomicAdd(slow_count + 18, (uint32_t)__popcll(mm)); }
         }
 #endif
-        if (!__any(!done || pend != 0u)) break;     // the whole wave is finished
     }
-    if (!cplx) EMIT_PATH(r3);
-    if (!cplx) EMIT_PATH(r2);
-    if (!cplx) EMIT_PATH(r1);
-    if (!cplx) EMIT_PATH(r0);
+    if (dn) { FLUSH_DECLINED(); }
+#undef FLUSH_DECLINED
+    if (ln >= 1u && ln <= 10u && cause_acc) atomicAdd(slow_count + 1 + ln, cause_acc);
 #undef EMIT_PATH
 #undef EVICT
-    {
-        // declined chunks: ONE atomic per wavefront for the list (a counter shared by the whole device takes an atomic every
-        // ~10 ns: a million lanes adding one each were the kernel's time), the lanes take consecutive places; the per-cause
-        // statistics likewise
-        const bool decl = live && cplx;
-        const unsigned long long dm = __ballot(decl);
-        if (dm) {
-            const uint32_t ln = threadIdx.x & 63u, leader = (uint32_t)__ffsll((long long)dm) - 1u;
-            uint32_t base = 0;
-            if (ln == leader) base = atomicAdd(decl_count, (uint32_t)__popcll(dm));
-            base = (uint32_t)__shfl((int)base, (int)leader, 64);
-            if (decl) { chunk_state[t] = CHUNK_SLOW; decl_list[base + (uint32_t)__popcll(dm & ((1ull << ln) - 1ull))] = t; }
-            for (uint32_t cz = 1; cz <= 10u; cz++) {
-                const unsigned long long cm = __ballot(decl && cause == cz);
-                if (cm && ln == 0) atomicAdd(slow_count + 1 + cz, (uint32_t)__popcll(cm));
-            }
-        }
-        if (live && !cplx) {
-            chunk_state[t] = nfin;
-            if (ia) atomicAdd(&pair_na[pi], ia);
-        }
-    }
-    }   // items of this lane
 }
 
 
 void launch_chain_runs(hipStream_t st, unsigned grid, SetView A, SetView B, const PairDesc *pairs, uint32_t npairs, const uint32_t *gen_list,
                        const uint32_t *gen_cnt, uint32_t gen_cap, const RunRec *recs, const uint32_t *chunk_rec0, const uint4 *multi,
                        ChainRec *fast_chains, uint32_t *chunk_state, uint32_t *slow_list, uint32_t *slow_count, uint32_t *pair_na,
-                       const uint32_t *chunk_pair, uint32_t *decl_list, uint32_t *decl_count)
+                       const uint32_t *chunk_pair, uint32_t *decl_list, uint32_t *decl_count, uint32_t *work_next)
 {
+    static const uint32_t refill_min = getenv("SKDER_AMD_RUNS_REFILL") ? (uint32_t)atoi(getenv("SKDER_AMD_RUNS_REFILL")) : RUNS_REFILL_MIN;
     hipLaunchKernelGGL(chain_runs_kernel, dim3(grid), dim3(256), 0, st, A, B, pairs, npairs, gen_list, gen_cnt, gen_cap, recs, chunk_rec0, multi,
-                       fast_chains, chunk_state, slow_list, slow_count, pair_na, chunk_pair, decl_list, decl_count);
+                       fast_chains, chunk_state, slow_list, slow_count, pair_na, chunk_pair, decl_list, decl_count, work_next,
+                       refill_min < 1u ? 1u : refill_min > 64u ? 64u : refill_min);
 }

@@ -506,18 +506,6 @@ const char *gunzip_status_text(GunzipStatus s)
     }
 }
 
-bool gunzip_member_layout(const uint8_t *in, size_t in_len, size_t *deflate_off, uint32_t *crc, uint32_t *isize)
-{
-    const uint8_t *p = in, *end = in + in_len;
-    if (parse_header(p, end) != GUNZIP_OK) return false;
-    if ((size_t)(end - p) < 8 + 2) return false;
-    *deflate_off = (size_t)(p - in);
-    const uint8_t *t = end - 8;
-    *crc = (uint32_t)t[0] | (uint32_t)t[1] << 8 | (uint32_t)t[2] << 16 | (uint32_t)t[3] << 24;
-    *isize = (uint32_t)t[4] | (uint32_t)t[5] << 8 | (uint32_t)t[6] << 16 | (uint32_t)t[7] << 24;
-    return true;
-}
-
 GunzipStatus gunzip_buffer(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap, size_t *out_len)
 {
     *out_len = 0;

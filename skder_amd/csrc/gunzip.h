@@ -20,8 +20,3 @@ GunzipStatus gunzip_buffer(const uint8_t *in, size_t in_len, uint8_t *out, size_
 // CRC-32 of the gzip trailer (carry-less multiplication where the CPU has it, slicing tables elsewhere)
 uint32_t gunzip_crc32(uint32_t crc, const uint8_t *p, size_t n);
 const char *gunzip_status_text(GunzipStatus s);
-
-// Where the DEFLATE stream of the FIRST member of a gzip file begins, and the CRC-32 / length its trailer would hold if the file is that
-// one member (the last eight bytes): what a caller needs to hand the stream to another decoder (ginflate.hip) and check its result.
-// false: no valid gzip header, or the file is too short to hold a stream and a trailer.
-bool gunzip_member_layout(const uint8_t *in, size_t in_len, size_t *deflate_off, uint32_t *crc, uint32_t *isize);

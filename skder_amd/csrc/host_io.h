@@ -40,8 +40,6 @@ struct HostGenome {
 // else into region[0 .. region_cap) (SkError "region" if it does not fit).  Throws SkError.
 // scratch: a reader thread's reusable working memory (text buffer, inflate state); nullptr: one per calling thread
 struct IoScratch;
-IoScratch *io_scratch_new();
-void io_scratch_free(IoScratch *p);
 void read_fasta(const std::string &path, HostGenome &g, uint8_t *region = nullptr, size_t region_cap = 0, IoScratch *scratch = nullptr);
 std::vector<std::string> read_listing(const std::string &path);
 
@@ -71,5 +69,3 @@ void write_n50_tsv(const std::string &out, const GenomeNames &names);
 void store_save(const std::string &out, skder_sketches *s, const GenomeNames &names);
 void store_load(const std::string &path, skder_sketches *s, GenomeNames &names);
 bool staging_release(int device);      // free the device's cached ingest buffers (false: in use)
-// DEFLATE on the device (ginflate.hip), asynchronous on `st`: d_jobs / d_results are device arrays
-void ginflate_enqueue(hipStream_t st, const uint8_t *d_in, const skder_gz_job_t *d_jobs, uint32_t n, uint8_t *d_out, skder_gz_result_t *d_results);

@@ -66,8 +66,6 @@ struct IoScratch {
     IoScratch(const IoScratch &) = delete;
     IoScratch &operator=(const IoScratch &) = delete;
 };
-IoScratch *io_scratch_new() { return new IoScratch(); }
-void io_scratch_free(IoScratch *p) { delete p; }
 
 namespace {
 // decoded text of a plain or gzip file, a buffer at a time.  gzip: every member of the file (concatenated members --
@@ -140,8 +138,7 @@ static size_t read_text(const std::string &path, bool gz, uint8_t *dst, size_t c
     FileCloser fc;
     fc.fd = open(path.c_str(), O_RDONLY);
     if (fc.fd < 0) throw SkError("cannot open " + path);
-    static const bool use_zlib = getenv("SKDER_AMD_ZLIB") != nullptr;      // zlib's streaming inflate instead of gunzip.cpp (A/B; same text)
-    if (gz && !use_zlib) {
+    if (gz) {
         // the compressed file into memory, then decoded straight into the region
         struct stat sb;
         if (fstat(fc.fd, &sb) != 0) throw SkError("cannot open " + path);
@@ -473,8 +470,7 @@ static uint64_t n50_of(std::vector<uint64_t> &all_len)
 // header lines, N50 from the length lists) and parses the files the kernel declined (blanks inside sequence lines, ...) itself.
 static void device_parse(skder_sketches *s, Slot &S,
                          std::vector<FastaFile> &ff, uint64_t out_total, uint64_t table_total, std::vector<HostGenome> &gs,
-                         std::vector<uint64_t> &rec_off, std::vector<uint32_t> &rec_len, std::vector<uint32_t> &gbegin,
-                         const std::vector<uint8_t> &text_on_device)
+                         std::vector<uint64_t> &rec_off, std::vector<uint32_t> &rec_len, std::vector<uint32_t> &gbegin)
 {
     hipStream_t st = s->ctx->stream;
     const uint32_t nf = (uint32_t)ff.size();
@@ -520,25 +516,9 @@ static void device_parse(skder_sketches *s, Slot &S,
     HIPCHECK(hipMemcpyAsync(len, d_len.p, table_total * 4, hipMemcpyDeviceToHost, st));
     HIPCHECK(hipMemcpyAsync(all, d_all.p, table_total * 4, hipMemcpyDeviceToHost, st));
     HIPCHECK(hipStreamSynchronize(st));
-    // files inflated on the device have no text in the pinned buffer: the header line of their first kept record comes back in one
-    // small copy each (512 bytes; a longer line in a second, larger one)
-    const size_t NAME_CHUNK = 512;
-    std::vector<uint8_t> name_buf;
-    std::vector<uint32_t> name_len(nf, 0);
-    if (!text_on_device.empty()) {
-        name_buf.resize((size_t)nf * NAME_CHUNK);
-        bool any = false;
-        for (uint32_t k = 0; k < nf; k++) {
-            if (!text_on_device[k] || res[k].flags || !res[k].n_kept) continue;
-            const uint64_t from = (uint64_t)res[k].first_hdr + 1u;
-            if (from >= ff[k].text_len) continue;
-            name_len[k] = (uint32_t)std::min<uint64_t>(NAME_CHUNK, ff[k].text_len - from);
-            HIPCHECK(hipMemcpyAsync(name_buf.data() + (size_t)k * NAME_CHUNK, d_text + ff[k].text_off + from, name_len[k], hipMemcpyDeviceToHost, st));
-            any = true;
-        }
-        if (any) HIPCHECK(hipStreamSynchronize(st));
-    }
     rec_off.clear(); rec_len.clear(); gbegin.clear();
+    const char *dbg_env = getenv("SKDER_AMD_DEBUG");
+    const bool dbg_fasta = dbg_env && atoi(dbg_env) >= 2;          // SKDER_AMD_DEBUG=2: one line per file with what the parser found
     for (uint32_t k = 0; k < nf; k++) {
         const FastaFile &f = ff[k];
         const FastaResult &r = res[k];
@@ -557,24 +537,13 @@ static void device_parse(skder_sketches *s, Slot &S,
             continue;
         }
         if (r.n_lens == 0) throw SkError("no sequence in " + g.path);
-        if (getenv("SKDER_AMD_DEBUG_FASTA"))
+        if (dbg_fasta)
             fprintf(stderr, "[skder_amd] %s: text %u bytes, %u kept records, %u lengths, first header at %u, packed %u\n", g.path.c_str(), f.text_len, r.n_kept, r.n_lens, r.first_hdr, r.packed_size);
         for (uint32_t q = 0; q < r.n_kept; q++) { rec_off.push_back(f.out_off + rel[f.table_off + q]); rec_len.push_back(len[f.table_off + q]); }
         std::vector<uint64_t> al(all + f.table_off, all + f.table_off + r.n_lens);
         g.n50 = n50_of(al);
         g.first_name.clear();
-        if (r.n_kept && !text_on_device.empty() && text_on_device[k]) {
-            const uint8_t *p = name_buf.data() + (size_t)k * NAME_CHUNK, *e = p + name_len[k];
-            std::vector<uint8_t> more;
-            if (std::find(p, e, (uint8_t)'\n') == e && (uint64_t)r.first_hdr + 1u + name_len[k] < f.text_len) {       // a header line beyond the chunk
-                const uint64_t from = (uint64_t)r.first_hdr + 1u, n = std::min<uint64_t>(1u << 20, f.text_len - from);
-                more.resize(n);
-                HIPCHECK(hipMemcpyAsync(more.data(), d_text + f.text_off + from, n, hipMemcpyDeviceToHost, st));
-                HIPCHECK(hipStreamSynchronize(st));
-                p = more.data(); e = p + n;
-            }
-            for (; p < e && *p != '\n'; p++) if (*p != '\r') g.first_name.push_back((char)*p);
-        } else if (r.n_kept) {
+        if (r.n_kept) {
             const uint8_t *p = h_text + f.text_off + r.first_hdr + 1, *e = h_text + f.text_off + f.text_len;
             for (; p < e && *p != '\n'; p++) if (*p != '\r') g.first_name.push_back((char)*p);
         }
@@ -629,45 +598,13 @@ void sketch_files(skder_sketches *s, const std::vector<std::string> &paths, Geno
         }
     });
     auto bound = [](uint64_t fsize) { return ((fsize + fsize / 15 + 256) + 31) & ~(uint64_t)31; };
-    // Which gzip files the DEVICE inflates (ginflate.hip) -- by default NONE.  A DEFLATE stream is serial: one wavefront decodes 9 - 16 MB/s
-    // of it (gzip -1 .. -9), a host thread 640; with 1,024 streams in flight the decoder reaches 9.6 - 16 GB/s of text, the 16 CPUs a box
-    // grants 10.  Inside the ingest a batch's device stage lasts as long as ONE stream takes (0.15 - 0.33 s for a 2 - 3 Mb genome) and
-    // overlaps with nothing, and every share measured was slower than the host threads alone (2,048 files, 6.2 GB of text, gzip -1:
-    // 0.61 s host, 0.92 s with 40 - 60 % on the device, 1.20 s all on the device: profiles/round4_ingest_gz_device_share.json).
-    // The path stays behind a switch, parity-tested: SKDER_AMD_GPU_INFLATE = percent of the gzip text that goes to the device (default 0),
-    // from SKDER_AMD_GPU_INFLATE_MIN eligible files on (default 384: below that the streams cannot fill the device)
-    std::vector<uint8_t> to_dev(paths.size(), 0);
-    bool any_dev = false;
-    {
-        const char *e = getenv("SKDER_AMD_GPU_INFLATE");
-        int share = e ? atoi(e) : 0;
-        share = share < 0 ? 0 : share > 100 ? 100 : share;
-        const char *m = getenv("SKDER_AMD_GPU_INFLATE_MIN");
-        const size_t min_files = m ? (size_t)atoi(m) : 384;
-        auto eligible = [&](const FileInfo &fi) { return fi.gz && fi.trusted && fi.size >= 32 && fi.size <= 0xF0000000ull && fi.text <= 0xF0000000ull; };
-        size_t n_el = 0;
-        for (const FileInfo &fi : info) n_el += eligible(fi);
-        if (share > 0 && n_el >= min_files && getenv("SKDER_AMD_HOST_PARSE") == nullptr && getenv("SKDER_AMD_IO_TWO_PHASE") == nullptr) {
-            uint64_t gz_all = 0, gz_dev = 0;
-            for (size_t k = 0; k < paths.size(); k++) {
-                if (!eligible(info[k])) continue;
-                gz_all += info[k].text;
-                if ((gz_dev + info[k].text) * 100u > (uint64_t)share * gz_all) continue;
-                gz_dev += info[k].text;
-                to_dev[k] = 1; any_dev = true;
-            }
-        }
-    }
     // the batch starting at i0: files until ~batch_bytes of layout
     auto batch_end = [&](size_t i0) {
         size_t i1 = i0;
-        uint64_t est = 0, dev_text = 0;
-        // with streams for the device in the call a batch is sized for ~1,000 of them (their pinned cost is the compressed file)
-        const uint64_t full = any_dev ? std::max<uint64_t>(batch_bytes, 1ull << 30) : batch_bytes;
-        const uint64_t budget = i0 == 0 ? full / 4 : full;      // a short first batch: the device starts early
-        while (i1 < paths.size() && (i1 == i0 || (est < budget && dev_text < (6ull << 30)))) {
-            if (to_dev[i1]) { est += (info[i1].size + 127u) & ~(uint64_t)63u; dev_text += info[i1].text + 192u; }
-            else est += bound(info[i1].text);
+        uint64_t est = 0;
+        const uint64_t budget = i0 == 0 ? batch_bytes / 4 : batch_bytes;      // a short first batch: the device starts early
+        while (i1 < paths.size() && (i1 == i0 || est < budget)) {
+            est += bound(info[i1].text);
             i1++;
         }
         return i1;
@@ -682,16 +619,11 @@ void sketch_files(skder_sketches *s, const std::vector<std::string> &paths, Geno
         double ms = 0;
         // device parse: the slot's pinned buffer holds FASTA text; the kernel of fasta.hip builds the layout
         bool dev_parse = false;
-        // gzip files whose text the DEVICE inflates (ginflate.hip): their compressed bytes sit behind the text regions of the batch
-        struct GzDev { uint32_t k; uint64_t comp_off; uint32_t comp_len, deflate_off, crc, isize; };
-        std::vector<GzDev> gz;
-        std::vector<uint8_t> text_on_device;      // per file of the batch (empty: none)
-        uint64_t dev_text_begin = 0, dev_text_end = 0;      // where their texts lie in the DEVICE buffer (behind everything that is copied over)
         std::vector<FastaFile> ff;
         uint64_t out_total = 0, table_total = 0;
     };
     const bool want_dev_parse = getenv("SKDER_AMD_HOST_PARSE") == nullptr;
-    auto prepare_host = [&](size_t i0, size_t i1, int sl, bool host_two_phase) {
+    auto prepare_host = [&](size_t i0, size_t i1, int sl) {
         const double t0 = now();
         HIPCHECK(hipSetDevice(ctx->device));          // may run on a helper thread
         Prepared P;
@@ -701,8 +633,8 @@ void sketch_files(skder_sketches *s, const std::vector<std::string> &paths, Geno
         std::vector<uint64_t> gbase(ng + 1);
         uint64_t off = 32;
         Slot &S = slot[sl];
-        auto room = [&](uint64_t total, uint64_t device_total = 0) {            // regions: 32 readable bytes in front, SKDER_TILE + 64 behind
-            if (device_total < total) device_total = total;
+        auto room = [&](uint64_t total) {            // regions: 32 readable bytes in front, SKDER_TILE + 64 behind
+            uint64_t device_total = total;
             if (total > S.cap) {
                 if (i1 - i0 < paths.size()) total = std::max<uint64_t>(total, batch_bytes + batch_bytes / 16);     // several batches: full size at once (the first batch is a short one)
                 if (S.h) (void)hipHostFree(S.h);
@@ -718,7 +650,7 @@ void sketch_files(skder_sketches *s, const std::vector<std::string> &paths, Geno
                 HIPCHECK(hipMalloc(&S.d, S.dcap));
             }
         };
-        bool direct = getenv("SKDER_AMD_IO_TWO_PHASE") == nullptr && !host_two_phase;
+        bool direct = getenv("SKDER_AMD_IO_TWO_PHASE") == nullptr;
         for (size_t k = 0; k < ng; k++) direct = direct && info[i0 + k].trusted;
         bool text_only = direct && want_dev_parse;
         for (size_t k = 0; k < ng && text_only; k++) text_only = bound(info[i0 + k].text) <= 0xFFFFFFFFull;       // (its output region is addressed in 32 bits)
@@ -728,9 +660,6 @@ void sketch_files(skder_sketches *s, const std::vector<std::string> &paths, Geno
             gs.clear(); gs.resize(ng);
             P.ff.assign(ng, FastaFile());
             uint64_t toff = 64, ooff = 32, tabs = 0;
-            // pinned buffer (copied to the device as one piece): the texts the host reads or inflates, then the COMPRESSED files of the
-            // device's share; device buffer: the same, then the texts the device inflates (never in host memory)
-            std::vector<int> dev_slot(ng, -1);
             for (size_t k = 0; k < ng; k++) {
                 FastaFile &f = P.ff[k];
                 f.text_len = (uint32_t)info[i0 + k].text;      // (gzip: the trailer's figure; the true length follows)
@@ -738,58 +667,14 @@ void sketch_files(skder_sketches *s, const std::vector<std::string> &paths, Geno
                 ooff += f.out_cap;
                 f.rec_cap = (uint32_t)(info[i0 + k].text / 256u + 64u); f.table_off = (uint32_t)tabs;
                 tabs += f.rec_cap;
-                if (to_dev[i0 + k]) continue;
                 f.text_off = toff;
                 toff += (info[i0 + k].text + 128u + 63u) & ~(uint64_t)63u;
             }
-            uint64_t coff = toff;
-            for (size_t k = 0; k < ng; k++) {
-                if (!to_dev[i0 + k]) continue;
-                const FileInfo &fi = info[i0 + k];
-                dev_slot[k] = (int)P.gz.size();
-                Prepared::GzDev g;
-                g.k = (uint32_t)k; g.comp_off = coff; g.comp_len = (uint32_t)fi.size; g.deflate_off = 0; g.crc = 0; g.isize = (uint32_t)fi.text;
-                P.gz.push_back(g);
-                coff += (fi.size + 127u) & ~(uint64_t)63u;
-            }
-            uint64_t doff = coff + 64;
-            if (!P.gz.empty()) {
-                P.text_on_device.assign(ng, 0);
-                P.dev_text_begin = doff;
-                for (const auto &g : P.gz) {
-                    P.ff[g.k].text_off = doff;
-                    doff += ((uint64_t)g.isize + 128u + 63u) & ~(uint64_t)63u;
-                }
-                P.dev_text_end = doff;
-            }
-            room(coff + 64, doff + 64);
+            room(toff + 64);
             std::atomic<bool> too_small(false);
             pool.run(ng, [&](size_t k, IoScratch &sc) {
                 if (too_small.load()) return;
                 FastaFile &f = P.ff[k];
-                if (dev_slot[k] >= 0) {
-                    // read only: the compressed file into its place behind the text regions; header and trailer are parsed here
-                    Prepared::GzDev &g = P.gz[(size_t)dev_slot[k]];
-                    FileCloser fc;
-                    fc.fd = open(paths[i0 + k].c_str(), O_RDONLY);
-                    if (fc.fd < 0) throw SkError("cannot open " + paths[i0 + k]);
-                    uint8_t *z = S.h + g.comp_off;
-                    size_t got = 0;
-                    while (got < g.comp_len) {
-                        const long r = (long)read(fc.fd, z + got, g.comp_len - got);
-                        if (r < 0) throw SkError("read error in " + paths[i0 + k]);
-                        if (r == 0) break;
-                        got += (size_t)r;
-                    }
-                    size_t hdr = 0;
-                    uint32_t crc = 0, isize = 0;
-                    if (got != g.comp_len || !gunzip_member_layout(z, got, &hdr, &crc, &isize) || isize != g.isize)
-                        throw SkError("truncated or corrupt gzip file " + paths[i0 + k]);
-                    g.deflate_off = (uint32_t)hdr; g.crc = crc;
-                    f.text_len = g.isize;                 // (its text region exists on the device only: the line feeds around it are set there)
-                    gs[k].path = paths[i0 + k];
-                    return;
-                }
                 uint8_t *t = S.h + f.text_off;
                 try {
                     const size_t n = read_text(paths[i0 + k], info[i0 + k].gz, t, info[i0 + k].text, sc);
@@ -804,12 +689,11 @@ void sketch_files(skder_sketches *s, const std::vector<std::string> &paths, Geno
             });
             if (!too_small.load()) {
                 P.dev_parse = true;
-                P.total = coff + 64; P.out_total = ooff + SKDER_TILE + 64; P.table_total = tabs;
+                P.total = toff + 64; P.out_total = ooff + SKDER_TILE + 64; P.table_total = tabs;
                 P.ms = now() - t0;
                 return P;
             }
             direct = false;
-            P.gz.clear(); P.text_on_device.clear();
         }
         if (direct) {
             // every file straight into its region
@@ -867,8 +751,8 @@ void sketch_files(skder_sketches *s, const std::vector<std::string> &paths, Geno
     };
     // ... and its copy to the device, on the slot's own stream (the slot's buffers are free: the batch that used them two
     // rounds ago was copied, parsed and sketched before this one was asked for)
-    auto prepare = [&](size_t i0, size_t i1, int sl, bool host_two_phase = false) {
-        Prepared P = prepare_host(i0, i1, sl, host_two_phase);
+    auto prepare = [&](size_t i0, size_t i1, int sl) {
+        Prepared P = prepare_host(i0, i1, sl);
         Slot &S = slot[sl];
         if (!S.cs) HIPCHECK(hipStreamCreateWithFlags(&S.cs, hipStreamNonBlocking));
         if (!S.ev) HIPCHECK(hipEventCreateWithFlags(&S.ev, hipEventDisableTiming));
@@ -886,69 +770,14 @@ void sketch_files(skder_sketches *s, const std::vector<std::string> &paths, Geno
         if (more) {
             const size_t n0 = cur.i1, n1 = batch_end(cur.i1);
             const int nsl = cur.sl ^ 1;
-            next = std::async(std::launch::async, [&prepare, n0, n1, nsl]() { return prepare(n0, n1, nsl, false); });
+            next = std::async(std::launch::async, [&prepare, n0, n1, nsl]() { return prepare(n0, n1, nsl); });
         }
         const double t2 = now();
         t_parse += cur.ms;
         try {
             Slot &S = slot[cur.sl];
             HIPCHECK(hipStreamWaitEvent(st, S.ev, 0));
-            if (cur.dev_parse && !cur.gz.empty()) {
-                // the device's share of the batch's gzip files: inflated in place (compressed bytes behind the text regions -> the text regions),
-                // CRC-32 computed, both checked here against the trailers.  A stream the device does not confirm -- damaged, several members,
-                // data behind the member -- is decoded by the host's decoder into the pinned region and copied over (or refused by it, loudly)
-                const uint32_t nz = (uint32_t)cur.gz.size();
-                std::vector<skder_gz_job_t> jobs(nz);
-                std::vector<skder_gz_result_t> zres(nz);
-                for (uint32_t j = 0; j < nz; j++) {
-                    const auto &g = cur.gz[j];
-                    jobs[j].in_off = g.comp_off + g.deflate_off; jobs[j].in_len = g.comp_len - g.deflate_off - 8u; jobs[j].pad = 0;
-                    jobs[j].out_off = cur.ff[g.k].text_off; jobs[j].out_cap = g.isize;
-                }
-                DevBuf<skder_gz_job_t> d_jobs;
-                DevBuf<skder_gz_result_t> d_zres;
-                d_jobs.resize(nz, st); d_zres.resize(nz, st);
-                HIPCHECK(hipMemcpyAsync(d_jobs.p, jobs.data(), nz * sizeof(skder_gz_job_t), hipMemcpyHostToDevice, st));
-                HIPCHECK(hipMemsetAsync(d_zres.p, 0, nz * sizeof(skder_gz_result_t), st));
-                // their text regions exist on the device only: line feeds everywhere first (the byte in front of a text, the 128 behind it)
-                HIPCHECK(hipMemsetAsync(S.d + cur.dev_text_begin - 64, '\n', cur.dev_text_end - cur.dev_text_begin + 64, st));
-                ginflate_enqueue(st, S.d, d_jobs.p, nz, S.d, d_zres.p);
-                HIPCHECK(hipMemcpyAsync(zres.data(), d_zres.p, nz * sizeof(skder_gz_result_t), hipMemcpyDeviceToHost, st));
-                HIPCHECK(hipStreamSynchronize(st));
-                bool redo_on_host = false;
-                IoScratch *fallback_sc = nullptr;
-                struct ScFree { IoScratch *&p; ~ScFree() { if (p) io_scratch_free(p); } } sc_guard{fallback_sc};
-                std::vector<uint8_t> tmp_text;
-                for (uint32_t j = 0; j < nz && !redo_on_host; j++) {
-                    const auto &g = cur.gz[j];
-                    const skder_gz_result_t &r = zres[j];
-                    if (r.status == 0 && r.out_len == g.isize && r.crc == g.crc && r.in_used == jobs[j].in_len) { cur.text_on_device[g.k] = 1; continue; }
-                    FastaFile &f = cur.ff[g.k];
-                    if (dbg) fprintf(stderr, "[skder_amd] %s: not confirmed by the device decoder (status %u): decoded on the host\n", cur.gs[g.k].path.c_str(), r.status);
-                    if (!fallback_sc) fallback_sc = io_scratch_new();
-                    const size_t region = ((size_t)g.isize + 128u + 63u) & ~(size_t)63u;
-                    tmp_text.assign(region, (uint8_t)'\n');
-                    size_t n = 0;
-                    try { n = read_text(cur.gs[g.k].path, true, tmp_text.data(), g.isize, *fallback_sc); }
-                    catch (const SkError &e) {
-                        // several members whose last one happened to look like the whole file: the text is longer than the region the trailer
-                        // gave it -- the batch is laid out again from exact sizes, by the host alone
-                        if (std::string(e.what()) == "region") { redo_on_host = true; break; }
-                        throw;
-                    }
-                    f.text_len = (uint32_t)n;
-                    memset(tmp_text.data() + n, '\n', region - n);
-                    HIPCHECK(hipMemcpyAsync(S.d + f.text_off, tmp_text.data(), region, hipMemcpyHostToDevice, st));
-                    HIPCHECK(hipStreamSynchronize(st));          // (tmp_text is reused)
-                    cur.text_on_device[g.k] = 1;                 // still only on the device: its name comes back from there
-                }
-                if (redo_on_host) {
-                    HIPCHECK(hipStreamSynchronize(S.cs));
-                    cur = prepare(cur.i0, cur.i1, cur.sl, true);
-                    HIPCHECK(hipStreamWaitEvent(st, slot[cur.sl].ev, 0));
-                }
-            }
-            if (cur.dev_parse) device_parse(s, S, cur.ff, cur.out_total, cur.table_total, cur.gs, cur.rec_off, cur.rec_len, cur.gbegin, cur.text_on_device);
+            if (cur.dev_parse) device_parse(s, S, cur.ff, cur.out_total, cur.table_total, cur.gs, cur.rec_off, cur.rec_len, cur.gbegin);
             skder_batch_t b;
             b.n_genomes = (uint32_t)cur.gs.size();
             b.n_records = (uint32_t)cur.rec_len.size();

@@ -80,7 +80,7 @@ __device__ __forceinline__ uint64_t revcomp21(uint64_t f)
 // multiplications (each several times the price of a v_mad_u64_u32, which is cheap here -- the compiler's pair of multiply-adds
 // with two register moves in between is hard to beat), and both hashes written out as one assembly stream on fixed
 // registers (strictly in order: slower than what the compiler's scheduler makes of the same arithmetic).
-// SKDER_AMD_SKETCH_VARIANT=0 runs the compiler-selected body (A/B measurements; the parity reference of the others).
+// (-DSK_BODY_DEFAULT=0 builds the compiler-selected body: A/B measurements, the parity reference of the others.)
 
 #define PACKED_WORDS ((SKDER_TILE + 32) / 16)   // 514
 
@@ -427,12 +427,7 @@ void sketch_batch_impl(skder_sketches *s, const uint8_t *d_bases, const skder_ba
 
         HIPCHECK(hipEventRecord(ctx->ev[0], st));
         if (nt) {
-            static const int variant = getenv("SKDER_AMD_SKETCH_VARIANT") ? atoi(getenv("SKDER_AMD_SKETCH_VARIANT")) : SK_BODY_DEFAULT;
-            if (variant == 0)
-                hipLaunchKernelGGL(sketch_tiles_kernel<0>, dim3(nt), dim3(SK_THREADS), 0, st, d_bases, d_tiles.p, slot_kmer.p,
-                                   slot_gpos.p, slot_mark.p, tile_ns.p, tile_nm.p, ctx->d_flags);
-            else
-                hipLaunchKernelGGL(sketch_tiles_kernel<SK_BODY_DEFAULT>, dim3(nt), dim3(SK_THREADS), 0, st, d_bases, d_tiles.p, slot_kmer.p,
+            hipLaunchKernelGGL(sketch_tiles_kernel<SK_BODY_DEFAULT>, dim3(nt), dim3(SK_THREADS), 0, st, d_bases, d_tiles.p, slot_kmer.p,
                                    slot_gpos.p, slot_mark.p, tile_ns.p, tile_nm.p, ctx->d_flags);
         }
         HIPCHECK(hipEventRecord(ctx->ev[1], st));

@@ -1346,42 +1346,6 @@ def test_structural_variants_randomized(gpu, oracle, realistic):
     assert (slow < 0.15 * chunks) if realistic else (slow > 0.3 * chunks)
 
 
-@pytest.mark.parametrize("mode", ["1", "2"])
-def test_run_dp_in_row_form(gpu, oracle, monkeypatch, mode):
-    """chain_rruns.hip -- the run DP with a chunk's runs held across the 16 lanes of a DPP row (opt-in: SKDER_AMD_RRUNS): behind the run
-    loop (1) or instead of it (2), bit-equal with the oracle on structural-variant families (both kinds) and on real assemblies, and
-    with fewer chunks left for the general kernel than the run loop alone leaves (branching chains, dead tails, look-backs beyond
-    the ring of four and any number of chains are settled on the runs)."""
-    engine, ctx, torch = gpu
-    p = oracle.default_params()
-    alpha = np.frombuffer(b"ACGT", np.uint8)
-
-    def family(seed, realistic):
-        rng = np.random.RandomState(seed)
-        anc = alpha[rng.randint(0, 4, rng.randint(300000, 700000))]
-        fam = [_structural_variant(rng, anc, realistic) for _ in range(4)]
-        return [g[1] for g in fam], [g[0] for g in fam]
-
-    sets = [family(2000, True), family(2001, True), family(7, False), family(309, False)]
-    names = GENOMES[:6]
-    recs = [_read_records(os.path.join(GOLDEN, "genomes", n)) for n in names]
-    sets.append(([r[0] for r in recs], [r[1] for r in recs]))
-    general = {}
-    for setting in ("0", mode):
-        monkeypatch.setenv("SKDER_AMD_RRUNS", setting)
-        tot = 0
-        for lens, bases in sets:
-            s, _ = _sketch(gpu, lens, bases)
-            og = [oracle.Genome.from_bases(b, l, p) for b, l in zip(bases, lens)]
-            edges = s.triangle_rows(0, 1, 0.0)
-            _check_edges(edges, _oracle_edges(oracle, og, p, 0.0))
-            tot += int(ctx.counters()[1])
-            s.close()
-        general[setting] = tot
-    monkeypatch.delenv("SKDER_AMD_RRUNS")
-    assert general[mode] < 0.6 * general["0"], general
-
-
 def test_real_derived_family_sampled_against_oracle(gpu, oracle):
     """bench.py's `real_derived` workload in small: the 34 real assemblies with two descendants each (substitutions, short
     indels, inversions / translocations / deletions, the assembly's own contig structure) -- 102 genomes of one species, all
@@ -1911,40 +1875,6 @@ def test_device_descendants_of_real_assemblies(gpu, oracle):
     assert len(want) == 28
     _check_edges(edges, want)
     s.close()
-
-
-@pytest.mark.parametrize("share", [100, 50])
-def test_gzip_ingest_with_streams_inflated_on_the_device(gpu, tmp_path, monkeypatch, share):
-    """the opt-in ingest path (SKDER_AMD_GPU_INFLATE): a share of the .fasta.gz files is only READ by the host, inflated by ginflate.hip in
-    HBM and checked against its trailer there; files the device does not confirm (several members, data behind the member) fall back to
-    the host decoder, a text longer than its trailer says sends the batch back to the host's two-phase layout.  Tables, N50 values
-    and names must equal the host path's byte for byte."""
-    import ctypes as C
-    from skder_amd import _lib
-    gdir = os.path.join(GOLDEN, "genomes")
-    names = sorted(os.listdir(gdir))
-    paths = [os.path.join(gdir, n) for n in names[:12]]
-    texts = [gzip.open(p, "rb").read() for p in paths[:4]]
-    odd = tmp_path / "odd"
-    odd.mkdir()
-    (odd / "two_members.fasta.gz").write_bytes(gzip.compress(texts[0][:700000], 6) + gzip.compress(texts[0][700000:], 6))
-    (odd / "many_members.fasta.gz").write_bytes(b"".join(gzip.compress(texts[1][i:i + 50000], 1) for i in range(0, len(texts[1]), 50000)))
-    (odd / "trailing_bytes.fasta.gz").write_bytes(gzip.compress(texts[2], 9) + b"\0" * 40)
-    (odd / "stored.fasta.gz").write_bytes(gzip.compress(texts[3], 0))
-    (odd / "long_header.fasta.gz").write_bytes(gzip.compress(b">" + b"x" * 3000 + b" a very long header line\n" + texts[3][texts[3].index(b"\n") + 1:], 6))
-    paths += [str(odd / n) for n in sorted(os.listdir(odd))]
-    listing = tmp_path / "l.txt"
-    listing.write_text("".join(p + "\n" for p in paths))
-    err = C.create_string_buffer(2048)
-    out = {}
-    for tag, env in (("host", {"SKDER_AMD_GPU_INFLATE": "0"}), ("device", {"SKDER_AMD_GPU_INFLATE": str(share), "SKDER_AMD_GPU_INFLATE_MIN": "1"})):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        t, n = tmp_path / (tag + ".tsv"), tmp_path / (tag + "_n50.tsv")
-        assert _lib.lib().skder_amd_triangle_n50(str(listing).encode(), 10.0, 89.5, 0, str(t).encode(), str(n).encode(), err, 2048) == 0, err.value
-        out[tag] = (t.read_text(), n.read_text())
-    assert out["host"] == out["device"]
-    assert out["host"][0].count("\n") == 1 + len(paths) * (len(paths) - 1) // 2
 
 
 def test_driver_test_cutoffs_mode(gpu, tmp_path):
