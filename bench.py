@@ -803,13 +803,18 @@ def main():
             t = ctx.timing()
             tm[0] += t[0]; tm[1] += t[1]
         t1 = time.perf_counter()
-        if dist_on:
+        by_components = dist_on and os.environ.get("SKDER_AMD_EXCHANGE") == "components"
+        if dist_on and not by_components:
             raw = multigpu.exchange_raw(multigpu.raw_from_sketches(sk), staging="cpu" if backend != "nccl" else None, parts=True)
             sk.close()
             sk = multigpu.sketches_from_raw(ctx, raw)
         t2 = time.perf_counter()
         # no explicit sk.index(): triangle_rows builds the seed index itself, on a second stream beside the marker screen
-        if dist_on:
+        if by_components:
+            # markers to everyone, every genome's seeds only to the rank that owns its connected component of candidate pairs
+            edges = multigpu.triangle_by_components(ctx, sk, mine.start, N, rank, world, args.screen, staging="cpu" if backend != "nccl" else None)
+            step.exchange_stats = dict(multigpu.triangle_by_components.last_stats)
+        elif dist_on:
             # index only the genomes this rank owns, screen its rows, chain the pairs that probe its genomes
             edges = multigpu.triangle_sharded(sk, rank, world, args.screen, copy=False)
         else:
@@ -825,7 +830,7 @@ def main():
             t5 = time.perf_counter()
             edges = multigpu.gather_edges(edges, copy=False)
             wall["gather"] += time.perf_counter() - t5
-            for k, v in getattr(multigpu.triangle_sharded, "last_stage_ms", {}).items():
+            for k, v in getattr(multigpu.triangle_by_components if by_components else multigpu.triangle_sharded, "last_stage_ms", {}).items():
                 stage[k] = stage.get(k, 0.0) + v
         sk.close()
         return edges, tm
@@ -992,6 +997,12 @@ def main():
                          "other_ms": {"sketch_post": float(tm[1]), "index_beside_screen": float(step.index_ms), "screen": float(tm[2]), "chain_slow_path": float(tm[4]),
                                       "finalize": float(tm[5])}},
         }
+        if dist_on:
+            by_comp = os.environ.get("SKDER_AMD_EXCHANGE") == "components"
+            out["exchange"] = {"mode": "components: markers all-gathered, seeds to the owner of each connected component" if by_comp else
+                               "replicate: raw sketches all-gathered, candidate pairs to the owner of the probed genome"}
+            if by_comp:
+                out["exchange"].update(getattr(step, "exchange_stats", {}))
         out["config"]["us_per_chained_pair"] = 1e3 * (join_ms + step.runs_ms + tm[3] + tm[4] + tm[5]) / max(n_chained, 1.0)
         if world == 1 and not args.no_cpu_baseline and args.parity_pairs > 0:
             out["parity_sample"] = parity_sample(recipe, edges, args.parity_pairs)
@@ -1089,6 +1100,10 @@ def main():
             batches.clear()      # the headline's resident bases are not needed any more
             torch.cuda.empty_cache()
             out["realistic"] = realistic_workloads(engine, ctx, torch, synth, args)
+            for k, v in out["realistic"].items():            # (scalars under config survive the driver's parse of the line)
+                if k.startswith("real_derived_") and isinstance(v, dict) and "us_per_chained_pair" in v:
+                    out["config"]["real_derived_us_per_chained_pair"] = v["us_per_chained_pair"]
+                    out["config"]["real_derived_genomes"] = v["genomes"]
             if args.low_mem_genomes > 0:
                 try:
                     out["realistic"]["low_mem_greedy_%d" % args.low_mem_genomes] = low_mem_greedy_scale(engine, ctx, torch, synth, args.low_mem_genomes, 2_800_000, dev)

@@ -97,7 +97,10 @@ void launch_chain_rows(hipStream_t st, unsigned grid, SetView A, SetView B, cons
 
 // ---- the run loop (chain_runs.hip)
 #define GEN_LISTS 256u
-void launch_chain_runs(hipStream_t st, unsigned grid, SetView A, SetView B, const PairDesc *pairs, uint32_t npairs, const uint32_t *gen_list,
+// an item of the run loop's lists: two uint4 -- (chunk, pair, first record, end of the chunk's seeds), (the pair's record region,
+// its multi-occurrence lists, the chunk's number inside the pair, first seed): the sieve has them in registers when it passes a
+// chunk on, and the run loop starts a chunk with ONE dependent load instead of four
+void launch_chain_runs(hipStream_t st, unsigned grid, SetView A, SetView B, const PairDesc *pairs, uint32_t npairs, const uint4 *gen_list,
                        const uint32_t *gen_cnt, uint32_t gen_cap, const RunRec *recs, const uint32_t *chunk_rec0, const uint4 *multi,
                        ChainRec *fast_chains, uint32_t *chunk_state, uint32_t *slow_list, uint32_t *slow_count, uint32_t *pair_na,
                        const uint32_t *chunk_pair, uint32_t *decl_list, uint32_t *decl_count, uint32_t *work_next);
@@ -132,7 +135,7 @@ void launch_run_extract(hipStream_t st, unsigned grid, SetView A, SetView B, con
                         uint32_t *pair_over, uint32_t *chunk_rec0);
 void launch_chain_single(hipStream_t st, unsigned grid, SetView A, SetView B, const PairDesc *pairs, uint32_t npairs, uint32_t total_chunks,
                          const RunRec *recs, const uint32_t *pair_over, const uint32_t *chunk_rec0, const uint32_t *wg_pair, const uint4 *multi,
-                         ChainRec *fast_chains, uint32_t *chunk_state, uint32_t *slow_list, uint32_t *counters, uint32_t *gen_list,
+                         ChainRec *fast_chains, uint32_t *chunk_state, uint32_t *slow_list, uint32_t *counters, uint4 *gen_list,
                          uint32_t *gen_cnt, uint32_t gen_cap, uint32_t *pair_na, int xcd_remap, uint32_t *chunk_pair);
 
 // ---- the fall-through tiers (chain_slow.hip)

@@ -58,7 +58,8 @@ struct ChainSlot {
     DevBuf<uint32_t> hits, pair_nmulti, groups, over_list, flags;
     DevBuf<uint4> multi;
     DevBuf<RunRec> recs;
-    DevBuf<uint32_t> pair_over, chunk_rec0, wg_pair, gen_list, gen_cnt, chunk_pair, rows_next;
+    DevBuf<uint32_t> pair_over, chunk_rec0, wg_pair, gen_cnt, chunk_pair, rows_next;
+    DevBuf<uint4> gen_list;
     std::vector<uint32_t> h_wg_pair;
     DevBuf<ChainRec> fast_chains, chains;
     DevBuf<PairOut> d_out;
@@ -328,7 +329,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         grow(S.counters, 64); grow(S.flags, 16); grow(S.rows_next, nchunks + 1);
         grow(S.pair_na, nb); grow(S.pair_nch, nb); grow(S.pair_nmulti, nb);
         grow(S.hits, nhits + 64); grow(S.multi, nmulti + 1);
-        grow(S.recs, nrecs + 8); grow(S.pair_over, nb + 1); grow(S.chunk_rec0, nchunks + 1); grow(S.gen_list, nchunks + 256ull * GEN_LISTS + 1); grow(S.gen_cnt, GEN_LISTS);
+        grow(S.recs, nrecs + 8); grow(S.pair_over, nb + 1); grow(S.chunk_rec0, nchunks + 1); grow(S.gen_list, 2 * (nchunks + 256ull * GEN_LISTS + 1)); grow(S.gen_cnt, GEN_LISTS);
         grow(S.chains, ccap + 1);
         grow(S.d_out, nb);
         if (getenv("SKDER_AMD_DEBUG"))

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void chain_single_kernel(SetView A, SetView B,
                                                            const uint32_t *__restrict__ wg_pair, const uint4 *__restrict__ multi,
                                                            ChainRec *__restrict__ fast_chains,
                                                            uint32_t *__restrict__ chunk_state, uint32_t *__restrict__ slow_list,
-                                                           uint32_t *__restrict__ counters, uint32_t *__restrict__ gen_list,
+                                                           uint32_t *__restrict__ counters, uint4 *__restrict__ gen_list,
                                                            uint32_t *__restrict__ gen_cnt, uint32_t gen_cap,
                                                            uint32_t *__restrict__ pair_na, int xcd_remap, uint32_t *__restrict__ chunk_pair)
 {
@@ -229,6 +229,7 @@ __global__ __launch_bounds__(256) void chain_single_kernel(SetView A, SetView B,
     const bool in = t < total_chunks;
     uint32_t pi = 0, n_add = 0, slow_why = 0;
     bool to_gen = false, to_slow = false;
+    uint4 gd0 = make_uint4(0, 0, 0, 0), gd1 = gd0;       // what the run loop needs of a chunk it is handed (chain.h, GenItem)
     if (in) {
         const uint32_t idx0 = chunk_rec0[t];                 // independent of the descriptor: in flight beside it
         pi = wg_pair[wg];
@@ -362,7 +363,10 @@ __global__ __launch_bounds__(256) void chain_single_kernel(SetView A, SetView B,
                 if (fail) SIEVE_WHY(15);
             }
             if (!fail) { n_add = anchors; chunk_state[t] = nfin; }
-            else { to_gen = true; chunk_pair[t] = pi; }
+            else {
+                to_gen = true; chunk_pair[t] = pi;
+                gd0 = make_uint4(t, pi, idx0, s1); gd1 = make_uint4(pd.rec_base, pd.multi_base, c, s0);
+            }
         }
     }
     {
@@ -388,7 +392,10 @@ __global__ __launch_bounds__(256) void chain_single_kernel(SetView A, SetView B,
             uint32_t base = 0;
             if (lane == leader) base = atomicAdd(gen_cnt + li, (uint32_t)__popcll(gm));
             base = (uint32_t)__shfl((int)base, (int)leader, 64);
-            if (to_gen) gen_list[(uint64_t)li * gen_cap + base + (uint32_t)__popcll(gm & ((1ull << lane) - 1ull))] = t;
+            if (to_gen) {
+                uint4 *gi = gen_list + 2u * ((uint64_t)li * gen_cap + base + (uint32_t)__popcll(gm & ((1ull << lane) - 1ull)));
+                gi[0] = gd0; gi[1] = gd1;
+            }
         }
     }
     // anchors of the pair: one atomic per wavefront when all its chunks belong to one pair (nearly always)
@@ -410,7 +417,7 @@ void launch_run_extract(hipStream_t st, unsigned grid, SetView A, SetView B, con
 }
 void launch_chain_single(hipStream_t st, unsigned grid, SetView A, SetView B, const PairDesc *pairs, uint32_t npairs, uint32_t total_chunks,
                          const RunRec *recs, const uint32_t *pair_over, const uint32_t *chunk_rec0, const uint32_t *wg_pair, const uint4 *multi,
-                         ChainRec *fast_chains, uint32_t *chunk_state, uint32_t *slow_list, uint32_t *counters, uint32_t *gen_list,
+                         ChainRec *fast_chains, uint32_t *chunk_state, uint32_t *slow_list, uint32_t *counters, uint4 *gen_list,
                          uint32_t *gen_cnt, uint32_t gen_cap, uint32_t *pair_na, int xcd_remap, uint32_t *chunk_pair)
 {
     hipLaunchKernelGGL(chain_single_kernel, dim3(grid), dim3(256), 0, st, A, B, pairs, npairs, total_chunks, recs, pair_over, chunk_rec0, wg_pair, multi,

@@ -36,7 +36,7 @@ struct Run {
 };
 
 __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs, uint32_t npairs,
-                                                         const uint32_t *__restrict__ gen_list, const uint32_t *__restrict__ gen_cnt,
+                                                         const uint4 *__restrict__ gen_list, const uint32_t *__restrict__ gen_cnt,
                                                          uint32_t gen_cap, const RunRec *__restrict__ recs,
                                                          const uint32_t *__restrict__ chunk_rec0, const uint4 *__restrict__ multi,
                                                          ChainRec *__restrict__ fast_chains, uint32_t *__restrict__ chunk_state,
@@ -222,16 +222,12 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, c
                     if (!busy && w < w_lim) {
                         uint32_t lo = 0, hi = GEN_LISTS;              // the list that holds item w: last offset <= w
                         while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (g_off[mid] <= w) lo = mid; else hi = mid; }
-                        t = gen_list[(uint64_t)lo * gen_cap + (w - g_off[lo])];
-                        pi = chunk_pair[t];        // (chain_single_kernel left it there: a binary search over the pairs is 15 dependent loads)
-                        const PairDesc pd = pairs[pi];
-                        idx = chunk_rec0[t];
-                        c = t - pd.chunk_base;
-                        const uint32_t *cs = ((pd.flags & 2u) ? B.chunk_start : A.chunk_start) + pd.q_chunk_off + c;
-                        const uint32_t s0 = cs[0];
-                        s1 = cs[1];
-                        multi_base = pd.multi_base;
-                        prec = reinterpret_cast<const uint4 *>(recs + pd.rec_base);
+                        const uint4 *gi = gen_list + 2u * ((uint64_t)lo * gen_cap + (w - g_off[lo]));
+                        const uint4 i0 = gi[0], i1 = gi[1];       // (chain.h: what the sieve knew of the chunk)
+                        t = i0.x; pi = i0.y; idx = i0.z; s1 = i0.w;
+                        multi_base = i1.y; c = i1.z;
+                        const uint32_t s0 = i1.w;
+                        prec = reinterpret_cast<const uint4 *>(recs + i1.x);
                         slots = fast_chains + (uint64_t)t * FAST_SLOTS;
                         busy = true; cplx = false; cause = 0u;
                         done = idx == 0xFFFFFFFFu || s1 <= s0;
@@ -444,7 +440,7 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, c
 }
 
 
-void launch_chain_runs(hipStream_t st, unsigned grid, SetView A, SetView B, const PairDesc *pairs, uint32_t npairs, const uint32_t *gen_list,
+void launch_chain_runs(hipStream_t st, unsigned grid, SetView A, SetView B, const PairDesc *pairs, uint32_t npairs, const uint4 *gen_list,
                        const uint32_t *gen_cnt, uint32_t gen_cap, const RunRec *recs, const uint32_t *chunk_rec0, const uint4 *multi,
                        ChainRec *fast_chains, uint32_t *chunk_state, uint32_t *slow_list, uint32_t *slow_count, uint32_t *pair_na,
                        const uint32_t *chunk_pair, uint32_t *decl_list, uint32_t *decl_count, uint32_t *work_next)

@@ -11,7 +11,14 @@ with torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" i
   * edge records are gathered on rank 0.
 Collectives: the sketch all-gather (the only large one: one padded collective of everything a rank has, behind a 40-byte header),
 the repetitive-cut-off table (4 B per genome), the candidate pairs (8 B per pair, all_to_all_single: each pair to its owner only)
-and the edge gather."""
+and the edge gather.
+
+`triangle_by_components` (SKDER_AMD_EXCHANGE=components in bench.py) is the exchange that does NOT replicate the seeds: only the
+MARKERS are all-gathered (8 B per 1000 bases), every rank screens its rows of the triangle, the candidate pairs are all-gathered
+(8 B each), every connected component of the candidate-pair graph -- a species -- is given to ONE rank (heaviest first to the least
+loaded rank, weight = the seeds its pairs read), and each genome's seeds travel ONCE, to the rank that owns its component, by one
+all_to_all_single per array.  A rank then holds, indexes and chains only its components' genomes: 1/world of the seeds instead of all
+of them, and no genome of another rank is needed while chaining."""
 from typing import Dict, List
 
 import numpy as np
@@ -253,4 +260,172 @@ def triangle_sharded(sk, rank: int, world: int, screen_pct: float, group=None, c
     triangle_sharded.last_stage_ms = {k: 1e3 * (t[i + 1] - t[i]) for i, k in enumerate(names)}      # (bench.py --gpus N reports them per rank)
     if dbg and rank == 0:
         print("[skder_amd] triangle_sharded: " + ", ".join("%s %.2f ms" % kv for kv in triangle_sharded.last_stage_ms.items()), file=sys.stderr)
+    return edges
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# ownership by connected component: markers to everyone, seeds only to the rank that chains them
+
+
+def component_labels(n: int, ref: np.ndarray, query: np.ndarray) -> np.ndarray:
+    """label[g] = smallest genome index of g's connected component in the graph whose edges are the candidate pairs (label
+    propagation with pointer jumping: a species is a near-clique, two or three sweeps)"""
+    lab = np.arange(n, dtype=np.int64)
+    if len(ref) == 0:
+        return lab
+    ref, query = ref.astype(np.int64), query.astype(np.int64)
+    while True:
+        low = np.minimum(lab[ref], lab[query])
+        new = lab.copy()
+        np.minimum.at(new, ref, low)
+        np.minimum.at(new, query, low)
+        new = new[new]
+        if np.array_equal(new, lab):
+            return lab
+        lab = new
+
+
+def component_owners(n: int, ref: np.ndarray, query: np.ndarray, n_seeds: np.ndarray, world: int) -> np.ndarray:
+    """owner[g] = the rank that chains every pair of g's component, -1 for a genome without a candidate pair (its seeds go nowhere).
+    Components by descending weight (sum over their pairs of the two genomes' seed counts: what chaining them reads), ties by label,
+    each to the least loaded rank (ties: the lowest) -- a pure function of its arguments, so every rank computes the same table."""
+    owner = np.full(n, -1, np.int64)
+    if len(ref) == 0:
+        return owner
+    lab = component_labels(n, ref, query)
+    w_pair = n_seeds[ref].astype(np.float64) + n_seeds[query].astype(np.float64)
+    labels, inv = np.unique(lab[ref], return_inverse=True)
+    weight = np.bincount(inv, weights=w_pair, minlength=len(labels))
+    load = np.zeros(world)
+    owner_of = {}
+    for k in np.lexsort((labels, -weight)):
+        r = int(np.argmin(load))
+        owner_of[int(labels[k])] = r
+        load[r] += weight[k]
+    in_pair = np.zeros(n, bool)
+    in_pair[ref] = True
+    in_pair[query] = True
+    g = np.flatnonzero(in_pair)
+    owner[g] = [owner_of[int(l)] for l in lab[g]]
+    return owner
+
+
+def _ranges_index(starts: np.ndarray, lens: np.ndarray, device) -> torch.Tensor:
+    """the concatenation of arange(starts[i], starts[i] + lens[i]) as an int64 tensor on `device`"""
+    lens_t = torch.from_numpy(np.ascontiguousarray(lens, np.int64)).to(device)
+    total = int(lens.sum())
+    if total == 0:
+        return torch.empty(0, dtype=torch.int64, device=device)
+    first = torch.from_numpy(np.ascontiguousarray(starts, np.int64)).to(device)
+    before = torch.cumsum(lens_t, 0) - lens_t
+    return torch.repeat_interleave(first - before, lens_t) + torch.arange(total, dtype=torch.int64, device=device)
+
+
+def exchange_seeds(raw: Dict, first_genome: int, owner: np.ndarray, n_seeds: np.ndarray, blocks: List[range], group=None, staging: str = None):
+    """this rank's genomes are [first_genome, first_genome + raw['n_genomes']); owner / n_seeds are the global per-genome tables.
+    Every genome's seed k-mers and positions go to owner[g] (nowhere if -1) by ONE all_to_all_single per array; the receive sizes
+    follow from the global tables, so no counts are exchanged.  Returns (global indices of the genomes received, ascending;
+    their k-mers; their positions) -- the arrays hold the genomes back to back in that order."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    nccl = dist.get_backend(group) == "nccl"
+    dev = raw["seed_kmer"].device if (nccl or staging != "cpu") else torch.device("cpu")
+    ng = int(raw["n_genomes"])
+    mine = np.arange(first_genome, first_genome + ng)
+    local_off = (np.asarray(raw["seed_off"], np.uint64) - np.uint64(raw["seed_off"][0])).astype(np.int64) if ng else np.zeros(1, np.int64)
+    dest = owner[mine] if ng else np.zeros(0, np.int64)
+    order = np.flatnonzero(dest >= 0)
+    order = order[np.argsort(dest[order], kind="stable")]              # by destination, ascending genome inside one
+    idx = _ranges_index(local_off[order], n_seeds[mine[order]], dev)
+    n_out = [int(n_seeds[mine[order][dest[order] == r]].sum()) for r in range(world)]
+    n_in = [int(n_seeds[[g for g in blocks[r] if owner[g] == rank]].sum()) if len(blocks[r]) else 0 for r in range(world)]
+    got = []
+    for key in ("seed_kmer", "seed_gpos"):
+        send = raw[key].to(dev)[idx].contiguous()
+        recv = torch.empty(sum(n_in), dtype=send.dtype, device=dev)
+        if not nccl:
+            send, recv = send.cpu(), recv.cpu()
+        dist.all_to_all_single(recv, send, output_split_sizes=n_in, input_split_sizes=n_out, group=group)
+        got.append(recv.to(raw[key].device))
+    return np.flatnonzero(owner == rank), got[0], got[1]
+
+
+def triangle_by_components(ctx, sk, first_genome: int, n_total: int, rank: int, world: int, screen_pct: float, group=None,
+                           staging: str = None, copy: bool = True) -> np.ndarray:
+    """this rank's share of the all-pairs table when `sk` holds only the genomes the rank sketched itself (module text).  The edge
+    records carry global genome indices; their union over the ranks equals the one-rank table record for record."""
+    import time
+    from .engine import EDGE_DTYPE, Sketches
+    t = [time.perf_counter()]
+    lap = lambda: t.append(time.perf_counter())
+    raw = raw_from_sketches(sk)
+    blocks = partition(n_total, world)
+    empty = raw["seed_kmer"][:0]
+    mk = exchange_raw(dict(raw, seed_kmer=empty, seed_gpos=empty), group=group, staging=staging, parts=True)["parts"]
+    n_seeds = np.concatenate([np.diff(np.asarray(p["seed_off"], np.uint64).astype(np.int64)) for p in mk]).astype(np.int64)
+    lap()
+    # every genome's markers, no seeds: the set the rows are screened on
+    ms = Sketches(ctx)
+    torch.cuda.synchronize()
+    ms.reserve(0, sum(int(p["markers"].numel()) for p in mk))
+    for p in mk:
+        if int(p["n_genomes"]):
+            ms.append_raw(p["n_genomes"], 0, 0, None, p["markers"].data_ptr(), np.zeros(p["n_genomes"] + 1, np.uint64), p["marker_off"],
+                          p["genome_len"], p["genome_nrec"], p["rec_goff"])
+    ms.index_part(np.zeros(n_total, np.uint8))
+    ref, query = ms.screen_rows(rank, world, screen_pct)
+    lap()
+    # all candidate pairs to everyone (8 bytes each): the component table must be the same on every rank
+    nccl = dist.get_backend(group) == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
+    packed = torch.from_numpy((ref.astype(np.int64) << 32) | query.astype(np.int64)).to(dev)
+    cnt = torch.tensor([len(ref)], dtype=torch.int64, device=dev)
+    cnts = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(cnts, cnt, group=group)
+    cnts = [int(x) for x in cnts.cpu().tolist()]
+    mx = max(max(cnts), 1)
+    buf = torch.zeros(mx, dtype=torch.int64, device=dev)
+    buf[:len(ref)] = packed
+    allp = torch.empty(world * mx, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(allp, buf, group=group)
+    allp = allp.cpu().numpy().reshape(world, mx)
+    pairs = np.concatenate([allp[r, :cnts[r]] for r in range(world)])
+    aref, aquery = (pairs >> 32).astype(np.int64), (pairs & 0xFFFFFFFF).astype(np.int64)
+    owner = component_owners(n_total, aref, aquery, n_seeds, world)
+    lap()
+    have, kmer, gpos = exchange_seeds(raw, first_genome, owner, n_seeds, blocks, group=group, staging=staging)
+    lap()
+    # the set this rank chains on: its components' genomes, ascending global index, local indices 0 ..
+    edges = np.zeros(0, EDGE_DTYPE)
+    stats = {"genomes_held": int(len(have)), "seeds_received": int(kmer.numel()), "bytes_sent_seeds": int(8 * n_seeds[[g for g in blocks[rank] if owner[g] >= 0 and owner[g] != rank]].sum()),
+             "bytes_sent_markers": int(8 * sum(int(p["markers"].numel()) for i, p in enumerate(mk) if i == rank) * (world - 1)), "pairs_all": int(len(pairs))}
+    if len(have):
+        m_off = np.concatenate([np.asarray(p["marker_off"], np.uint64).astype(np.int64)[:-1] + b for p, b in
+                                zip(mk, np.concatenate([[0], np.cumsum([int(p["markers"].numel()) for p in mk])])[:-1])])
+        m_len = np.concatenate([np.diff(np.asarray(p["marker_off"], np.uint64).astype(np.int64)) for p in mk])
+        allm = torch.cat([p["markers"] for p in mk])
+        markers = allm[_ranges_index(m_off[have], m_len[have], allm.device)].contiguous()
+        g_len = np.concatenate([p["genome_len"] for p in mk])[have]
+        g_nrec = np.concatenate([p["genome_nrec"] for p in mk])
+        all_goff = np.concatenate([p["rec_goff"] for p in mk])
+        r_off = np.concatenate([[0], np.cumsum(g_nrec.astype(np.int64) + 1)])
+        rec_goff = np.concatenate([all_goff[r_off[g]:r_off[g + 1]] for g in have])
+        ls = Sketches(ctx)
+        torch.cuda.synchronize()
+        ls.append_raw(len(have), kmer.data_ptr(), gpos.data_ptr(), None, markers.data_ptr(),
+                      np.concatenate([[0], np.cumsum(n_seeds[have])]).astype(np.uint64), np.concatenate([[0], np.cumsum(m_len[have])]).astype(np.uint64),
+                      g_len, g_nrec[have], rec_goff)
+        ls.index()
+        local = np.full(n_total, -1, np.int64)
+        local[have] = np.arange(len(have))
+        sel = owner[aref] == rank
+        e = ls.chain_pairs(local[aref[sel]].astype(np.uint32), local[aquery[sel]].astype(np.uint32), copy=True)
+        e["ref"] = have[e["ref"]]
+        e["query"] = have[e["query"]]
+        edges = e
+        ls.close()
+    ms.close()
+    lap()
+    names = ("markers_all_gather", "screen", "pairs_all_gather_components", "seeds_all_to_all", "index_chain")
+    triangle_by_components.last_stage_ms = {k: 1e3 * (t[i + 1] - t[i]) for i, k in enumerate(names)}
+    triangle_by_components.last_stats = stats
     return edges

@@ -380,17 +380,19 @@ def test_dropin_tables_match_oracle_and_golden(gpu, oracle, tmp_path):
         _lib.lib().skder_amd_db_free(db)
 
 
+@pytest.mark.parametrize("exchange", ["replicate", "components"])
 @pytest.mark.parametrize("world", [2, 3])
-def test_ranks_share_the_triangle(gpu, tmp_path, world):
+def test_ranks_share_the_triangle(gpu, tmp_path, world, exchange):
     """N > 1 path end to end on the real kernels: `world` ranks (gloo, all on this GPU) sketch a share of the genomes
-    each, exchange raw sketches, index the genomes they own, screen their rows and chain the pairs that probe their
-    genomes (skder_amd/multigpu.py triangle_sharded).  The edge RECORDS gathered on rank 0 -- sorted by (ref, query) --
-    must equal the single-rank run's bit for bit, every field."""
+    each, then either exchange raw sketches, index the genomes they own, screen their rows and chain the pairs that probe their
+    genomes (skder_amd/multigpu.py triangle_sharded: "replicate"), or all-gather the markers only, screen their rows, give every
+    connected component of candidate pairs to one rank and send each genome's seeds to that rank alone (triangle_by_components).
+    The edge RECORDS gathered on rank 0 -- sorted by (ref, query) -- must equal the single-rank run's bit for bit, every field."""
     import json
     import subprocess
     import sys
     from conftest import ROOT
-    env = dict(os.environ, SKDER_AMD_DIST_BACKEND="gloo")
+    env = dict(os.environ, SKDER_AMD_DIST_BACKEND="gloo", SKDER_AMD_EXCHANGE=exchange)
     common = ["--genomes", "40", "--genome-len", "200000", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
     f1, f2 = str(tmp_path / "one.npy"), str(tmp_path / "many.npy")
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common + ["--dump-edges", f1], capture_output=True, text=True,

@@ -187,3 +187,89 @@ def test_pairs_go_to_the_owner_of_the_probed_genome(world):
             assert (int(a), int(b)) not in seen
             seen[(int(a), int(b))] = r
     assert seen == want and len(want) > 100
+
+
+# ---- ownership by connected component (multigpu.triangle_by_components): the host logic and the seed exchange
+
+
+def test_components_and_their_owners():
+    """component_labels / component_owners: three cliques of different weight, a chain of pairs and genomes without any pair.  Every
+    genome of a component gets ONE owner, genomes without a pair get none, the heaviest components go to different ranks, and the
+    table does not depend on the order the pairs are listed in"""
+    sys.path.insert(0, ROOT)
+    from skder_amd import multigpu
+    n = 40
+    groups = [list(range(0, 12)), list(range(12, 20)), list(range(20, 25)), [30, 33, 31, 38]]          # the last one a chain 30-33-31-38
+    ref, query = [], []
+    for g in groups[:3]:
+        for i in g:
+            for j in g:
+                if i < j:
+                    ref.append(i); query.append(j)
+    for a, b in zip(groups[3][:-1], groups[3][1:]):
+        ref.append(min(a, b)); query.append(max(a, b))
+    ref, query = np.array(ref), np.array(query)
+    n_seeds = np.full(n, 1000, np.int64)
+    lab = multigpu.component_labels(n, ref, query)
+    for g in groups:
+        assert len({int(lab[i]) for i in g}) == 1 and int(lab[g[0]]) == min(g)
+    assert all(int(lab[i]) == i for i in (25, 26, 29, 32, 39))
+    for world in (1, 2, 3, 8):
+        own = multigpu.component_owners(n, ref, query, n_seeds, world)
+        for g in groups:
+            assert len({int(own[i]) for i in g}) == 1 and 0 <= int(own[g[0]]) < world
+        assert all(int(own[i]) == -1 for i in (25, 26, 29, 32, 39))
+        if world >= 3:
+            assert len({int(own[g[0]]) for g in groups[:3]}) == 3          # heaviest first, each to the least loaded rank
+        perm = np.random.RandomState(world).permutation(len(ref))
+        assert np.array_equal(own, multigpu.component_owners(n, ref[perm], query[perm], n_seeds, world))
+
+
+def _seeds_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from skder_amd import multigpu
+    raws = [_fake_raw(r) for r in range(world)]
+    n = sum(x["n_genomes"] for x in raws)
+    cuts = np.concatenate([[0], np.cumsum([x["n_genomes"] for x in raws])])
+    blocks = [range(int(cuts[r]), int(cuts[r + 1])) for r in range(world)]
+    n_seeds = np.concatenate([np.diff(x["seed_off"].astype(np.int64)) for x in raws])
+    owner = (np.arange(n) * 5 + 1) % (world + 1) - 1                      # -1 .. world-1: some genomes go nowhere
+    have, kmer, gpos = multigpu.exchange_seeds(raws[rank], int(cuts[rank]), owner, n_seeds, blocks, staging="cpu")
+    q.put((rank, have, kmer.numpy(), gpos.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_seeds_go_to_the_owner_of_their_component(world):
+    """multigpu.exchange_seeds: every genome's seed arrays arrive on owner[g] and nowhere else, back to back in ascending genome order"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + os.getpid() % 2000 + world
+    procs = [ctx.Process(target=_seeds_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, have, kmer, gpos = q.get(timeout=120)
+        got[r] = (have, kmer, gpos)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    raws = [_fake_raw(r) for r in range(world)]
+    per_genome = []
+    for x in raws:
+        off = (x["seed_off"] - x["seed_off"][0]).astype(np.int64)
+        for g in range(x["n_genomes"]):
+            per_genome.append((x["seed_kmer"].numpy()[off[g]:off[g + 1]], x["seed_gpos"].numpy()[off[g]:off[g + 1]]))
+    n = len(per_genome)
+    owner = (np.arange(n) * 5 + 1) % (world + 1) - 1
+    assert (owner == -1).any()
+    for r in range(world):
+        have, kmer, gpos = got[r]
+        assert np.array_equal(have, np.flatnonzero(owner == r)) and len(have) > 0
+        assert np.array_equal(kmer, np.concatenate([per_genome[g][0] for g in have]))
+        assert np.array_equal(gpos, np.concatenate([per_genome[g][1] for g in have]))
