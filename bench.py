@@ -27,7 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0
-PMC_TRAFFIC = os.path.join("profiles", "round4_pmc_traffic.json")     # rocprofv3 --pmc passes of THIS build (profiles/collect.sh)
+PMC_TRAFFIC = os.path.join("profiles", "round5_pmc_traffic.json")     # rocprofv3 --pmc passes of THIS build (profiles/collect.sh)
 ONE_QUEUE_STEPS = 3
 
 
@@ -594,7 +594,7 @@ def one_species_database(engine, ctx, torch, synth, n, device, keep_bases=None):
     return sk, paths, n50, time.perf_counter() - t0
 
 
-def low_mem_greedy_one_species(engine, ctx, torch, synth, n, device):
+def low_mem_greedy_one_species(engine, ctx, torch, synth, n, device, sequential=True):
     """The reference's published workload in its REAL SHAPE (README.md:27: `skder -d low_mem_greedy` on > 20,000 genomes of one genus,
     mostly one species, 2.25 h on 20 threads): lowMemGreedyDerep -i 99.5 -f 50 (skder.py:95-134) over n genomes of ONE species with
     real genome structure -- nearly every `search` passes the screen against thousands of genomes and chains them all, unlike the
@@ -622,12 +622,15 @@ def low_mem_greedy_one_species(engine, ctx, torch, synth, n, device):
             lowMemGreedyDerep(listing, ws, n50_file, res, ws, 99.5, 50.0, None, search_batch=width, database=db)
             return time.perf_counter() - t0, open(res).read(), dict(getattr(lowMemGreedyDerep, "last_stats", {}))
         t_spec, reps_spec, st = run(0, "spec")
-        t_seq, reps_seq, _ = run(1, "seq")
+        t_seq, reps_seq = None, reps_spec
+        if sequential:
+            t_seq, reps_seq, _ = run(1, "seq")
         db.close()
         nrep = len(reps_spec.split())
         return {"genomes": len(paths), "representatives": nrep, "seconds_speculative_batches": t_spec, "seconds_one_search_per_representative": t_seq,
-                "listings_identical": reps_spec == reps_seq, "searches": st.get("searches"), "search_batches": st.get("batches"),
+                "listings_identical": (reps_spec == reps_seq) if sequential else None, "searches": st.get("searches"), "search_batches": st.get("batches"),
                 "rows_per_search": (st.get("rows", 0) / max(st.get("searches", 1), 1)), "rows_total": st.get("rows"),
+                "seconds_inside_search_batch": st.get("search_s"), "seconds_rows_pass": st.get("rows_pass_s"),
                 "sketching_s_incl_generating_the_bases": t_sketch, "database_from_resident_sketches_s": t_db,
                 "reference_published": {"seconds": 2.25 * 3600, "what": "README.md:27: low_mem_greedy on > 20,000 Staphylococcus genomes (GTDB R220), 20 threads, machine "
                                         "unspecified; other genomes, other hardware, FASTA ingest and skani's own arithmetic included there -- quoted, not compared"},

@@ -14,24 +14,28 @@
  * be reconstructed, so ANI is skani's published chunk-level estimator plus a two-parameter stand-in (skder_amd_spec.h).
  * Against the reference's golden table (561 pairs, one species, ANI 96.4-100): ANI rms 0.14 / max 0.42 points, AF rms
  * 0.37 / max 1.10; unpinned beyond.  skder_edge_t carries ani_raw and its integer counts for callers with their own model.
+ * (648 sampling and chaining-rule hypotheses were scored against that table in round 5, profiles/round5_sample_hypotheses.json:
+ * none reproduces skani's sample; the residual is what an independent FracMinHash sample leaves.)
  *
  * Every function returns 0 on success; on failure it returns non-zero and writes a message into
  * err[0..errlen) -- the Python shim raises RuntimeError from it, as util.runCmd does (util.py:652).
  * There is NO CPU fallback anywhere behind this header: without a gfx950 device every compute entry
  * point fails with an error.
  *
- * ENVIRONMENT SWITCHES read by the library (all of them; none is needed for normal use; results are identical under every one):
+ * ENVIRONMENT SWITCHES read by the library (all thirteen of them; none is needed for normal use; results are identical under every one):
  *   SKDER_AMD_DEBUG=1|2        per-batch counters (chunks per path, decline causes) and host timings on stderr; 2: one line per ingested file
  *   SKDER_AMD_QUEUES=n         HIP queues the chaining batches alternate between (default 2; 1 = batch after batch: per-kernel timings)
  *   SKDER_AMD_CHUNK_BUDGET=n   chunks per chaining batch (default 6 M);  SKDER_AMD_PAIR_BUDGET=n  candidate pairs per screening block (2^31);
  *   SKDER_AMD_REC_DIV=n        seeds per run-record slot (default 4)                       -- the three are exercised by the parity tests
  *   SKDER_AMD_FORCE_SLOW=1     every chunk through the general (unabridged) chaining kernel;  SKDER_AMD_NO_SIEVE=1  none settled by the sieve;
  *   SKDER_AMD_NO_ROWS=1        declined chunks to the one-wavefront-per-chunk kernel instead of the rows kernel  -- parity A/B of the chaining paths
+ *   SKDER_AMD_RUNS_REFILL=n    free lanes of a wavefront at which the run loop writes finished chunks out and hands new ones over (default 24; 1 - 64)
  *   SKDER_AMD_IO_THREADS=n     reader threads of the ingest (default: the cgroup's CPUs, at most 128);  SKDER_AMD_IO_BATCH_MB=n  pinned staging batch (256)
  *   SKDER_AMD_IO_TWO_PHASE=1   .gz files through memory of their own instead of straight into the staging buffer
  *   SKDER_AMD_HOST_PARSE=1     FASTA parsed by the host reader instead of the device;  SKDER_AMD_FASTA_WAVE=1  by the one-wavefront-per-file kernel
  * Read by the Python host mirror (skder_amd/skder.py): SKDER_AMD_DEVICE, SKDER_AMD_DEVICES (device list of the drop-in entry points),
- * SKDER_AMD_SEARCH_BATCH, SKDER_AMD_SEARCH_ALL (lowMemGreedyDerep's speculative batches); by bench.py: SKDER_AMD_FORCE_DIST, SKDER_AMD_DIST_BACKEND.
+ * SKDER_AMD_SEARCH_BATCH, SKDER_AMD_SEARCH_ALL (lowMemGreedyDerep's speculative batches); by bench.py: SKDER_AMD_FORCE_DIST, SKDER_AMD_DIST_BACKEND,
+ * SKDER_AMD_EXCHANGE=components (N > 1: markers all-gathered, seeds to the owner of each connected component; skder_amd/multigpu.py).
  */
 #ifndef SKDER_AMD_H
 #define SKDER_AMD_H

@@ -104,7 +104,7 @@ void launch_chain_runs(hipStream_t st, unsigned grid, SetView A, SetView B, cons
                        const uint32_t *gen_cnt, uint32_t gen_cap, const RunRec *recs, const uint32_t *chunk_rec0, const uint4 *multi,
                        ChainRec *fast_chains, uint32_t *chunk_state, uint32_t *slow_list, uint32_t *slow_count, uint32_t *pair_na,
                        const uint32_t *chunk_pair, uint32_t *decl_list, uint32_t *decl_count, uint32_t *work_next);
-#define RUNS_DRAW 512u          // items a wavefront takes from the shared counter at a time
+#define RUNS_DRAW 512u          // most items a wavefront takes from the shared counter at a time
 #define RUNS_DECL_FLUSH 64u     // declined chunks a wavefront collects before it appends them to the shared list
 #define RUNS_REFILL_MIN 24u     // lanes of a wavefront that must be free before finished chunks are written out and new ones handed over
 

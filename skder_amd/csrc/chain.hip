@@ -189,6 +189,9 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
     hipStream_t queues[3] = {st, st, st};
     if (const char *e = getenv("SKDER_AMD_CHUNK_BUDGET")) budget = strtoull(e, nullptr, 10);
     ChainWork &W = *chain_work(ctx);
+    // which ANI the records of THIS call carry (skder_amd_set_ani_output): read once, so that a call's records are of one kind even if
+    // another thread flips the switch while it runs
+    const bool ani_raw_out = g_ani_output_raw.load(std::memory_order_relaxed) != 0;
     const SetView VA = view_of(SA), VB = view_of(SB);
     // debugging switches: SKDER_AMD_FORCE_SLOW sends every chunk down the slow path;
     // SKDER_AMD_NO_SIEVE hands every chunk with hits to chain_runs_kernel (to tell the two fast kernels apart behind a parity failure)
@@ -568,7 +571,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
             const bool cq = S.hp[i].flags & 1u;
             skder_edge_t e;
             e.ref = pref[jobs[S.p0 + i].orig]; e.query = pquery[jobs[S.p0 + i].orig];
-            e.ani = g_ani_output_raw.load(std::memory_order_relaxed) ? o.ani_raw : o.ani;
+            e.ani = ani_raw_out ? o.ani_raw : o.ani;
             e.af_query = cq ? o.af_q : o.af_r;
             e.af_ref = cq ? o.af_r : o.af_q;
             e.n_chains = o.n_chains; e.n_anchors = o.n_anchors;

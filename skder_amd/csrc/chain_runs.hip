@@ -64,6 +64,10 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, c
     const uint32_t n_items = g_off[GEN_LISTS];
     if (blockIdx.x == 0 && threadIdx.x == 0) slow_count[11] = n_items;      // for the host's statistics
     const uint32_t ln = threadIdx.x & 63u;
+    // items a wavefront draws at a time: about a quarter of its share of the list, between 64 (a short list still reaches every
+    // wavefront: the benchmark's batches leave 50,000 chunks for 4,096 wavefronts) and RUNS_DRAW
+    const uint32_t share = n_items / (gridDim.x * 16u);
+    const uint32_t draw = share < 64u ? 64u : share > RUNS_DRAW ? RUNS_DRAW : share;
     const int32_t NEG = -0x40000000;
     // ---- a lane's chunk (valid while busy)
     bool busy = false, done = true, cplx = false, exhausted = false;
@@ -211,9 +215,9 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, c
                     const uint32_t nfree = (uint32_t)__popcll(freem);
                     if (w_cur >= w_end) {
                         uint32_t base = 0;
-                        if (ln == 0) base = atomicAdd(work_next, RUNS_DRAW);
+                        if (ln == 0) base = atomicAdd(work_next, draw);
                         w_cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                        w_end = w_cur + RUNS_DRAW < n_items ? w_cur + RUNS_DRAW : n_items;
+                        w_end = w_cur + draw < n_items ? w_cur + draw : n_items;
                         if (w_cur >= n_items) { exhausted = true; w_cur = w_end = n_items; }
                     }
                     const uint32_t w = w_cur + (uint32_t)__popcll(freem & ((1ull << ln) - 1ull));

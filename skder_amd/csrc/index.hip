@@ -128,6 +128,9 @@ __global__ __launch_bounds__(IDX_THREADS) void index_genome_kernel(
 // the multiplicity histogram all live in LDS; global memory sees only coalesced reads of the
 // position-ordered arrays, gathers through the finished permutation and coalesced writes.
 #define IDXF_THREADS 1024
+#ifndef IDX_PACKED
+#define IDX_PACKED 1            // 1: a (k-mer, position, record) copy of the seeds written in phase A and gathered in D / E with ONE request per seed
+#endif
 #define IDXF_U 8                // independent loads per thread and trip
 #define IDXF_FIXED_BYTES (IDX_REP_HIST * 4)
 __host__ __device__ inline size_t idxf_smem_bytes(uint32_t nb, uint32_t n)
@@ -160,6 +163,7 @@ __global__ __launch_bounds__(IDXF_THREADS) void index_genome_lds_kernel(
     uint32_t *boff = boff_all + m.bucket_off;
     const uint32_t *rg = rec_goff + m.rec_goff_off;
     uint4 *packed = packed_all + m.seed_off;      // written in A, gathered in E: one 16-byte request per seed instead of three
+    (void)packed;
 
     for (uint32_t b = tid; b < nb / 2; b += IDXF_THREADS) cntp[b] = 0;
     for (uint32_t b = tid; b < IDX_REP_HIST; b += IDXF_THREADS) hist[b] = 0;
@@ -168,17 +172,25 @@ __global__ __launch_bounds__(IDXF_THREADS) void index_genome_lds_kernel(
     // A. bucket sizes.  (Here and below: IDXF_U loads in flight per thread before anything depends on them --
     // the kernel is a chain of short phases whose cost is the memory latency they expose.)
     for (uint32_t s0 = tid; s0 < n; s0 += IDXF_U * IDXF_THREADS) {
+#if IDX_PACKED
         uint32_t kv[IDXF_U], gv[IDXF_U], cv[IDXF_U];
 #pragma unroll
         for (int u = 0; u < IDXF_U; u++) {
             const uint32_t s = s0 + u * IDXF_THREADS;
             kv[u] = s < n ? pk[s] : 0u; gv[u] = s < n ? pg[s] : 0u; cv[u] = s < n ? pc[s] : 0u;
         }
+#else
+        uint32_t kv[IDXF_U];
+#pragma unroll
+        for (int u = 0; u < IDXF_U; u++) { const uint32_t s = s0 + u * IDXF_THREADS; kv[u] = s < n ? pk[s] : 0u; }
+#endif
 #pragma unroll
         for (int u = 0; u < IDXF_U; u++) {
             const uint32_t s = s0 + u * IDXF_THREADS;
             if (s < n) {
+#if IDX_PACKED
                 packed[s] = make_uint4(kv[u], gv[u], cv[u], 0u);
+#endif
                 const uint32_t b = kmer_bucket(kv[u] & SK_SEED_MASK, bits);
                 atomicAdd(&cntp[b >> 1], 1u << ((b & 1u) * 16u));
             }
@@ -262,7 +274,11 @@ __global__ __launch_bounds__(IDXF_THREADS) void index_genome_lds_kernel(
                 if ((uint32_t)i < kmax) {       // wave-uniform
                     const bool in = (uint32_t)i < k;
                     const uint32_t si = in ? perm[lo + i] : 0u;
+#if IDX_PACKED
                     const uint32_t kk = packed[si].x & SK_SEED_MASK;
+#else
+                    const uint32_t kk = pk[si] & SK_SEED_MASK;
+#endif
                     key[i] = in ? (((uint64_t)kk << 16) | si) : ~0ull;
                 }
             }
@@ -345,7 +361,12 @@ __global__ __launch_bounds__(IDXF_THREADS) void index_genome_lds_kernel(
 #pragma unroll
         for (int u = 0; u < IDXF_U; u++) {
             const uint32_t pos = p0 + u * IDXF_THREADS;
+#if IDX_PACKED
             pv[u] = packed[pos < n ? perm[pos] : 0u];
+#else
+            const uint32_t si = pos < n ? perm[pos] : 0u;
+            pv[u] = make_uint4(pk[si], pg[si], pc[si], 0u);
+#endif
         }
 #pragma unroll
         for (int u = 0; u < IDXF_U; u++) {

@@ -326,13 +326,15 @@ class _DeviceArray:
         self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2, "strides": None}
 
 
-def device_view(ptr: int, n: int, torch_dtype):
-    """n elements at a raw device pointer as a torch tensor WITHOUT a copy; the memory stays the owner's (keep it alive while the view is used)"""
+def device_view(ptr: int, n: int, torch_dtype, device: int = None):
+    """n elements at a raw device pointer as a torch tensor WITHOUT a copy; the memory stays the owner's (keep it alive while the view is
+    used).  device: the GPU the pointer lives on (default: torch's current device)"""
     import torch
+    dev = "cuda" if device is None else "cuda:%d" % device
     if n <= 0 or not ptr:
-        return torch.empty(0, dtype=torch_dtype, device="cuda")
+        return torch.empty(0, dtype=torch_dtype, device=dev)
     typestr = {torch.int32: "<i4", torch.int64: "<i8", torch.uint8: "|u1"}[torch_dtype]
-    return torch.as_tensor(_DeviceArray(ptr, n, typestr), device="cuda")
+    return torch.as_tensor(_DeviceArray(ptr, n, typestr), device=dev)
 
 
 def download_tensor(ptr: int, n: int, torch_dtype, ctx=None):

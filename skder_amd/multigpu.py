@@ -176,18 +176,19 @@ def gather_edges(edges: np.ndarray, group=None, copy: bool = True) -> np.ndarray
 
 
 def raw_from_sketches(sk, copy: bool = False) -> Dict:
-    """a Sketches object's raw arrays as torch tensors on the current device: views of the set's own memory (no copy; valid while the set
-    lives and is not appended to), or copies with copy=True"""
+    """a Sketches object's raw arrays as torch tensors on the current device: views of the set's own memory (copy=False: no copy; valid
+    ONLY while the set lives and is not appended to -- the dict keeps a reference to the set under "owner" so that it cannot be collected
+    while the views are in use, but closing it by hand is the caller's mistake to avoid), or copies with copy=True"""
     from .engine import device_view, download_tensor
     v = sk.view()
     torch.cuda.synchronize()          # the set's arrays were written on the library's stream, torch reads them on its own
-    get = (lambda p, n, dt: download_tensor(p, n, dt, sk.ctx)) if copy else device_view
+    get = (lambda p, n, dt: download_tensor(p, n, dt, sk.ctx)) if copy else (lambda p, n, dt: device_view(p, n, dt, sk.ctx.device))
     return dict(n_genomes=v["n_genomes"],
                 seed_kmer=get(v["d_seed_kmer"], v["n_seeds"], torch.int32),
                 seed_gpos=get(v["d_seed_gpos"], v["n_seeds"], torch.int32),
                 markers=get(v["d_markers"], v["n_markers"], torch.int64),
                 seed_off=v["seed_off"], marker_off=v["marker_off"], genome_len=v["genome_len"],
-                genome_nrec=v["genome_nrec"], rec_goff=v["rec_goff"])
+                genome_nrec=v["genome_nrec"], rec_goff=v["rec_goff"], owner=None if copy else sk)
 
 
 def sketches_from_raw(ctx, raw: Dict):
@@ -268,12 +269,21 @@ def triangle_sharded(sk, rank: int, world: int, screen_pct: float, group=None, c
 
 
 def component_labels(n: int, ref: np.ndarray, query: np.ndarray) -> np.ndarray:
-    """label[g] = smallest genome index of g's connected component in the graph whose edges are the candidate pairs (label
-    propagation with pointer jumping: a species is a near-clique, two or three sweeps)"""
+    """label[g] = smallest genome index of g's connected component in the graph whose edges are the candidate pairs (scipy's
+    connected_components when it is there; else label propagation with pointer jumping: a species is a near-clique, two or three sweeps)"""
     lab = np.arange(n, dtype=np.int64)
     if len(ref) == 0:
         return lab
     ref, query = ref.astype(np.int64), query.astype(np.int64)
+    try:
+        from scipy.sparse import coo_matrix
+        from scipy.sparse.csgraph import connected_components
+        _, c = connected_components(coo_matrix((np.ones(len(ref), np.int8), (ref, query)), shape=(n, n)), directed=False)
+        first = np.full(int(c.max()) + 1, n, np.int64)
+        np.minimum.at(first, c, lab)                       # smallest member of every component
+        return first[c]
+    except ImportError:
+        pass
     while True:
         low = np.minimum(lab[ref], lab[query])
         new = lab.copy()
@@ -297,16 +307,15 @@ def component_owners(n: int, ref: np.ndarray, query: np.ndarray, n_seeds: np.nda
     labels, inv = np.unique(lab[ref], return_inverse=True)
     weight = np.bincount(inv, weights=w_pair, minlength=len(labels))
     load = np.zeros(world)
-    owner_of = {}
+    owner_of_label = np.full(n, -1, np.int64)
     for k in np.lexsort((labels, -weight)):
         r = int(np.argmin(load))
-        owner_of[int(labels[k])] = r
+        owner_of_label[labels[k]] = r
         load[r] += weight[k]
     in_pair = np.zeros(n, bool)
     in_pair[ref] = True
     in_pair[query] = True
-    g = np.flatnonzero(in_pair)
-    owner[g] = [owner_of[int(l)] for l in lab[g]]
+    owner[in_pair] = owner_of_label[lab[in_pair]]
     return owner
 
 
@@ -336,8 +345,9 @@ def exchange_seeds(raw: Dict, first_genome: int, owner: np.ndarray, n_seeds: np.
     order = np.flatnonzero(dest >= 0)
     order = order[np.argsort(dest[order], kind="stable")]              # by destination, ascending genome inside one
     idx = _ranges_index(local_off[order], n_seeds[mine[order]], dev)
-    n_out = [int(n_seeds[mine[order][dest[order] == r]].sum()) for r in range(world)]
-    n_in = [int(n_seeds[[g for g in blocks[r] if owner[g] == rank]].sum()) if len(blocks[r]) else 0 for r in range(world)]
+    n_out = [int(x) for x in np.bincount(dest[order], weights=n_seeds[mine[order]], minlength=world)] if len(order) else [0] * world
+    to_me = np.where(owner == rank, n_seeds, 0)
+    n_in = [int(to_me[blocks[r].start:blocks[r].stop].sum()) for r in range(world)]
     got = []
     for key in ("seed_kmer", "seed_gpos"):
         send = raw[key].to(dev)[idx].contiguous()
@@ -396,8 +406,10 @@ def triangle_by_components(ctx, sk, first_genome: int, n_total: int, rank: int, 
     lap()
     # the set this rank chains on: its components' genomes, ascending global index, local indices 0 ..
     edges = np.zeros(0, EDGE_DTYPE)
-    stats = {"genomes_held": int(len(have)), "seeds_received": int(kmer.numel()), "bytes_sent_seeds": int(8 * n_seeds[[g for g in blocks[rank] if owner[g] >= 0 and owner[g] != rank]].sum()),
-             "bytes_sent_markers": int(8 * sum(int(p["markers"].numel()) for i, p in enumerate(mk) if i == rank) * (world - 1)), "pairs_all": int(len(pairs))}
+    ob = owner[blocks[rank].start:blocks[rank].stop]
+    stats = {"genomes_held": int(len(have)), "seeds_received": int(kmer.numel()),
+             "bytes_sent_seeds": int(8 * n_seeds[blocks[rank].start:blocks[rank].stop][(ob >= 0) & (ob != rank)].sum()),
+             "bytes_sent_markers": int(8 * int(mk[rank]["markers"].numel()) * (world - 1)), "pairs_all": int(len(pairs))}
     if len(have):
         m_off = np.concatenate([np.asarray(p["marker_off"], np.uint64).astype(np.int64)[:-1] + b for p, b in
                                 zip(mk, np.concatenate([[0], np.cumsum([int(p["markers"].numel()) for p in mk])])[:-1])])
@@ -408,7 +420,8 @@ def triangle_by_components(ctx, sk, first_genome: int, n_total: int, rank: int, 
         g_nrec = np.concatenate([p["genome_nrec"] for p in mk])
         all_goff = np.concatenate([p["rec_goff"] for p in mk])
         r_off = np.concatenate([[0], np.cumsum(g_nrec.astype(np.int64) + 1)])
-        rec_goff = np.concatenate([all_goff[r_off[g]:r_off[g + 1]] for g in have])
+        rl = (g_nrec.astype(np.int64) + 1)[have]
+        rec_goff = all_goff[np.repeat(r_off[have] - (np.cumsum(rl) - rl), rl) + np.arange(int(rl.sum()))]
         ls = Sketches(ctx)
         torch.cuda.synchronize()
         ls.append_raw(len(have), kmer.data_ptr(), gpos.data_ptr(), None, markers.data_ptr(),

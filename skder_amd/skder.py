@@ -174,12 +174,14 @@ class Database:
             raise RuntimeError('Had an issue running: skder_amd_db_save: %s' % err.value.decode())
 
     @staticmethod
-    def _rows(p, n):
+    def _rows(p, n, copy=True):
+        """copy=False: a view of the library's row buffer, valid until the next call on this database"""
         import numpy as np
         from .engine import EDGE_DTYPE
         if n.value == 0:
             return np.zeros(0, EDGE_DTYPE)
-        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (n.value * EDGE_DTYPE.itemsize,)).view(EDGE_DTYPE).copy()
+        v = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (n.value * EDGE_DTYPE.itemsize,)).view(EDGE_DTYPE)
+        return v.copy() if copy else v
 
     def triangle(self, min_af, screen, out_tsv=None):
         """rows of `skani triangle` over the database, in skani's order, as an edge array"""
@@ -191,9 +193,10 @@ class Database:
             raise RuntimeError('Had an issue running: skder_amd_db_triangle: %s' % err.value.decode())
         return self._rows(p, n)
 
-    def search_batch(self, queries, min_af=SKANI_DEFAULT_MIN_AF, screen=SKANI_DEFAULT_SCREEN, out_tsvs=None, live=None):
+    def search_batch(self, queries, min_af=SKANI_DEFAULT_MIN_AF, screen=SKANI_DEFAULT_SCREEN, out_tsvs=None, live=None, copy=True):
         """rows of `skani search` for several queries at once; `query` = position in `queries`.  live: one flag per database genome
-        (uint8 / bool array), 0 = the caller has no use for rows of that genome (they are not computed)"""
+        (uint8 / bool array), 0 = the caller has no use for rows of that genome (they are not computed).  copy=False: the rows are a
+        view of the library's buffer, valid until the next call on this database (a one-species search returns gigabytes of rows)"""
         k = len(queries)
         qs = (C.c_char_p * max(k, 1))(*[q.encode() for q in queries])
         outs = None
@@ -211,7 +214,7 @@ class Database:
                                                     mask.ctypes.data if mask is not None else None, C.byref(p), C.byref(n), err, _lib.ERRLEN)
         if rc != 0:
             raise RuntimeError('Had an issue running: skder_amd_search_batch: %s' % err.value.decode())
-        return self._rows(p, n)
+        return self._rows(p, n, copy)
 
     def close(self):
         if self._h:
@@ -290,7 +293,8 @@ def lowMemGreedyDerep(all_genomes_listing_file, skder_lm_workspace, concat_n50_r
             is_acc = lambda g: acc[index_of[g]] if g in index_of else g in extra
             width = search_batch if search_batch > 1 else 4       # 0: adaptive, starting at 4
             pos = 0
-            stats = {"searches": 0, "rows": 0, "batches": 0}
+            import time as _time
+            stats = {"searches": 0, "rows": 0, "batches": 0, "search_s": 0.0, "rows_pass_s": 0.0}
             while pos < len(order):
                 batch = []
                 while pos < len(order) and len(batch) < width:
@@ -299,13 +303,17 @@ def lowMemGreedyDerep(all_genomes_listing_file, skder_lm_workspace, concat_n50_r
                     pos += 1
                 if not batch:
                     break
-                rows = db.search_batch(batch, live=~(acc | handled) if live_only else None)
+                _t0 = _time.perf_counter()
+                rows = db.search_batch(batch, live=~(acc | handled) if live_only else None, copy=False)    # consumed before the next search
+                stats["search_s"] += _time.perf_counter() - _t0
                 for genome in batch:
                     if genome in index_of:
                         handled[index_of[genome]] = True
                 ok = np.zeros(len(rows), np.uint8)
+                _t0 = _time.perf_counter()
                 if len(rows):
                     _lib.lib().skder_amd_rows_pass(rows.ctypes.data, len(rows), float(ani_cutoff), float(af_cutoff), 5, ok.ctypes.data)
+                stats["rows_pass_s"] += _time.perf_counter() - _t0
                 bounds = np.searchsorted(rows['query'], np.arange(len(batch) + 1))          # rows come grouped by query, in order
                 stats["batches"] += 1
                 kept = 0
