@@ -11,7 +11,8 @@
  * /root/reference/bin/skder:83-84) and is pinned ONLY against the five golden edge tables the
  * reference's own test run holds (tests/golden/G1..G5: 2-decimal ANI/AF, one species).  Measured
  * residual on G5 (561 pairs): AF rms 0.37 / max 1.1 points, ANI rms 0.14 / max 0.43 points
- * (held out: rms 0.15, oracle/fit_calibration.py); the
+ * (held out: rms 0.15, oracle/fit_calibration.py; round 5 scored 648 sampling / chaining-rule hypotheses against G5,
+ * oracle/sample_hypotheses.py -> profiles/round5_sample_hypotheses.json: none reproduces skani's k-mer sample); the
  * representative listings derived from G1/G5 are reproduced where the goldens are not knife-edge
  * (tests/test_oracle_golden.py).  Beyond those tables: **parity unpinned**.
  *
