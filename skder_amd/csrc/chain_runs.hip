@@ -109,10 +109,37 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, c
     r0.seg = r1.seg = r2.seg = r3.seg = 0;
     r0.gs = r1.gs = r2.gs = r3.gs = 0;
 
+    // (for EMIT_PATH: is ring entry X the run that ends at the peak of the path that ends with E?)
+#define PEAK_OF(E, X)                                                                        \
+    if (((X).cnt & SUCC_BIT) && (X).first_qi == (E).first_qi && (X).r_pfirst == (E).r_pfirst && \
+        (((X).rr_last ^ (E).rr_last) & HIT_KEY_MASK) == 0u && (X).f == (E).pmax && (X).f > (X).pmax) { \
+        pk_n++; pk_cnt = (X).cnt & ~SUCC_BIT; pk_qi1 = (X).qi_last; pk_q1 = (X).q_last; pk_rr = (X).rr_last; pk_f = (X).f; \
+    }
 #define EMIT_PATH(E)                                                                         \
     do {                                                                                     \
         if ((E).cnt && !((E).cnt & SUCC_BIT) && (E).cnt >= ANI_MIN_ANCHORS) {                \
-            if (!((E).f > (E).pmax)) { cplx = true; cause = 5; } /* best end is not the last anchor */ \
+            if (!((E).f > (E).pmax)) {                                                      \
+                /* the path's best end is an EARLIER anchor: the oracle takes the chain that ends THERE first, and what lies behind it is   \
+                   left to later ends.  Settled here when at most two anchors lie behind it (they cannot form a chain, whatever their    \
+                   order) and the run that ends at the peak is still in the ring: same first anchor (seed, place on the other genome,     \
+                   record and strand), marked as having a successor, its score the path's maximum and above everything before it; its     \
+                   chain is the prefix.  Anything else -- the peak's run gone, a longer tail, a second candidate -- is declined */         \
+                uint32_t pk_n = 0, pk_cnt = 0, pk_qi1 = 0, pk_q1 = 0, pk_rr = 0;                 \
+                int32_t pk_f = 0;                                                               \
+                PEAK_OF(E, r0) PEAK_OF(E, r1) PEAK_OF(E, r2) PEAK_OF(E, r3)                       \
+                const uint32_t tail_ = (E).cnt - pk_cnt;                                         \
+                if (pk_n != 1u || pk_cnt < ANI_MIN_ANCHORS || tail_ < 1u || tail_ > 2u) { cplx = true; cause = 5; } \
+                else if (nfin >= FAST_SLOTS) { cplx = true; cause = 1; }                         \
+                else {                                                                           \
+                    ChainRec cr;                                                                 \
+                    cr.score = pk_f; cr.n = pk_cnt; cr.n_seeds = pk_qi1 - (E).first_qi + 1;         \
+                    cr.q0 = (E).q_first; cr.q1 = pk_q1;                                            \
+                    { const uint32_t rl_ = pk_rr & HIT_POS_MASK;                                  \
+                      cr.r0 = rl_ < (E).r_pfirst ? rl_ : (E).r_pfirst; cr.r1 = rl_ > (E).r_pfirst ? rl_ : (E).r_pfirst; } \
+                    cr.chunk = c;                                                                \
+                    slots[nfin++] = cr;                                                          \
+                }                                                                                \
+            }                                                                                    \
             else if (nfin >= FAST_SLOTS) { cplx = true; cause = 1; }                         \
             else {                                                                           \
                 ChainRec cr;                                                                 \
@@ -440,6 +467,7 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, c
 #undef FLUSH_DECLINED
     if (ln >= 1u && ln <= 10u && cause_acc) atomicAdd(slow_count + 1 + ln, cause_acc);
 #undef EMIT_PATH
+#undef PEAK_OF
 #undef EVICT
 }
 
