@@ -109,6 +109,11 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, c
     r0.seg = r1.seg = r2.seg = r3.seg = 0;
     r0.gs = r1.gs = r2.gs = r3.gs = 0;
 
+#ifdef SKDER_PEAK_STATS      // (measurement build: "best end is not last" split into: the peak's run not in the ring -> 6, a tail of 3 or more -> 8, else 5)
+#define PEAK_CAUSE(N, T) ((N) == 0u ? 6u : ((N) == 1u && (T) > 2u) ? 8u : 5u)
+#else
+#define PEAK_CAUSE(N, T) 5u
+#endif
     // (for EMIT_PATH: is ring entry X the run that ends at the peak of the path that ends with E?)
 #define PEAK_OF(E, X)                                                                        \
     if (((X).cnt & SUCC_BIT) && (X).first_qi == (E).first_qi && (X).r_pfirst == (E).r_pfirst && \
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, c
                 int32_t pk_f = 0;                                                               \
                 PEAK_OF(E, r0) PEAK_OF(E, r1) PEAK_OF(E, r2) PEAK_OF(E, r3)                       \
                 const uint32_t tail_ = (E).cnt - pk_cnt;                                         \
-                if (pk_n != 1u || pk_cnt < ANI_MIN_ANCHORS || tail_ < 1u || tail_ > 2u) { cplx = true; cause = 5; } \
+                if (pk_n != 1u || pk_cnt < ANI_MIN_ANCHORS || tail_ < 1u || tail_ > 2u) { cplx = true; cause = PEAK_CAUSE(pk_n, tail_); } \
                 else if (nfin >= FAST_SLOTS) { cplx = true; cause = 1; }                         \
                 else {                                                                           \
                     ChainRec cr;                                                                 \
