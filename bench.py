@@ -904,6 +904,35 @@ def main():
         t = torch.tensor([tm[6]], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         n_chained_all = float(t.item())
+    # N > 1: a few steps of the OTHER exchange as well, outside the timed region (never part of `value`): the first multi-GPU run of this
+    # line then prices both -- replicate (raw sketches all-gathered) and components (markers all-gathered, seeds to their component's owner)
+    other_exchange = None
+    if dist_on and world > 1 and os.environ.get("SKDER_AMD_NO_OTHER_EXCHANGE") is None:
+        was = os.environ.get("SKDER_AMD_EXCHANGE")
+        other = "replicate" if was == "components" else "components"
+        kept = (np.array(step.counters, copy=True), step.runs_ms, step.index_ms, getattr(step, "exchange_stats", None))
+        try:
+            os.environ["SKDER_AMD_EXCHANGE"] = other
+            step()
+            sync()
+            t0o = time.perf_counter()
+            for _ in range(3):
+                e_other, _ = step()
+            sync()
+            dto = torch.tensor([time.perf_counter() - t0o], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(dto, op=dist.ReduceOp.MAX)
+            other_exchange = {"mode": other, "ms_per_step": float(dto.item()) / 3 * 1e3, "steps": 3, "edges": int(len(e_other)),
+                              "stats_rank0": dict(getattr(step, "exchange_stats", {})) if other == "components" else None}
+        except Exception as ex:          # the extra measurement must never cost the line
+            other_exchange = {"mode": other, "error": repr(ex)}
+        finally:
+            if was is None:
+                os.environ.pop("SKDER_AMD_EXCHANGE", None)
+            else:
+                os.environ["SKDER_AMD_EXCHANGE"] = was
+            step.counters, step.runs_ms, step.index_ms = kept[:3]      # the line's per-kernel figures are those of the timed mode
+            if kept[3] is not None:
+                step.exchange_stats = kept[3]
 
     if rank == 0 and args.dump_edges:
         e = np.array(edges, copy=True)
@@ -1006,6 +1035,7 @@ def main():
                                "replicate: raw sketches all-gathered, candidate pairs to the owner of the probed genome"}
             if by_comp:
                 out["exchange"].update(getattr(step, "exchange_stats", {}))
+            out["exchange"]["other_exchange"] = other_exchange
         out["config"]["us_per_chained_pair"] = 1e3 * (join_ms + step.runs_ms + tm[3] + tm[4] + tm[5]) / max(n_chained, 1.0)
         if world == 1 and not args.no_cpu_baseline and args.parity_pairs > 0:
             out["parity_sample"] = parity_sample(recipe, edges, args.parity_pairs)
