@@ -1181,26 +1181,31 @@ def test_store_of_a_database_built_from_resident_sketches(gpu, tmp_path):
     assert seen == {0, 1}, "the recipe no longer yields both an odd and an even number of seeds: adjust it"
 
 
-def test_rccl_process_group_on_one_gpu(gpu):
+@pytest.mark.parametrize("exchange", ["replicate", "components"])
+def test_rccl_process_group_on_one_gpu(gpu, tmp_path, exchange):
     """the N > 1 code path with the REAL backend (nccl = RCCL): one rank under torch.distributed.run, device
-    tensors through all_gather / all_gather_object / gather_object; same edges as the plain path"""
+    tensors through all_gather / all_to_all_single / gather; both exchanges (components: the label propagation runs on the GPU there);
+    the edge records equal the plain path's byte for byte"""
     import json
     import subprocess
     import sys
     from conftest import ROOT
     common = ["--genomes", "40", "--genome-len", "200000", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
-    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, timeout=600)
+    f1, f2 = str(tmp_path / "one.npy"), str(tmp_path / "dist.npy")
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common + ["--dump-edges", f1], capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
-    env = dict(os.environ, SKDER_AMD_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, SKDER_AMD_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", SKDER_AMD_EXCHANGE=exchange)
     env.pop("SKDER_AMD_DIST_BACKEND", None)
     rc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
                          "127.0.0.1", "--master-port", str(29900 + os.getpid() % 90), os.path.join(ROOT, "bench.py"), "--gpus", "1"]
-                        + common, capture_output=True, text=True, env=env, timeout=900)
+                        + common + ["--dump-edges", f2], capture_output=True, text=True, env=env, timeout=900)
     assert rc.returncode == 0, rc.stderr[-3000:]
     j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     j2 = json.loads([l for l in rc.stdout.splitlines() if l.startswith("{")][-1])
     assert j1["config"]["edges"] == j2["config"]["edges"] > 0
     assert j1["config"]["chained_pairs"] == j2["config"]["chained_pairs"]
+    assert j2["exchange"]["mode"].startswith(exchange)
+    assert np.load(f1).tobytes() == np.load(f2).tobytes()
 
 
 def test_repeats_indels_and_inversions(gpu, oracle):
