@@ -100,10 +100,9 @@ void launch_chain_rows(hipStream_t st, unsigned grid, SetView A, SetView B, cons
 // an item of the run loop's lists: two uint4 -- (chunk, pair, first record, end of the chunk's seeds), (the pair's record region,
 // its multi-occurrence lists, the chunk's number inside the pair, first seed): the sieve has them in registers when it passes a
 // chunk on, and the run loop starts a chunk with ONE dependent load instead of four
-void launch_chain_runs(hipStream_t st, unsigned grid, SetView A, SetView B, const PairDesc *pairs, uint32_t npairs, const uint4 *gen_list,
-                       const uint32_t *gen_cnt, uint32_t gen_cap, const RunRec *recs, const uint32_t *chunk_rec0, const uint4 *multi,
-                       ChainRec *fast_chains, uint32_t *chunk_state, uint32_t *slow_list, uint32_t *slow_count, uint32_t *pair_na,
-                       const uint32_t *chunk_pair, uint32_t *decl_list, uint32_t *decl_count, uint32_t *work_next);
+void launch_chain_runs(hipStream_t st, unsigned grid, const uint4 *gen_list, const uint32_t *gen_cnt, uint32_t gen_cap, const RunRec *recs,
+                       const uint4 *multi, ChainRec *fast_chains, uint32_t *chunk_state, uint32_t *slow_count, uint32_t *pair_na,
+                       uint32_t *decl_list, uint32_t *decl_count, uint32_t *work_next);
 #define RUNS_DRAW 512u          // most items a wavefront takes from the shared counter at a time
 #define RUNS_DECL_FLUSH 64u     // declined chunks a wavefront collects before it appends them to the shared list
 #define RUNS_REFILL_MIN 24u     // lanes of a wavefront that must be free before finished chunks are written out and new ones handed over

@@ -223,9 +223,8 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
                                S.pair_over.p, S.chunk_rec0.p, S.wg_pair.p, S.multi.p, S.fast_chains.p, S.chunk_state.p, S.slow_list.p, S.counters.p,
                                S.gen_list.p, S.gen_cnt.p, gen_cap, S.pair_na.p, xcd_remap, S.chunk_pair.p);
             // what the sieve left: the run loop (one lane per chunk, a ring of four runs); what it gives up goes to the general kernel.
-            launch_chain_runs(S.st, nwg < 1024u ? nwg : 1024u, VA, VB, S.d_pairs.p, nb, S.gen_list.p, S.gen_cnt.p, gen_cap, S.recs.p, S.chunk_rec0.p, S.multi.p,
-                              S.fast_chains.p, S.chunk_state.p, S.slow_list.p, S.counters.p, S.pair_na.p, S.chunk_pair.p, S.slow_list.p, S.counters.p,
-                              S.counters.p + 40);
+            launch_chain_runs(S.st, nwg < 1024u ? nwg : 1024u, S.gen_list.p, S.gen_cnt.p, gen_cap, S.recs.p, S.multi.p, S.fast_chains.p, S.chunk_state.p,
+                              S.counters.p, S.pair_na.p, S.slow_list.p, S.counters.p, S.counters.p + 40);
         } else {
             HIPCHECK(hipEventRecord(S.ev[6], S.st));
         }

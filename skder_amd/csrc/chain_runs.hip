@@ -1,6 +1,9 @@
-// chain_runs.hip -- the RUN LOOP of the chaining stage: the chunks the sieve (chain_single_kernel, chain.hip) could not settle,
+// chain_runs.hip -- the RUN LOOP of the chaining stage: the chunks the sieve (chain_single_kernel, chain_extract.hip) could not settle,
 // one lane each, a banded DP over the chunk's run records against a ring of four runs; what it cannot prove goes on to the
-// general kernel (chain_rows.hip).
+// general kernel (chain_rows.hip).  Since round 5 the kernel is a loop of SERVICE + ROUND per wavefront: a lane whose chunk is finished
+// waits; when enough lanes are free the wavefront writes their chains out, appends the declined chunks to its LDS buffer and hands
+// every free lane the next chunk of the wavefront's range of the work list (the sieve's 32-byte items), so that the rounds run with
+// most lanes at work instead of as many as the longest of 64 chunks leaves.
 #include "chain.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -22,7 +25,7 @@
 // score, last position, diagonal range); a look-back that would have to continue into them is accepted only
 // if no summarised anchor can reach the current best.  The lane proves as it goes that its result is the
 // oracle's; a chunk where the proof fails (branching chains, best end not last, too many hits or chains)
-// goes to the slow path.  Rounds are uniform across the wavefront: every live lane takes one record per round.
+// goes to the slow path.  Rounds are uniform across the wavefront: every lane that holds a chunk takes one anchor per round.
 struct Run {
     uint32_t q_last, rr_last;         // last anchor: query pos; hit word (ref pos | record tag << 24 | rev << 31)
     int32_t f;                        // score of the last anchor
@@ -35,13 +38,10 @@ struct Run {
     int32_t gs;                       // diagonal steps inside the run: its earlier anchors lie at most this far off the last one's diagonal
 };
 
-__global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, const PairDesc *__restrict__ pairs, uint32_t npairs,
-                                                         const uint4 *__restrict__ gen_list, const uint32_t *__restrict__ gen_cnt,
-                                                         uint32_t gen_cap, const RunRec *__restrict__ recs,
-                                                         const uint32_t *__restrict__ chunk_rec0, const uint4 *__restrict__ multi,
+__global__ __launch_bounds__(256) void chain_runs_kernel(const uint4 *__restrict__ gen_list, const uint32_t *__restrict__ gen_cnt,
+                                                         uint32_t gen_cap, const RunRec *__restrict__ recs, const uint4 *__restrict__ multi,
                                                          ChainRec *__restrict__ fast_chains, uint32_t *__restrict__ chunk_state,
-                                                         uint32_t *__restrict__ slow_list, uint32_t *__restrict__ slow_count,
-                                                         uint32_t *__restrict__ pair_na, const uint32_t *__restrict__ chunk_pair,
+                                                         uint32_t *__restrict__ slow_count, uint32_t *__restrict__ pair_na,
                                                          uint32_t *__restrict__ decl_list, uint32_t *__restrict__ decl_count,
                                                          uint32_t *__restrict__ work_next, uint32_t refill_min)
 {
@@ -477,13 +477,11 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(SetView A, SetView B, c
 }
 
 
-void launch_chain_runs(hipStream_t st, unsigned grid, SetView A, SetView B, const PairDesc *pairs, uint32_t npairs, const uint4 *gen_list,
-                       const uint32_t *gen_cnt, uint32_t gen_cap, const RunRec *recs, const uint32_t *chunk_rec0, const uint4 *multi,
-                       ChainRec *fast_chains, uint32_t *chunk_state, uint32_t *slow_list, uint32_t *slow_count, uint32_t *pair_na,
-                       const uint32_t *chunk_pair, uint32_t *decl_list, uint32_t *decl_count, uint32_t *work_next)
+void launch_chain_runs(hipStream_t st, unsigned grid, const uint4 *gen_list, const uint32_t *gen_cnt, uint32_t gen_cap, const RunRec *recs,
+                       const uint4 *multi, ChainRec *fast_chains, uint32_t *chunk_state, uint32_t *slow_count, uint32_t *pair_na,
+                       uint32_t *decl_list, uint32_t *decl_count, uint32_t *work_next)
 {
     static const uint32_t refill_min = getenv("SKDER_AMD_RUNS_REFILL") ? (uint32_t)atoi(getenv("SKDER_AMD_RUNS_REFILL")) : RUNS_REFILL_MIN;
-    hipLaunchKernelGGL(chain_runs_kernel, dim3(grid), dim3(256), 0, st, A, B, pairs, npairs, gen_list, gen_cnt, gen_cap, recs, chunk_rec0, multi,
-                       fast_chains, chunk_state, slow_list, slow_count, pair_na, chunk_pair, decl_list, decl_count, work_next,
-                       refill_min < 1u ? 1u : refill_min > 64u ? 64u : refill_min);
+    hipLaunchKernelGGL(chain_runs_kernel, dim3(grid), dim3(256), 0, st, gen_list, gen_cnt, gen_cap, recs, multi, fast_chains, chunk_state, slow_count,
+                       pair_na, decl_list, decl_count, work_next, refill_min < 1u ? 1u : refill_min > 64u ? 64u : refill_min);
 }
