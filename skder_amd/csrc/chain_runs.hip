@@ -116,8 +116,8 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(const uint4 *__restrict
 #endif
     // (for EMIT_PATH: is ring entry X the run that ends at the peak of the path that ends with E?)
 #define PEAK_OF(E, X)                                                                        \
-    if (((X).cnt & SUCC_BIT) && (X).first_qi == (E).first_qi && (X).r_pfirst == (E).r_pfirst && \
-        (((X).rr_last ^ (E).rr_last) & HIT_KEY_MASK) == 0u && (X).f == (E).pmax && (X).f > (X).pmax) { \
+    if (((X).cnt & SUCC_BIT) && (X).first_qi == pk_e_qi && (X).r_pfirst == pk_e_r &&          \
+        (((X).rr_last ^ pk_e_rr) & HIT_KEY_MASK) == 0u && (X).f == pk_e_pmax && (X).f > (X).pmax) { \
         pk_n++; pk_cnt = (X).cnt & ~SUCC_BIT; pk_qi1 = (X).qi_last; pk_q1 = (X).q_last; pk_rr = (X).rr_last; pk_f = (X).f; \
     }
 #define EMIT_PATH(E)                                                                         \
@@ -131,6 +131,8 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(const uint4 *__restrict
                    chain is the prefix.  Anything else -- the peak's run gone, a longer tail, a second candidate -- is declined */         \
                 uint32_t pk_n = 0, pk_cnt = 0, pk_qi1 = 0, pk_q1 = 0, pk_rr = 0;                 \
                 int32_t pk_f = 0;                                                               \
+                const uint32_t pk_e_qi = (E).first_qi, pk_e_r = (E).r_pfirst, pk_e_rr = (E).rr_last; \
+                const int32_t pk_e_pmax = (E).pmax;                                             \
                 PEAK_OF(E, r0) PEAK_OF(E, r1) PEAK_OF(E, r2) PEAK_OF(E, r3)                       \
                 const uint32_t tail_ = (E).cnt - pk_cnt;                                         \
                 if (pk_n != 1u || pk_cnt < ANI_MIN_ANCHORS || tail_ < 1u || tail_ > 2u) { cplx = true; cause = PEAK_CAUSE(pk_n, tail_); } \
@@ -326,33 +328,30 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(const uint4 *__restrict
                 int32_t best = ANI_ANCHOR_SCORE, pgap = 0;
                 int bj = -1;
                 bool exact = false;
+    // (straight-line form: every condition of the oracle's look-back loop is evaluated for every lane and applied by selects -- the
+    // nested form executed four copies of a six-level branch nest with a third of the lanes in each arm)
     #define TRY(K, E)                                                                                   \
-                if (!exact && !cplx) {                                                                  \
-                    if (!(E).cnt) exact = true;                       /* no older anchors at all */     \
-                    else if (best >= runmax + ANI_ANCHOR_SCORE) exact = true;                           \
-                    else if (ia - (E).idx_last > ANI_BAND) exact = true;                                \
-                    else {                                                                              \
-                        const int32_t dq = qp - (int32_t)(E).q_last;                                    \
-                        if (dq > ANI_BP_BAND) exact = true;                                             \
-                        else if (((E).rr_last & HIT_KEY_MASK) == key) {                                 \
-                            const int32_t rpj = (int32_t)((E).rr_last & HIT_POS_MASK);                   \
-                            const int32_t dr = rev ? rpj - rp : rp - rpj;                               \
-                            const int32_t ed = rev ? rpj + (int32_t)(E).q_last : rpj - (int32_t)(E).q_last; /* run diagonal */ \
-                            const int32_t off = dg > ed ? dg - ed : ed - dg;                            \
-                            /* an earlier anchor of a run with steps may be in reach where the last one is not */ \
-                            if (off > ANI_MAX_GAP && off - (E).gs <= ANI_MAX_GAP) { cplx = true; cause = 7; } \
-                            else if (off <= ANI_MAX_GAP) {                                              \
-                                /* an INTERIOR anchor of the run could be a valid predecessor where the last one is not */ \
-                                const int32_t rf = (int32_t)(E).r_first;                                \
-                                const bool inside = rev ? (rp < rf && dr <= 0) : (rp > rf && dr <= 0);  \
-                                if (dq <= 0 || inside) { cplx = true; cause = 7; }                      \
-                                else if (dr > 0 && dq <= ANI_MAX_LIN && dr <= ANI_MAX_LIN) {            \
-                                    const int32_t sc = (E).f + ANI_ANCHOR_SCORE - off;                  \
-                                    if (sc > best) { best = sc; bj = (K); pgap = off; }                 \
-                                }                                                                       \
-                            }                                                                           \
-                        }                                                                               \
-                    }                                                                                   \
+                {                                                                                       \
+                    const bool act_ = !exact && !cplx;                                                  \
+                    const int32_t dq = qp - (int32_t)(E).q_last;                                        \
+                    const bool stop_ = !(E).cnt || best >= runmax + ANI_ANCHOR_SCORE || ia - (E).idx_last > ANI_BAND || dq > ANI_BP_BAND; \
+                    const bool look_ = act_ && !stop_ && ((E).rr_last & HIT_KEY_MASK) == key;           \
+                    const int32_t rpj = (int32_t)((E).rr_last & HIT_POS_MASK);                           \
+                    const int32_t dr = rev ? rpj - rp : rp - rpj;                                       \
+                    const int32_t ed = rev ? rpj + (int32_t)(E).q_last : rpj - (int32_t)(E).q_last; /* run diagonal */ \
+                    const int32_t off = dg > ed ? dg - ed : ed - dg;                                    \
+                    /* an earlier anchor of a run with steps may be in reach where the last one is not */ \
+                    const bool far_ = look_ && off > ANI_MAX_GAP && off - (E).gs <= ANI_MAX_GAP;         \
+                    const bool near_ = look_ && off <= ANI_MAX_GAP;                                     \
+                    /* an INTERIOR anchor of the run could be a valid predecessor where the last one is not */ \
+                    const int32_t rf = (int32_t)(E).r_first;                                            \
+                    const bool inside = (rev ? rp < rf : rp > rf) && dr <= 0;                           \
+                    const bool in_ = near_ && (dq <= 0 || inside);                                      \
+                    const int32_t sc = (E).f + ANI_ANCHOR_SCORE - off;                                  \
+                    const bool take_ = near_ && !in_ && dr > 0 && dq <= ANI_MAX_LIN && dr <= ANI_MAX_LIN && sc > best; \
+                    best = take_ ? sc : best; bj = take_ ? (K) : bj; pgap = take_ ? off : pgap;         \
+                    if (far_ || in_) { cplx = true; cause = 7; }                                        \
+                    exact = exact || (act_ && stop_);                                                   \
                 }
                 TRY(0, r0) TRY(1, r1) TRY(2, r2) TRY(3, r3)
     #undef TRY
