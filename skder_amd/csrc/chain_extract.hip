@@ -207,6 +207,11 @@ __global__ __launch_bounds__(256) void run_extract_kernel(SetView A, SetView B, 
 // Everything else goes on a list for chain_runs_kernel (lanes packed with chunks that need its loop); pairs
 // whose records overflowed and pairs that need the unabridged algorithm go to the slow path.
 #define SIEVE_RECORDS 6
+#ifndef SIEVE_SORT
+#define SIEVE_SORT 0            // 1: a workgroup's chunks dealt to its lanes by record count (below).  Measured in round 5 and left off: the
+#endif                          // wavefronts finish together, but neighbouring chunks' records no longer load together -- 448 against 425 us per launch
+                                // on the real-structure set, no change on the benchmark (profiles/run/r5_sieve.sh)
+#define SIEVE_CLASSES 10u
 #ifdef SKDER_SIEVE_STATS
 #define SIEVE_WHY(I) atomicAdd(counters + 16 + (I), 1u)
 #else
@@ -225,13 +230,58 @@ __global__ __launch_bounds__(256) void chain_single_kernel(SetView A, SetView B,
     // workgroups in launch order (dealt round-robin to the 8 XCDs): every record is read once, there is nothing an XCD's L2
     // could share, and one contiguous stream over the chip measured 1.8 ms per step faster than an eighth of the list per XCD
     const uint32_t wg = blockIdx.x;
+#if SIEVE_SORT
+    // The loop below takes as many trips as a chunk has records (1, 3, 5 ... with 0, 1, 2 strays), and a wavefront as many as its
+    // longest chunk: 21 of 64 lanes at work on the benchmark.  A chunk's record count is (nearly always) the distance to the next
+    // chunk's first record, known before any record is read: the workgroup's 256 chunks are dealt to its lanes in the order of that
+    // count (a counting sort over ten classes through LDS), so that the chunks of a wavefront finish together.  Which lane takes
+    // which chunk changes nothing a chunk computes.
+    __shared__ uint32_t s_cnt[4][SIEVE_CLASSES], s_off[4][SIEVE_CLASSES], s_t[256], s_i[256];
+    uint32_t t, idx0_pre;
+    {
+        const uint32_t t0 = wg * 256u + threadIdx.x, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+        uint32_t key = SIEVE_CLASSES - 1u, i0 = 0xFFFFFFFFu;            // beyond the last chunk: behind everything
+        if (t0 < total_chunks) {
+            i0 = chunk_rec0[t0];
+            const uint32_t i1 = t0 + 1u < total_chunks ? chunk_rec0[t0 + 1u] : 0xFFFFFFFFu;
+            const uint32_t d = i1 - i0;
+            key = i0 == 0xFFFFFFFFu ? 0u : (i1 != 0xFFFFFFFFu && d - 1u < SIEVE_CLASSES - 3u) ? d : SIEVE_CLASSES - 2u;   // unknown (the pair's or quarter's last chunk): with the long ones
+        }
+        uint32_t rank = 0;
+#pragma unroll
+        for (uint32_t v = 0; v < SIEVE_CLASSES; v++) {
+            const unsigned long long m = __ballot(key == v);
+            if (lane == 0) s_cnt[wv][v] = (uint32_t)__popcll(m);
+            if (key == v) rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        }
+        __syncthreads();
+        if (threadIdx.x < 4u * SIEVE_CLASSES) {         // exclusive prefix over (class, wavefront) pairs, class-major
+            const uint32_t v = threadIdx.x / 4u, w = threadIdx.x & 3u;
+            uint32_t o = 0;
+            for (uint32_t vv = 0; vv < SIEVE_CLASSES; vv++)
+                for (uint32_t ww = 0; ww < 4u; ww++)
+                    o += (vv < v || (vv == v && ww < w)) ? s_cnt[ww][vv] : 0u;
+            s_off[w][v] = o;
+        }
+        __syncthreads();
+        const uint32_t at = s_off[wv][key] + rank;
+        s_t[at] = t0; s_i[at] = i0;
+        __syncthreads();
+        t = s_t[threadIdx.x]; idx0_pre = s_i[threadIdx.x];
+    }
+#else
     const uint32_t t = wg * 256u + threadIdx.x;
+#endif
     const bool in = t < total_chunks;
     uint32_t pi = 0, n_add = 0, slow_why = 0;
     bool to_gen = false, to_slow = false;
     uint4 gd0 = make_uint4(0, 0, 0, 0), gd1 = gd0;       // what the run loop needs of a chunk it is handed (chain.h, GenItem)
     if (in) {
+#if SIEVE_SORT
+        const uint32_t idx0 = idx0_pre;
+#else
         const uint32_t idx0 = chunk_rec0[t];                 // independent of the descriptor: in flight beside it
+#endif
         pi = wg_pair[wg];
         // a workgroup's 256 chunks rarely span more than three pairs.  The descriptors of the first two are requested whole
         // at once (the same two addresses for the whole wavefront) and the third one's first chunk beside them: the
@@ -398,15 +448,20 @@ __global__ __launch_bounds__(256) void chain_single_kernel(SetView A, SetView B,
             }
         }
     }
-    // anchors of the pair: one atomic per wavefront when all its chunks belong to one pair (nearly always)
-    const uint32_t pi0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)pi);
-    if (__all(!in || pi == pi0)) {
-        uint32_t v = n_add;
+    // anchors of the pairs: one atomic per wavefront and pair (a wavefront's chunks belong to one pair, or since the lanes are dealt out by
+    // record count to the two or three pairs of the workgroup's window)
+    {
+        unsigned long long todo = __ballot(in && n_add != 0u);
+        while (todo) {
+            const uint32_t first = (uint32_t)__ffsll((long long)todo) - 1u;
+            const uint32_t p0 = (uint32_t)__shfl((int)pi, (int)first, 64);
+            const bool mine = in && n_add != 0u && pi == p0;
+            uint32_t v = mine ? n_add : 0u;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-        if ((threadIdx.x & 63u) == 0 && v) atomicAdd(&pair_na[pi0], v);
-    } else if (n_add) {
-        atomicAdd(&pair_na[pi], n_add);
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+            if ((threadIdx.x & 63u) == 0 && v) atomicAdd(&pair_na[p0], v);
+            todo &= ~__ballot(mine);
+        }
     }
 }
 
