@@ -39,6 +39,21 @@ extern "C" skder_ctx_t *skder_amd_ctx_create(int device, char *err, size_t errle
             throw SkError(std::string("libskder_amd is built for gfx950 (MI355X) only; device is ") + prop.gcnArchName);
         ctx = new skder_ctx();
         ctx->device = device;
+#ifdef SKDER_CU_MASK_PROBE
+        // (measurement build, profiles/run/r5_cu_mask.sh: the context's main queue confined to the first SKDER_AMD_CU_MASK compute units of
+        // every group of 256 mask bits -- how do the chain stage's kernels scale with the CUs they get?)
+        if (const char *e = getenv("SKDER_AMD_CU_MASK")) {
+            const int ncu = atoi(e);
+            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const char *mode = getenv("SKDER_AMD_CU_MASK_MODE");
+            for (int c = 0; c < 256; c++) {
+                // mode "spread": every k-th bit; default: the first ncu bits
+                const bool on = (mode && mode[0] == 's') ? ((long long)c * ncu / 256 != (long long)(c + 1) * ncu / 256) : c < ncu;
+                if (on) mask[c >> 5] |= 1u << (c & 31);
+            }
+            HIPCHECK(hipExtStreamCreateWithCUMask(&ctx->stream, 8, mask));
+        } else
+#endif
         HIPCHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
         HIPCHECK(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
         for (auto &e : ctx->ev) HIPCHECK(hipEventCreate(&e));
