@@ -907,7 +907,7 @@ def main():
     # N > 1: a few steps of the OTHER exchange as well, outside the timed region (never part of `value`): the first multi-GPU run of this
     # line then prices both -- replicate (raw sketches all-gathered) and components (markers all-gathered, seeds to their component's owner)
     other_exchange = None
-    if dist_on and world > 1 and os.environ.get("SKDER_AMD_NO_OTHER_EXCHANGE") is None:
+    if dist_on and world > 1 and os.environ.get("SKDER_AMD_OTHER_EXCHANGE") == "1":       # opt-in: a collective that hangs would cost the whole line
         was = os.environ.get("SKDER_AMD_EXCHANGE")
         other = "replicate" if was == "components" else "components"
         kept = (np.array(step.counters, copy=True), step.runs_ms, step.index_ms, getattr(step, "exchange_stats", None))

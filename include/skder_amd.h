@@ -35,7 +35,8 @@
  *   SKDER_AMD_HOST_PARSE=1     FASTA parsed by the host reader instead of the device;  SKDER_AMD_FASTA_WAVE=1  by the one-wavefront-per-file kernel
  * Read by the Python host mirror (skder_amd/skder.py): SKDER_AMD_DEVICE, SKDER_AMD_DEVICES (device list of the drop-in entry points),
  * SKDER_AMD_SEARCH_BATCH, SKDER_AMD_SEARCH_ALL (lowMemGreedyDerep's speculative batches); by bench.py: SKDER_AMD_FORCE_DIST, SKDER_AMD_DIST_BACKEND,
- * SKDER_AMD_EXCHANGE=components (N > 1: markers all-gathered, seeds to the owner of each connected component; skder_amd/multigpu.py).
+ * SKDER_AMD_EXCHANGE=components (N > 1: markers all-gathered, seeds to the owner of each connected component; skder_amd/multigpu.py),
+ * SKDER_AMD_OTHER_EXCHANGE=1 (N > 1: three extra steps of the exchange that was not selected, outside the timed region).
  */
 #ifndef SKDER_AMD_H
 #define SKDER_AMD_H
