@@ -50,7 +50,9 @@ struct PairOut {
 #define FIN_LDS_CHAINS 2048
 #define FIN_BINS 1024
 #ifndef FAST_SLOTS
-#define FAST_SLOTS 6         // chain slots per chunk of the two fast kernels (the run loop declines a chunk with more chains)
+#define FAST_SLOTS 6         // chain slots per chunk of the two fast kernels (the run loop declines a chunk with more chains).
+                             // fast_chains is slot-major: slot k of chunk t at [k * (chunks of the batch) + t], so that the first slots of
+                             // neighbouring chunks -- nearly all that is ever written or read -- share cache lines
 #endif
 #define SIEVE_PATHS 3        // paths the sieve follows (its own limit; its chains use the first slots)
 #ifndef CF_OCC
@@ -101,7 +103,7 @@ void launch_chain_rows(hipStream_t st, unsigned grid, SetView A, SetView B, cons
 // its multi-occurrence lists, the chunk's number inside the pair, first seed): the sieve has them in registers when it passes a
 // chunk on, and the run loop starts a chunk with ONE dependent load instead of four
 void launch_chain_runs(hipStream_t st, unsigned grid, const uint4 *gen_list, const uint32_t *gen_cnt, uint32_t gen_cap, const RunRec *recs,
-                       const uint4 *multi, ChainRec *fast_chains, uint32_t *chunk_state, uint32_t *slow_count, uint32_t *pair_na,
+                       const uint4 *multi, ChainRec *fast_chains, uint32_t fast_stride, uint32_t *chunk_state, uint32_t *slow_count, uint32_t *pair_na,
                        uint32_t *decl_list, uint32_t *decl_count, uint32_t *work_next);
 #define RUNS_DRAW 512u          // most items a wavefront takes from the shared counter at a time
 #define RUNS_DECL_FLUSH 64u     // declined chunks a wavefront collects before it appends them to the shared list
@@ -153,10 +155,10 @@ void launch_slow_chain(hipStream_t st, SetView A, SetView B, const PairDesc *pai
                        uint32_t *BP, uint64_t *ORD, ChainRec *chains, uint32_t *pair_nch, uint32_t *pair_na, uint32_t *flags);
 
 // ---- finalize (chain_finalize.hip)
-void launch_finalize(hipStream_t st, unsigned grid, uint32_t lds_cap, SetView A, SetView B, const PairDesc *pairs, const ChainRec *fast_chains,
+void launch_finalize(hipStream_t st, unsigned grid, uint32_t lds_cap, SetView A, SetView B, const PairDesc *pairs, const ChainRec *fast_chains, uint32_t fast_stride,
                      const uint32_t *chunk_state, const ChainRec *chains, const uint32_t *pair_nch, const uint32_t *pair_na, PairOut *out,
                      uint32_t *flags, uint32_t *chunk_mark);
-void launch_finalize_global(hipStream_t st, unsigned grid, SetView A, SetView B, const PairDesc *pairs, const ChainRec *fast_chains,
+void launch_finalize_global(hipStream_t st, unsigned grid, SetView A, SetView B, const PairDesc *pairs, const ChainRec *fast_chains, uint32_t fast_stride,
                             const uint32_t *chunk_state, const ChainRec *chains, const uint32_t *pair_nch, const uint32_t *pair_na, PairOut *out,
                             uint32_t *flags, uint32_t *chunk_mark, unsigned char *gws, const uint64_t *goff, const uint32_t *glist, const uint32_t *gcap);
 void finalize_allow_large_lds();

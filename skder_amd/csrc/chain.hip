@@ -223,7 +223,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
                                S.pair_over.p, S.chunk_rec0.p, S.wg_pair.p, S.multi.p, S.fast_chains.p, S.chunk_state.p, S.slow_list.p, S.counters.p,
                                S.gen_list.p, S.gen_cnt.p, gen_cap, S.pair_na.p, xcd_remap, S.chunk_pair.p);
             // what the sieve left: the run loop (one lane per chunk, a ring of four runs); what it gives up goes to the general kernel.
-            launch_chain_runs(S.st, nwg < 1024u ? nwg : 1024u, S.gen_list.p, S.gen_cnt.p, gen_cap, S.recs.p, S.multi.p, S.fast_chains.p, S.chunk_state.p,
+            launch_chain_runs(S.st, nwg < 1024u ? nwg : 1024u, S.gen_list.p, S.gen_cnt.p, gen_cap, S.recs.p, S.multi.p, S.fast_chains.p, (uint32_t)S.nchunks, S.chunk_state.p,
                               S.counters.p, S.pair_na.p, S.slow_list.p, S.counters.p, S.counters.p + 40);
         } else {
             HIPCHECK(hipEventRecord(S.ev[6], S.st));
@@ -256,7 +256,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         while (lds_cap < 3u * max_chunks / 2 + 128 && lds_cap < 4096) lds_cap <<= 1;   // retried with more if a pair needs it
         S.lds_cap = lds_cap;
         if (nb)
-            launch_finalize(S.st, nb, lds_cap, VA, VB, S.d_pairs.p, S.fast_chains.p, S.chunk_state.p, S.chains.p, S.pair_nch.p, S.pair_na.p, S.d_out.p,
+            launch_finalize(S.st, nb, lds_cap, VA, VB, S.d_pairs.p, S.fast_chains.p, (uint32_t)S.nchunks, S.chunk_state.p, S.chains.p, S.pair_nch.p, S.pair_na.p, S.d_out.p,
                             S.flags.p, S.chunk_mark.p);
         HIPCHECK(hipGetLastError());     // a rejected launch (resources) must not pass as an empty result
         HIPCHECK(hipEventRecord(S.ev[4], S.st));
@@ -464,6 +464,9 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         if (S.h_cnt[29] && getenv("SKDER_AMD_DEBUG"))
         fprintf(stderr, "[skder_amd] general path: %u chunks, %u anchors, %u full look-backs (%u passes), %u stretches, %u chain ends, %u ladder visits; %u chunks on to the wavefront kernel\n", S.h_cnt[29], S.h_cnt[24], S.h_cnt[25], S.h_cnt[30], S.h_cnt[26], S.h_cnt[27], S.h_cnt[28], S.h_cnt[17]);
 #endif
+#ifdef FIN_TIMING
+        { void finalize_timing_dump(); if (getenv("SKDER_AMD_DEBUG")) finalize_timing_dump(); }
+#endif
         if (getenv("SKDER_AMD_DEBUG")) {
             const uint32_t *hcnt = S.h_cnt;
             fprintf(stderr, "[skder_amd] batch: over %u; %u pairs %llu chunks, room for %llu run records, %u to the run loop, %u on to the general kernel (none %u, slots %u, hits %u, ring %u, branch %u, score %u, qrep %u, inside %u, records-full %u, run-not-dominant %u)\n",
@@ -476,7 +479,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         //    holds the number wanted: every pair gets exactly that and the chaining stage runs again;
         //  * flag 16: a pair has more chains than the LDS capacity chosen for finalize: again at 4096.
         auto finalize_and_fetch = [&]() {
-            launch_finalize(S.st, nb, S.lds_cap, VA, VB, S.d_pairs.p, S.fast_chains.p, S.chunk_state.p, S.chains.p, S.pair_nch.p, S.pair_na.p, S.d_out.p,
+            launch_finalize(S.st, nb, S.lds_cap, VA, VB, S.d_pairs.p, S.fast_chains.p, (uint32_t)S.nchunks, S.chunk_state.p, S.chains.p, S.pair_nch.p, S.pair_na.p, S.d_out.p,
                             S.flags.p, S.chunk_mark.p);
             HIPCHECK(hipGetLastError());
             HIPCHECK(hipMemcpyAsync(S.h_out, S.d_out.p, nb * sizeof(PairOut), hipMemcpyDeviceToHost, S.st));
@@ -549,7 +552,7 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
                     HIPCHECK(hipMemcpyAsync(d_cap.p, gcap.data(), ng * 4, hipMemcpyHostToDevice, S.st));
                     HIPCHECK(hipMemcpyAsync(d_off.p, goff.data(), ng * 8, hipMemcpyHostToDevice, S.st));
                     HIPCHECK(hipMemsetAsync(S.flags.p, 0, 64, S.st));
-                    launch_finalize_global(S.st, (unsigned)ng, VA, VB, S.d_pairs.p, S.fast_chains.p, S.chunk_state.p, S.chains.p, S.pair_nch.p, S.pair_na.p,
+                    launch_finalize_global(S.st, (unsigned)ng, VA, VB, S.d_pairs.p, S.fast_chains.p, (uint32_t)S.nchunks, S.chunk_state.p, S.chains.p, S.pair_nch.p, S.pair_na.p,
                                            S.d_out.p, S.flags.p, S.chunk_mark.p, gws.p, d_off.p, d_list.p, d_cap.p);
                     HIPCHECK(hipGetLastError());
                     HIPCHECK(hipMemcpyAsync(S.h_out, S.d_out.p, nb * sizeof(PairOut), hipMemcpyDeviceToHost, S.st));

@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void chain_single_kernel(SetView A, SetView B,
             uint32_t p_hw[SIEVE_PATHS] = {0, 0, 0}, p_G[SIEVE_PATHS] = {0, 0, 0};     // closed and current paths: key, first diagonal, steps
             int32_t p_D[SIEVE_PATHS] = {0, 0, 0};
             uint32_t p_lq[SIEVE_PATHS] = {0, 0, 0};                                   // ... and the position of their last anchor
-            ChainRec *slots = fast_chains + (uint64_t)t * FAST_SLOTS;
+            ChainRec *slots = fast_chains + t;          // slot k of chunk t lies at [k * total_chunks + t] (chain.h)
             // the current path ends: its chain, and what the strays have to be checked against
 #define CLOSE_PATH()                                                                                                  \
             do {                                                                                                      \
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void chain_single_kernel(SetView A, SetView B,
                     const uint32_t ra = m_hw & HIT_POS_MASK, rb = l_hw & HIT_POS_MASK;                                \
                     cr.r0 = ra < rb ? ra : rb; cr.r1 = ra > rb ? ra : rb;                                             \
                     cr.chunk = c;                                                                                     \
-                    slots[nfin++] = cr;                                                                               \
+                    slots[(uint64_t)(nfin++) * total_chunks] = cr;                                                                               \
                 }                                                                                                     \
             } while (0)
             for (int k = 0; k < SIEVE_RECORDS + 1 && !fail; k++) {

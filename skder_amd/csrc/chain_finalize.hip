@@ -47,9 +47,31 @@ __device__ __forceinline__ bool better(const int32_t *sc, const uint32_t *q0, co
 // host), one workgroup per pair of the batch.  GLOBAL = true: the same code for the few pairs with more
 // chains than LDS holds (repeat-rich genomes): arrays in a global workspace, workgroup b handles pair
 // glist[b] with capacity gcap[b] at gws + goff[b].
+// the most chunks of a pair whose marks live in LDS (the bin counters' words); a test build lowers it to send every pair through the global marks
+#ifndef FIN_LDS_MARKS
+#define FIN_LDS_MARKS (FIN_BINS + 1u)
+#endif
+static_assert(FIN_LDS_MARKS <= FIN_BINS + 1u, "the marks reuse the bin counters");
+
+#ifdef FIN_TIMING
+// measurement build: wall-clock ticks (100 MHz) of the phases of a workgroup, summed over the workgroups
+__device__ unsigned long long fin_ticks[8];
+#define FIN_T(k) do { if (tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&fin_ticks[k], now_ - t_prev_); t_prev_ = now_; } } while (0)
+void finalize_timing_dump()
+{
+    unsigned long long h[8];
+    HIPCHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(fin_ticks), sizeof h));
+    fprintf(stderr, "[skder_amd] finalize ticks (10 ns): gather %llu, bins %llu, rounds %llu, sums %llu, roots+out %llu; workgroups %llu\n", h[0], h[1], h[2], h[3], h[4], h[7]);
+    memset(h, 0, sizeof h);
+    HIPCHECK(hipMemcpyToSymbol(HIP_SYMBOL(fin_ticks), h, sizeof h));
+}
+#else
+#define FIN_T(k) do { } while (0)
+#endif
+
 template <bool GLOBAL>
 __global__ __launch_bounds__(256) void finalize_kernel_t(SetView A, SetView B, const PairDesc *__restrict__ pairs,
-                                                         const ChainRec *__restrict__ fast_chains, const uint32_t *__restrict__ chunk_state,
+                                                         const ChainRec *__restrict__ fast_chains, uint32_t fast_stride, const uint32_t *__restrict__ chunk_state,
                                                          const ChainRec *__restrict__ chains, const uint32_t *__restrict__ pair_nch,
                                                          const uint32_t *__restrict__ pair_na, PairOut *__restrict__ out,
                                                          uint32_t *__restrict__ flags, uint32_t *__restrict__ chunk_mark, uint32_t cap_arg,
@@ -67,20 +89,31 @@ __global__ __launch_bounds__(256) void finalize_kernel_t(SetView A, SetView B, c
     uint8_t *state = reinterpret_cast<uint8_t *>(nsd + lds_cap);   // 0 unknown, 1 kept, 2 dropped
     uint16_t *order = reinterpret_cast<uint16_t *>(state + lds_cap);  // chain indices grouped by bin
     __shared__ unsigned long long s_cells, s_seeds, s_anch, s_span;
-    __shared__ uint32_t s_kept, s_unknown, s_n;
+    __shared__ uint32_t s_kept, s_n;
+    __shared__ uint32_t s_maxlen, s_maxr;
+    __shared__ uint32_t bin_start[FIN_BINS + 2], bin_fill[FIN_BINS + 1];
+    __shared__ uint32_t wsum[4];
 
     const PairDesc pd = pairs[pidx];
     const uint32_t tid = threadIdx.x;
-    if (tid == 0) { s_cells = 0; s_seeds = 0; s_anch = 0; s_span = 0; s_kept = 0; s_unknown = 0; s_n = 0; }
+#ifdef FIN_TIMING
+    unsigned long long t_prev_ = wall_clock64();
+    if (tid == 0) atomicAdd(&fin_ticks[7], 1ull);
+#endif
+    if (tid == 0) { s_cells = 0; s_seeds = 0; s_anch = 0; s_span = 0; s_kept = 0; s_n = 0; s_maxlen = 0; s_maxr = 0; }
     // what the last lane standing needs at the very end is requested now (the workgroup holds its LDS until then)
     const uint64_t len_q = ((pd.flags & 2u) ? B : A).meta[pd.q].total_len, len_r = ((pd.flags & 4u) ? B : A).meta[pd.r].total_len;
     const uint32_t n_anchors_pair = pair_na[pidx];
+    // the seeds of this thread's chunk (the cell sum at the end wants them for the chunks that keep a chain): one trip for
+    // a pair of up to 256 chunks, requested with the chunk states
+    const uint32_t *const cst = ((pd.flags & 2u) ? B : A).chunk_start + pd.q_chunk_off;
+    const uint32_t my_cell_seeds = tid < pd.n_chunks ? cst[tid + 1] - cst[tid] : 0u;
     __syncthreads();
     // gather: chains of the fast path (per-chunk slots) and of the slow path (per-pair list)
     uint32_t nslow = pair_nch[pidx];
     if (nslow > pd.c_cap) nslow = pd.c_cap;
     auto put = [&](const ChainRec &c) {
-        const uint32_t d = atomicAdd(&s_n, 1u);
+        const uint32_t d = atomicAdd(&s_n, 1u);       // (one atomic per wavefront and call, the lanes ranked by ballot, was measured: 3 % slower)
         if (d < lds_cap) {
             sc[d] = c.score; q0[d] = c.q0; q1[d] = c.q1; r0[d] = c.r0; r1[d] = c.r1; ckc[d] = c.chunk;
             na[d] = c.n; nsd[d] = c.n_seeds;
@@ -91,13 +124,15 @@ __global__ __launch_bounds__(256) void finalize_kernel_t(SetView A, SetView B, c
     for (uint32_t ck = tid; ck < pd.n_chunks; ck += 256) {
         const uint32_t st = chunk_state[pd.chunk_base + ck];
         if (st == CHUNK_SLOW || st == 0u) continue;
-        const ChainRec *fc = fast_chains + (uint64_t)(pd.chunk_base + ck) * FAST_SLOTS;
+        // slot k of the chunk at fc[k * fast_stride]: slot-major, the first slots of a pair's chunks lie side by side (chain.h).
+        // (The first two slots requested together with the state, before it is known whether they hold anything: no change.)
+        const ChainRec *fc = fast_chains + (pd.chunk_base + ck);
         ChainRec c[3];        // the first three at once (nearly every chunk has no more), the rest one by one
 #pragma unroll
-        for (uint32_t k = 0; k < 3u; k++) if (k < st) c[k] = fc[k];
+        for (uint32_t k = 0; k < 3u; k++) if (k < st) c[k] = fc[(uint64_t)k * fast_stride];
 #pragma unroll
         for (uint32_t k = 0; k < 3u; k++) if (k < st) put(c[k]);
-        for (uint32_t k = 3u; k < st && k < FAST_SLOTS; k++) put(fc[k]);
+        for (uint32_t k = 3u; k < st && k < FAST_SLOTS; k++) put(fc[(uint64_t)k * fast_stride]);
     }
     for (uint32_t i = tid; i < nslow; i += 256) put(chains[pd.c_base + i]);
     __syncthreads();
@@ -114,16 +149,11 @@ __global__ __launch_bounds__(256) void finalize_kernel_t(SetView A, SetView B, c
         }
         return;
     }
-    __syncthreads();
+    FIN_T(0);
     // Spatial binning on the other genome so that a chain is compared only with chains that can
     // overlap it: bins of width 2^shift >= the longest chain, chains filed under the bin of r0; a chain
     // in bin b can only overlap chains of bins b-1, b, b+1.  (Exact for any input: a very long chain
     // just makes the bins wide.)
-    __shared__ uint32_t s_maxlen, s_maxr;
-    __shared__ uint32_t bin_start[FIN_BINS + 2], bin_fill[FIN_BINS + 1];
-    __shared__ uint32_t wsum[4];
-    if (tid == 0) { s_maxlen = 0; s_maxr = 0; }
-    __syncthreads();
     {
         uint32_t ml = 0, mr = 0;
         for (uint32_t i = tid; i < n; i += 256) { ml = max(ml, r1[i] - r0[i]); mr = max(mr, r1[i]); }
@@ -159,6 +189,13 @@ __global__ __launch_bounds__(256) void finalize_kernel_t(SetView A, SetView B, c
         order[bin_start[b] + atomicAdd(&bin_fill[b], 1u)] = (uint16_t)i;
     }
     __syncthreads();
+    // the fill counters are free from here on: they become the marks of the chunks that keep a chain (a word per chunk;
+    // a pair with more chunks than bins marks in global memory instead)
+    FIN_T(1);
+    const bool lds_marks = pd.n_chunks <= FIN_LDS_MARKS;
+    uint32_t *const gmark = chunk_mark + pd.chunk_base;
+    if (lds_marks) { for (uint32_t i = tid; i < pd.n_chunks; i += 256) bin_fill[i] = 0u; }
+    else { for (uint32_t i = tid; i < pd.n_chunks; i += 256) gmark[i] = 0u; }
     // a chain is dropped when ONE better kept chain on the same record covers more than half of
     // its span on the other genome.  Chains without any better overlapping chain are kept at once;
     // the rest resolve in rounds, each chain waiting for its better overlapping chains.
@@ -186,20 +223,11 @@ __global__ __launch_bounds__(256) void finalize_kernel_t(SetView A, SetView B, c
             else if (!pending) state[i] = 1;
             else my_unknown++;
         }
-        if (my_unknown) atomicAdd(&s_unknown, my_unknown);
-        __syncthreads();
-        const uint32_t u = s_unknown;
-        __syncthreads();
-        if (tid == 0) s_unknown = 0;
-        __syncthreads();
-        if (!u) break;
+        if (!__syncthreads_or((int)my_unknown)) break;
     }
-    // sums over the kept chains; the cells (chunks) that hold one are marked in global memory -- a pair
-    // can have any number of chunks -- and their seed counts summed from the chunk table afterwards (an LDS bitmap for the
-    // marks was measured: slower, 4.4 against 4.0 ms)
-    uint32_t *mark = chunk_mark + pd.chunk_base;
-    for (uint32_t i = tid; i < pd.n_chunks; i += 256) mark[i] = 0u;
-    __syncthreads();
+    FIN_T(2);
+    // sums over the kept chains; the cells (chunks) that hold one are marked (cleared before the rounds above, which end
+    // on a barrier) and their seed counts summed afterwards
     unsigned long long sd = 0, an = 0, sp = 0, cs = 0;
     uint32_t kept = 0;
     for (uint32_t i = tid; i < n; i += 256) {
@@ -208,15 +236,12 @@ __global__ __launch_bounds__(256) void finalize_kernel_t(SetView A, SetView B, c
         an += na[i];
         sp += q1[i] - q0[i];
         kept++;
-        mark[ckc[i]] = 1u;
+        if (lds_marks) bin_fill[ckc[i]] = 1u; else gmark[ckc[i]] = 1u;
     }
     __syncthreads();
-    {
-        const SetView &QS = (pd.flags & 2u) ? B : A;
-        const uint32_t *cst = QS.chunk_start + pd.q_chunk_off;
-        for (uint32_t i = tid; i < pd.n_chunks; i += 256)
-            if (mark[i]) cs += cst[i + 1] - cst[i];
-    }
+    if (tid < pd.n_chunks && (lds_marks ? bin_fill[tid] : gmark[tid])) cs += my_cell_seeds;
+    for (uint32_t i = tid + 256u; i < pd.n_chunks; i += 256)
+        if (lds_marks ? bin_fill[i] : gmark[i]) cs += cst[i + 1] - cst[i];
     // wave-level reduction first: 4 LDS atomics per sum and workgroup instead of 256
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -229,6 +254,7 @@ __global__ __launch_bounds__(256) void finalize_kernel_t(SetView A, SetView B, c
         atomicAdd(&s_kept, kept);
     }
     __syncthreads();
+    FIN_T(3);
     if (tid >= 64) return;
     // the two 15-th roots are serial double arithmetic: one lane each
     double root = 0.0;
@@ -251,21 +277,22 @@ __global__ __launch_bounds__(256) void finalize_kernel_t(SetView A, SetView B, c
         if (afr > 1.0) afr = 1.0;
         o.af_q = afq; o.af_r = afr;
         out[pidx] = o;
+        FIN_T(4);
     }
 }
 
-void launch_finalize(hipStream_t st, unsigned grid, uint32_t lds_cap, SetView A, SetView B, const PairDesc *pairs, const ChainRec *fast_chains,
+void launch_finalize(hipStream_t st, unsigned grid, uint32_t lds_cap, SetView A, SetView B, const PairDesc *pairs, const ChainRec *fast_chains, uint32_t fast_stride,
                      const uint32_t *chunk_state, const ChainRec *chains, const uint32_t *pair_nch, const uint32_t *pair_na, PairOut *out,
                      uint32_t *flags, uint32_t *chunk_mark)
 {
-    hipLaunchKernelGGL(finalize_kernel_t<false>, dim3(grid), dim3(256), lds_cap * 35u, st, A, B, pairs, fast_chains, chunk_state, chains, pair_nch, pair_na,
+    hipLaunchKernelGGL(finalize_kernel_t<false>, dim3(grid), dim3(256), lds_cap * 35u, st, A, B, pairs, fast_chains, fast_stride, chunk_state, chains, pair_nch, pair_na,
                        out, flags, chunk_mark, lds_cap, nullptr, nullptr, nullptr, nullptr);
 }
-void launch_finalize_global(hipStream_t st, unsigned grid, SetView A, SetView B, const PairDesc *pairs, const ChainRec *fast_chains,
+void launch_finalize_global(hipStream_t st, unsigned grid, SetView A, SetView B, const PairDesc *pairs, const ChainRec *fast_chains, uint32_t fast_stride,
                             const uint32_t *chunk_state, const ChainRec *chains, const uint32_t *pair_nch, const uint32_t *pair_na, PairOut *out,
                             uint32_t *flags, uint32_t *chunk_mark, unsigned char *gws, const uint64_t *goff, const uint32_t *glist, const uint32_t *gcap)
 {
-    hipLaunchKernelGGL(finalize_kernel_t<true>, dim3(grid), dim3(256), 0, st, A, B, pairs, fast_chains, chunk_state, chains, pair_nch, pair_na, out, flags,
+    hipLaunchKernelGGL(finalize_kernel_t<true>, dim3(grid), dim3(256), 0, st, A, B, pairs, fast_chains, fast_stride, chunk_state, chains, pair_nch, pair_na, out, flags,
                        chunk_mark, 0u, gws, goff, glist, gcap);
 }
 void finalize_allow_large_lds() { HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(finalize_kernel_t<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 35)); }

@@ -40,7 +40,7 @@ struct Run {
 
 __global__ __launch_bounds__(256) void chain_runs_kernel(const uint4 *__restrict__ gen_list, const uint32_t *__restrict__ gen_cnt,
                                                          uint32_t gen_cap, const RunRec *__restrict__ recs, const uint4 *__restrict__ multi,
-                                                         ChainRec *__restrict__ fast_chains, uint32_t *__restrict__ chunk_state,
+                                                         ChainRec *__restrict__ fast_chains, uint32_t fast_stride, uint32_t *__restrict__ chunk_state,
                                                          uint32_t *__restrict__ slow_count, uint32_t *__restrict__ pair_na,
                                                          uint32_t *__restrict__ decl_list, uint32_t *__restrict__ decl_count,
                                                          uint32_t *__restrict__ work_next, uint32_t refill_min)
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(const uint4 *__restrict
                     { const uint32_t rl_ = pk_rr & HIT_POS_MASK;                                  \
                       cr.r0 = rl_ < (E).r_pfirst ? rl_ : (E).r_pfirst; cr.r1 = rl_ > (E).r_pfirst ? rl_ : (E).r_pfirst; } \
                     cr.chunk = c;                                                                \
-                    slots[nfin++] = cr;                                                          \
+                    slots[(uint64_t)(nfin++) * fast_stride] = cr;                                                          \
                 }                                                                                \
             }                                                                                    \
             else if (nfin >= FAST_SLOTS) { cplx = true; cause = 1; }                         \
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(const uint4 *__restrict
                   const uint32_t rl_ = (E).rr_last & HIT_POS_MASK;                            \
                   cr.r0 = rl_ < (E).r_pfirst ? rl_ : (E).r_pfirst; cr.r1 = rl_ > (E).r_pfirst ? rl_ : (E).r_pfirst; } \
                 cr.chunk = c; \
-                slots[nfin++] = cr;                                                          \
+                slots[(uint64_t)(nfin++) * fast_stride] = cr;                                                          \
             }                                                                                \
         }                                                                                    \
     } while (0)
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(const uint4 *__restrict
                         multi_base = i1.y; c = i1.z;
                         const uint32_t s0 = i1.w;
                         prec = reinterpret_cast<const uint4 *>(recs + i1.x);
-                        slots = fast_chains + (uint64_t)t * FAST_SLOTS;
+                        slots = fast_chains + t;
                         busy = true; cplx = false; cause = 0u;
                         done = idx == 0xFFFFFFFFu || s1 <= s0;
                         if (!done) { a0 = prec[2u * idx]; a1 = prec[2u * idx + 1u]; b0 = prec[2u * idx + 2u]; b1 = prec[2u * idx + 3u]; }   // a run record is never the last of its quarter
@@ -477,10 +477,10 @@ __global__ __launch_bounds__(256) void chain_runs_kernel(const uint4 *__restrict
 
 
 void launch_chain_runs(hipStream_t st, unsigned grid, const uint4 *gen_list, const uint32_t *gen_cnt, uint32_t gen_cap, const RunRec *recs,
-                       const uint4 *multi, ChainRec *fast_chains, uint32_t *chunk_state, uint32_t *slow_count, uint32_t *pair_na,
+                       const uint4 *multi, ChainRec *fast_chains, uint32_t fast_stride, uint32_t *chunk_state, uint32_t *slow_count, uint32_t *pair_na,
                        uint32_t *decl_list, uint32_t *decl_count, uint32_t *work_next)
 {
     static const uint32_t refill_min = getenv("SKDER_AMD_RUNS_REFILL") ? (uint32_t)atoi(getenv("SKDER_AMD_RUNS_REFILL")) : RUNS_REFILL_MIN;
-    hipLaunchKernelGGL(chain_runs_kernel, dim3(grid), dim3(256), 0, st, gen_list, gen_cnt, gen_cap, recs, multi, fast_chains, chunk_state, slow_count,
+    hipLaunchKernelGGL(chain_runs_kernel, dim3(grid), dim3(256), 0, st, gen_list, gen_cnt, gen_cap, recs, multi, fast_chains, fast_stride, chunk_state, slow_count,
                        pair_na, decl_list, decl_count, work_next, refill_min < 1u ? 1u : refill_min > 64u ? 64u : refill_min);
 }
