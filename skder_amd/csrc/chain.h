@@ -48,7 +48,9 @@ struct PairOut {
 
 #define USED_BIT 0x80000000u
 #define FIN_LDS_CHAINS 2048
-#define FIN_BINS 1024
+#ifndef FIN_BINS
+#define FIN_BINS 256
+#endif
 #ifndef FAST_SLOTS
 #define FAST_SLOTS 6         // chain slots per chunk of the two fast kernels (the run loop declines a chunk with more chains).
                              // fast_chains is slot-major: slot k of chunk t at [k * (chunks of the batch) + t], so that the first slots of

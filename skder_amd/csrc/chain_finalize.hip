@@ -48,6 +48,9 @@ __device__ __forceinline__ bool better(const int32_t *sc, const uint32_t *q0, co
 // chains than LDS holds (repeat-rich genomes): arrays in a global workspace, workgroup b handles pair
 // glist[b] with capacity gcap[b] at gws + goff[b].
 // the most chunks of a pair whose marks live in LDS (the bin counters' words); a test build lowers it to send every pair through the global marks
+#ifndef FIN_THREADS
+#define FIN_THREADS 256     // threads of the workgroup of a pair whose chains fit in LDS
+#endif
 #ifndef FIN_LDS_MARKS
 #define FIN_LDS_MARKS (FIN_BINS + 1u)
 #endif
@@ -69,8 +72,8 @@ void finalize_timing_dump()
 #define FIN_T(k) do { } while (0)
 #endif
 
-template <bool GLOBAL>
-__global__ __launch_bounds__(256) void finalize_kernel_t(SetView A, SetView B, const PairDesc *__restrict__ pairs,
+template <bool GLOBAL, int NT>
+__global__ __launch_bounds__(NT) void finalize_kernel_t(SetView A, SetView B, const PairDesc *__restrict__ pairs,
                                                          const ChainRec *__restrict__ fast_chains, uint32_t fast_stride, const uint32_t *__restrict__ chunk_state,
                                                          const ChainRec *__restrict__ chains, const uint32_t *__restrict__ pair_nch,
                                                          const uint32_t *__restrict__ pair_na, PairOut *__restrict__ out,
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(256) void finalize_kernel_t(SetView A, SetView B, c
         }
     };
     // one chunk per thread: its state, then all of its chains at once (a 3 Mb genome has 150 chunks: one trip)
-    for (uint32_t ck = tid; ck < pd.n_chunks; ck += 256) {
+    for (uint32_t ck = tid; ck < pd.n_chunks; ck += NT) {
         const uint32_t st = chunk_state[pd.chunk_base + ck];
         if (st == CHUNK_SLOW || st == 0u) continue;
         // slot k of the chunk at fc[k * fast_stride]: slot-major, the first slots of a pair's chunks lie side by side (chain.h).
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(256) void finalize_kernel_t(SetView A, SetView B, c
         for (uint32_t k = 0; k < 3u; k++) if (k < st) put(c[k]);
         for (uint32_t k = 3u; k < st && k < FAST_SLOTS; k++) put(fc[(uint64_t)k * fast_stride]);
     }
-    for (uint32_t i = tid; i < nslow; i += 256) put(chains[pd.c_base + i]);
+    for (uint32_t i = tid; i < nslow; i += NT) put(chains[pd.c_base + i]);
     __syncthreads();
     uint32_t n = s_n;
     if (n > lds_cap) {
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(256) void finalize_kernel_t(SetView A, SetView B, c
     // just makes the bins wide.)
     {
         uint32_t ml = 0, mr = 0;
-        for (uint32_t i = tid; i < n; i += 256) { ml = max(ml, r1[i] - r0[i]); mr = max(mr, r1[i]); }
+        for (uint32_t i = tid; i < n; i += NT) { ml = max(ml, r1[i] - r0[i]); mr = max(mr, r1[i]); }
         if (ml) atomicMax(&s_maxlen, ml);
         if (mr) atomicMax(&s_maxr, mr);
     }
@@ -165,16 +168,16 @@ __global__ __launch_bounds__(256) void finalize_kernel_t(SetView A, SetView B, c
     while ((1u << shift) <= s_maxlen) shift++;
     while ((s_maxr >> shift) >= FIN_BINS) shift++;
     const uint32_t nb_used = (s_maxr >> shift) + 1u;     // bins that can hold a chain (a 3 Mb genome with 20 kb chunks: ~90 of 1024)
-    for (uint32_t b = tid; b <= nb_used; b += 256) bin_fill[b] = 0;
+    for (uint32_t b = tid; b <= nb_used; b += NT) bin_fill[b] = 0;
     __syncthreads();
-    for (uint32_t i = tid; i < n; i += 256) atomicAdd(&bin_fill[r0[i] >> shift], 1u);
+    for (uint32_t i = tid; i < n; i += NT) atomicAdd(&bin_fill[r0[i] >> shift], 1u);
     __syncthreads();
     {
         uint32_t running = 0;
-        for (uint32_t base = 0; base < nb_used; base += 256) {
+        for (uint32_t base = 0; base < nb_used; base += NT) {
             const uint32_t v = base + tid < nb_used ? bin_fill[base + tid] : 0u;
             uint32_t total;
-            const uint32_t ex = block_excl_scan_256(v, wsum, total);
+            const uint32_t ex = block_excl_scan<NT / 64>(v, wsum, total);
             bin_start[base + tid] = running + ex;
             running += total;
         }
@@ -182,9 +185,9 @@ __global__ __launch_bounds__(256) void finalize_kernel_t(SetView A, SetView B, c
         if (tid == 0) { bin_start[nb_used] = n; bin_start[nb_used + 1] = n; }
     }
     __syncthreads();
-    for (uint32_t b = tid; b <= nb_used; b += 256) bin_fill[b] = 0;
+    for (uint32_t b = tid; b <= nb_used; b += NT) bin_fill[b] = 0;
     __syncthreads();
-    for (uint32_t i = tid; i < n; i += 256) {
+    for (uint32_t i = tid; i < n; i += NT) {
         const uint32_t b = r0[i] >> shift;
         order[bin_start[b] + atomicAdd(&bin_fill[b], 1u)] = (uint16_t)i;
     }
@@ -194,14 +197,14 @@ __global__ __launch_bounds__(256) void finalize_kernel_t(SetView A, SetView B, c
     FIN_T(1);
     const bool lds_marks = pd.n_chunks <= FIN_LDS_MARKS;
     uint32_t *const gmark = chunk_mark + pd.chunk_base;
-    if (lds_marks) { for (uint32_t i = tid; i < pd.n_chunks; i += 256) bin_fill[i] = 0u; }
-    else { for (uint32_t i = tid; i < pd.n_chunks; i += 256) gmark[i] = 0u; }
+    if (lds_marks) { for (uint32_t i = tid; i < pd.n_chunks; i += NT) bin_fill[i] = 0u; }
+    else { for (uint32_t i = tid; i < pd.n_chunks; i += NT) gmark[i] = 0u; }
     // a chain is dropped when ONE better kept chain on the same record covers more than half of
     // its span on the other genome.  Chains without any better overlapping chain are kept at once;
     // the rest resolve in rounds, each chain waiting for its better overlapping chains.
     for (;;) {
         uint32_t my_unknown = 0;
-        for (uint32_t i = tid; i < n; i += 256) {
+        for (uint32_t i = tid; i < n; i += NT) {
             if (state[i]) continue;
             const uint32_t li = r1[i] - r0[i];
             bool dropped = false, pending = false;
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(256) void finalize_kernel_t(SetView A, SetView B, c
     // on a barrier) and their seed counts summed afterwards
     unsigned long long sd = 0, an = 0, sp = 0, cs = 0;
     uint32_t kept = 0;
-    for (uint32_t i = tid; i < n; i += 256) {
+    for (uint32_t i = tid; i < n; i += NT) {
         if (state[i] != 1) continue;
         sd += nsd[i];
         an += na[i];
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(256) void finalize_kernel_t(SetView A, SetView B, c
     }
     __syncthreads();
     if (tid < pd.n_chunks && (lds_marks ? bin_fill[tid] : gmark[tid])) cs += my_cell_seeds;
-    for (uint32_t i = tid + 256u; i < pd.n_chunks; i += 256)
+    for (uint32_t i = tid + (uint32_t)NT; i < pd.n_chunks; i += NT)
         if (lds_marks ? bin_fill[i] : gmark[i]) cs += cst[i + 1] - cst[i];
     // wave-level reduction first: 4 LDS atomics per sum and workgroup instead of 256
 #pragma unroll
@@ -285,14 +288,14 @@ void launch_finalize(hipStream_t st, unsigned grid, uint32_t lds_cap, SetView A,
                      const uint32_t *chunk_state, const ChainRec *chains, const uint32_t *pair_nch, const uint32_t *pair_na, PairOut *out,
                      uint32_t *flags, uint32_t *chunk_mark)
 {
-    hipLaunchKernelGGL(finalize_kernel_t<false>, dim3(grid), dim3(256), lds_cap * 35u, st, A, B, pairs, fast_chains, fast_stride, chunk_state, chains, pair_nch, pair_na,
+    hipLaunchKernelGGL((finalize_kernel_t<false, FIN_THREADS>), dim3(grid), dim3(FIN_THREADS), lds_cap * 35u, st, A, B, pairs, fast_chains, fast_stride, chunk_state, chains, pair_nch, pair_na,
                        out, flags, chunk_mark, lds_cap, nullptr, nullptr, nullptr, nullptr);
 }
 void launch_finalize_global(hipStream_t st, unsigned grid, SetView A, SetView B, const PairDesc *pairs, const ChainRec *fast_chains, uint32_t fast_stride,
                             const uint32_t *chunk_state, const ChainRec *chains, const uint32_t *pair_nch, const uint32_t *pair_na, PairOut *out,
                             uint32_t *flags, uint32_t *chunk_mark, unsigned char *gws, const uint64_t *goff, const uint32_t *glist, const uint32_t *gcap)
 {
-    hipLaunchKernelGGL(finalize_kernel_t<true>, dim3(grid), dim3(256), 0, st, A, B, pairs, fast_chains, fast_stride, chunk_state, chains, pair_nch, pair_na, out, flags,
+    hipLaunchKernelGGL((finalize_kernel_t<true, 256>), dim3(grid), dim3(256), 0, st, A, B, pairs, fast_chains, fast_stride, chunk_state, chains, pair_nch, pair_na, out, flags,
                        chunk_mark, 0u, gws, goff, glist, gcap);
 }
-void finalize_allow_large_lds() { HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(finalize_kernel_t<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 35)); }
+void finalize_allow_large_lds() { HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&finalize_kernel_t<false, FIN_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 35)); }
