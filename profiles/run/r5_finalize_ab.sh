@@ -1,5 +1,8 @@
 #!/bin/bash
-# A/B on one box: the finalize kernel before (lib_old) and after (lib_new), same bench command under rocprofv3, twice each, interleaved
+# A/B on one box: two builds of the library, same bench command under rocprofv3, twice each, interleaved.
+# The two builds are made beforehand (they travel with the snapshot, git-ignored):
+#   git stash; make -C skder_amd/csrc; cp skder_amd/libskder_amd.so skder_amd/lib_old.so.bin; git stash pop
+#   make -C skder_amd/csrc; cp skder_amd/libskder_amd.so skder_amd/lib_new.so.bin
 mkdir -p gpurun_out/r5fin
 B="--steps 10 --warmup 3 --no-cpu-baseline --no-realistic --e2e-genomes 0 --parity-pairs 0 --low-mem-genomes 0 --one-species-genomes 0"
 for rep in 1 2; do for v in old new; do

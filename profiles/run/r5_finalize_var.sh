@@ -1,5 +1,7 @@
 #!/bin/bash
-# finalize variants (threads per workgroup x bins) on one box, interleaved twice: kernel average on the headline, real-structure us per pair
+# finalize variants (threads per workgroup x bins) on one box, interleaved twice: kernel average on the headline, real-structure us per pair.
+# The variants are built beforehand: for each "T B": make -C skder_amd/csrc EXTRA="-DFIN_THREADS=T -DFIN_BINS=B" (after touch chain.h);
+#   cp skder_amd/libskder_amd.so skder_amd/lib_vT_B.so.bin
 mkdir -p gpurun_out/r5fin
 B="--steps 10 --warmup 3 --no-cpu-baseline --no-realistic --e2e-genomes 0 --parity-pairs 0 --low-mem-genomes 0 --one-species-genomes 0"
 cp skder_amd/libskder_amd.so /tmp/keep.so
