@@ -252,8 +252,15 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         // the full 4096 (140 KB) when its results are read
         uint32_t max_chunks = 0;
         for (const PairDesc &d : S.hp) max_chunks = d.n_chunks > max_chunks ? d.n_chunks : max_chunks;
+#ifdef FIN_CAP_POW2
         uint32_t lds_cap = 512;
         while (lds_cap < 3u * max_chunks / 2 + 128 && lds_cap < 4096) lds_cap <<= 1;   // retried with more if a pair needs it
+#else
+        // (not rounded up to a power of two: the kernel's occupancy is bound by this LDS, 35 bytes per chain)
+        uint32_t lds_cap = (3u * max_chunks / 2 + 128 + 63u) & ~63u;                   // retried with more if a pair needs it
+        if (lds_cap < 256u) lds_cap = 256u;
+        if (lds_cap > 4096u) lds_cap = 4096u;
+#endif
         S.lds_cap = lds_cap;
         if (nb)
             launch_finalize(S.st, nb, lds_cap, VA, VB, S.d_pairs.p, S.fast_chains.p, (uint32_t)S.nchunks, S.chunk_state.p, S.chains.p, S.pair_nch.p, S.pair_na.p, S.d_out.p,

@@ -49,7 +49,8 @@ __device__ __forceinline__ bool better(const int32_t *sc, const uint32_t *q0, co
 // glist[b] with capacity gcap[b] at gws + goff[b].
 // the most chunks of a pair whose marks live in LDS (the bin counters' words); a test build lowers it to send every pair through the global marks
 #ifndef FIN_THREADS
-#define FIN_THREADS 256     // threads of the workgroup of a pair whose chains fit in LDS
+#define FIN_THREADS 192     // threads of the workgroup of a pair whose chains fit in LDS: ten pairs per CU (with the LDS sized to the batch, chain.hip);
+                            // measured 128 / 192 / 256: 423 / 386 / 500 us per launch on the headline, 0.374 / 0.367 / 0.365 us per pair on real structure
 #endif
 #ifndef FIN_LDS_MARKS
 #define FIN_LDS_MARKS (FIN_BINS + 1u)
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(NT) void finalize_kernel_t(SetView A, SetView B, co
             const uint32_t v = base + tid < nb_used ? bin_fill[base + tid] : 0u;
             uint32_t total;
             const uint32_t ex = block_excl_scan<NT / 64>(v, wsum, total);
-            bin_start[base + tid] = running + ex;
+            if (base + tid < nb_used) bin_start[base + tid] = running + ex;      // (the last trip is partial unless NT divides the bins in use)
             running += total;
         }
         __syncthreads();
