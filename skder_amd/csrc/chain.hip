@@ -97,6 +97,7 @@ struct ChainWork {
     DevBuf<uint64_t> ORD;
     ScanWorkspace ws;
     hipEvent_t ev_order = nullptr;
+    uint32_t fin_need = 0;                       // chains per pair the finalize step was last retried for (chain_stage sizes its LDS by it)
     const uint32_t *oriented_ref = nullptr;      // chain_pairs_orient ran for this pair list (W.jobs holds the ordered work)
     size_t oriented_np = 0;
     hipStream_t stream3 = nullptr;
@@ -259,6 +260,8 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
         // (not rounded up to a power of two: the kernel's occupancy is bound by this LDS, 35 bytes per chain)
         uint32_t lds_cap = (3u * max_chunks / 2 + 128 + 63u) & ~63u;                   // retried with more if a pair needs it
         if (lds_cap < 256u) lds_cap = 256u;
+        // genomes whose pairs hold more chains than that (fragmented assemblies): what the last batch that ran over needed, up to twice the estimate
+        if (W.fin_need > lds_cap) lds_cap = W.fin_need < 2u * lds_cap ? W.fin_need : 2u * lds_cap;
         if (lds_cap > 4096u) lds_cap = 4096u;
 #endif
         S.lds_cap = lds_cap;
@@ -531,7 +534,14 @@ void chain_pairs(skder_sketches *SA, skder_sketches *SB, const std::vector<uint3
                 continue;     // the over-list part runs again against the new regions
             }
             if ((flags_seen & 16u) && S.lds_cap < 4096) {
-                S.lds_cap = 4096;
+                // room for the pair with the most chains (the kernel reported what each such pair wants), not at once the full 4096 (140 KB: one pair per CU)
+                uint32_t want = 0;
+                for (uint32_t i = 0; i < nb; i++)
+                    if (S.h_out[i].n_chains == 0xFFFFFFFFu && S.h_out[i].n_chains_all > want) want = S.h_out[i].n_chains_all;
+                uint32_t cap = want > 4032u ? 4096u : (want + 63u) & ~63u;
+                if (cap <= S.lds_cap) cap = S.lds_cap + 64u;
+                W.fin_need = cap;
+                S.lds_cap = cap;
                 HIPCHECK(hipMemsetAsync(S.flags.p, 0, 64, S.st));
                 finalize_and_fetch();
                 flags_seen = (flags_seen & ~16u) | S.h_cnt[16];
