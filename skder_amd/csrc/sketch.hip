@@ -367,6 +367,8 @@ static uint32_t build_records(const skder_batch_t *b, std::vector<RecDesc> &recs
 {
     genome_tile_begin.assign(b->n_genomes + 1, 0);
     recs.reserve(b->n_records);
+    rec_goff.reserve((size_t)b->n_records + b->n_genomes);
+    genome_len.reserve(b->n_genomes);
     uint64_t nt = 0;
     for (uint32_t g = 0; g < b->n_genomes; g++) {
         genome_tile_begin[g] = (uint32_t)nt;
