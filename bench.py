@@ -27,26 +27,28 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0
-PMC_TRAFFIC = os.path.join("profiles", "round5_pmc_traffic.json")     # rocprofv3 --pmc passes of THIS build (profiles/collect.sh)
+SKETCH_BODY_NS = 93.4      # profiles/round3_sketch_body.json, variant 32781 (SK_BODY_DEFAULT): ns per position and wavefront per SIMD
+PMC_TRAFFIC = os.path.join("profiles", "round6_pmc_traffic.json")     # rocprofv3 --pmc passes of THIS build (profiles/collect.sh)
 ONE_QUEUE_STEPS = 3
 
 
-def write_sample_files(batches, n_sample):
-    """FASTA files of the first n_sample genomes, written from the device-resident bases (80 columns)"""
+def write_workload_sample(engine, ctx, torch, recipe, genomes, chunk=250):
+    """FASTA files (80 columns) of the workload's genomes `genomes`, generated on the device again after the timed region (any rank
+    can write any genome: at N > 1 rank 0 holds only its own block) and formatted on the host threads"""
     import tempfile
-    layout, d = batches[0]
-    n_sample = min(n_sample, layout.n_genomes)
-    host = d.cpu().numpy()
+    from concurrent.futures import ThreadPoolExecutor
     tmp = tempfile.mkdtemp(prefix="skder_amd_sample_")
-    paths, nbytes = [], 0
-    for g in range(n_sample):
+    paths, sizes = [], []
+
+    def one(job):
+        g, host, layout, k = job
         parts = []
-        for k in range(int(layout.genome_rec_begin[g]), int(layout.genome_rec_begin[g + 1])):
-            o, l = int(layout.rec_off[k]), int(layout.rec_len[k])
+        for r in range(int(layout.genome_rec_begin[k]), int(layout.genome_rec_begin[k + 1])):
+            o, l = int(layout.rec_off[r]), int(layout.rec_len[r])
             seq = host[o:o + l]
             full = (l // 80) * 80
             body = np.concatenate([seq[:full].reshape(-1, 80), np.full((full // 80, 1), ord("\n"), np.uint8)], axis=1).reshape(-1)
-            parts.append((">g%d_rec%d synthetic\n" % (g, k)).encode())
+            parts.append((">g%d_rec%d synthetic\n" % (g, r)).encode())
             parts.append(body.tobytes())
             if l > full:
                 parts.append(seq[full:].tobytes() + b"\n")
@@ -54,9 +56,21 @@ def write_sample_files(batches, n_sample):
         blob = b"".join(parts)
         with open(p, "wb") as f:
             f.write(blob)
-        nbytes += len(blob)
-        paths.append(p)
-    return tmp, paths, nbytes
+        return p, len(blob)
+    genomes = [int(g) for g in genomes]
+    with ThreadPoolExecutor(max_workers=max(1, min(16, granted_cpus()))) as ex:
+        for c0 in range(0, len(genomes), chunk):
+            gs = genomes[c0:c0 + chunk]
+            layout = engine.BatchLayout([recipe.rec_lens[g] for g in gs])
+            d = torch.empty(layout.total_bytes, dtype=torch.uint8, device="cuda")
+            ctx.synth_fill(d.data_ptr(), layout, recipe.lineage[gs], recipe.params[gs])
+            torch.cuda.synchronize()
+            host = d.cpu().numpy()
+            del d
+            for p, n in ex.map(one, [(g, host, layout, k) for k, g in enumerate(gs)]):
+                paths.append(p)
+                sizes.append(n)
+    return tmp, paths, sizes
 
 
 def gzip_sample_files(paths):
@@ -162,6 +176,7 @@ def golden_parity(device):
             raise RuntimeError(err.value.decode())
         call_s = time.perf_counter() - t0
         d_ani, d_af, seen = [], [], 0
+        values_equal = rows_equal = 0          # at the table's print precision: the distance to "bit-identical edge table" as integers
         with open(out) as f:
             next(f)
             for line in f:
@@ -174,6 +189,24 @@ def golden_parity(device):
                 afr, afq = (float(c[3]), float(c[4])) if os.path.basename(c[0]) == g[3] else (float(c[4]), float(c[3]))
                 d_ani.append(float(c[2]) - g[0])
                 d_af += [afr - g[1], afq - g[2]]
+                eq = [round(100 * float(c[2])) == round(100 * g[0]), round(100 * afr) == round(100 * g[1]), round(100 * afq) == round(100 * g[2])]
+                values_equal += sum(eq)
+                rows_equal += all(eq)
+        # the representative listings of the reference's -tc sweep (bin/skder:331-407: 6 ANI x 5 AF cut-offs) from THIS table against the
+        # 30 files the reference's own run holds
+        from skder_amd import selection as S
+        D = os.path.join(gold, "downstream")
+        tc_same, tc_differ = 0, []
+        edges_tc = [(os.path.basename(a), os.path.basename(b), x, y, z) for a, b, x, y, z in S.edges_from_table(out)]
+        n50_tc = S.read_n50(os.path.join(D, "skder_gtdb_results__Concatenated_N50.txt"))
+        for a in (90.0, 95.0, 97.0, 98.0, 99.0, 99.5):
+            for fcut in (10.0, 25.0, 50.0, 75.0, 90.0):
+                with open(os.path.join(D, "tc", "skDER_Results_ANI%s_AF%s.txt" % (a, fcut))) as fh:
+                    wanted = [l.rstrip("\n") for l in fh]
+                if S.greedy_from_edges(edges_tc, n50_tc, a, fcut) == wanted:
+                    tc_same += 1
+                else:
+                    tc_differ.append("ANI%s_AF%s" % (a, fcut))
         # the real engine, if this box has it (oracle/skani_ref.py): the same listing through `skani triangle`, cell by cell
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import skani_ref
@@ -188,6 +221,10 @@ def golden_parity(device):
             "max_abs_dANI": float(np.abs(d_ani).max()), "rms_dANI": float(np.sqrt((d_ani ** 2).mean())),
             "max_abs_dAF": float(np.abs(d_af).max()), "rms_dAF": float(np.sqrt((d_af ** 2).mean())),
             "pairs": seen, "golden_pairs": len(want), "unit": "percentage points",
+            "values_equal_at_print_precision": {"equal": values_equal, "of": 3 * len(want), "what": "ANI, AF_ref, AF_query of the golden rows that print the same two decimals"},
+            "rows_fully_equal": {"equal": rows_equal, "of": len(want)},
+            "tc_listings_identical": {"equal": tc_same, "of": 30, "differ": tc_differ,
+                                      "what": "greedy representative listings of the reference's 6 x 5 cut-off sweep from this table vs the reference's 30 files"},
             "drop_in_call": {"seconds": call_s, "gz_bytes": gz_bytes, "what": "skder_amd_triangle_n50 on the reference's 34 .fasta.gz files (listing -> N50 table + edge table on disk), one call incl. context creation"},
             "against": "skani table of the reference's own test run (tests/golden/G5: 34 C. granulosum genomes, ANI 96.4-100, two decimals); "
                        "skani's version is unpinned and its learned-ANI model is replaced by a fitted map (DESIGN.md 2)"}
@@ -643,11 +680,12 @@ def low_mem_greedy_one_species(engine, ctx, torch, synth, n, device, sequential=
 
 
 def cpu_baseline_files(tmp, paths, threads):
-    """oracle (CPU restatement, OpenMP) on the sample files, wall clock on `threads` host threads:
-      per genome   : read + sketch, from a triangle whose 101 % screen lets no pair through;
+    """oracle (CPU restatement, OpenMP) on the sample files, wall clock on `threads` host threads.  MEASURED: one `triangle` over all the
+    files -- every pair screened, every screened pair chained.  Beside it three rates for the extrapolation to the full workload:
+      per genome   : read + sketch, from a triangle over the first files whose 101 % screen lets no pair through;
       per pair     : the pairwise marker screen, timed on one thread over cross-genome pairs and divided
                      by `threads` (perfect scaling assumed: the optimistic choice for the CPU);
-      per chained  : the full triangle's extra time per pair that passes the screen."""
+      per chained  : the full triangle's remaining time per pair that passes the screen."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py
     p = oracle_py.default_params()
@@ -662,8 +700,9 @@ def cpu_baseline_files(tmp, paths, threads):
         return dt, sum(1 for _ in open(out)) - 1
 
     n = len(paths)
-    t_load, _ = run(paths, 101.0)
     t_full, chained = run(paths, 80.0)
+    n_load = min(n, 512)
+    t_load, _ = run(paths[:n_load], 101.0)
     k = min(n, 24)
     gs = [oracle_py.Genome.load(q, p) for q in paths[:k]]
     t0 = time.perf_counter()
@@ -675,9 +714,8 @@ def cpu_baseline_files(tmp, paths, threads):
                 npair += 1
     t_screen = (time.perf_counter() - t0) / max(npair, 1)
     per_pair = t_screen / threads
-    per_genome = t_load / n
-    # the full triangle's time beyond read + sketch is the screen of every pair plus the chaining of those that pass
-    per_chained = max(t_full - t_load - per_pair * (n * (n - 1) // 2), 0.0) / max(chained, 1)
+    per_genome = t_load / n_load
+    per_chained = max(t_full - per_genome * n - per_pair * (n * (n - 1) // 2), 0.0) / max(chained, 1)
     measured = {"files": n, "pairs": n * (n - 1) // 2, "chained_pairs": chained, "wall_s": t_full, "pairs_per_s": (n * (n - 1) // 2) / t_full,
                 "what": "one `triangle` of the oracle over the sample files, every pair screened, every screened pair chained: MEASURED wall clock"}
     return per_genome, per_pair, per_chained, chained, t_load + t_full + t_screen * npair, measured
@@ -731,6 +769,110 @@ def cpu_baseline_skani(tmp, paths, threads):
             "seconds": full["seconds"], "sample_pairs_per_s": n * (n - 1) / 2 / full["seconds"], "version": full["version"], "command": full["command"]}
 
 
+def end_to_end_legs(out, tmp, all_paths, sizes, args, dev, total_bases, ms_per_step):
+    """second clock: listing file -> TSV on disk through the drop-in entry point, on bounded samples; never part of
+    `value`.  Two nested samples (the first e2e_genomes files, and four times as many): the call has a fixed part (context, pinned
+    staging buffers, first-use allocations, the triangle of a small set) that a 0.8 GB sample cannot amortise; the RATE of the
+    ingest is the slope between the two, and the extrapolation uses intercept + slope.  Fills out["end_to_end"] and ["end_to_end_gz"]."""
+    n_small = min(args.e2e_genomes, len(all_paths))
+    big_paths = all_paths[:min(4 * args.e2e_genomes, len(all_paths))]
+    big_sizes = sizes[:len(big_paths)]
+    paths, nbytes = big_paths[:n_small], sum(big_sizes[:n_small])
+
+    def two_point(small_paths, small_bytes, big, big_bytes):
+        end_to_end_sample(tmp, small_paths[:8], sum(big_sizes[:8]), dev)      # code objects and the context's first-use allocations exist after this
+        cold = end_to_end_sample(tmp, small_paths, small_bytes, dev)      # pins the staging buffers at their working size (once per process)
+        a = end_to_end_sample(tmp, small_paths, small_bytes, dev)
+        a["first_call_s"] = cold["seconds"]
+        if len(big) <= len(small_paths):
+            return a
+        b = min((end_to_end_sample(tmp, big, big_bytes, dev) for _ in range(2)), key=lambda r: r["seconds"])
+        if b["seconds"] <= a["seconds"]:         # the big sample was not slower (noise): no slope to extrapolate from
+            b["small_sample"] = a
+            return a if a["seconds"] < b["seconds"] else b
+        slope = (b["fasta_bytes"] - a["fasta_bytes"]) / (b["seconds"] - a["seconds"])
+        b["small_sample"] = a
+        b["marginal_MB_per_s"] = slope / 1e6
+        b["fixed_s"] = max(a["seconds"] - a["fasta_bytes"] / slope, 0.0) + max(cold["seconds"] - a["seconds"], 0.0)
+        return b
+    e = two_point(paths, nbytes, big_paths, sum(big_sizes))
+    if "marginal_MB_per_s" in e:
+        e["extrapolated_full_workload_s"] = e["fixed_s"] + total_bases * 1.0125 / (e["marginal_MB_per_s"] * 1e6)
+    else:
+        e["extrapolated_full_workload_s"] = total_bases * 1.0125 / (e["fasta_bytes"] / e["seconds"]) + ms_per_step * 1e-3
+    try:
+        # the same call with the files' pages dropped from the page cache first: what the storage of this box gives
+        fs = evict_from_page_cache(big_paths)
+        cold = end_to_end_sample(tmp, big_paths, sum(big_sizes), dev)
+        e["cold_page_cache"] = {"seconds": cold["seconds"], "ingest_MB_per_s": cold["ingest_MB_per_s"], "file_system": fs,
+                                "how": "fsync + posix_fadvise(DONTNEED) on every file, then the call once"}
+    except Exception as ex:
+        e["cold_page_cache"] = {"error": repr(ex)}
+    e["sample"] = ("skder_amd_triangle_n50 on %d FASTA files of the workload (every second genome; page cache hot): read, PCIe copy, FASTA parse on the device, N50, "
+                   "sketch, index, screen, chain, TSV. ingest_MB_per_s = bytes / seconds of the whole call; marginal_MB_per_s = the slope "
+                   "between this sample and its first %d files (small_sample; both with the staging buffers of an earlier call), i.e. the ingest "
+                   "pipeline's rate without the call's fixed part; fixed_s = the small sample's intercept + what its FIRST call in the process "
+                   "took longer (pinning the staging buffers: first_call_s); extrapolation = fixed_s + the full workload's FASTA bytes at the marginal rate"
+                   % (e["genomes"], len(paths)))
+    out["end_to_end"] = e
+    # the same samples as .fasta.gz: one zlib stream per file, inflated on the host threads beside the parser
+    gz_all, _ = gzip_sample_files(big_paths)
+    gz_sizes = [os.path.getsize(q) for q in gz_all]
+    eg = two_point(gz_all[:len(paths)], nbytes, gz_all, sum(big_sizes))
+    eg["gz_bytes"] = sum(gz_sizes[:eg["genomes"]])
+    eg["gz_MB_per_s"] = eg["gz_bytes"] / eg["seconds"] / 1e6
+    if "marginal_MB_per_s" in eg:
+        eg["extrapolated_full_workload_s"] = eg["fixed_s"] + total_bases * 1.0125 / (eg["marginal_MB_per_s"] * 1e6)
+    eg["sample"] = ("the same files gzip-compressed (level 1, %.2f x): skder_amd_triangle_n50 from .fasta.gz; ingest_MB_per_s and marginal_MB_per_s count "
+                    "uncompressed FASTA bytes, gz_MB_per_s compressed ones; page cache hot" % (sum(big_sizes) / max(sum(gz_sizes), 1)))
+    out["end_to_end_gz"] = eg
+    for q in gz_all:
+        os.remove(q)
+
+
+def cpu_baseline(tmp, all_paths, N, pairs, n_chained):
+    """the `cpu_baseline` object of the line: the reference engine itself when the box has it (kind "reference"), else the oracle
+    (kind "port").  `value` is MEASURED -- the sample's pairs over the wall clock of one triangle on the sample, whose share of chained
+    pairs is the full workload's; the extrapolation to the full workload from the per-stage rates is a side field."""
+    threads = max(1, min(32, granted_cpus()))
+    n = len(all_paths)
+    sample_what = ("every second genome of the workload: %d FASTA files, %d pairs -- every species of the workload with half of its strains, so the "
+                   "share of pairs that are chained equals the full workload's" % (n, n * (n - 1) // 2))
+    sk = cpu_baseline_skani(tmp, all_paths, granted_cpus())
+    if sk is not None:
+        est = N * sk["per_genome"] + n_chained * sk["per_chained"]
+        return {"value": sk["sample_pairs_per_s"], "unit": "genome-pairs/s", "cores": granted_cpus(), "kind": "reference", "skani_version": sk["version"],
+                "value_is": "measured: the sample's pairs / the wall clock of `skani triangle` on the sample", "extrapolated_full_workload_pairs_per_s": pairs / est,
+                "sample": "%s; %s, wall clock %.1f s, %d rows; a -s 100 run prices read + sketch at %.4f s/genome, the rest is %.5f s per chained pair"
+                          % (sample_what, sk["command"], sk["seconds"], sk["chained"], sk["per_genome"], sk["per_chained"])}
+    pg, pp, pc, chained, spent, measured = cpu_baseline_files(tmp, all_paths, threads)
+    est = N * pg + pairs * pp + n_chained * pc
+    return {"value": measured["pairs_per_s"], "unit": "genome-pairs/s", "cores": threads, "kind": "port", "measured_on_sample": measured,
+            "value_is": "measured: the sample's pairs / the wall clock of one oracle `triangle` over the sample's files (read, sketch, every pair screened, "
+                        "every screened pair chained); the sample has %.2f x the full workload's share of chained pairs" 
+                        % ((measured["chained_pairs"] / max(measured["pairs"], 1)) / max(n_chained / max(pairs, 1), 1e-12)),
+            "extrapolated_full_workload_pairs_per_s": pairs / est,
+            "extrapolation": "genomes x %.4f s (read + sketch) + pairs x %.2e s (marker screen) + chained pairs x %.5f s, the three rates measured on the sample: "
+                             "%d genomes, %d pairs, %d chained pairs" % (pg, pp, pc, N, pairs, int(n_chained)),
+            "skani": "unavailable on this host (oracle/skani_ref.py looked for it on PATH and in the usual conda locations): the repo's own CPU restatement is timed instead",
+            "sample": "%s; oracle (CPU restatement, OpenMP, %d threads, wall clock), %.1f s of wall time spent in this leg" % (sample_what, threads, spent)}
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: N ranks of this script under torch.distributed.run (one rank per GPU over RCCL),
+    started as a child process BEFORE torch or the library is imported here; the rendezvous is on 127.0.0.1 at a free port."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -744,6 +886,7 @@ def main():
     ap.add_argument("--batch-genomes", type=int, default=2500, help="genomes per resident input batch (one sketch call each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--e2e-genomes", type=int, default=256, help="genomes in the file-based end-to-end sample (0: skip)")
+    ap.add_argument("--cpu-sample-genomes", type=int, default=2500, help="genomes of the CPU baseline's sample: every second genome of the workload, at most this many")
     ap.add_argument("--dump-edges", default=None, metavar="FILE.npy", help="rank 0 writes the last step's edge records, sorted by (ref, query)")
     ap.add_argument("--no-realistic", action="store_true", help="skip the extra workloads (real genomes, indels, mixed sizes)")
     ap.add_argument("--indel-genomes", type=int, default=48, help="genomes of the host-generated indel family")
@@ -755,11 +898,22 @@ def main():
     ap.add_argument("--low-mem-genomes", type=int, default=20000, help="genomes of the low_mem_greedy leg (README.md:27's workload shape: 20000; 0: skip)")
     args = ap.parse_args()
 
+    # --gpus N is the contract's flag.  Under a launcher (WORLD_SIZE set) it must agree with the launcher's world size; without one and
+    # with N > 1 this process starts N ranks itself, as a CHILD (never an exec: nothing here has touched the GPU yet, and the child's
+    # stdout is this process's, so the JSON line stays the last line), and returns the child's exit code.
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d does not match the launcher's WORLD_SIZE=%d (run `python bench.py --gpus N` without a launcher, "
+                 "or pass the same N to both)" % (args.gpus, world))
+
     import torch
     import torch.distributed as dist
     from skder_amd import engine, multigpu, synth
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # SKDER_AMD_DIST_BACKEND=gloo lets several ranks share one GPU (functional check of the N>1 path on
@@ -773,6 +927,9 @@ def main():
     if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
+            if world > max(ndev, 0):
+                sys.exit("bench.py: --gpus %d but this node shows %d GPU(s): RCCL needs one GPU per rank (SKDER_AMD_DIST_BACKEND=gloo lets "
+                         "ranks share a GPU for a functional check)" % (world, ndev))
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
         else:
             dist.init_process_group(backend)
@@ -874,14 +1031,14 @@ def main():
     tm = np.mean(tms, axis=0)
     # In the timed region the chaining batches alternate between two queues and overlap, so the event bracket
     # of a chain-stage kernel there includes the chip time it shared with the other queue.  Per-kernel durations of that
-    # stage are therefore taken from two extra steps, outside the timed region, with all batches on one queue; the sketch
+    # stage are therefore taken from ONE_QUEUE_STEPS extra steps (their mean), outside the timed region, with all batches on one queue; the sketch
     # kernel (the longest, never overlapped) keeps the timed region's figure.
     overlapped = {"join_probe_kernel": float(step.counters[2]) / 1000.0, "run_extract_kernel": float(step.runs_ms),
                   "chain_single_kernel+chain_runs_kernel": float(tm[3]), "chain_slow_path": float(tm[4]), "finalize": float(tm[5])}
     one_queue_ms, one_queue_steps_ms = None, None
     if not dist_on and os.environ.get("SKDER_AMD_QUEUES") is None:
         # one discarded step after the queue count changes (the work buffers are laid out again), then ONE_QUEUE_STEPS steps timed one
-        # by one; the figures are those of the fastest step, and every step's time is in the line so that an outlier can be seen
+        # by one; the figures are the MEAN over those steps, and every step's time is in the line so that an outlier can be seen
         os.environ["SKDER_AMD_QUEUES"] = "1"
         step()
         torch.cuda.synchronize()
@@ -893,12 +1050,14 @@ def main():
             one_queue_steps_ms.append((time.perf_counter() - t1q) * 1e3)
             tq.append((t_, np.array(step.counters, copy=True), step.runs_ms, step.index_ms))
         del os.environ["SKDER_AMD_QUEUES"]
-        fastest = int(np.argmin(one_queue_steps_ms))
-        one_queue_ms = one_queue_steps_ms[fastest]
-        tm[2:6] = tq[fastest][0][2:6]
+        # the MEAN of the one-queue steps, like ms_per_step is the mean of the timed steps: the same statistic on both sides of every ratio
+        one_queue_ms = float(np.mean(one_queue_steps_ms))
+        tm[2:6] = np.mean([q[0][2:6] for q in tq], axis=0)
         edges, _ = step()          # back on the shipped two queues: the edges checked below are those of the shipped path
         torch.cuda.synchronize()
-        _, step.counters, step.runs_ms, step.index_ms = tq[fastest]       # per-kernel figures: the fastest one-queue step's
+        step.counters = np.mean([q[1].astype(np.float64) for q in tq], axis=0)
+        step.runs_ms = float(np.mean([q[2] for q in tq]))
+        step.index_ms = float(np.mean([q[3] for q in tq]))
     n_chained_all = float(tm[6])
     if dist_on:
         t = torch.tensor([tm[6]], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
@@ -934,6 +1093,11 @@ def main():
             if kept[3] is not None:
                 step.exchange_stats = kept[3]
 
+    # the last collective is behind us: the ranks part here, and rank 0 finishes the line (and its CPU legs) on its own
+    rccl_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "devices_visible": ndev} if dist_on else None
+    if dist_on:
+        dist.barrier()
+        dist.destroy_process_group()
     if rank == 0 and args.dump_edges:
         e = np.array(edges, copy=True)
         np.save(args.dump_edges, e[np.lexsort((e["query"], e["ref"]))])
@@ -965,7 +1129,7 @@ def main():
         limiter = {"sketch_tiles_kernel": "VALU issue: two mm_hash64 per position; the body costs 93 ns per position and wavefront against 107 for the compiler's "
                                           "instruction selection (profiles/round3_sketch_body.json), HBM traffic = 1.07 x algorithmic",
                    "join_probe_kernel": "instruction issue: ~118 wavefront instructions per 64 probes (79 VALU, 25 SALU) at two workgroups per CU; "
-                                        "LDS bank conflicts 7 % of LDS cycles (profiles/round3_pmc_join_probe_kernel.txt)",
+                                        "LDS bank conflicts 7 % of LDS cycles (profiles/round6_pmc_join_probe_kernel.txt)",
                    "run_extract_kernel": "HBM: 9 B per seed at ~5 TB/s",
                    "chain_single_kernel+chain_runs_kernel": "memory latency: a dozen dependent loads per wavefront"}
         bound_of = {"sketch_tiles_kernel": "valu-issue", "join_probe_kernel": "valu-issue", "run_extract_kernel": "hbm",
@@ -983,24 +1147,29 @@ def main():
         s8_all = gbs(s8_sketch["bytes"] + s8_chain["bytes"], ms_per_step)          # over the whole step's wall time
         # measured HBM traffic of the dominant kernel per step (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
         # separate passes, profiles/round1_pmc_traffic.json; only valid for the default workload on 1 GPU)
-        traffic, traffic_source = None, None
-        try:
-            if N == 5000 and world == 1 and args.len_range is None and args.genome_len == 3_000_000:
-                src = PMC_TRAFFIC
-                if not os.path.isfile(os.path.join(ROOT, src)):
-                    raise RuntimeError("%s is missing: roofline.traffic has no source (collect it with profiles/collect.sh)" % src)
-                pm = json.load(open(os.path.join(ROOT, src)))[dom.split("+")[0]]
+        traffic, traffic_source, step_traffic = None, None, None
+        if N == 5000 and world == 1 and args.len_range is None and args.genome_len == 3_000_000:
+            src = PMC_TRAFFIC
+            try:
+                allk = json.load(open(os.path.join(ROOT, src)))
+                pm = allk[dom.split("+")[0]]
                 # counter values corrected by the calibration of profiles/calib (profiles/summarise.py)
                 traffic = sum(pm[c].get("corrected_bytes", pm[c]["sum_counter_kb"] * 1024.0) for c in ("FETCH_SIZE", "WRITE_SIZE"))
                 traffic_source = src + " (static: rocprofv3 --pmc passes of this build, not measured in this run)"
-        except (KeyError, ValueError):
-            traffic = None
+                step_traffic = allk.get("__step__", {}).get("bytes")
+            except OSError:
+                traffic_source = "missing: %s (collect it with profiles/collect.sh)" % src       # an auxiliary field never costs the line
+            except (KeyError, ValueError) as ex:
+                traffic_source = "unreadable: %s (%r)" % (src, ex)
+        # the VALU-bound kernel against its own issue floor: the inner body alone (profiles/calib/sketch_body_bench.hip, the shipped
+        # instruction selection, ns per position and wavefront per SIMD) over what the whole kernel takes per position and wavefront
+        ns_pw = float(tm[0] * 1e6 * 1024 / (total_bases / 64.0)) if total_bases else 0.0
         out = {
             "metric": "genome-pairs ANI/sec on 5k x 3Mb synthetic", "value": pairs / (ms_per_step * 1e-3),
             "unit": "genome-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u64 hash / i32 chaining / f64 ANI", "data": "synthetic",
-            "rccl": ({"world_size": dist.get_world_size(), "backend": dist.get_backend(), "devices_visible": ndev} if dist_on else None),
+            "rccl": rccl_info,
             "config": {"workload": "%d synthetic genomes x %s Mb (%d species x 10 strains x 10 isolates), triangle, screen %.0f"
                        % (N, "%.1f" % (args.genome_len / 1e6) if args.len_range is None else
                           "%.1f-%.1f" % (args.len_range[0] / 1e6, args.len_range[1] / 1e6), max(1, N // 100), args.screen), "genomes": N, "pairs": pairs,
@@ -1012,14 +1181,20 @@ def main():
             # against the measured issue time of its own inner body (profiles/calib/sketch_body_bench.hip)
             "roofline": {"bound": bound_of[dom], "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "issue": ({"ns_per_position_wavefront_per_simd": float(dms * 1e6 * 1024 / (total_bases / 64.0)), "body_alone_ns": 93.4,
-                                    "compiler_selected_body_ns": 107.4, "source": "profiles/round3_sketch_body.json (256 CUs x 4 SIMDs)"}
+                         "valu_frac": (SKETCH_BODY_NS / ns_pw if (dom == "sketch_tiles_kernel" and ns_pw > 0) else None),
+                         "issue": ({"ns_per_position_wavefront_per_simd": ns_pw, "body_alone_ns": SKETCH_BODY_NS,
+                                    "compiler_selected_body_ns": 107.4, "source": "profiles/round3_sketch_body.json (256 CUs x 4 SIMDs)",
+                                    "valu_frac_is": "body_alone_ns / ns_per_position_wavefront_per_simd: the kernel against the measured issue time of "
+                                                    "its own inner loop -- the yardstick for a kernel whose HBM fraction says nothing"}
                                    if dom == "sketch_tiles_kernel" else None),
+                         "step_traffic_bytes": step_traffic,
+                         "step_traffic_GBs": (step_traffic / (ms_per_step * 1e-3) / 1e9 if step_traffic else None),
+                         "step_traffic_frac_of_peak": (step_traffic / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS if step_traffic else None),
                          "limited_by": limiter[dom], "algorithmic_bytes": dbytes,
                          "survey_8d": {"sketch": s8_sketch, "chain": s8_chain, "step": s8_all},
                          "kernel_ms": {k: float(v[0]) for k, v in cand.items()},
                          "kernel_ms_note": "chain-stage kernels (join, run extraction, sieve + run loop, slow path, finalize): HIP-event "
-                                           "durations of two extra steps with all batches on ONE queue; in the timed region the batches "
+                                           "durations of three extra steps (mean) with all batches on ONE queue; in the timed region the batches "
                                            "alternate between two queues and overlap, and their event brackets (kernel_ms_two_queues) "
                                            "include the wait for the other queue's share of the chip",
                          "kernel_ms_two_queues": overlapped, "ms_per_step_one_queue": one_queue_ms, "one_queue_steps_ms": one_queue_steps_ms,
@@ -1037,101 +1212,33 @@ def main():
                 out["exchange"].update(getattr(step, "exchange_stats", {}))
             out["exchange"]["other_exchange"] = other_exchange
         out["config"]["us_per_chained_pair"] = 1e3 * (join_ms + step.runs_ms + tm[3] + tm[4] + tm[5]) / max(n_chained, 1.0)
-        if world == 1 and not args.no_cpu_baseline and args.parity_pairs > 0:
+        extras = not args.no_cpu_baseline
+        # (rank 0 of an N > 1 job works on alone from here: the process group is gone, the other ranks have left)
+        if extras and args.parity_pairs > 0:
             out["parity_sample"] = parity_sample(recipe, edges, args.parity_pairs)
             out["config"]["parity_sample_pairs"] = out["parity_sample"]["pairs"]
             out["config"]["parity_sample_mismatches"] = out["parity_sample"]["mismatches"]
-        if world == 1 and not args.no_cpu_baseline:
+        if extras:
             out["parity_vs_skani"] = golden_parity(dev)
-        if world == 1 and not args.no_cpu_baseline and args.e2e_genomes > 0:
+            for k in ("values_equal_at_print_precision", "rows_fully_equal", "tc_listings_identical"):
+                out["config"]["golden_" + k] = out["parity_vs_skani"][k]["equal"]
+        batches.clear()      # the headline's resident bases are not needed any more
+        torch.cuda.empty_cache()
+        if extras:
             import shutil
-            # two nested samples (the first e2e_genomes files, and four times as many): the call has a fixed part (context,
-            # pinned staging buffers, first-use allocations, the triangle of a small set) that a 0.8 GB sample cannot amortise;
-            # the RATE of the ingest is the slope between the two, and the extrapolation uses intercept + slope
-            n_big = min(4 * args.e2e_genomes, batches[0][0].n_genomes)
-            tmp, all_paths, _ = write_sample_files(batches, n_big)
-            sizes = [os.path.getsize(q) for q in all_paths]
-            paths, nbytes = all_paths[:args.e2e_genomes], sum(sizes[:args.e2e_genomes])
+            # The CPU sample: every second genome of the workload -- with 100 genomes per species (10 strains x 10 isolates) that is
+            # every species with 5 strains x 10 isolates, so the share of pairs that pass the screen and are chained is the full
+            # workload's (1.96 % against 1.98 %), unlike a block of consecutive genomes (a few whole species: 4.8 x denser)
+            sample = list(range(0, N, 2))[:args.cpu_sample_genomes] if args.cpu_sample_genomes > 0 else []
+            tmp, all_paths, sizes = write_workload_sample(engine, ctx, torch, recipe, sample)
             try:
-                # second clock: listing file -> TSV on disk through the drop-in entry point, on a
-                # bounded sample; never part of `value`
-                def two_point(small_paths, small_bytes, big_paths, big_bytes):
-                    end_to_end_sample(tmp, small_paths[:8], sum(sizes[:8]), dev)      # code objects and the context's first-use allocations exist after this
-                    cold = end_to_end_sample(tmp, small_paths, small_bytes, dev)      # pins the staging buffers at their working size (once per process)
-                    a = end_to_end_sample(tmp, small_paths, small_bytes, dev)
-                    a["first_call_s"] = cold["seconds"]
-                    if len(big_paths) <= len(small_paths):
-                        return a
-                    b = min((end_to_end_sample(tmp, big_paths, big_bytes, dev) for _ in range(2)), key=lambda r: r["seconds"])
-                    if b["seconds"] <= a["seconds"]:         # the big sample was not slower (noise): no slope to extrapolate from
-                        b["small_sample"] = a
-                        return a if a["seconds"] < b["seconds"] else b
-                    slope = (b["fasta_bytes"] - a["fasta_bytes"]) / (b["seconds"] - a["seconds"])
-                    b["small_sample"] = a
-                    b["marginal_MB_per_s"] = slope / 1e6
-                    b["fixed_s"] = max(a["seconds"] - a["fasta_bytes"] / slope, 0.0) + max(cold["seconds"] - a["seconds"], 0.0)
-                    return b
-                e = two_point(paths, nbytes, all_paths, sum(sizes))
-                if "marginal_MB_per_s" in e:
-                    e["extrapolated_full_workload_s"] = e["fixed_s"] + total_bases * 1.0125 / (e["marginal_MB_per_s"] * 1e6)
-                else:
-                    e["extrapolated_full_workload_s"] = total_bases * 1.0125 / (e["fasta_bytes"] / e["seconds"]) + ms_per_step * 1e-3
-                try:
-                    # the same call with the files' pages dropped from the page cache first: what the storage of this box gives
-                    fs = evict_from_page_cache(all_paths)
-                    cold = end_to_end_sample(tmp, all_paths, sum(sizes), dev)
-                    e["cold_page_cache"] = {"seconds": cold["seconds"], "ingest_MB_per_s": cold["ingest_MB_per_s"], "file_system": fs,
-                                            "how": "fsync + posix_fadvise(DONTNEED) on every file, then the call once"}
-                except Exception as ex:
-                    e["cold_page_cache"] = {"error": repr(ex)}
-                e["sample"] = ("skder_amd_triangle_n50 on %d FASTA files written from the resident bases (page cache hot): read, PCIe copy, FASTA parse on the device, N50, "
-                               "sketch, index, screen, chain, TSV. ingest_MB_per_s = bytes / seconds of the whole call; marginal_MB_per_s = the slope "
-                               "between this sample and its first %d files (small_sample; both with the staging buffers of an earlier call), i.e. the ingest "
-                               "pipeline's rate without the call's fixed part; fixed_s = the small sample's intercept + what its FIRST call in the process "
-                               "took longer (pinning the staging buffers: first_call_s); extrapolation = fixed_s + the full workload's FASTA bytes at the marginal rate (the sample is denser in "
-                               "chained pairs than the full workload, so its triangle share is on the safe side)" % (e["genomes"], len(paths)))
-                out["end_to_end"] = e
-                # the same samples as .fasta.gz: one zlib stream per file, inflated on the host threads beside the parser
-                gz_all, _ = gzip_sample_files(all_paths)
-                gz_sizes = [os.path.getsize(q) for q in gz_all]
-                eg = two_point(gz_all[:len(paths)], nbytes, gz_all, sum(sizes))
-                eg["gz_bytes"] = sum(gz_sizes[:eg["genomes"]])
-                eg["gz_MB_per_s"] = eg["gz_bytes"] / eg["seconds"] / 1e6
-                if "marginal_MB_per_s" in eg:
-                    eg["extrapolated_full_workload_s"] = eg["fixed_s"] + total_bases * 1.0125 / (eg["marginal_MB_per_s"] * 1e6)
-                eg["sample"] = ("the same files gzip-compressed (level 1, %.2f x): skder_amd_triangle_n50 from .fasta.gz; ingest_MB_per_s and marginal_MB_per_s count "
-                                "uncompressed FASTA bytes, gz_MB_per_s compressed ones; page cache hot" % (sum(sizes) / max(sum(gz_sizes), 1)))
-                out["end_to_end_gz"] = eg
-                threads = max(1, min(32, granted_cpus()))
-                sk = cpu_baseline_skani(tmp, paths, granted_cpus())
-                if sk is not None:
-                    # the reference engine is on this box: it IS the baseline (kind "reference")
-                    est = N * sk["per_genome"] + n_chained * sk["per_chained"]
-                    out["cpu_baseline"] = {"value": pairs / est, "unit": "genome-pairs/s", "cores": granted_cpus(), "kind": "reference",
-                                           "skani_version": sk["version"],
-                                           "sample": "%s on the same %d FASTA files, wall clock %.1f s (%.0f pairs/s on the sample itself, %d rows): "
-                                                     "%.4f s/genome read+sketch (a -s 100 run), %.5f s per chained pair; extrapolated to %d genomes, "
-                                                     "%d chained pairs" % (sk["command"], len(paths), sk["seconds"], sk["sample_pairs_per_s"], sk["chained"],
-                                                                           sk["per_genome"], sk["per_chained"], N, int(n_chained))}
-                else:
-                    # MEASURED on the large sample (1,024 files of the workload: 523,776 pairs, every screened pair chained), and the
-                    # extrapolation to the full workload from its three measured rates beside it
-                    pg, pp, pc, chained, spent, measured = cpu_baseline_files(tmp, all_paths, threads)
-                    est = N * pg + pairs * pp + n_chained * pc
-                    out["cpu_baseline"] = {"value": pairs / est, "unit": "genome-pairs/s", "cores": threads, "kind": "port", "measured_on_sample": measured,
-                                           "value_is": "the extrapolation to the full workload (genomes x read+sketch + pairs x screen + chained pairs x chaining, all three rates "
-                                                       "measured on the sample); measured_on_sample.pairs_per_s is the sample's own wall-clock rate (it has %.1f x the full workload's share of chained pairs)"
-                                                       % ((measured["chained_pairs"] / max(measured["pairs"], 1)) / max(n_chained / max(pairs, 1), 1e-12)),
-                                           "skani": "unavailable on this host (oracle/skani_ref.py looked for it on PATH): the repo's own CPU restatement is timed instead",
-                                           "sample": "oracle (CPU restatement, OpenMP, %d threads, wall clock) on the same %d FASTA files: "
-                                                     "%.4f s/genome read+sketch, %.2e s/pair marker screen, %.5f s/chained pair (%d pairs); "
-                                                     "%.1f s of wall time spent; extrapolated to %d genomes, %d pairs, %d chained pairs"
-                                                     % (threads, len(all_paths), pg, pp, pc, chained, spent, N, pairs, int(n_chained))}
+                if world == 1 and args.e2e_genomes > 0 and len(all_paths) >= 8:
+                    end_to_end_legs(out, tmp, all_paths, sizes, args, dev, total_bases, ms_per_step)
+                if all_paths:
+                    out["cpu_baseline"] = cpu_baseline(tmp, all_paths, N, pairs, n_chained_all)
             finally:
                 shutil.rmtree(tmp, ignore_errors=True)
-        if world == 1 and not args.no_realistic and not args.no_cpu_baseline:
-            batches.clear()      # the headline's resident bases are not needed any more
-            torch.cuda.empty_cache()
+        if world == 1 and not args.no_realistic and extras:
             out["realistic"] = realistic_workloads(engine, ctx, torch, synth, args)
             for k, v in out["realistic"].items():            # (scalars under config survive the driver's parse of the line)
                 if k.startswith("real_derived_") and isinstance(v, dict) and "us_per_chained_pair" in v:
@@ -1148,10 +1255,8 @@ def main():
                     out["realistic"]["low_mem_greedy_one_species"] = low_mem_greedy_one_species(engine, ctx, torch, synth, args.one_species_genomes, dev)
                 except Exception as ex:
                     out["realistic"]["low_mem_greedy_one_species"] = {"error": repr(ex)}
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     ctx.close()
-    if dist_on:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

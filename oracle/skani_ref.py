@@ -17,9 +17,31 @@ import subprocess
 import time
 
 
+def _candidates():
+    """where a conda / mamba install of skDER's environment (skDER_env.yml:12) would put the binary, beyond PATH"""
+    import glob
+    home = os.path.expanduser("~")
+    pre = [os.environ.get("CONDA_PREFIX"), os.environ.get("MAMBA_ROOT_PREFIX")]
+    dirs = [os.path.join(p, "bin") for p in pre if p]
+    for root in (os.path.join(home, "miniconda3"), os.path.join(home, "miniforge3"), os.path.join(home, "mambaforge"), os.path.join(home, "anaconda3"),
+                 os.path.join(home, "micromamba"), "/opt/conda", "/opt/miniconda3", "/opt/miniforge3", "/usr/local/conda"):
+        dirs.append(os.path.join(root, "bin"))
+        dirs += sorted(glob.glob(os.path.join(root, "envs", "*", "bin")))
+    dirs += [os.path.join(home, ".cargo", "bin"), "/usr/local/bin"]
+    return dirs
+
+
 def find():
-    """absolute path of the skani executable, or None"""
-    return shutil.which("skani")
+    """absolute path of the skani executable, or None: PATH first, then the usual conda / cargo locations
+    (SKANI_REF_NO_SEARCH=1 restricts the probe to PATH: the tests' "absent" state)"""
+    exe = shutil.which("skani")
+    if exe or os.environ.get("SKANI_REF_NO_SEARCH") == "1":
+        return exe
+    for d in _candidates():
+        q = os.path.join(d, "skani")
+        if os.path.isfile(q) and os.access(q, os.X_OK):
+            return q
+    return None
 
 
 def version(exe=None):

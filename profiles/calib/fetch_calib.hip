@@ -10,6 +10,9 @@
 //   D write4_coalesced    4 B per lane, consecutive (join_probe_kernel's hit words)
 //   E gather4_random      4 B per lane at pseudo-random addresses in a 96 KB window that moves along the
 //                         buffer (join_probe_kernel's position gather: window = one genome's sgpos array)
+//   F gather16_random     16 B per lane at pseudo-random 16-byte slots of a 384 KB window that moves along the buffer
+//                         (index_genome_lds_kernel's dominant read stream: one genome's (k-mer, position, record) records
+//                         gathered through the bucket permutation; round 6)
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -63,6 +66,20 @@ __global__ void gather4_random(const uint32_t *__restrict__ p, size_t n4, uint32
     }
     if (acc == 0x12345678u) *sink = acc;
 }
+__global__ void gather16_random(const uint4 *__restrict__ p, size_t n16, uint32_t *sink)
+{
+    uint32_t acc = 0;
+    const size_t win = 24576;   // 384 KB of 16-byte records: one 3 Mb genome's seeds
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t base = (i / win) * win;
+        uint32_t h = (uint32_t)i * 2654435761u;
+        h ^= h >> 15;
+        const size_t j = base + h % win;
+        const uint4 v = p[j < n16 ? j : 0];
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x12345678u) *sink = acc;
+}
 
 int main()
 {
@@ -79,9 +96,10 @@ int main()
     hipLaunchKernelGGL(read_line_per_lane, grid, block, 0, 0, (const uint4 *)buf, bytes / 640, sink);
     hipLaunchKernelGGL(write4_coalesced, grid, block, 0, 0, (uint32_t *)buf, bytes / 4);
     hipLaunchKernelGGL(gather4_random, grid, block, 0, 0, (const uint32_t *)buf, bytes / 4, sink);
+    hipLaunchKernelGGL(gather16_random, grid, block, 0, 0, (const uint4 *)buf, bytes / 16, sink);
     CK(hipDeviceSynchronize());
     printf("known_bytes read16_coalesced %zu\nknown_bytes read4_coalesced %zu\nknown_bytes read_line_per_lane %zu\n"
-           "known_bytes write4_coalesced %zu\nknown_bytes gather4_random %zu\n",
-           bytes, bytes, (bytes / 640) * 640, bytes, bytes);
+           "known_bytes write4_coalesced %zu\nknown_bytes gather4_random %zu\nknown_bytes gather16_random %zu\n",
+           bytes, bytes, (bytes / 640) * 640, bytes, bytes, bytes);
     return 0;
 }

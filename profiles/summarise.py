@@ -30,7 +30,13 @@ PATTERN = {
     "run_extract_kernel": ("read16_coalesced", "write4_coalesced"),
     "chain_single_kernel": ("read_line_per_lane", "write4_coalesced"),
     "chain_runs_kernel": ("read_line_per_lane", "write4_coalesced"),
+    # round 6: the index build's reads are the coalesced pass over the position-ordered seeds and, per seed, one 16-byte gather of its
+    # (k-mer, position, record) copy through the bucket permutation -- the gather dominates the request count
+    "index_genome_lds_kernel": ("gather16_random", "write4_coalesced"),
 }
+# kernels without a pattern of their own (copies, fills, scans, table builds: streaming accesses): the guide's rule for gfx950 -- a wide
+# coalesced read reports half its bytes -- i.e. the read16_coalesced factor for FETCH_SIZE, WRITE_SIZE as counted
+DEFAULT_PATTERN = ("read16_coalesced", "write4_coalesced")
 
 
 def counters(path):
@@ -83,6 +89,21 @@ def main():
                 e[cname]["factor"] = calib[pat]["factor"]
                 e[cname]["corrected_bytes"] = kb * 1024.0 * calib[pat]["factor"]
         traffic[k] = e
+    # the whole step: every kernel's counters after the calibration factors (its own pattern, else DEFAULT_PATTERN); the input generator
+    # (synth_fill_kernel) is not part of a step
+    step = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "kernels": 0}
+    for k, e in traffic.items():
+        if k.startswith("synth_fill"):
+            continue
+        step["kernels"] += 1
+        for idx, cname in enumerate(("FETCH_SIZE", "WRITE_SIZE")):
+            fac = calib.get(DEFAULT_PATTERN[idx], {}).get("factor") or 1.0
+            step[cname] += e[cname].get("corrected_bytes", e[cname]["sum_counter_kb"] * 1024.0 * fac)
+    step["bytes"] = step["FETCH_SIZE"] + step["WRITE_SIZE"]
+    step["what"] = ("sum over the kernels of one step (--steps 1 --warmup 0) of FETCH_SIZE and WRITE_SIZE after the calibration factors: "
+                    "a kernel's own pattern where it has one, else the guide's rule for streaming reads (x %.3f) and writes as counted"
+                    % (calib.get(DEFAULT_PATTERN[0], {}).get("factor") or 1.0))
+    traffic["__step__"] = step
     json.dump(traffic, open(os.path.join(DST, R + "_pmc_traffic.json"), "w"), indent=1)
     line = json.loads([l for l in open(os.path.join(SRC, "bench_line.json")) if l.startswith("{")][-1])
     # the bench line was printed before this summary existed: put this collection's traffic into it

@@ -310,28 +310,69 @@ def component_labels(n: int, ref: np.ndarray, query: np.ndarray, device=None) ->
         lab = new
 
 
-def component_owners(n: int, ref: np.ndarray, query: np.ndarray, n_seeds: np.ndarray, world: int, device=None) -> np.ndarray:
-    """owner[g] = the rank that chains every pair of g's component, -1 for a genome without a candidate pair (its seeds go nowhere).
-    Components by descending weight (sum over their pairs of the two genomes' seed counts: what chaining them reads), ties by label,
-    each to the least loaded rank (ties: the lowest) -- a pure function of its arguments, so every rank computes the same table."""
-    owner = np.full(n, -1, np.int64)
+def probed_genome(ref: np.ndarray, query: np.ndarray, genome_len: np.ndarray, genome_nrec: np.ndarray, n_seeds: np.ndarray,
+                  n_markers: np.ndarray) -> np.ndarray:
+    """the genome of every pair that is PROBED (the other one is cut into chunks): the library's rule (chain.hip chunk_the_query --
+    the less contiguous genome is chunked: total length x mean record length, then seed count, then marker count) on the per-genome
+    tables every rank holds after the marker all-gather; the same IEEE double operations, so the same answer"""
+    tq, tr = genome_len[query].astype(np.float64), genome_len[ref].astype(np.float64)
+    sq = tq * (tq / np.maximum(genome_nrec[query], 1).astype(np.float64))
+    sr = tr * (tr / np.maximum(genome_nrec[ref], 1).astype(np.float64))
+    sq_n, sr_n = n_seeds[query].astype(np.int64), n_seeds[ref].astype(np.int64)
+    mq_n, mr_n = n_markers[query].astype(np.int64), n_markers[ref].astype(np.int64)
+    chunk_query = np.where(sq != sr, sq < sr, np.where(sq_n != sr_n, sq_n < sr_n, np.where(mq_n != mr_n, mq_n < mr_n, True)))
+    return np.where(chunk_query, ref, query).astype(np.int64)
+
+
+def component_plan(n: int, ref: np.ndarray, query: np.ndarray, n_seeds: np.ndarray, world: int, probed: np.ndarray = None, device=None):
+    """Who chains which pair, and who must therefore hold which genome's seeds: (pair_rank[k], holds[world, n] bool).
+
+    Components of the candidate-pair graph by descending weight (sum over their pairs of the two genomes' seed counts: what chaining
+    them reads), ties by label.  A component no heavier than a rank's fair share (total / world) is an atom: all its pairs to the least
+    loaded rank (ties: the lowest).  A HEAVIER one -- one species holding most of the genomes, the shape of the reference's published
+    low_mem_greedy workload (README.md:27) -- goes back to the replicate rule INSIDE the component: it is shared by the
+    ceil(weight / fair) least loaded ranks, its pairs dealt out by probed genome (probed mod the number of sharing ranks, so that the
+    pairs probing one genome stay together, as the join wants them), and every sharing rank holds the genomes its pairs touch.
+    A pure function of its arguments: every rank computes the same plan."""
+    pair_rank = np.full(len(ref), -1, np.int64)
+    holds = np.zeros((world, n), bool)
     if len(ref) == 0:
-        return owner
+        return pair_rank, holds
+    ref, query = np.asarray(ref, np.int64), np.asarray(query, np.int64)
     lab = component_labels(n, ref, query, device)
     w_pair = n_seeds[ref].astype(np.float64) + n_seeds[query].astype(np.float64)
-    w_label = np.bincount(lab[ref], weights=w_pair, minlength=n)            # (a pair's two genomes carry one label)
-    labels = np.flatnonzero(np.bincount(lab[ref], minlength=n))
+    plab = lab[ref]                                                         # (a pair's two genomes carry one label)
+    w_label = np.bincount(plab, weights=w_pair, minlength=n)
+    labels = np.flatnonzero(np.bincount(plab, minlength=n))
     weight = w_label[labels]
+    fair = float(weight.sum()) / world
+    by_label = np.argsort(plab, kind="stable")                              # the pairs of one component side by side
+    first = np.searchsorted(plab[by_label], labels, side="left")
+    last = np.searchsorted(plab[by_label], labels, side="right")
     load = np.zeros(world)
-    owner_of_label = np.full(n, -1, np.int64)
     for k in np.lexsort((labels, -weight)):
-        r = int(np.argmin(load))
-        owner_of_label[labels[k]] = r
-        load[r] += weight[k]
-    in_pair = np.zeros(n, bool)
-    in_pair[ref] = True
-    in_pair[query] = True
-    owner[in_pair] = owner_of_label[lab[in_pair]]
+        sel = by_label[first[k]:last[k]]
+        if world > 1 and weight[k] > fair and probed is not None:
+            share = min(world, int(np.ceil(weight[k] / fair)))
+            ranks = np.argsort(load, kind="stable")[:share]               # the least loaded ranks, ties to the lowest
+            pair_rank[sel] = ranks[np.asarray(probed, np.int64)[sel] % share]
+            load += np.bincount(pair_rank[sel], weights=w_pair[sel], minlength=world)
+        else:
+            r = int(np.argmin(load))
+            pair_rank[sel] = r
+            load[r] += weight[k]
+    holds[pair_rank, ref] = True
+    holds[pair_rank, query] = True
+    return pair_rank, holds
+
+
+def component_owners(n: int, ref: np.ndarray, query: np.ndarray, n_seeds: np.ndarray, world: int, device=None) -> np.ndarray:
+    """owner[g] = the rank that chains every pair of g's component when components are atoms (component_plan without a probed table:
+    nothing is split), -1 for a genome without a candidate pair (its seeds go nowhere)"""
+    pair_rank, holds = component_plan(n, ref, query, n_seeds, world, None, device)
+    owner = np.full(n, -1, np.int64)
+    r, g = np.nonzero(holds)
+    owner[g] = r
     return owner
 
 
@@ -346,23 +387,27 @@ def _ranges_index(starts: np.ndarray, lens: np.ndarray, device) -> torch.Tensor:
     return torch.repeat_interleave(first - before, lens_t) + torch.arange(total, dtype=torch.int64, device=device)
 
 
-def exchange_seeds(raw: Dict, first_genome: int, owner: np.ndarray, n_seeds: np.ndarray, blocks: List[range], group=None, staging: str = None):
-    """this rank's genomes are [first_genome, first_genome + raw['n_genomes']); owner / n_seeds are the global per-genome tables.
-    Every genome's seed k-mers and positions go to owner[g] (nowhere if -1) by ONE all_to_all_single per array; the receive sizes
-    follow from the global tables, so no counts are exchanged.  Returns (global indices of the genomes received, ascending;
-    their k-mers; their positions) -- the arrays hold the genomes back to back in that order."""
+def exchange_seeds(raw: Dict, first_genome: int, holds: np.ndarray, n_seeds: np.ndarray, blocks: List[range], group=None, staging: str = None):
+    """this rank's genomes are [first_genome, first_genome + raw['n_genomes']); holds[r, g]: rank r chains a pair of genome g and needs
+    its seeds (component_plan; a one-dimensional owner table -- owner[g] or -1 -- is accepted as well); n_seeds is the global per-genome
+    table.  Every genome's seed k-mers and positions go to each rank that holds it by ONE all_to_all_single per array; the receive
+    sizes follow from the global tables, so no counts are exchanged.  Returns (global indices of the genomes received, ascending; their
+    k-mers; their positions) -- the arrays hold the genomes back to back in that order."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    holds = np.asarray(holds)
+    if holds.ndim == 1:
+        holds = holds[None, :] == np.arange(world)[:, None]
     nccl = dist.get_backend(group) == "nccl"
     dev = raw["seed_kmer"].device if (nccl or staging != "cpu") else torch.device("cpu")
     ng = int(raw["n_genomes"])
     mine = np.arange(first_genome, first_genome + ng)
     local_off = (np.asarray(raw["seed_off"], np.uint64) - np.uint64(raw["seed_off"][0])).astype(np.int64) if ng else np.zeros(1, np.int64)
-    dest = owner[mine] if ng else np.zeros(0, np.int64)
-    order = np.flatnonzero(dest >= 0)
-    order = order[np.argsort(dest[order], kind="stable")]              # by destination, ascending genome inside one
+    # by destination, ascending genome inside one; a genome held by several ranks is sent to each
+    send_g = [np.flatnonzero(holds[d, mine]) for d in range(world)] if ng else [np.zeros(0, np.int64)] * world
+    order = np.concatenate(send_g) if ng else np.zeros(0, np.int64)
     idx = _ranges_index(local_off[order], n_seeds[mine[order]], dev)
-    n_out = [int(x) for x in np.bincount(dest[order], weights=n_seeds[mine[order]], minlength=world)] if len(order) else [0] * world
-    to_me = np.where(owner == rank, n_seeds, 0)
+    n_out = [int(n_seeds[mine[g]].sum()) for g in send_g]
+    to_me = np.where(holds[rank], n_seeds, 0)
     n_in = [int(to_me[blocks[r].start:blocks[r].stop].sum()) for r in range(world)]
     got = []
     for key in ("seed_kmer", "seed_gpos"):
@@ -372,11 +417,11 @@ def exchange_seeds(raw: Dict, first_genome: int, owner: np.ndarray, n_seeds: np.
             send, recv = send.cpu(), recv.cpu()
         dist.all_to_all_single(recv, send, output_split_sizes=n_in, input_split_sizes=n_out, group=group)
         got.append(recv.to(raw[key].device))
-    return np.flatnonzero(owner == rank), got[0], got[1]
+    return np.flatnonzero(holds[rank]), got[0], got[1]
 
 
 def triangle_by_components(ctx, sk, first_genome: int, n_total: int, rank: int, world: int, screen_pct: float, group=None,
-                           staging: str = None, copy: bool = True) -> np.ndarray:
+                           staging: str = None) -> np.ndarray:
     """this rank's share of the all-pairs table when `sk` holds only the genomes the rank sketched itself (module text).  The edge
     records carry global genome indices; their union over the ranks equals the one-rank table record for record."""
     import time
@@ -416,16 +461,24 @@ def triangle_by_components(ctx, sk, first_genome: int, n_total: int, rank: int, 
     allp = allp.cpu().numpy().reshape(world, mx)
     pairs = np.concatenate([allp[r, :cnts[r]] for r in range(world)])
     aref, aquery = (pairs >> 32).astype(np.int64), (pairs & 0xFFFFFFFF).astype(np.int64)
-    owner = component_owners(n_total, aref, aquery, n_seeds, world, device=dev if nccl else None)
+    g_len_all = np.concatenate([p["genome_len"] for p in mk]).astype(np.int64)
+    g_nrec_all = np.concatenate([p["genome_nrec"] for p in mk]).astype(np.int64)
+    n_markers = np.concatenate([np.diff(np.asarray(p["marker_off"], np.uint64).astype(np.int64)) for p in mk])
+    probed = probed_genome(aref, aquery, g_len_all, g_nrec_all, n_seeds, n_markers)
+    pair_rank, holds = component_plan(n_total, aref, aquery, n_seeds, world, probed, device=dev if nccl else None)
     lap()
-    have, kmer, gpos = exchange_seeds(raw, first_genome, owner, n_seeds, blocks, group=group, staging=staging)
+    have, kmer, gpos = exchange_seeds(raw, first_genome, holds, n_seeds, blocks, group=group, staging=staging)
     lap()
-    # the set this rank chains on: its components' genomes, ascending global index, local indices 0 ..
+    # the set this rank chains on: the genomes its pairs touch, ascending global index, local indices 0 ..
     edges = np.zeros(0, EDGE_DTYPE)
-    ob = owner[blocks[rank].start:blocks[rank].stop]
+    hb = holds[:, blocks[rank].start:blocks[rank].stop].copy()
+    hb[rank] = False                                            # (what a rank keeps for itself does not travel)
+    loads = np.bincount(pair_rank, weights=(n_seeds[aref] + n_seeds[aquery]).astype(np.float64), minlength=world) if len(aref) else np.zeros(world)
     stats = {"genomes_held": int(len(have)), "seeds_received": int(kmer.numel()),
-             "bytes_sent_seeds": int(8 * n_seeds[blocks[rank].start:blocks[rank].stop][(ob >= 0) & (ob != rank)].sum()),
-             "bytes_sent_markers": int(8 * int(mk[rank]["markers"].numel()) * (world - 1)), "pairs_all": int(len(pairs))}
+             "bytes_sent_seeds": int(8 * (hb.sum(axis=0) * n_seeds[blocks[rank].start:blocks[rank].stop]).sum()),
+             "bytes_sent_markers": int(8 * int(mk[rank]["markers"].numel()) * (world - 1)), "pairs_all": int(len(pairs)),
+             "pairs_mine": int((pair_rank == rank).sum()), "genomes_held_by_several_ranks": int((holds.sum(axis=0) > 1).sum()),
+             "chain_load_max_over_mean": float(loads.max() / max(loads.mean(), 1e-30)) if len(aref) else 1.0}
     if len(have):
         m_off = np.concatenate([np.asarray(p["marker_off"], np.uint64).astype(np.int64)[:-1] + b for p, b in
                                 zip(mk, np.concatenate([[0], np.cumsum([int(p["markers"].numel()) for p in mk])])[:-1])])
@@ -446,7 +499,7 @@ def triangle_by_components(ctx, sk, first_genome: int, n_total: int, rank: int, 
         ls.index()
         local = np.full(n_total, -1, np.int64)
         local[have] = np.arange(len(have))
-        sel = owner[aref] == rank
+        sel = pair_rank == rank
         e = ls.chain_pairs(local[aref[sel]].astype(np.uint32), local[aquery[sel]].astype(np.uint32), copy=True)
         e["ref"] = have[e["ref"]]
         e["query"] = have[e["query"]]

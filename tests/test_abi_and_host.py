@@ -139,3 +139,15 @@ def test_sketch_store_staleness_rule(tmp_path):
     assert driver._store_is_fresh(then, driver._file_stamps(files))
     assert not driver._store_is_fresh(then, driver._file_stamps(files[::-1]))
     assert not driver._store_is_fresh(then, driver._file_stamps(files[:2]))
+
+
+def test_bench_gpus_flag_must_agree_with_the_launcher():
+    """bench.py --gpus N under a launcher whose WORLD_SIZE differs fails loudly, before torch or the library is imported
+    (the flag used to be parsed and never read)"""
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=3" in r.stderr and "--gpus 2" in r.stderr
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "0"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0

@@ -409,6 +409,44 @@ def test_ranks_share_the_triangle(gpu, tmp_path, world, exchange):
     e1, e2 = np.load(f1), np.load(f2)
     assert e1.dtype == e2.dtype and len(e1) == len(e2) > 0
     assert e1.tobytes() == e2.tobytes()
+    if exchange == "components":
+        # the 40 genomes are ONE species, i.e. one connected component heavier than any rank's fair share: it is split back into
+        # shares (multigpu.component_plan) -- every rank chains some of its pairs and genomes are held by several ranks
+        ex = j2["exchange"]
+        assert ex["genomes_held_by_several_ranks"] > 0 and 0 < ex["pairs_mine"] < ex["pairs_all"]
+        assert ex["chain_load_max_over_mean"] < 1.5
+
+
+def test_bench_gpus_flag_starts_its_own_ranks(gpu, tmp_path):
+    """`python bench.py --gpus 2` WITHOUT a launcher (the way the driver runs the bench): the script starts two ranks itself as a
+    child process (gloo here, both on this GPU), reports n_gpus 2, its edge records equal the one-rank run's bit for bit, and the
+    N > 1 line still carries the CPU baseline and the parity sample (rank 0 computes them after the ranks have parted)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SKDER_AMD_DIST_BACKEND"] = "gloo"
+    common = ["--genomes", "40", "--genome-len", "200000", "--steps", "1", "--warmup", "0", "--no-realistic", "--e2e-genomes", "0"]
+    f1, f2 = str(tmp_path / "one.npy"), str(tmp_path / "two.npy")
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common + ["--no-cpu-baseline", "--dump-edges", f1],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common + ["--dump-edges", f2],
+                         capture_output=True, text=True, env=env, timeout=900)
+    assert two.returncode == 0, two.stderr[-2000:]
+    last = [l for l in two.stdout.splitlines() if l.strip()][-1]
+    j2 = json.loads(last)                                   # the JSON line is the LAST line of the parent's stdout
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    assert j1["n_gpus"] == 1 and j1["rccl"] is None
+    assert j2["n_gpus"] == 2 and j2["rccl"]["world_size"] == 2 and j2["config"]["parallelism"] == "rows2"
+    assert len(j2["roofline"]["per_rank_stage_ms"]) == 2
+    e1, e2 = np.load(f1), np.load(f2)
+    assert len(e1) == len(e2) > 0 and e1.tobytes() == e2.tobytes()
+    assert j2["parity_sample"]["pairs"] > 0 and j2["parity_sample"]["mismatches"] == 0
+    cb = j2["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["measured_on_sample"]["files"] == 20
+    assert j2["parity_vs_skani"]["rows_fully_equal"]["of"] == 561 and j2["parity_vs_skani"]["tc_listings_identical"]["of"] == 30
 
 
 def test_several_gpus_in_one_process(gpu, tmp_path):

@@ -273,3 +273,135 @@ def test_seeds_go_to_the_owner_of_their_component(world):
         assert np.array_equal(have, np.flatnonzero(owner == r)) and len(have) > 0
         assert np.array_equal(kmer, np.concatenate([per_genome[g][0] for g in have]))
         assert np.array_equal(gpos, np.concatenate([per_genome[g][1] for g in have]))
+
+
+def _one_giant_and_small(seed=3, giant=300, small=(40, 25, 12, 6)):
+    """candidate pairs of one giant clique (a species holding most of the genomes) and a few small ones, per-genome tables made up so
+    that the probed-genome rule has something to decide on"""
+    rng = np.random.RandomState(seed)
+    sizes = (giant,) + tuple(small)
+    n = sum(sizes) + 5                       # five genomes without any pair at the end
+    groups, at = [], 0
+    for k in sizes:
+        groups.append(np.arange(at, at + k)); at += k
+    ref, query = [], []
+    for g in groups:
+        i, j = np.triu_indices(len(g), 1)
+        ref.append(g[i]); query.append(g[j])
+    ref, query = np.concatenate(ref), np.concatenate(query)
+    glen = rng.randint(2_000_000, 3_000_000, n).astype(np.int64)
+    nrec = rng.randint(1, 200, n).astype(np.int64)
+    n_seeds = (glen // 125 + rng.randint(-500, 500, n)).astype(np.int64)
+    n_mark = (glen // 1000).astype(np.int64)
+    return n, groups, ref, query, glen, nrec, n_seeds, n_mark
+
+
+def test_probed_genome_is_the_librarys_rule():
+    """multigpu.probed_genome against a scalar statement of chain.hip's chunk_the_query (the less contiguous genome is chunked)"""
+    sys.path.insert(0, ROOT)
+    from skder_amd import multigpu
+    n, _, ref, query, glen, nrec, n_seeds, n_mark = _one_giant_and_small()
+    glen[7] = glen[9]; nrec[7] = nrec[9]                        # ties fall through to the seed counts, then the marker counts
+    n_seeds[11] = n_seeds[13]; glen[11] = glen[13]; nrec[11] = nrec[13]; n_mark[11] = n_mark[13] + 1
+    got = multigpu.probed_genome(ref, query, glen, nrec, n_seeds, n_mark)
+    for k in np.random.RandomState(0).choice(len(ref), 2000, replace=False).tolist() + [int(np.flatnonzero((ref == 7) & (query == 9))[0]),
+                                                                                          int(np.flatnonzero((ref == 11) & (query == 13))[0])]:
+        r, q = int(ref[k]), int(query[k])
+        sq = float(glen[q]) * (float(glen[q]) / max(int(nrec[q]), 1)); sr = float(glen[r]) * (float(glen[r]) / max(int(nrec[r]), 1))
+        if sq != sr: cq = sq < sr
+        elif n_seeds[q] != n_seeds[r]: cq = n_seeds[q] < n_seeds[r]
+        elif n_mark[q] != n_mark[r]: cq = n_mark[q] < n_mark[r]
+        else: cq = True
+        assert int(got[k]) == (r if cq else q)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_an_oversized_component_is_split_back_into_shares(world):
+    """component_plan with one giant component + several small ones (the shape of README.md:27's workload): every pair
+    is chained on exactly one rank, the giant's pairs are dealt by probed genome over several ranks with the pairs of one probed genome
+    together, the small components stay atoms, a rank holds exactly the genomes its pairs touch, the chaining load is within 1.15 x
+    the mean, and the plan does not depend on the order of the pairs"""
+    sys.path.insert(0, ROOT)
+    from skder_amd import multigpu
+    n, groups, ref, query, glen, nrec, n_seeds, n_mark = _one_giant_and_small()
+    probed = multigpu.probed_genome(ref, query, glen, nrec, n_seeds, n_mark)
+    pair_rank, holds = multigpu.component_plan(n, ref, query, n_seeds, world, probed)
+    assert pair_rank.min() >= 0 and pair_rank.max() < world                      # every pair exactly once, somewhere
+    giant = np.isin(ref, groups[0])
+    assert len(set(pair_rank[giant].tolist())) == world                          # (its weight is > 90 % of everything: all ranks share it)
+    for g in np.unique(probed[giant]):                                           # the pairs that probe one genome stay together
+        assert len(set(pair_rank[giant & (probed == g)].tolist())) == 1
+    for g in groups[1:]:                                                         # small components are atoms
+        assert len(set(pair_rank[np.isin(ref, g)].tolist())) == 1
+    for r in range(world):
+        touched = np.zeros(n, bool)
+        touched[ref[pair_rank == r]] = True; touched[query[pair_rank == r]] = True
+        assert np.array_equal(holds[r], touched)
+    assert not holds[:, -5:].any()                                                # genomes without a pair go nowhere
+    w = (n_seeds[ref] + n_seeds[query]).astype(np.float64)
+    load = np.bincount(pair_rank, weights=w, minlength=world)
+    assert load.max() <= 1.15 * load.mean(), load / load.mean()
+    perm = np.random.RandomState(world).permutation(len(ref))
+    pr2, h2 = multigpu.component_plan(n, ref[perm], query[perm], n_seeds, world, probed[perm])
+    assert np.array_equal(pr2, pair_rank[perm]) and np.array_equal(h2, holds)
+    # without a probed table (component_owners' form) nothing is split
+    own = multigpu.component_owners(n, ref, query, n_seeds, world)
+    assert len(set(own[groups[0]].tolist())) == 1
+
+
+def _shared_seeds_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from skder_amd import multigpu
+    raws = [_fake_raw(r) for r in range(world)]
+    n = sum(x["n_genomes"] for x in raws)
+    cuts = np.concatenate([[0], np.cumsum([x["n_genomes"] for x in raws])])
+    blocks = [range(int(cuts[r]), int(cuts[r + 1])) for r in range(world)]
+    n_seeds = np.concatenate([np.diff(x["seed_off"].astype(np.int64)) for x in raws])
+    holds = _fake_holds(n, world)
+    have, kmer, gpos = multigpu.exchange_seeds(raws[rank], int(cuts[rank]), holds, n_seeds, blocks, staging="cpu")
+    q.put((rank, have, kmer.numpy(), gpos.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _fake_holds(n, world):
+    """genome g is held by rank (g mod world); every third genome by ALL ranks (a shared component's genome); every seventh by none"""
+    h = np.zeros((world, n), bool)
+    h[np.arange(n) % world, np.arange(n)] = True
+    h[:, ::3] = True
+    h[:, ::7] = False
+    return h
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_seeds_of_a_shared_component_reach_every_sharing_rank(world):
+    """multigpu.exchange_seeds with a holds matrix: a genome held by several ranks arrives on each of them, one held by none nowhere"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 37500 + os.getpid() % 2000 + world
+    procs = [ctx.Process(target=_shared_seeds_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, have, kmer, gpos = q.get(timeout=120)
+        got[r] = (have, kmer, gpos)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    raws = [_fake_raw(r) for r in range(world)]
+    per_genome = []
+    for x in raws:
+        off = (x["seed_off"] - x["seed_off"][0]).astype(np.int64)
+        for g in range(x["n_genomes"]):
+            per_genome.append((x["seed_kmer"].numpy()[off[g]:off[g + 1]], x["seed_gpos"].numpy()[off[g]:off[g + 1]]))
+    holds = _fake_holds(len(per_genome), world)
+    assert (holds.sum(axis=0) > 1).any() and (holds.sum(axis=0) == 0).any()
+    for r in range(world):
+        have, kmer, gpos = got[r]
+        assert np.array_equal(have, np.flatnonzero(holds[r])) and len(have) > 0
+        assert np.array_equal(kmer, np.concatenate([per_genome[g][0] for g in have]))
+        assert np.array_equal(gpos, np.concatenate([per_genome[g][1] for g in have]))

@@ -67,3 +67,22 @@ def test_skani_that_writes_no_table_is_a_failure(monkeypatch, tmp_path):
     _install_double(tmp_path, monkeypatch, "", fail=True)
     with pytest.raises(RuntimeError, match="Had an issue running"):
         skani_ref.triangle("LISTING", str(tmp_path / "none.tsv"), 50.0, 80.0, 2)
+
+
+def test_probe_looks_beyond_path_in_conda_environments(monkeypatch, tmp_path):
+    """skDER is installed from bioconda (skDER_env.yml:12): a box may hold skani in an environment that is not activated"""
+    import skani_ref
+    g5 = os.path.join(GOLDEN, "G5_triangle_minaf10_s89.5.tsv")
+    _install_double(tmp_path, monkeypatch, g5)
+    env_bin = tmp_path / "conda" / "bin"
+    env_bin.parent.mkdir()
+    os.rename(tmp_path / "bin", env_bin)
+    monkeypatch.setenv("PATH", "/usr/bin:/bin")
+    monkeypatch.setenv("HOME", str(tmp_path / "nobody"))
+    monkeypatch.delenv("CONDA_PREFIX", raising=False)
+    monkeypatch.delenv("MAMBA_ROOT_PREFIX", raising=False)
+    if skani_ref.find() is None:                 # (a machine that really has skani somewhere is not this test's business)
+        monkeypatch.setenv("CONDA_PREFIX", str(tmp_path / "conda"))
+        assert skani_ref.find() == str(env_bin / "skani") and skani_ref.version() == "skani 0.0.0-test-double"
+        monkeypatch.setenv("SKANI_REF_NO_SEARCH", "1")
+        assert skani_ref.find() is None
