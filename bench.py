@@ -32,31 +32,44 @@ PMC_TRAFFIC = os.path.join("profiles", "round6_pmc_traffic.json")     # rocprofv
 ONE_QUEUE_STEPS = 3
 
 
+def _write_fasta(tmp, g, host, layout, k):
+    """genome k of a batch held in `host` (device layout) as an 80-column FASTA file tmp/g<g>.fasta; -> (path, bytes)"""
+    parts = []
+    for r in range(int(layout.genome_rec_begin[k]), int(layout.genome_rec_begin[k + 1])):
+        o, l = int(layout.rec_off[r]), int(layout.rec_len[r])
+        seq = host[o:o + l]
+        full = (l // 80) * 80
+        body = np.concatenate([seq[:full].reshape(-1, 80), np.full((full // 80, 1), ord("\n"), np.uint8)], axis=1).reshape(-1)
+        parts.append((">g%d_rec%d synthetic\n" % (g, r)).encode())
+        parts.append(body.tobytes())
+        if l > full:
+            parts.append(seq[full:].tobytes() + b"\n")
+    p = os.path.join(tmp, "g%05d.fasta" % g)
+    blob = b"".join(parts)
+    with open(p, "wb") as f:
+        f.write(blob)
+    return p, len(blob)
+
+
+def write_sample_files(batches, n_sample):
+    """FASTA files of the first n_sample genomes of a resident batch [(layout, device tensor)] (the measurement scripts under
+    profiles/run write their inputs with this); -> (directory, paths, bytes)"""
+    import tempfile
+    layout, d = batches[0]
+    n_sample = min(n_sample, layout.n_genomes)
+    host = d.cpu().numpy()
+    tmp = tempfile.mkdtemp(prefix="skder_amd_sample_")
+    res = [_write_fasta(tmp, g, host, layout, g) for g in range(n_sample)]
+    return tmp, [r[0] for r in res], sum(r[1] for r in res)
+
+
 def write_workload_sample(engine, ctx, torch, recipe, genomes, chunk=250):
     """FASTA files (80 columns) of the workload's genomes `genomes`, generated on the device again after the timed region (any rank
-    can write any genome: at N > 1 rank 0 holds only its own block) and formatted on the host threads"""
+    can write any genome: at N > 1 rank 0 holds only its own block) and formatted on the host threads; -> (directory, paths, sizes)"""
     import tempfile
     from concurrent.futures import ThreadPoolExecutor
     tmp = tempfile.mkdtemp(prefix="skder_amd_sample_")
     paths, sizes = [], []
-
-    def one(job):
-        g, host, layout, k = job
-        parts = []
-        for r in range(int(layout.genome_rec_begin[k]), int(layout.genome_rec_begin[k + 1])):
-            o, l = int(layout.rec_off[r]), int(layout.rec_len[r])
-            seq = host[o:o + l]
-            full = (l // 80) * 80
-            body = np.concatenate([seq[:full].reshape(-1, 80), np.full((full // 80, 1), ord("\n"), np.uint8)], axis=1).reshape(-1)
-            parts.append((">g%d_rec%d synthetic\n" % (g, r)).encode())
-            parts.append(body.tobytes())
-            if l > full:
-                parts.append(seq[full:].tobytes() + b"\n")
-        p = os.path.join(tmp, "g%05d.fasta" % g)
-        blob = b"".join(parts)
-        with open(p, "wb") as f:
-            f.write(blob)
-        return p, len(blob)
     genomes = [int(g) for g in genomes]
     with ThreadPoolExecutor(max_workers=max(1, min(16, granted_cpus()))) as ex:
         for c0 in range(0, len(genomes), chunk):
@@ -67,7 +80,7 @@ def write_workload_sample(engine, ctx, torch, recipe, genomes, chunk=250):
             torch.cuda.synchronize()
             host = d.cpu().numpy()
             del d
-            for p, n in ex.map(one, [(g, host, layout, k) for k, g in enumerate(gs)]):
+            for p, n in ex.map(lambda kg: _write_fasta(tmp, kg[1], host, layout, kg[0]), list(enumerate(gs))):
                 paths.append(p)
                 sizes.append(n)
     return tmp, paths, sizes

@@ -133,7 +133,9 @@ __global__ __launch_bounds__(IDX_THREADS) void index_genome_kernel(
 #ifndef IDX_PACKED
 #define IDX_PACKED 1            // 1: a (k-mer, position, record) copy of the seeds written in phase A and gathered in D / E with ONE request per seed
 #endif
+#ifndef IDXF_U
 #define IDXF_U 8                // independent loads per thread and trip
+#endif
 #define IDXF_FIXED_BYTES (IDX_REP_HIST * 4)
 __host__ __device__ inline size_t idxf_smem_bytes(uint32_t nb, uint32_t n)
 {
@@ -143,6 +145,9 @@ __host__ __device__ inline size_t idxf_smem_bytes(uint32_t nb, uint32_t n)
 }
 static_assert(IDX_REP_HIST == 4 * IDXF_THREADS, "rep-cut scan assumes four histogram bins per thread");
 
+#ifdef IDXF_WAVES
+__attribute__((amdgpu_waves_per_eu(IDXF_WAVES, IDXF_WAVES)))       // occupancy probe (profiles/run/r6_index_occ.sh)
+#endif
 __global__ __launch_bounds__(IDXF_THREADS) void index_genome_lds_kernel(
     GenomeMeta *__restrict__ meta, const uint32_t *__restrict__ list, const uint32_t *__restrict__ rec_goff,
     const uint32_t *__restrict__ seed_kmer, const uint32_t *__restrict__ seed_gpos, const uint32_t *__restrict__ seed_ctg,

@@ -1710,7 +1710,7 @@ def test_low_complexity_tiles(gpu, oracle):
 
 
 def _synthetic_files(gpu, tmp_path, n, genome_len=None, len_range=None, n_species=None, seed=None):
-    """n synthetic genomes generated on the device and written as FASTA files (bench.write_sample_files); listing order = index"""
+    """n synthetic genomes generated on the device and written as FASTA files (bench.write_workload_sample); listing order = index"""
     import bench
     from skder_amd import synth
     engine, ctx, torch = gpu
@@ -1718,19 +1718,13 @@ def _synthetic_files(gpu, tmp_path, n, genome_len=None, len_range=None, n_specie
     if seed is not None:
         kw["seed"] = seed
     recipe = synth.make_recipe(n, genome_len=genome_len or 3_000_000, len_range=len_range, **kw)
-    paths, step = [], 250
-    for b0 in range(0, n, step):
-        gs = range(b0, min(b0 + step, n))
-        layout = engine.BatchLayout([recipe.rec_lens[g] for g in gs])
-        d = torch.empty(layout.total_bytes, dtype=torch.uint8, device="cuda")
-        ctx.synth_fill(d.data_ptr(), layout, recipe.lineage[gs.start:gs.stop], recipe.params[gs.start:gs.stop])
-        tmp, ps, _ = bench.write_sample_files([(layout, d)], len(gs))
-        for k, src in enumerate(ps):
-            dst = str(tmp_path / ("g%05d.fasta" % (b0 + k)))
-            shutil.move(src, dst)
-            paths.append(dst)
-        shutil.rmtree(tmp, ignore_errors=True)
-        del d
+    tmp, ps, _ = bench.write_workload_sample(engine, ctx, torch, recipe, range(n))
+    paths = []
+    for k, src in enumerate(ps):
+        dst = str(tmp_path / ("g%05d.fasta" % k))
+        shutil.move(src, dst)
+        paths.append(dst)
+    shutil.rmtree(tmp, ignore_errors=True)
     return recipe, paths
 
 
