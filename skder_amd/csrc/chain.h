@@ -7,7 +7,7 @@
 struct SetView {
     const GenomeMeta *meta;
     const uint32_t *pkmer, *pgpos, *pchunk;   // position order
-    const uint16_t *pd16;                     // position order: chunk-start flag | step from the seed in front (engine.h pd16_word)
+    const uint8_t *pcs;                       // position order: 1 = first seed of its chunk
     const uint32_t *skmer, *sgpos, *sctg;     // bucket order
     const uint32_t *stag;                     // bucket order: sgpos | (sctg & 63) << 24 | strand of the k-mer << 31
     const uint32_t *boff;

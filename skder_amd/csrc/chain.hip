@@ -30,7 +30,7 @@ static SetView view_of(skder_sketches *s)
 {
     SetView v;
     v.meta = s->d_meta.p;
-    v.pkmer = s->seed_kmer.p; v.pgpos = s->seed_gpos.p; v.pchunk = s->pchunk.p; v.pd16 = s->pd16.p;
+    v.pkmer = s->seed_kmer.p; v.pgpos = s->seed_gpos.p; v.pchunk = s->pchunk.p; v.pcs = s->pcs.p;
     v.skmer = s->skmer.p; v.sgpos = s->sgpos.p; v.sctg = s->sctg.p; v.stag = s->stag.p; v.boff = s->boff.p;
     v.chunk_start = s->chunk_start.p; v.rec_goff = s->d_rec_goff.p;
     return v;

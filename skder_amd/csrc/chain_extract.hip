@@ -34,8 +34,8 @@ __global__ __launch_bounds__(256) void run_extract_kernel(SetView A, SetView B, 
     const uint32_t nq = Qm->n_seeds, a = (uint32_t)(Qm->seed_off & 3u), nv = nq + a;
     // virtual seed index v = s + a: v = 0 sits on a 16-byte boundary of all three streams (the hit words of a pair
     // start at an entry congruent to the genome's seed offset)
-    const uint32_t *qg_of = QS.pgpos + Qm->seed_off;
-    const uint16_t *pd_al = QS.pd16 + (Qm->seed_off - a);
+    const uint32_t *qg_al = QS.pgpos + (Qm->seed_off - a);
+    const uint8_t *cs_al = QS.pcs + (Qm->seed_off - a);
     const uint32_t *ck_of = QS.pchunk + Qm->seed_off;
     const uint32_t *hit_al = hits + (pd.hit_base - a);
     uint32_t *rec0 = chunk_rec0 + pd.chunk_base;
@@ -49,46 +49,25 @@ __global__ __launch_bounds__(256) void run_extract_kernel(SetView A, SetView B, 
     bool car_ok = false;                                             // there is such a hit and no chunk began since
     bool overflow = false;
     const unsigned long long lowbits = (1ull << lane) - 1ull;
-    // Positions arrive as 16-bit steps (engine.h pd16_word: 6 bytes per seed with the hit word, where a 4-byte position and a flag
-    // byte made 9): the position of the seed in front of this wave's first one is read once, a wave scan over the lanes' step
-    // sums gives every lane its base, and the wave-uniform total carries into the next segment.  (wave-uniform)
-    uint32_t seg_q;
-    {
-        const uint32_t vf = sg_lo * SEG_SEEDS;                       // first virtual seed of the quarter
-        seg_q = (vf > a && vf - a <= nq) ? qg_of[vf - a - 1u] : 0u;
-    }
     for (uint32_t sg = sg_lo; sg < sg_hi; sg++) {
         const uint32_t v0 = sg * SEG_SEEDS + lane * 4u;
-        uint32_t hv[4], qv[4], dw[4];
+        uint32_t hv[4], qv[4], csw = 0;
         if (v0 >= a && v0 + 4u <= nv) {
             const uint4 h4 = *reinterpret_cast<const uint4 *>(hit_al + v0);
-            const uint2 d2 = *reinterpret_cast<const uint2 *>(pd_al + v0);
+            const uint4 q4 = *reinterpret_cast<const uint4 *>(qg_al + v0);
+            csw = *reinterpret_cast<const uint32_t *>(cs_al + v0);
             hv[0] = h4.x; hv[1] = h4.y; hv[2] = h4.z; hv[3] = h4.w;
-            dw[0] = d2.x & 0xFFFFu; dw[1] = d2.x >> 16; dw[2] = d2.y & 0xFFFFu; dw[3] = d2.y >> 16;
+            qv[0] = q4.x; qv[1] = q4.y; qv[2] = q4.z; qv[3] = q4.w;
         } else {
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const uint32_t v = v0 + u;
                 const bool in = v >= a && v < nv;
                 hv[u] = in ? hit_al[v] : HIT_NONE;
-                dw[u] = in ? (uint32_t)pd_al[v] : 0u;
+                qv[u] = in ? qg_al[v] : 0u;
+                csw |= in ? (uint32_t)cs_al[v] << (8 * u) : 0u;
             }
         }
-        uint32_t stp[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) stp[u] = dw[u] & PD16_ESC;
-        if (__any((stp[0] == PD16_ESC) | (stp[1] == PD16_ESC) | (stp[2] == PD16_ESC) | (stp[3] == PD16_ESC))) {
-#pragma unroll
-            for (int u = 0; u < 4; u++)                                  // (a stored PD16_ESC is always a seed of the genome)
-                if (stp[u] == PD16_ESC) { const uint32_t si = v0 + u - a; stp[u] = qg_of[si] - (si ? qg_of[si - 1u] : 0u); }
-        }
-        {
-            uint32_t seg_tot;
-            const uint32_t before = wave_excl_scan(stp[0] + stp[1] + stp[2] + stp[3], seg_tot);
-            qv[0] = seg_q + before + stp[0]; qv[1] = qv[0] + stp[1]; qv[2] = qv[1] + stp[2]; qv[3] = qv[2] + stp[3];
-            seg_q += seg_tot;
-        }
-        const uint32_t csw = (dw[0] >> 15) | ((dw[1] >> 15) << 8) | ((dw[2] >> 15) << 16) | ((dw[3] >> 15) << 24);
         // A. the lane's own four seeds: hit or not, chunk start or not, and the DIAGONAL WORD of a hit -- the hit word with
         // the position replaced by one value per diagonal (position - q forward, -position - 1 - q reverse, modulo
         // 2^32 across the record tag and strand above it): for two hits of the same record and strand the difference

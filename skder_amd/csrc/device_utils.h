@@ -3,19 +3,16 @@
 #include "common.h"
 
 // exclusive scan of one value per lane across a 64-wide wavefront; total = sum over the wave
-// Exclusive prefix sum over the 64 lanes of a wavefront.  Six DPP adds (row_shr 1 / 2 / 4 / 8 inside each row of 16 lanes, then
-// row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3): no trip through the LDS crossbar, where six __shfl_up steps
-// (ds_bpermute_b32 each, with a compare and a select) cost the run extraction 1.3 ms per step of the benchmark (round 6).
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total)
 {
+    const uint32_t lane = threadIdx.x & 63u;
     uint32_t x = v;
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);    // row_shr:1 (lanes without a source add 0)
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);    // row_shr:2
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);    // row_shr:4
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);    // row_shr:8
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
-    total = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t y = __shfl_up(x, o, 64);
+        if (lane >= (uint32_t)o) x += y;
+    }
+    total = __shfl(x, 63, 64);
     return x - v;
 }
 

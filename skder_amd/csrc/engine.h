@@ -57,8 +57,7 @@ struct skder_sketches {
     DevBuf<uint32_t> stag;                 // sgpos | (sctg & 63) << 24: the word the join hands to the chaining kernel
     DevBuf<uint32_t> boff;                 // bucket offset tables
     DevBuf<uint32_t> pchunk;               // chunk id of every seed (position order)
-    DevBuf<uint16_t> pd16;                 // position order: bit 15 = first seed of its chunk, bits 0..14 = bases since the seed in front (pd16_word): what
-                                           // the run extraction streams per seed instead of a 4-byte position and a flag byte
+    DevBuf<uint8_t> pcs;                   // 1 where a seed is the first of its chunk (position order): the run extraction reads 4 flags per lane
     DevBuf<uint32_t> chunk_start;          // first seed of every chunk (+ end sentinel), per genome
     ScreenIndex screen;
 };
@@ -79,15 +78,6 @@ void pairs_probed_impl(skder_sketches *SA, skder_sketches *SB, const uint32_t *r
 void chain_pairs_impl(skder_sketches *SA, skder_sketches *SB, const uint32_t *ref, const uint32_t *query, uint64_t n);
 void synth_fill_impl(skder_ctx *ctx, uint8_t *d_bases, const skder_batch_t *b, const uint64_t *lineage,
                      const uint32_t *params);
-
-// One 16-bit word per seed in position order (round 6): the chunk-start flag and the position as a DIFFERENCE to the seed in front
-// (seed 0: to position 0).  Seeds are sampled at 1 in 125 positions, so a step of PD16_ESC = 32767 bases or more is rare (a long array
-// of a short repeat none of whose k-mers is sampled); it is stored as PD16_ESC and the reader fetches the two absolute positions.
-#define PD16_ESC 0x7FFFu
-__host__ __device__ inline uint16_t pd16_word(uint32_t step, uint32_t chunk_start)
-{
-    return (uint16_t)((step < PD16_ESC ? step : PD16_ESC) | (chunk_start ? 0x8000u : 0u));
-}
 
 // Multiplication by an odd constant is a bijection of the 30-bit k-mers: the bucket is the top `bits` bits
 // of the 30-bit product and the remaining 30 - bits bits (kmer_rem) identify the k-mer inside its bucket,

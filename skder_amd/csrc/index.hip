@@ -14,7 +14,7 @@ __global__ __launch_bounds__(IDX_THREADS) void index_genome_kernel(
     GenomeMeta *__restrict__ meta, const uint32_t *__restrict__ list, const uint32_t *__restrict__ rec_goff,
     const uint32_t *__restrict__ seed_kmer, const uint32_t *__restrict__ seed_gpos, const uint32_t *__restrict__ seed_ctg,
     uint32_t *__restrict__ skmer, uint32_t *__restrict__ sgpos, uint32_t *__restrict__ sctg, uint32_t *__restrict__ stag,
-    uint32_t *__restrict__ boff_all, uint32_t *__restrict__ pchunk, uint32_t *__restrict__ chunk_start_all, uint16_t *__restrict__ pd16)
+    uint32_t *__restrict__ boff_all, uint32_t *__restrict__ pchunk, uint32_t *__restrict__ chunk_start_all, uint8_t *__restrict__ pcs)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t *cnt = reinterpret_cast<uint32_t *>(smem_raw);   // 2^bits counters, later cursor, later histogram
@@ -101,22 +101,20 @@ __global__ __launch_bounds__(IDX_THREADS) void index_genome_kernel(
     uint32_t crun = 0;
     for (uint32_t base = 0; base < n; base += IDX_THREADS) {
         uint32_t s = base + tid;
-        uint32_t flag = 0, step = 0;
+        uint32_t flag = 0;
         if (s < n) {
             uint32_t c = pc[s], ck = (pg[s] - rg[c]) / ANI_CHUNK_LEN;
-            step = pg[s];
             if (s == 0) flag = 1;
             else {
                 uint32_t c2 = pc[s - 1], ck2 = (pg[s - 1] - rg[c2]) / ANI_CHUNK_LEN;
                 flag = (c != c2) || (ck != ck2);
-                step -= pg[s - 1];
             }
         }
         uint32_t total;
         uint32_t ex = block_excl_scan<IDX_THREADS / 64>(flag, wsum, total);
         if (s < n) {
             pchunk[m.seed_off + s] = crun + ex + flag - 1u;
-            pd16[m.seed_off + s] = pd16_word(step, flag);
+            pcs[m.seed_off + s] = (uint8_t)flag;
             if (flag) chunk_start_all[m.chunk_off + crun + ex] = s;
         }
         crun += total;
@@ -133,9 +131,7 @@ __global__ __launch_bounds__(IDX_THREADS) void index_genome_kernel(
 #ifndef IDX_PACKED
 #define IDX_PACKED 1            // 1: a (k-mer, position, record) copy of the seeds written in phase A and gathered in D / E with ONE request per seed
 #endif
-#ifndef IDXF_U
 #define IDXF_U 8                // independent loads per thread and trip
-#endif
 #define IDXF_FIXED_BYTES (IDX_REP_HIST * 4)
 __host__ __device__ inline size_t idxf_smem_bytes(uint32_t nb, uint32_t n)
 {
@@ -145,15 +141,12 @@ __host__ __device__ inline size_t idxf_smem_bytes(uint32_t nb, uint32_t n)
 }
 static_assert(IDX_REP_HIST == 4 * IDXF_THREADS, "rep-cut scan assumes four histogram bins per thread");
 
-#ifdef IDXF_WAVES
-__attribute__((amdgpu_waves_per_eu(IDXF_WAVES, IDXF_WAVES)))       // occupancy probe (profiles/run/r6_index_occ.sh)
-#endif
 __global__ __launch_bounds__(IDXF_THREADS) void index_genome_lds_kernel(
     GenomeMeta *__restrict__ meta, const uint32_t *__restrict__ list, const uint32_t *__restrict__ rec_goff,
     const uint32_t *__restrict__ seed_kmer, const uint32_t *__restrict__ seed_gpos, const uint32_t *__restrict__ seed_ctg,
     uint32_t *__restrict__ skmer, uint32_t *__restrict__ sgpos, uint32_t *__restrict__ sctg, uint32_t *__restrict__ stag,
     uint32_t *__restrict__ boff_all, uint32_t *__restrict__ pchunk, uint32_t *__restrict__ chunk_start_all,
-    uint4 *__restrict__ packed_all, uint16_t *__restrict__ pd16)
+    uint4 *__restrict__ packed_all, uint8_t *__restrict__ pcs)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ uint32_t wsum[IDXF_THREADS / 64];
@@ -423,7 +416,7 @@ __global__ __launch_bounds__(IDXF_THREADS) void index_genome_lds_kernel(
             const uint32_t upto = (uint32_t)__popcll(bal & (~0ull >> (63u - lane)));   // flags at lanes <= mine
             const uint32_t id = blk_off[s / 64u] + upto;                                // chunks started up to and including s
             pchunk[m.seed_off + s] = id - 1u;
-            pd16[m.seed_off + s] = pd16_word(pg[s] - (s ? pg[s - 1] : 0u), (uint32_t)((bal >> lane) & 1ull));
+            pcs[m.seed_off + s] = (uint8_t)((bal >> lane) & 1ull);
             if ((bal >> lane) & 1ull) chunk_start_all[m.chunk_off + id - 1u] = s;
         }
         if (tid == 0) { meta[g].n_chunks = total; chunk_start_all[m.chunk_off + total] = n; }
@@ -437,7 +430,7 @@ __global__ __launch_bounds__(IDXF_THREADS) void index_genome_lds_kernel(
 __global__ __launch_bounds__(IDX_THREADS) void chunk_tables_kernel(
     GenomeMeta *__restrict__ meta, const uint32_t *__restrict__ list, const uint32_t *__restrict__ rec_goff,
     const uint32_t *__restrict__ seed_gpos, const uint32_t *__restrict__ seed_ctg,
-    uint32_t *__restrict__ pchunk, uint32_t *__restrict__ chunk_start_all, uint16_t *__restrict__ pd16)
+    uint32_t *__restrict__ pchunk, uint32_t *__restrict__ chunk_start_all, uint8_t *__restrict__ pcs)
 {
     __shared__ uint32_t wsum[IDX_THREADS / 64];
     const uint32_t g = list[blockIdx.x], tid = threadIdx.x;
@@ -448,22 +441,20 @@ __global__ __launch_bounds__(IDX_THREADS) void chunk_tables_kernel(
     uint32_t crun = 0;
     for (uint32_t base = 0; base < n; base += IDX_THREADS) {
         const uint32_t s = base + tid;
-        uint32_t flag = 0, step = 0;
+        uint32_t flag = 0;
         if (s < n) {
             const uint32_t c = pc[s], ck = (pg[s] - rg[c]) / ANI_CHUNK_LEN;
-            step = pg[s];
             if (s == 0) flag = 1;
             else {
                 const uint32_t c2 = pc[s - 1], ck2 = (pg[s - 1] - rg[c2]) / ANI_CHUNK_LEN;
                 flag = (c != c2) || (ck != ck2);
-                step -= pg[s - 1];
             }
         }
         uint32_t total;
         const uint32_t ex = block_excl_scan<IDX_THREADS / 64>(flag, wsum, total);
         if (s < n) {
             pchunk[m.seed_off + s] = crun + ex + flag - 1u;
-            pd16[m.seed_off + s] = pd16_word(step, flag);
+            pcs[m.seed_off + s] = (uint8_t)flag;
             if (flag) chunk_start_all[m.chunk_off + crun + ex] = s;
         }
         crun += total;
@@ -511,19 +502,19 @@ static void index_launch(skder_sketches *s, const std::vector<uint32_t> &which, 
                                      (int)lds_limit));
         hipLaunchKernelGGL(index_genome_lds_kernel, dim3((unsigned)small.size()), dim3(IDXF_THREADS), small_bytes, st, s->d_meta.p, d_list.p,
                            s->d_rec_goff.p, s->seed_kmer.p, s->seed_gpos.p, s->seed_ctg.p, s->skmer.p, s->sgpos.p, s->sctg.p, s->stag.p, s->boff.p,
-                           s->pchunk.p, s->chunk_start.p, s->idx_packed.p, s->pd16.p);
+                           s->pchunk.p, s->chunk_start.p, s->idx_packed.p, s->pcs.p);
     }
     if (!big.empty()) {
         HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(index_genome_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)((1u << max_bits) * 4)));
         hipLaunchKernelGGL(index_genome_kernel, dim3((unsigned)big.size()), dim3(IDX_THREADS), (1u << max_bits) * 4, st, s->d_meta.p,
                            d_list.p + small.size(), s->d_rec_goff.p, s->seed_kmer.p, s->seed_gpos.p, s->seed_ctg.p, s->skmer.p, s->sgpos.p,
-                           s->sctg.p, s->stag.p, s->boff.p, s->pchunk.p, s->chunk_start.p, s->pd16.p);
+                           s->sctg.p, s->stag.p, s->boff.p, s->pchunk.p, s->chunk_start.p, s->pcs.p);
     }
     if (!light.empty())
         hipLaunchKernelGGL(chunk_tables_kernel, dim3((unsigned)light.size()), dim3(IDX_THREADS), 0, st, s->d_meta.p,
                            d_list.p + small.size() + big.size(), s->d_rec_goff.p, s->seed_gpos.p, s->seed_ctg.p, s->pchunk.p, s->chunk_start.p,
-                           s->pd16.p);
+                           s->pcs.p);
 }
 
 void index_begin(skder_sketches *s, hipStream_t st, const uint8_t *full)
@@ -559,7 +550,7 @@ void index_begin(skder_sketches *s, hipStream_t st, const uint8_t *full)
     s->d_rec_goff.resize(s->h_rec_goff.size() + 1, st);
     s->skmer.resize(ns + 1, st); s->sgpos.resize(ns + 1, st); s->sctg.resize(ns + 1, st); s->stag.resize(ns + 1, st);
     s->pchunk.resize(ns + 1, st);
-    s->pd16.resize(ns + 16, st);
+    s->pcs.resize(ns + 16, st);
     s->boff.resize(boff_total + 1, st);
     s->chunk_start.resize(chunk_total + 1, st);
     if (G) {
