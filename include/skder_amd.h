@@ -22,7 +22,7 @@
  * There is NO CPU fallback anywhere behind this header: without a gfx950 device every compute entry
  * point fails with an error.
  *
- * ENVIRONMENT SWITCHES read by the library (all thirteen of them; none is needed for normal use; results are identical under every one):
+ * ENVIRONMENT SWITCHES read by the library (all fourteen of them; none is needed for normal use; results are identical under every one):
  *   SKDER_AMD_DEBUG=1|2        per-batch counters (chunks per path, decline causes) and host timings on stderr; 2: one line per ingested file
  *   SKDER_AMD_QUEUES=n         HIP queues the chaining batches alternate between (default 2; 1 = batch after batch: per-kernel timings)
  *   SKDER_AMD_CHUNK_BUDGET=n   chunks per chaining batch (default 6 M);  SKDER_AMD_PAIR_BUDGET=n  candidate pairs per screening block (2^31);

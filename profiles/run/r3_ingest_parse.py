@@ -1,3 +1,6 @@
+# HISTORICAL (kept as the record of how a committed figure was measured): this script sets SKDER_AMD_ZLIB, a switch the library
+# stopped reading in round 5 (include/skder_amd.h lists the live ones) -- on today's tree it would measure the default build under a
+# variant's label.  To repeat the measurement check out the round it belongs to (r3_* : round 3, r4_* : round 4).
 """ingest with the FASTA parse on the device against the host parse: the drop-in on 256 and 1024 sample files (plain, then gzip),
 two-point (fixed + marginal) as bench.py's end_to_end does; each leg in its own process, SKDER_AMD_DEBUG phase lines kept"""
 import json, os, subprocess, sys

@@ -1,4 +1,7 @@
 #!/bin/bash
+# HISTORICAL (kept as the record of how a committed figure was measured): this script sets SKDER_AMD_SKETCH_VARIANT, a switch the library
+# stopped reading in round 5 (include/skder_amd.h lists the live ones) -- on today's tree it would measure the default build under a
+# variant's label.  To repeat the measurement check out the round it belongs to (r3_* : round 3, r4_* : round 4).
 # round 3: the sketch body's instruction-selection table, parity of the chosen body, its effect on the step
 mkdir -p gpurun_out/r3c
 ./profiles/calib/sketch_body_bench > gpurun_out/r3c/sketch_body.json

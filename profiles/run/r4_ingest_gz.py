@@ -1,3 +1,6 @@
+# HISTORICAL (kept as the record of how a committed figure was measured): this script sets SKDER_AMD_GPU_INFLATE, a switch the library
+# stopped reading in round 5 (include/skder_amd.h lists the live ones) -- on today's tree it would measure the default build under a
+# variant's label.  To repeat the measurement check out the round it belongs to (r3_* : round 3, r4_* : round 4).
 """round 4: the gzip ingest with a share of the streams inflated on the device (SKDER_AMD_GPU_INFLATE = percent of the gzip text):
 the drop-in on N .fasta.gz sample files, shares 0 / 40 / 60 / 80 / 100, each in its own process, SKDER_AMD_DEBUG phase lines kept"""
 import json, os, subprocess, sys

@@ -1,4 +1,7 @@
 #!/bin/bash
+# HISTORICAL (kept as the record of how a committed figure was measured): this script sets SKDER_AMD_RRUNS, a switch the library
+# stopped reading in round 5 (include/skder_amd.h lists the live ones) -- on today's tree it would measure the default build under a
+# variant's label.  To repeat the measurement check out the round it belongs to (r3_* : round 3, r4_* : round 4).
 # round 4: SQ counters of the chaining kernels on the real-structure workload (34 assemblies x D descendants), separate passes.
 # TAG names the output; extra environment (SKDER_AMD_RRUNS=1, SKDER_AMD_NO_ROWS=1 ...) selects a variant
 export TMPDIR=/tmp D=${D:-8}

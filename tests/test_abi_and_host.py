@@ -151,3 +151,25 @@ def test_bench_gpus_flag_must_agree_with_the_launcher():
     assert r.returncode != 0 and "WORLD_SIZE=3" in r.stderr and "--gpus 2" in r.stderr
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "0"], capture_output=True, text=True, timeout=120)
     assert r.returncode != 0
+
+
+def test_header_lists_exactly_the_switches_the_library_reads():
+    """include/skder_amd.h promises ONE list of every environment switch the library reads: the names in that comment equal the
+    names the sources pass to getenv (measurement builds behind -DSKDER_CU_MASK_PROBE aside), and the count it states is right"""
+    src = os.path.join(ROOT, "skder_amd", "csrc")
+    read = set()
+    for fn in os.listdir(src):
+        if fn.endswith((".hip", ".cpp", ".h")):
+            read |= set(re.findall(r'getenv\("(SKDER_AMD_[A-Z0-9_]+)"\)', open(os.path.join(src, fn)).read()))
+    read -= {"SKDER_AMD_CU_MASK", "SKDER_AMD_CU_MASK_MODE"}
+    head = open(os.path.join(ROOT, "include", "skder_amd.h")).read()
+    block = head[head.index("ENVIRONMENT SWITCHES read by the library"):head.index("Read by the Python host mirror")]
+    listed = set(re.findall(r"SKDER_AMD_[A-Z0-9_]+", block))
+    assert listed == read, (sorted(listed - read), sorted(read - listed))
+    words = {13: "thirteen", 14: "fourteen", 15: "fifteen", 16: "sixteen"}
+    assert "all %s of them" % words[len(read)] in block
+    # and nothing else in the repository's documentation names a switch that no longer exists
+    known = read | {"SKDER_AMD_DEVICE", "SKDER_AMD_DEVICES", "SKDER_AMD_SEARCH_BATCH", "SKDER_AMD_SEARCH_ALL", "SKDER_AMD_FORCE_DIST",
+                    "SKDER_AMD_DIST_BACKEND", "SKDER_AMD_EXCHANGE", "SKDER_AMD_OTHER_EXCHANGE"}
+    named = set(re.findall(r"SKDER_AMD_[A-Z0-9_]+=", open(os.path.join(ROOT, "INTEGRATION.md")).read()))
+    assert {n.rstrip("=") for n in named} <= known, sorted({n.rstrip("=") for n in named} - known)

@@ -210,8 +210,9 @@ def test_config5_mixed_sizes_on_50000_genomes(gpu, oracle, tmp_path):
     engine, ctx, torch = gpu
     n, nsp = 50000, 500
     free, total = torch.cuda.mem_get_info()
-    if free < 215e9:
-        pytest.skip("needs 215 GB of free HBM (%.0f of %.0f GB are free)" % (free / 1e9, total / 1e9))
+    # a FAILURE, not a skip: config 5 is one of BASELINE.json's five configs and an MI355X holds it (288 GB); a box that cannot is not the
+    # hardware this repository is measured on, and a skip would read as green
+    assert free >= 215e9, "BASELINE config 5 needs 215 GB of free HBM; %.0f of %.0f GB are free on this device" % (free / 1e9, total / 1e9)
     rec = synth.make_recipe(n, len_range=(1_000_000, 8_000_000))
     sk = _streamed_sketches(gpu, rec, 1000)
     paths = ["/mixed/species%03d/g%05d.fasta" % (int(rec.species[g]), g) for g in range(n)]
