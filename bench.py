@@ -1227,14 +1227,27 @@ def main():
         out["config"]["us_per_chained_pair"] = 1e3 * (join_ms + step.runs_ms + tm[3] + tm[4] + tm[5]) / max(n_chained, 1.0)
         extras = not args.no_cpu_baseline
         # (rank 0 of an N > 1 job works on alone from here: the process group is gone, the other ranks have left)
+        def leg(name, fn):
+            """an auxiliary leg never costs the headline line: its failure is recorded under its own key (and on stderr)"""
+            try:
+                return fn()
+            except Exception as ex:
+                import traceback
+                traceback.print_exc(file=sys.stderr)
+                out[name] = {"error": repr(ex)}
+                return None
         if extras and args.parity_pairs > 0:
-            out["parity_sample"] = parity_sample(recipe, edges, args.parity_pairs)
-            out["config"]["parity_sample_pairs"] = out["parity_sample"]["pairs"]
-            out["config"]["parity_sample_mismatches"] = out["parity_sample"]["mismatches"]
+            ps = leg("parity_sample", lambda: parity_sample(recipe, edges, args.parity_pairs))
+            if ps is not None:
+                out["parity_sample"] = ps
+                out["config"]["parity_sample_pairs"] = ps["pairs"]
+                out["config"]["parity_sample_mismatches"] = ps["mismatches"]
         if extras:
-            out["parity_vs_skani"] = golden_parity(dev)
-            for k in ("values_equal_at_print_precision", "rows_fully_equal", "tc_listings_identical"):
-                out["config"]["golden_" + k] = out["parity_vs_skani"][k]["equal"]
+            gp = leg("parity_vs_skani", lambda: golden_parity(dev))
+            if gp is not None:
+                out["parity_vs_skani"] = gp
+                for k in ("values_equal_at_print_precision", "rows_fully_equal", "tc_listings_identical"):
+                    out["config"]["golden_" + k] = gp[k]["equal"]
         batches.clear()      # the headline's resident bases are not needed any more
         torch.cuda.empty_cache()
         if extras:
@@ -1243,14 +1256,18 @@ def main():
             # every species with 5 strains x 10 isolates, so the share of pairs that pass the screen and are chained is the full
             # workload's (1.96 % against 1.98 %), unlike a block of consecutive genomes (a few whole species: 4.8 x denser)
             sample = list(range(0, N, 2))[:args.cpu_sample_genomes] if args.cpu_sample_genomes > 0 else []
-            tmp, all_paths, sizes = write_workload_sample(engine, ctx, torch, recipe, sample)
-            try:
-                if world == 1 and args.e2e_genomes > 0 and len(all_paths) >= 8:
-                    end_to_end_legs(out, tmp, all_paths, sizes, args, dev, total_bases, ms_per_step)
-                if all_paths:
-                    out["cpu_baseline"] = cpu_baseline(tmp, all_paths, N, pairs, n_chained_all)
-            finally:
-                shutil.rmtree(tmp, ignore_errors=True)
+            written = leg("cpu_baseline", lambda: write_workload_sample(engine, ctx, torch, recipe, sample))
+            if written is not None:
+                tmp, all_paths, sizes = written
+                try:
+                    if world == 1 and args.e2e_genomes > 0 and len(all_paths) >= 8:
+                        leg("end_to_end", lambda: end_to_end_legs(out, tmp, all_paths, sizes, args, dev, total_bases, ms_per_step))
+                    if all_paths:
+                        cb = leg("cpu_baseline", lambda: cpu_baseline(tmp, all_paths, N, pairs, n_chained_all))
+                        if cb is not None:
+                            out["cpu_baseline"] = cb
+                finally:
+                    shutil.rmtree(tmp, ignore_errors=True)
         if world == 1 and not args.no_realistic and extras:
             out["realistic"] = realistic_workloads(engine, ctx, torch, synth, args)
             for k, v in out["realistic"].items():            # (scalars under config survive the driver's parse of the line)

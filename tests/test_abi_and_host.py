@@ -173,3 +173,83 @@ def test_header_lists_exactly_the_switches_the_library_reads():
                     "SKDER_AMD_DIST_BACKEND", "SKDER_AMD_EXCHANGE", "SKDER_AMD_OTHER_EXCHANGE"}
     named = set(re.findall(r"SKDER_AMD_[A-Z0-9_]+=", open(os.path.join(ROOT, "INTEGRATION.md")).read()))
     assert {n.rstrip("=") for n in named} <= known, sorted({n.rstrip("=") for n in named} - known)
+
+
+def test_bench_sample_writers_on_stubs(tmp_path):
+    """bench.write_workload_sample / write_sample_files (the FASTA files the CPU baseline and the end-to-end legs read) with the device
+    replaced by stubs: a `torch` whose tensors are numpy arrays and a context whose synth_fill writes the numpy statement of the
+    generator into the device layout.  Every file must hold exactly the genome's records, 80 columns, in record order."""
+    import sys
+    import types
+    sys.path.insert(0, ROOT)
+    import bench
+    from skder_amd import engine, synth
+
+    class T:
+        def __init__(self, n): self.a = np.zeros(n, np.uint8)
+        def data_ptr(self): return self
+        def cpu(self): return self
+        def numpy(self): return self.a
+    fake_torch = types.SimpleNamespace(empty=lambda n, dtype=None, device=None: T(n), uint8=None,
+                                       cuda=types.SimpleNamespace(synchronize=lambda: None))
+
+    class Ctx:
+        def synth_fill(self, t, layout, lineage, params):
+            # (lineage / params select the genomes: find them in the recipe by their isolate seed)
+            for k in range(layout.n_genomes):
+                g = int(np.flatnonzero((rec.lineage == lineage[k]).all(axis=1))[0])
+                bases, at = synth.bases_numpy(rec, g), 0
+                for r in range(int(layout.genome_rec_begin[k]), int(layout.genome_rec_begin[k + 1])):
+                    o, l = int(layout.rec_off[r]), int(layout.rec_len[r])
+                    t.a[o:o + l] = bases[at:at + l]
+                    at += l
+    rec = synth.make_recipe(9, genome_len=30000, n_species=1, strains_per_species=3)
+    picked = [0, 2, 4, 6, 8]
+    tmp, paths, sizes = bench.write_workload_sample(engine, Ctx(), fake_torch, rec, picked, chunk=2)
+    try:
+        assert len(paths) == len(picked) and all(os.path.getsize(p) == n for p, n in zip(paths, sizes))
+        for g, p in zip(picked, paths):
+            assert os.path.basename(p) == "g%05d.fasta" % g
+            lens, seq = bench._read_fasta_records(p)
+            assert np.array_equal(lens, rec.rec_lens[g]) and np.array_equal(seq, synth.bases_numpy(rec, g))
+            body = [l for l in open(p, "rb").read().split(b"\n") if l and not l.startswith(b">")]
+            assert max(len(l) for l in body) == 80
+    finally:
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+    # the resident-batch form the measurement scripts use
+    layout = engine.BatchLayout([rec.rec_lens[g] for g in (1, 3)])
+    t = T(layout.total_bytes)
+    Ctx().synth_fill(t, layout, rec.lineage[[1, 3]], rec.params[[1, 3]])
+    tmp, paths, nbytes = bench.write_sample_files([(layout, t)], 5)
+    try:
+        assert len(paths) == 2 and nbytes == sum(os.path.getsize(p) for p in paths)
+        for g, p in zip((1, 3), paths):
+            lens, seq = bench._read_fasta_records(p)
+            assert np.array_equal(lens, rec.rec_lens[g]) and np.array_equal(seq, synth.bases_numpy(rec, g))
+    finally:
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def test_bench_cpu_baseline_leg_on_small_files(oracle, tmp_path, monkeypatch):
+    """bench.cpu_baseline (the `cpu_baseline` object of the line) on a dozen small genomes: `value` is the MEASURED rate of one oracle
+    triangle over the sample, the extrapolation is a side field, kind is "port" when no skani is installed"""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    from skder_amd import synth
+    monkeypatch.setenv("SKANI_REF_NO_SEARCH", "1")
+    monkeypatch.setenv("PATH", "/usr/bin:/bin")
+    rec = synth.make_recipe(12, genome_len=60000, n_species=2, strains_per_species=3)
+    paths = []
+    for g in range(0, 12, 2):                      # every second genome, as the bench samples
+        p = str(tmp_path / ("g%05d.fasta" % g))
+        synth.write_fasta(rec, g, p)
+        paths.append(p)
+    cb = bench.cpu_baseline(str(tmp_path), paths, 12, 66, 30.0)
+    m = cb["measured_on_sample"]
+    assert cb["kind"] == "port" and cb["unit"] == "genome-pairs/s" and cb["cores"] >= 1
+    assert m["files"] == 6 and m["pairs"] == 15 and m["chained_pairs"] == 6 and m["wall_s"] > 0       # two species x C(3, 2)
+    assert cb["value"] == m["pairs_per_s"] == m["pairs"] / m["wall_s"]
+    assert cb["extrapolated_full_workload_pairs_per_s"] > 0 and "measured" in cb["value_is"]
