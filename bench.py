@@ -162,13 +162,12 @@ def end_to_end_sample(tmp, paths, nbytes, device):
     return {"genomes": len(paths), "fasta_bytes": nbytes, "seconds": dt, "rows": rows, "ingest_MB_per_s": nbytes / dt / 1e6}
 
 
-def golden_parity(device):
-    """BASELINE.json's second figure, "max |dANI| vs skani": the drop-in triangle on the 34 genomes of the
-    reference's own test run against the skani table that run holds (tests/golden/G5, two decimals).
-    Outside the timed region; skani itself is not available on this box."""
-    import ctypes as C
-    import tempfile
-    from skder_amd import _lib
+def golden_compare(table):
+    """a 7-column edge table of the reference's 34 genomes against the skani table the reference's own run holds (tests/golden/G5, two
+    decimals): differences in percentage points and -- the distance to "bit-identical edge table" as integers -- how many golden values
+    and rows the table reproduces at print precision and how many of the 30 `-tc` representative listings (bin/skder:331-407: 6 ANI x 5
+    AF cut-offs) come out identical from it"""
+    from skder_amd import selection as S
     gold = os.path.join(ROOT, "tests", "golden")
     want = {}
     with open(os.path.join(gold, "G5_triangle_minaf10_s89.5.tsv")) as f:
@@ -176,6 +175,53 @@ def golden_parity(device):
         for line in f:
             c = line.rstrip("\n").split("\t")
             want[frozenset((os.path.basename(c[0]), os.path.basename(c[1])))] = (float(c[2]), float(c[3]), float(c[4]), os.path.basename(c[0]))
+    d_ani, d_af, seen = [], [], 0
+    values_equal = rows_equal = 0
+    with open(table) as f:
+        next(f)
+        for line in f:
+            c = line.rstrip("\n").split("\t")
+            k = frozenset((os.path.basename(c[0]), os.path.basename(c[1])))
+            if k not in want:
+                continue
+            seen += 1
+            g = want[k]
+            afr, afq = (float(c[3]), float(c[4])) if os.path.basename(c[0]) == g[3] else (float(c[4]), float(c[3]))
+            d_ani.append(float(c[2]) - g[0])
+            d_af += [afr - g[1], afq - g[2]]
+            eq = [round(100 * float(c[2])) == round(100 * g[0]), round(100 * afr) == round(100 * g[1]), round(100 * afq) == round(100 * g[2])]
+            values_equal += sum(eq)
+            rows_equal += all(eq)
+    D = os.path.join(gold, "downstream")
+    tc_same, tc_differ = 0, []
+    edges_tc = [(os.path.basename(a), os.path.basename(b), x, y, z) for a, b, x, y, z in S.edges_from_table(table)]
+    n50_tc = S.read_n50(os.path.join(D, "skder_gtdb_results__Concatenated_N50.txt"))
+    for a in (90.0, 95.0, 97.0, 98.0, 99.0, 99.5):
+        for fcut in (10.0, 25.0, 50.0, 75.0, 90.0):
+            with open(os.path.join(D, "tc", "skDER_Results_ANI%s_AF%s.txt" % (a, fcut))) as fh:
+                wanted = [l.rstrip("\n") for l in fh]
+            if S.greedy_from_edges(edges_tc, n50_tc, a, fcut) == wanted:
+                tc_same += 1
+            else:
+                tc_differ.append("ANI%s_AF%s" % (a, fcut))
+    d_ani, d_af = np.array(d_ani), np.array(d_af)
+    return {"max_abs_dANI": float(np.abs(d_ani).max()), "rms_dANI": float(np.sqrt((d_ani ** 2).mean())),
+            "max_abs_dAF": float(np.abs(d_af).max()), "rms_dAF": float(np.sqrt((d_af ** 2).mean())),
+            "pairs": seen, "golden_pairs": len(want), "unit": "percentage points",
+            "values_equal_at_print_precision": {"equal": values_equal, "of": 3 * len(want), "what": "ANI, AF_ref, AF_query of the golden rows that print the same two decimals"},
+            "rows_fully_equal": {"equal": rows_equal, "of": len(want)},
+            "tc_listings_identical": {"equal": tc_same, "of": 30, "differ": tc_differ,
+                                      "what": "greedy representative listings of the reference's 6 x 5 cut-off sweep from this table vs the reference's 30 files"}}
+
+
+def golden_parity(device):
+    """BASELINE.json's second figure, "max |dANI| vs skani": the drop-in triangle on the 34 genomes of the
+    reference's own test run against the skani table that run holds (golden_compare).
+    Outside the timed region; skani itself is not available on this box."""
+    import ctypes as C
+    import tempfile
+    from skder_amd import _lib
+    gold = os.path.join(ROOT, "tests", "golden")
     names = sorted(os.listdir(os.path.join(gold, "genomes")))
     with tempfile.TemporaryDirectory(prefix="skder_amd_gold_") as tmp:
         listing = os.path.join(tmp, "listing.txt")
@@ -188,59 +234,21 @@ def golden_parity(device):
         if _lib.lib().skder_amd_triangle_n50(listing.encode(), 10.0, 89.5, device, out.encode(), n50.encode(), err, _lib.ERRLEN) != 0:
             raise RuntimeError(err.value.decode())
         call_s = time.perf_counter() - t0
-        d_ani, d_af, seen = [], [], 0
-        values_equal = rows_equal = 0          # at the table's print precision: the distance to "bit-identical edge table" as integers
-        with open(out) as f:
-            next(f)
-            for line in f:
-                c = line.rstrip("\n").split("\t")
-                k = frozenset((os.path.basename(c[0]), os.path.basename(c[1])))
-                if k not in want:
-                    continue
-                seen += 1
-                g = want[k]
-                afr, afq = (float(c[3]), float(c[4])) if os.path.basename(c[0]) == g[3] else (float(c[4]), float(c[3]))
-                d_ani.append(float(c[2]) - g[0])
-                d_af += [afr - g[1], afq - g[2]]
-                eq = [round(100 * float(c[2])) == round(100 * g[0]), round(100 * afr) == round(100 * g[1]), round(100 * afq) == round(100 * g[2])]
-                values_equal += sum(eq)
-                rows_equal += all(eq)
-        # the representative listings of the reference's -tc sweep (bin/skder:331-407: 6 ANI x 5 AF cut-offs) from THIS table against the
-        # 30 files the reference's own run holds
-        from skder_amd import selection as S
-        D = os.path.join(gold, "downstream")
-        tc_same, tc_differ = 0, []
-        edges_tc = [(os.path.basename(a), os.path.basename(b), x, y, z) for a, b, x, y, z in S.edges_from_table(out)]
-        n50_tc = S.read_n50(os.path.join(D, "skder_gtdb_results__Concatenated_N50.txt"))
-        for a in (90.0, 95.0, 97.0, 98.0, 99.0, 99.5):
-            for fcut in (10.0, 25.0, 50.0, 75.0, 90.0):
-                with open(os.path.join(D, "tc", "skDER_Results_ANI%s_AF%s.txt" % (a, fcut))) as fh:
-                    wanted = [l.rstrip("\n") for l in fh]
-                if S.greedy_from_edges(edges_tc, n50_tc, a, fcut) == wanted:
-                    tc_same += 1
-                else:
-                    tc_differ.append("ANI%s_AF%s" % (a, fcut))
+        res = golden_compare(out)
         # the real engine, if this box has it (oracle/skani_ref.py): the same listing through `skani triangle`, cell by cell
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import skani_ref
-        live = "skani unavailable on this host (not on PATH): the golden table of the reference's own run stands in"
+        live = "skani unavailable on this host (not on PATH nor in the usual conda locations): the golden table of the reference's own run stands in"
         if skani_ref.find():
             sk_out = os.path.join(tmp, "tri_skani.tsv")
             run = skani_ref.triangle(listing, sk_out, 10.0, 89.5, os.cpu_count() or 1)
             live = skani_ref.compare_tables(out, sk_out)
             live.update({"skani_version": run["version"], "skani_seconds": run["seconds"], "command": run["command"]})
-    d_ani, d_af = np.array(d_ani), np.array(d_af)
-    return {"live_skani": live,
-            "max_abs_dANI": float(np.abs(d_ani).max()), "rms_dANI": float(np.sqrt((d_ani ** 2).mean())),
-            "max_abs_dAF": float(np.abs(d_af).max()), "rms_dAF": float(np.sqrt((d_af ** 2).mean())),
-            "pairs": seen, "golden_pairs": len(want), "unit": "percentage points",
-            "values_equal_at_print_precision": {"equal": values_equal, "of": 3 * len(want), "what": "ANI, AF_ref, AF_query of the golden rows that print the same two decimals"},
-            "rows_fully_equal": {"equal": rows_equal, "of": len(want)},
-            "tc_listings_identical": {"equal": tc_same, "of": 30, "differ": tc_differ,
-                                      "what": "greedy representative listings of the reference's 6 x 5 cut-off sweep from this table vs the reference's 30 files"},
-            "drop_in_call": {"seconds": call_s, "gz_bytes": gz_bytes, "what": "skder_amd_triangle_n50 on the reference's 34 .fasta.gz files (listing -> N50 table + edge table on disk), one call incl. context creation"},
-            "against": "skani table of the reference's own test run (tests/golden/G5: 34 C. granulosum genomes, ANI 96.4-100, two decimals); "
-                       "skani's version is unpinned and its learned-ANI model is replaced by a fitted map (DESIGN.md 2)"}
+    res.update({"live_skani": live,
+                "drop_in_call": {"seconds": call_s, "gz_bytes": gz_bytes, "what": "skder_amd_triangle_n50 on the reference's 34 .fasta.gz files (listing -> N50 table + edge table on disk), one call incl. context creation"},
+                "against": "skani table of the reference's own test run (tests/golden/G5: 34 C. granulosum genomes, ANI 96.4-100, two decimals); "
+                           "skani's version is unpinned and its learned-ANI model is replaced by a fitted map (DESIGN.md 2)"})
+    return res
 
 
 def _read_fasta_records(path):

@@ -252,3 +252,23 @@ def test_estimator_against_clustered_truth(oracle):
     assert all(0.94 <= q <= 1.20 for _, q in seen[1.0][1]), seen[1.0][1]   # moderately clustered: the stand-in is about right
     assert all(0.60 <= q <= 1.13 for _, q in seen[0.3][1]), seen[0.3][1]   # strongly clustered: it reads low, increasingly with divergence
     assert min(q for _, q in seen[0.3][1]) < 0.75 and max(q for _, q in seen[0.3][0]) <= 0.93
+
+
+def test_the_distance_to_a_bit_identical_edge_table_in_integers(oracle, tmp_path):
+    """bench.golden_compare -- the counts the bench line carries under `parity_vs_skani` -- on the ORACLE's table of the 34 reference genomes
+    (the HIP path prints the same table: tests/test_gpu_parity.py holds the two texts equal): how many of the reference's 1,683 printed golden
+    values, 561 rows and 30 `-tc` listings are reproduced.  These are the integers behind "parity: partial"; a change of the restatement that
+    moves them must move them here, on the CPU, first."""
+    import bench
+    listing = tmp_path / "l.txt"
+    names = sorted(os.listdir(os.path.join(GOLDEN, "genomes")))
+    listing.write_text("".join(os.path.join(GOLDEN, "genomes", n) + "\n" for n in names))
+    out = tmp_path / "tri.tsv"
+    oracle.triangle(str(listing), 10.0, 89.5, 8, str(out), oracle.default_params())
+    r = bench.golden_compare(str(out))
+    assert r["pairs"] == r["golden_pairs"] == 561
+    assert r["values_equal_at_print_precision"] == {"equal": 27, "of": 1683, "what": r["values_equal_at_print_precision"]["what"]}
+    assert r["rows_fully_equal"]["equal"] == 0 and r["rows_fully_equal"]["of"] == 561
+    assert r["tc_listings_identical"]["equal"] == 19 and r["tc_listings_identical"]["of"] == 30 and len(r["tc_listings_identical"]["differ"]) == 11
+    assert all(not d.startswith(("ANI99.0", "ANI99.5")) for d in r["tc_listings_identical"]["differ"])      # the cut-offs skDER is run with
+    assert r["max_abs_dANI"] <= 0.45 and r["max_abs_dAF"] <= 1.15
