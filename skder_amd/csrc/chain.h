@@ -54,7 +54,9 @@ struct PairOut {
 #ifndef FAST_SLOTS
 #define FAST_SLOTS 6         // chain slots per chunk of the two fast kernels (the run loop declines a chunk with more chains).
                              // fast_chains is slot-major: slot k of chunk t at [k * (chunks of the batch) + t], so that the first slots of
-                             // neighbouring chunks -- nearly all that is ever written or read -- share cache lines
+                             // neighbouring chunks -- nearly all that is ever written or read -- share cache lines.
+                             // MEMORY: 32 bytes per slot and chunk in each of the three work-buffer slots -- at the default budget of
+                             // 6 M chunks per batch 1.15 GB per slot set (3.5 GB in all; it was 1.7 GB at three slots per chunk)
 #endif
 #define SIEVE_PATHS 3        // paths the sieve follows (its own limit; its chains use the first slots)
 #ifndef CF_OCC
