@@ -1150,7 +1150,7 @@ def main():
         limiter = {"sketch_tiles_kernel": "VALU issue: two mm_hash64 per position; the body costs 93 ns per position and wavefront against 107 for the compiler's "
                                           "instruction selection (profiles/round3_sketch_body.json), HBM traffic = 1.07 x algorithmic",
                    "join_probe_kernel": "instruction issue: ~118 wavefront instructions per 64 probes (79 VALU, 25 SALU) at two workgroups per CU; "
-                                        "LDS bank conflicts 7 % of LDS cycles (profiles/round6_pmc_join_probe_kernel.txt)",
+                                        "LDS bank conflicts 7 % of LDS cycles (profiles/round4_pmc_join_probe_kernel.txt: the kernel is unchanged since)",
                    "run_extract_kernel": "HBM: 9 B per seed at ~5 TB/s",
                    "chain_single_kernel+chain_runs_kernel": "memory latency: a dozen dependent loads per wavefront"}
         bound_of = {"sketch_tiles_kernel": "valu-issue", "join_probe_kernel": "valu-issue", "run_extract_kernel": "hbm",
@@ -1167,7 +1167,7 @@ def main():
         s8_chain = gbs(n_chained * 16.0 * 2.0 * seeds_per_genome, join_ms + step.runs_ms + tm[3] + tm[4] + tm[5])
         s8_all = gbs(s8_sketch["bytes"] + s8_chain["bytes"], ms_per_step)          # over the whole step's wall time
         # measured HBM traffic of the dominant kernel per step (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-        # separate passes, profiles/round1_pmc_traffic.json; only valid for the default workload on 1 GPU)
+        # separate passes, PMC_TRAFFIC; only valid for the default workload on 1 GPU)
         traffic, traffic_source, step_traffic = None, None, None
         if N == 5000 and world == 1 and args.len_range is None and args.genome_len == 3_000_000:
             src = PMC_TRAFFIC

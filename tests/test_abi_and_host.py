@@ -253,3 +253,15 @@ def test_bench_cpu_baseline_leg_on_small_files(oracle, tmp_path, monkeypatch):
     assert m["files"] == 6 and m["pairs"] == 15 and m["chained_pairs"] == 6 and m["wall_s"] > 0       # two species x C(3, 2)
     assert cb["value"] == m["pairs_per_s"] == m["pairs"] / m["wall_s"]
     assert cb["extrapolated_full_workload_pairs_per_s"] > 0 and "measured" in cb["value_is"]
+
+
+def test_bench_cites_only_profile_files_that_exist():
+    """every profiles/... file bench.py names in its line or its comments is committed -- except the round's own PMC summary
+    (bench.PMC_TRAFFIC), whose absence the line reports as `traffic_source: missing` instead of reading a stale round's file"""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    text = open(os.path.join(ROOT, "bench.py")).read()
+    cited = set(re.findall(r"profiles/[A-Za-z0-9_./]+\.(?:json|txt|csv|hip|sh|py)", text))
+    missing = sorted(c for c in cited if not os.path.isfile(os.path.join(ROOT, c)) and c != bench.PMC_TRAFFIC.replace(os.sep, "/"))
+    assert not missing, missing
