@@ -1277,7 +1277,7 @@ def main():
                 finally:
                     shutil.rmtree(tmp, ignore_errors=True)
         if world == 1 and not args.no_realistic and extras:
-            out["realistic"] = realistic_workloads(engine, ctx, torch, synth, args)
+            out["realistic"] = leg("realistic", lambda: realistic_workloads(engine, ctx, torch, synth, args)) or out.get("realistic", {})
             for k, v in out["realistic"].items():            # (scalars under config survive the driver's parse of the line)
                 if k.startswith("real_derived_") and isinstance(v, dict) and "us_per_chained_pair" in v:
                     out["config"]["real_derived_us_per_chained_pair"] = v["us_per_chained_pair"]
