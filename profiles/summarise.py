@@ -61,6 +61,10 @@ def main():
     shutil.copy(find(os.path.join(SRC, "stats"), "domain_stats.csv"), os.path.join(DST, R + "_domain_stats.csv"))
     if os.path.isdir(os.path.join(SRC, "stats1q")):     # the same command with SKDER_AMD_QUEUES=1 (no overlap between chaining batches)
         shutil.copy(find(os.path.join(SRC, "stats1q"), "kernel_stats.csv"), os.path.join(DST, R + "_kernel_stats_one_queue.csv"))
+    # SQ counters of the longest kernels (collect.sh runs profiles/tools/pmc.sh for each): kept per round next to the statistics
+    for f in sorted(os.listdir(SRC)):
+        if f.startswith("pmc_") and f.endswith(".txt") and os.path.getsize(os.path.join(SRC, f)) > 0:
+            shutil.copy(os.path.join(SRC, f), os.path.join(DST, R + "_" + f))
     known = {}
     for line in open(os.path.join(SRC, "calib_fetch.log")):
         if line.startswith("known_bytes"):
