@@ -310,21 +310,33 @@ def component_labels(n: int, ref: np.ndarray, query: np.ndarray, device=None) ->
         lab = new
 
 
+def probe_rank(genome_len: np.ndarray, genome_nrec: np.ndarray, n_seeds: np.ndarray, n_markers: np.ndarray) -> np.ndarray:
+    """The library's orientation rule (chain.hip chunk_the_query: the less contiguous genome of a pair is cut into chunks, the other one
+    is PROBED) as one number per genome: genomes ordered by (total length x mean record length, seed count, marker count) -- the same
+    IEEE double operations as the C++ -- with equal keys sharing a rank.  Of a pair (ref, query) the query is chunked iff
+    rank[query] <= rank[ref]."""
+    t = genome_len.astype(np.float64)
+    s = t * (t / np.maximum(genome_nrec, 1).astype(np.float64))
+    ns, nm = n_seeds.astype(np.int64), n_markers.astype(np.int64)
+    order = np.lexsort((nm, ns, s))
+    so, no, mo = s[order], ns[order], nm[order]
+    new = np.ones(len(order), bool)
+    new[1:] = (so[1:] != so[:-1]) | (no[1:] != no[:-1]) | (mo[1:] != mo[:-1])
+    rank = np.empty(len(order), np.int64)
+    rank[order] = np.cumsum(new) - 1
+    return rank
+
+
 def probed_genome(ref: np.ndarray, query: np.ndarray, genome_len: np.ndarray, genome_nrec: np.ndarray, n_seeds: np.ndarray,
                   n_markers: np.ndarray) -> np.ndarray:
-    """the genome of every pair that is PROBED (the other one is cut into chunks): the library's rule (chain.hip chunk_the_query --
-    the less contiguous genome is chunked: total length x mean record length, then seed count, then marker count) on the per-genome
-    tables every rank holds after the marker all-gather; the same IEEE double operations, so the same answer"""
-    tq, tr = genome_len[query].astype(np.float64), genome_len[ref].astype(np.float64)
-    sq = tq * (tq / np.maximum(genome_nrec[query], 1).astype(np.float64))
-    sr = tr * (tr / np.maximum(genome_nrec[ref], 1).astype(np.float64))
-    sq_n, sr_n = n_seeds[query].astype(np.int64), n_seeds[ref].astype(np.int64)
-    mq_n, mr_n = n_markers[query].astype(np.int64), n_markers[ref].astype(np.int64)
-    chunk_query = np.where(sq != sr, sq < sr, np.where(sq_n != sr_n, sq_n < sr_n, np.where(mq_n != mr_n, mq_n < mr_n, True)))
-    return np.where(chunk_query, ref, query).astype(np.int64)
+    """the genome of every pair that is PROBED (the other one is cut into chunks): probe_rank on the per-genome tables every rank holds
+    after the marker all-gather"""
+    rank = probe_rank(genome_len, genome_nrec, n_seeds, n_markers)
+    return np.where(rank[query] <= rank[ref], ref, query).astype(np.int64)
 
 
-def component_plan(n: int, ref: np.ndarray, query: np.ndarray, n_seeds: np.ndarray, world: int, probed: np.ndarray = None, device=None):
+def component_plan(n: int, ref: np.ndarray, query: np.ndarray, n_seeds: np.ndarray, world: int, probed: np.ndarray = None, device=None,
+                   rank_of_genome: np.ndarray = None):
     """Who chains which pair, and who must therefore hold which genome's seeds: (pair_rank[k], holds[world, n] bool).
 
     Components of the candidate-pair graph by descending weight (sum over their pairs of the two genomes' seed counts: what chaining
@@ -333,36 +345,50 @@ def component_plan(n: int, ref: np.ndarray, query: np.ndarray, n_seeds: np.ndarr
     low_mem_greedy workload (README.md:27) -- goes back to the replicate rule INSIDE the component: it is shared by the
     ceil(weight / fair) least loaded ranks, its pairs dealt out by probed genome (probed mod the number of sharing ranks, so that the
     pairs probing one genome stay together, as the join wants them), and every sharing rank holds the genomes its pairs touch.
-    A pure function of its arguments: every rank computes the same plan."""
+    The probed genome of a pair comes from `probed` (one entry per pair) or, computed only for the pairs of components that are split,
+    from `rank_of_genome` (probe_rank); with neither, nothing is split.  A pure function of its arguments: every rank computes the
+    same plan.  (Written for the per-step cost: a handful of passes over the pairs, no sort -- 247,500 pairs in ~3 ms.)"""
     pair_rank = np.full(len(ref), -1, np.int64)
     holds = np.zeros((world, n), bool)
     if len(ref) == 0:
         return pair_rank, holds
     ref, query = np.asarray(ref, np.int64), np.asarray(query, np.int64)
     lab = component_labels(n, ref, query, device)
-    w_pair = n_seeds[ref].astype(np.float64) + n_seeds[query].astype(np.float64)
     plab = lab[ref]                                                         # (a pair's two genomes carry one label)
-    w_label = np.bincount(plab, weights=w_pair, minlength=n)
-    labels = np.flatnonzero(np.bincount(plab, minlength=n))
+    # a component's weight = sum over its pairs of both genomes' seeds = sum over its genomes of seeds x pairs the genome is in
+    deg = np.bincount(ref, minlength=n) + np.bincount(query, minlength=n)
+    w_label = np.bincount(lab, weights=n_seeds.astype(np.float64) * deg, minlength=n)
+    labels = np.flatnonzero(np.bincount(lab, minlength=n) >= 2)            # a component with two genomes or more has pairs
     weight = w_label[labels]
     fair = float(weight.sum()) / world
-    by_label = np.argsort(plab, kind="stable")                              # the pairs of one component side by side
-    first = np.searchsorted(plab[by_label], labels, side="left")
-    last = np.searchsorted(plab[by_label], labels, side="right")
+    can_split = world > 1 and (probed is not None or rank_of_genome is not None)
     load = np.zeros(world)
+    owner_of_label = np.full(n, -1, np.int64)                              # atoms: every pair of the component to this rank
+    shared = []
     for k in np.lexsort((labels, -weight)):
-        sel = by_label[first[k]:last[k]]
-        if world > 1 and weight[k] > fair and probed is not None:
+        if can_split and weight[k] > fair:
+            sel = np.flatnonzero(plab == labels[k])
             share = min(world, int(np.ceil(weight[k] / fair)))
             ranks = np.argsort(load, kind="stable")[:share]               # the least loaded ranks, ties to the lowest
-            pair_rank[sel] = ranks[np.asarray(probed, np.int64)[sel] % share]
-            load += np.bincount(pair_rank[sel], weights=w_pair[sel], minlength=world)
+            pr = (np.asarray(probed, np.int64)[sel] if probed is not None else
+                  np.where(rank_of_genome[query[sel]] <= rank_of_genome[ref[sel]], ref[sel], query[sel]))
+            pair_rank[sel] = ranks[pr % share]
+            load += np.bincount(pair_rank[sel], weights=(n_seeds[ref[sel]] + n_seeds[query[sel]]).astype(np.float64), minlength=world)
+            shared.append(sel)
         else:
             r = int(np.argmin(load))
-            pair_rank[sel] = r
+            owner_of_label[labels[k]] = r
             load[r] += weight[k]
-    holds[pair_rank, ref] = True
-    holds[pair_rank, query] = True
+    atom = owner_of_label[plab]
+    pair_rank = np.where(atom >= 0, atom, pair_rank)
+    # atoms: a rank holds every genome of its components; split components: the genomes its pairs touch
+    g_owner = owner_of_label[lab]
+    g = np.flatnonzero(g_owner >= 0)
+    holds[g_owner[g], g] = True
+    for sel in shared:
+        holds[pair_rank[sel], ref[sel]] = True
+        holds[pair_rank[sel], query[sel]] = True
+    component_plan.last_load = load                                        # chaining load per rank (seeds read), for the caller's statistics
     return pair_rank, holds
 
 
@@ -464,8 +490,8 @@ def triangle_by_components(ctx, sk, first_genome: int, n_total: int, rank: int, 
     g_len_all = np.concatenate([p["genome_len"] for p in mk]).astype(np.int64)
     g_nrec_all = np.concatenate([p["genome_nrec"] for p in mk]).astype(np.int64)
     n_markers = np.concatenate([np.diff(np.asarray(p["marker_off"], np.uint64).astype(np.int64)) for p in mk])
-    probed = probed_genome(aref, aquery, g_len_all, g_nrec_all, n_seeds, n_markers)
-    pair_rank, holds = component_plan(n_total, aref, aquery, n_seeds, world, probed, device=dev if nccl else None)
+    pair_rank, holds = component_plan(n_total, aref, aquery, n_seeds, world, device=dev if nccl else None,
+                                      rank_of_genome=probe_rank(g_len_all, g_nrec_all, n_seeds, n_markers))
     lap()
     have, kmer, gpos = exchange_seeds(raw, first_genome, holds, n_seeds, blocks, group=group, staging=staging)
     lap()
@@ -473,7 +499,7 @@ def triangle_by_components(ctx, sk, first_genome: int, n_total: int, rank: int, 
     edges = np.zeros(0, EDGE_DTYPE)
     hb = holds[:, blocks[rank].start:blocks[rank].stop].copy()
     hb[rank] = False                                            # (what a rank keeps for itself does not travel)
-    loads = np.bincount(pair_rank, weights=(n_seeds[aref] + n_seeds[aquery]).astype(np.float64), minlength=world) if len(aref) else np.zeros(world)
+    loads = component_plan.last_load if len(aref) else np.zeros(world)
     stats = {"genomes_held": int(len(have)), "seeds_received": int(kmer.numel()),
              "bytes_sent_seeds": int(8 * (hb.sum(axis=0) * n_seeds[blocks[rank].start:blocks[rank].stop]).sum()),
              "bytes_sent_markers": int(8 * int(mk[rank]["markers"].numel()) * (world - 1)), "pairs_all": int(len(pairs)),

@@ -347,6 +347,11 @@ def test_an_oversized_component_is_split_back_into_shares(world):
     # without a probed table (component_owners' form) nothing is split
     own = multigpu.component_owners(n, ref, query, n_seeds, world)
     assert len(set(own[groups[0]].tolist())) == 1
+    # the form triangle_by_components uses: one rank number per genome, the probed genome worked out only for the pairs of split components
+    rk = multigpu.probe_rank(glen, nrec, n_seeds, n_mark)
+    pr3, h3 = multigpu.component_plan(n, ref, query, n_seeds, world, rank_of_genome=rk)
+    assert np.array_equal(pr3, pair_rank) and np.array_equal(h3, holds)
+    assert np.allclose(multigpu.component_plan.last_load, load)
 
 
 def _shared_seeds_worker(rank, world, port, q):
