@@ -826,13 +826,19 @@ static void db_triangle_rows(skder_db *db, double min_af_pct, double screen_pct)
     E.clear();
     if (db->more.empty()) { triangle_rows_impl(db->refs, 0, 1, screen_pct); E.swap(db->ctx->edges); }
     else db_triangle_edges_multi(db, screen_pct, E);
-    for (auto &e : E) {
-        uint32_t a = rank[e.ref], b = rank[e.query];
-        if (a > b) { std::swap(a, b); std::swap(e.af_ref, e.af_query); }
-        e.ref = a; e.query = b;
-    }
+    // (both passes over the list on the host threads: at 10^8 records a plain loop is a second per pass)
+    host_parallel_chunks(E.size(), [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; i++) {
+            skder_edge_t &e = E[i];
+            uint32_t a = rank[e.ref], b = rank[e.query];
+            if (a > b) { std::swap(a, b); std::swap(e.af_ref, e.af_query); }
+            e.ref = a; e.query = b;
+        }
+    });
     triangle_rows_order_inplace(E, min_af_pct);
-    for (auto &e : E) { e.ref = perm[e.ref]; e.query = perm[e.query]; }
+    host_parallel_chunks(E.size(), [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; i++) { E[i].ref = perm[E[i].ref]; E[i].query = perm[E[i].query]; }
+    });
 }
 
 extern "C" int skder_amd_db_triangle(skder_db_t *db, double min_af_pct, double screen_pct, const char *out_tsv,

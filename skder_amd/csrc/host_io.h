@@ -1,6 +1,7 @@
 // host_io.h -- FASTA ingest, listing files, skani-format TSV output (host side of the drop-in)
 #pragma once
 #include <cstdlib>
+#include <functional>
 #include <string>
 #include <utility>
 #include <vector>
@@ -59,8 +60,11 @@ void write_rect_tsv(const std::string &out, const std::vector<skder_edge_t> &edg
 std::vector<skder_edge_t> triangle_rows_ordered(const std::vector<skder_edge_t> &edges, double min_af_pct);
 std::vector<skder_edge_t> rect_rows_ordered(const std::vector<skder_edge_t> &edges, double min_af_pct);
 // the same orders established in place (no copy of the edge list; the callers hand the list over by swap)
-void triangle_rows_order_inplace(std::vector<skder_edge_t> &edges, double min_af_pct);
+void triangle_rows_order_inplace(std::vector<skder_edge_t> &edges, double min_af_pct);      // the parallel form when the host has room for it, else the serial one
+void triangle_rows_order_serial(std::vector<skder_edge_t> &edges, double min_af_pct);       // one thread, strictly in place
+bool triangle_rows_order_parallel(std::vector<skder_edge_t> &edges, double min_af_pct, unsigned threads);   // false: not run (memory, size), nothing changed
 void rect_rows_order_inplace(std::vector<skder_edge_t> &edges, double min_af_pct);
+void host_parallel_chunks(size_t n, const std::function<void(size_t, size_t)> &fn);          // fn(lo, hi) over pieces of [0, n) on the host threads
 void write_rows_tsv(const std::string &out, const skder_edge_t *rows, size_t n, const GenomeNames &ref_names,
                     const GenomeNames &query_names);
 // Concatenated_N50.txt (util.py:476-501)

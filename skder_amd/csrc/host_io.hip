@@ -838,6 +838,36 @@ struct FxMap {
     }
 };
 
+// The same model for the inner maps of the parallel row order below: a key carries a VALUE (the record's index) in one word, and the
+// two flat arrays are reused from row to row (a thread orders thousands of rows); growth replays exactly what FxMap does -- the old
+// table's entries re-placed in bucket order into one of twice the size.
+struct FxValMap {
+    std::vector<uint64_t> slot, spare;        // key << 32 | value; ~0 = empty
+    uint32_t buckets = 0, items = 0;
+    void reset() { buckets = 0; items = 0; }
+    static void place(std::vector<uint64_t> &t, uint32_t nb, uint64_t kv)
+    {
+        const uint64_t h = (kv >> 32) * 0x517cc1b727220a95ULL;
+        const uint32_t mask = nb - 1;
+        uint32_t pos = (uint32_t)(h & mask);
+        while (t[pos] != ~0ull) pos = (pos + 1) & mask;
+        t[pos] = kv;
+    }
+    void insert(uint32_t k, uint32_t v)
+    {
+        if (buckets == 0 || items + 1 > FxMap::capacity(buckets)) {
+            const uint32_t nb = buckets ? buckets * 2 : 4;
+            if (spare.size() < nb) spare.resize(nb);
+            std::fill(spare.begin(), spare.begin() + nb, ~0ull);
+            for (uint32_t b = 0; b < buckets; b++) if (slot[b] != ~0ull) place(spare, nb, slot[b]);
+            slot.swap(spare);
+            buckets = nb;
+        }
+        place(slot, buckets, (uint64_t)k << 32 | v);
+        items++;
+    }
+};
+
 static bool passes_min_af(const skder_edge_t &e, double min_af_pct)
 {
     float afr = (float)e.af_ref, afq = (float)e.af_query;
@@ -922,11 +952,150 @@ std::vector<skder_edge_t> triangle_rows_ordered(const std::vector<skder_edge_t> 
     return rows;
 }
 
-// The same order established IN PLACE: at 50,000 genomes the edge list is 10^7-10^8 records of 88 bytes, and the copies the
+// The same order established IN PLACE on one thread (what runs when the host has no room for the parallel version's scratch copy, and
+// for small tables): at 50,000 genomes the edge list is 10^7-10^8 records of 88 bytes, and the copies the
 // simple version takes (sorted copy + output) are GBs.  (1) Ref groups are brought into the outer map's order by one
 // in-place pass (cycle-leader permutation over per-group windows, as in an American-flag sort); (2) every group is ordered
 // by its own inner map, groups in parallel on the host threads; (3) rows below --min-af are squeezed out in place.
+// what this process may still allocate: MemAvailable, and the cgroup's limit minus its use where there is one
+static uint64_t host_memory_available()
+{
+    uint64_t avail = ~0ull;
+    if (FILE *f = fopen("/proc/meminfo", "r")) {
+        char line[256];
+        while (fgets(line, sizeof line, f)) {
+            unsigned long long kb;
+            if (sscanf(line, "MemAvailable: %llu kB", &kb) == 1) { avail = (uint64_t)kb * 1024u; break; }
+        }
+        fclose(f);
+    }
+    unsigned long long mx = 0, cur = 0;
+    bool have = false;
+    if (FILE *f = fopen("/sys/fs/cgroup/memory.max", "r")) { have = fscanf(f, "%llu", &mx) == 1; fclose(f); }
+    if (have) {
+        if (FILE *f = fopen("/sys/fs/cgroup/memory.current", "r")) { have = fscanf(f, "%llu", &cur) == 1; fclose(f); } else have = false;
+        if (have && mx > cur && mx - cur < avail) avail = mx - cur;
+    }
+    return avail;
+}
+
+// fn(t, lo, hi) over T contiguous pieces of [0, n) on T host threads
+template <class F>
+static void host_parallel_ranges(size_t n, unsigned T, F fn)
+{
+    host_parallel_for(T, T, [&](size_t t) { fn((unsigned)t, n * t / T, n * (t + 1) / T); });
+}
+
+// fn(lo, hi) over contiguous pieces of [0, n) on the ingest's host threads (one piece per 16,384 items at most): for the plain passes over
+// an edge list of 10^7 - 10^8 records that the callers make around the row order (index mapping, AF swaps)
+void host_parallel_chunks(size_t n, const std::function<void(size_t, size_t)> &fn)
+{
+    const unsigned T = (unsigned)std::min<size_t>(ingest_threads(), n / 16384 + 1);
+    if (T <= 1) { fn(0, n); return; }
+    host_parallel_ranges(n, T, [&](unsigned, size_t lo, size_t hi) { fn(lo, hi); });
+}
+
+// Round 6: the row order on ALL host threads.  The in-place version below moves 88-byte records one at a time through a
+// cycle-leader pass on one thread (90 ns per record on the MI355X box's host: 9 of the 49 s that the default modes take on 14,000
+// genomes of one species); here nothing moves until the order is known: (1) per-thread histograms of Ref over
+// contiguous pieces of the list, (2) the outer map's bucket order -> a window per Ref, (3) a stable parallel counting scatter of
+// record INDICES into the windows, (4) every window ordered by its inner map -- (Query, index) words sorted, FxValMap replayed on
+// reused arrays, --min-af applied -- windows in parallel, (5) the surviving records gathered into a scratch block in parallel
+// (first touch on all threads) and copied back.  Needs the index array and room for one more copy of the kept records: taken when
+// the host has it (host_memory_available), else the in-place version runs.  Same rows in the same order: tests/host_writer_harness.cpp
+// holds both against triangle_rows_ordered under the sanitizers.
+bool triangle_rows_order_parallel(std::vector<skder_edge_t> &E, double min_af_pct, unsigned T)
+{
+    const size_t n = E.size();
+    if (n >= 0xFFFFFFF0ull || T < 2) return false;
+    if (host_memory_available() < (uint64_t)n * (sizeof(skder_edge_t) + 8u) + (256ull << 20)) return false;
+    std::vector<uint32_t> tmax(T, 0);
+    host_parallel_ranges(n, T, [&](unsigned t, size_t lo, size_t hi) {
+        uint32_t m = 0;
+        for (size_t i = lo; i < hi; i++) m = E[i].ref > m ? E[i].ref : m;
+        tmax[t] = m;
+    });
+    uint32_t max_ref = 0;
+    for (uint32_t m : tmax) max_ref = m > max_ref ? m : max_ref;
+    const size_t G = (size_t)max_ref + 1;
+    if (G * T > (512ull << 20) / 8) return false;                 // (the per-thread counters would be GBs: not this path's case)
+    std::vector<uint64_t> cur(G * T, 0);                          // [t * G + r]: records of Ref r in piece t, then their first slot
+    host_parallel_ranges(n, T, [&](unsigned t, size_t lo, size_t hi) {
+        uint64_t *c = cur.data() + (size_t)t * G;
+        for (size_t i = lo; i < hi; i++) c[E[i].ref]++;
+    });
+    std::vector<uint64_t> cnt(G, 0);
+    for (unsigned t = 0; t < T; t++) for (size_t r = 0; r < G; r++) cnt[r] += cur[(size_t)t * G + r];
+    FxMap outer;                                                 // distinct Refs enter in ascending order
+    for (uint32_t r = 0; r <= max_ref; r++) if (cnt[r]) outer.insert(r);
+    std::vector<uint64_t> group_begin;
+    uint64_t at = 0;
+    for (uint32_t b = 0; b < outer.buckets; b++) {
+        if (!outer.full[b]) continue;
+        const uint32_t r = (uint32_t)outer.key[b];
+        group_begin.push_back(at);
+        uint64_t a = at;
+        for (unsigned t = 0; t < T; t++) { uint64_t &c = cur[(size_t)t * G + r]; const uint64_t k = c; c = a; a += k; }
+        at += cnt[r];
+    }
+    group_begin.push_back(at);
+    const size_t ngroups = group_begin.size() - 1;
+    std::vector<uint32_t> idx(n);
+    host_parallel_ranges(n, T, [&](unsigned t, size_t lo, size_t hi) {
+        uint64_t *c = cur.data() + (size_t)t * G;
+        for (size_t i = lo; i < hi; i++) idx[c[E[i].ref]++] = (uint32_t)i;
+    });
+    // inner order + filter, window by window; the kept indices stay at the front of their window
+    std::vector<uint64_t> kept(ngroups + 1, 0);
+    host_parallel_for(ngroups, T, [&](size_t g) {
+        static thread_local std::vector<uint64_t> keys;
+        static thread_local FxValMap inner;
+        uint32_t *w = idx.data() + group_begin[g];
+        const size_t k = (size_t)(group_begin[g + 1] - group_begin[g]);
+        keys.resize(k);
+        for (size_t j = 0; j < k; j++) keys[j] = (uint64_t)E[w[j]].query << 32 | w[j];
+        std::sort(keys.begin(), keys.end());                     // ascending Query (one record per pair; the index breaks no tie that matters)
+        inner.reset();
+        for (size_t j = 0; j < k; j++) inner.insert((uint32_t)(keys[j] >> 32), (uint32_t)keys[j]);
+        size_t out = 0;
+        for (uint32_t b = 0; b < inner.buckets; b++) {
+            const uint64_t kv = inner.slot[b];
+            if (kv == ~0ull) continue;
+            const uint32_t i = (uint32_t)kv;
+            if (passes_min_af(E[i], min_af_pct)) w[out++] = i;
+        }
+        kept[g] = out;
+    });
+    uint64_t total = 0;
+    for (size_t g = 0; g < ngroups; g++) { const uint64_t k = kept[g]; kept[g] = total; total += k; }
+    kept[ngroups] = total;
+    if (total) {
+        skder_edge_t *R = static_cast<skder_edge_t *>(malloc((size_t)total * sizeof(skder_edge_t)));
+        if (!R) return false;                                    // (nothing has moved yet: the in-place version can still run)
+        host_parallel_for(ngroups, T, [&](size_t g) {
+            const uint32_t *w = idx.data() + group_begin[g];
+            skder_edge_t *o = R + kept[g];
+            const size_t k = (size_t)(kept[g + 1] - kept[g]);
+            for (size_t j = 0; j < k; j++) o[j] = E[w[j]];
+        });
+        host_parallel_ranges((size_t)total, T, [&](unsigned, size_t lo, size_t hi) {
+            if (hi > lo) memcpy(static_cast<void *>(E.data() + lo), R + lo, (hi - lo) * sizeof(skder_edge_t));
+        });
+        free(R);
+    }
+    E.resize((size_t)total);
+    return true;
+}
+
 void triangle_rows_order_inplace(std::vector<skder_edge_t> &E, double min_af_pct)
+{
+    const size_t n = E.size();
+    const unsigned T = (unsigned)std::min<size_t>(ingest_threads(), n / 16384 + 1);
+    if (n >= 65536 && triangle_rows_order_parallel(E, min_af_pct, T)) return;
+    triangle_rows_order_serial(E, min_af_pct);
+}
+
+void triangle_rows_order_serial(std::vector<skder_edge_t> &E, double min_af_pct)
 {
     const size_t n = E.size();
     if (n == 0) return;

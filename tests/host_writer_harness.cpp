@@ -61,6 +61,15 @@ int main(int argc, char **argv)
             std::vector<skder_edge_t> want = triangle_rows_ordered(E, min_af), got(E);
             triangle_rows_order_inplace(got, min_af);
             if (!same(want, got)) { printf("triangle order differs: round %u min_af %.1f (%zu / %zu rows)\n", round, min_af, want.size(), got.size()); bad++; }
+            // both forms behind it, explicitly (the dispatcher picks by size and memory): the serial in-place one, the parallel one on 2 and 5 threads
+            std::vector<skder_edge_t> ser(E);
+            triangle_rows_order_serial(ser, min_af);
+            if (!same(want, ser)) { printf("serial triangle order differs: round %u min_af %.1f\n", round, min_af); bad++; }
+            for (unsigned T : {2u, 5u}) {
+                std::vector<skder_edge_t> par(E);
+                if (!triangle_rows_order_parallel(par, min_af, T)) { printf("parallel triangle order declined: round %u T %u\n", round, T); bad++; }
+                else if (!same(want, par)) { printf("parallel triangle order differs: round %u min_af %.1f T %u (%zu / %zu rows)\n", round, min_af, T, want.size(), par.size()); bad++; }
+            }
             std::vector<skder_edge_t> r(E), w(E);
             rect_rows_order_inplace(r, min_af);
             w.erase(std::remove_if(w.begin(), w.end(), [&](const skder_edge_t &e) { float a = (float)e.af_ref, b = (float)e.af_query; return (double)(a > b ? a : b) * 100.0 < min_af; }), w.end());
@@ -90,6 +99,13 @@ int main(int argc, char **argv)
         double t0 = now_s();
         std::vector<skder_edge_t> E = make_edges(G, big + big / 2, 5, 1000);      // (duplicates are dropped: ask for more)
         const size_t n = E.size();
+        double t_serial = 0;
+        if (getenv("HARNESS_TIME_SERIAL")) {         // the one-thread in-place form on a copy, for the comparison
+            std::vector<skder_edge_t> S(E);
+            const double a = now_s();
+            triangle_rows_order_serial(S, 50.0);
+            t_serial = now_s() - a;
+        }
         double t1 = now_s();
         triangle_rows_order_inplace(E, 50.0);
         double t2 = now_s();
@@ -101,8 +117,8 @@ int main(int argc, char **argv)
         const long long bytes = ftell(f);
         fclose(f);
         remove(out.c_str());
-        printf("{\"edges\": %zu, \"rows_kept\": %zu, \"threads\": %u, \"order_in_place_s\": %.3f, \"write_s\": %.3f, \"table_bytes\": %lld, \"rows_per_s_write\": %.0f, \"generate_s\": %.3f}\n",
-               n, E.size(), ingest_threads(), t2 - t1, t3 - t2, bytes, E.size() / (t3 - t2), t1 - t0);
+        printf("{\"edges\": %zu, \"rows_kept\": %zu, \"threads\": %u, \"order_in_place_s\": %.3f, \"write_s\": %.3f, \"table_bytes\": %lld, \"rows_per_s_write\": %.0f, \"generate_s\": %.3f, \"order_serial_s\": %.3f}\n",
+               n, E.size(), ingest_threads(), t2 - t1, t3 - t2, bytes, E.size() / (t3 - t2), t1 - t0 - t_serial, t_serial);
     }
     printf("%s\n", bad ? "FAILED" : "ok");
     return bad ? 1 : 0;
