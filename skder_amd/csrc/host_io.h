@@ -62,8 +62,12 @@ std::vector<skder_edge_t> rect_rows_ordered(const std::vector<skder_edge_t> &edg
 // the same orders established in place (no copy of the edge list; the callers hand the list over by swap)
 void triangle_rows_order_inplace(std::vector<skder_edge_t> &edges, double min_af_pct);      // the parallel form when the host has room for it, else the serial one
 void triangle_rows_order_serial(std::vector<skder_edge_t> &edges, double min_af_pct);       // one thread, strictly in place
-bool triangle_rows_order_parallel(std::vector<skder_edge_t> &edges, double min_af_pct, unsigned threads);   // false: not run (memory, size), nothing changed
-void rect_rows_order_inplace(std::vector<skder_edge_t> &edges, double min_af_pct);
+// false: not run (memory, size), nothing changed.  small_table_bytes: up to this size the ordered list is built in a second list that is swapped in
+// (and kept for the next call); above it in a raw block that is copied back and released (the harness passes 0 to take that branch on small tables)
+bool triangle_rows_order_parallel(std::vector<skder_edge_t> &edges, double min_af_pct, unsigned threads, size_t small_table_bytes = 256ull << 20);
+void rect_rows_order_inplace(std::vector<skder_edge_t> &edges, double min_af_pct);          // likewise
+void rect_rows_order_serial(std::vector<skder_edge_t> &edges, double min_af_pct);           // pieces sorted on the host threads, merged pairwise, in place
+bool rect_rows_order_parallel(std::vector<skder_edge_t> &edges, double min_af_pct, unsigned threads, size_t small_table_bytes = 256ull << 20);
 void host_parallel_chunks(size_t n, const std::function<void(size_t, size_t)> &fn);          // fn(lo, hi) over pieces of [0, n) on the host threads
 void write_rows_tsv(const std::string &out, const skder_edge_t *rows, size_t n, const GenomeNames &ref_names,
                     const GenomeNames &query_names);

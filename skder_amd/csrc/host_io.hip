@@ -1004,7 +1004,12 @@ void host_parallel_chunks(size_t n, const std::function<void(size_t, size_t)> &f
 // (first touch on all threads) and copied back.  Needs the index array and room for one more copy of the kept records: taken when
 // the host has it (host_memory_available), else the in-place version runs.  Same rows in the same order: tests/host_writer_harness.cpp
 // holds both against triangle_rows_ordered under the sanitizers.
-bool triangle_rows_order_parallel(std::vector<skder_edge_t> &E, double min_af_pct, unsigned T)
+// The common part of the parallel row orders: records grouped by a 32-bit GROUP id (Ref of a triangle row, Query of a search table),
+// the groups laid out in the order `window_order` gives them, every window ordered (and filtered) by `order_window`, which gets the
+// window's record indices, rewrites them in output order and returns how many stay.
+template <class GroupOf, class WindowOrder, class OrderWindow>
+static bool rows_order_parallel(std::vector<skder_edge_t> &E, unsigned T, size_t small_table_bytes, GroupOf group_of, WindowOrder window_order,
+                                OrderWindow order_window)
 {
     const size_t n = E.size();
     if (n >= 0xFFFFFFF0ull || T < 2) return false;
@@ -1012,79 +1017,150 @@ bool triangle_rows_order_parallel(std::vector<skder_edge_t> &E, double min_af_pc
     std::vector<uint32_t> tmax(T, 0);
     host_parallel_ranges(n, T, [&](unsigned t, size_t lo, size_t hi) {
         uint32_t m = 0;
-        for (size_t i = lo; i < hi; i++) m = E[i].ref > m ? E[i].ref : m;
+        for (size_t i = lo; i < hi; i++) { const uint32_t g = group_of(E[i]); m = g > m ? g : m; }
         tmax[t] = m;
     });
-    uint32_t max_ref = 0;
-    for (uint32_t m : tmax) max_ref = m > max_ref ? m : max_ref;
-    const size_t G = (size_t)max_ref + 1;
+    uint32_t max_g = 0;
+    for (uint32_t m : tmax) max_g = m > max_g ? m : max_g;
+    const size_t G = (size_t)max_g + 1;
     if (G * T > (512ull << 20) / 8) return false;                 // (the per-thread counters would be GBs: not this path's case)
-    std::vector<uint64_t> cur(G * T, 0);                          // [t * G + r]: records of Ref r in piece t, then their first slot
+    std::vector<uint64_t> cur(G * T, 0);                          // [t * G + g]: records of group g in piece t, then their first slot
     host_parallel_ranges(n, T, [&](unsigned t, size_t lo, size_t hi) {
         uint64_t *c = cur.data() + (size_t)t * G;
-        for (size_t i = lo; i < hi; i++) c[E[i].ref]++;
+        for (size_t i = lo; i < hi; i++) c[group_of(E[i])]++;
     });
     std::vector<uint64_t> cnt(G, 0);
-    for (unsigned t = 0; t < T; t++) for (size_t r = 0; r < G; r++) cnt[r] += cur[(size_t)t * G + r];
-    FxMap outer;                                                 // distinct Refs enter in ascending order
-    for (uint32_t r = 0; r <= max_ref; r++) if (cnt[r]) outer.insert(r);
+    for (unsigned t = 0; t < T; t++) for (size_t g = 0; g < G; g++) cnt[g] += cur[(size_t)t * G + g];
+    std::vector<uint32_t> groups;                                 // the non-empty groups in output order
+    window_order(cnt, groups);
     std::vector<uint64_t> group_begin;
     uint64_t at = 0;
-    for (uint32_t b = 0; b < outer.buckets; b++) {
-        if (!outer.full[b]) continue;
-        const uint32_t r = (uint32_t)outer.key[b];
+    for (uint32_t g : groups) {
         group_begin.push_back(at);
         uint64_t a = at;
-        for (unsigned t = 0; t < T; t++) { uint64_t &c = cur[(size_t)t * G + r]; const uint64_t k = c; c = a; a += k; }
-        at += cnt[r];
+        for (unsigned t = 0; t < T; t++) { uint64_t &c = cur[(size_t)t * G + g]; const uint64_t k = c; c = a; a += k; }
+        at += cnt[g];
     }
     group_begin.push_back(at);
-    const size_t ngroups = group_begin.size() - 1;
+    const size_t ngroups = groups.size();
     std::vector<uint32_t> idx(n);
-    host_parallel_ranges(n, T, [&](unsigned t, size_t lo, size_t hi) {
+    host_parallel_ranges(n, T, [&](unsigned t, size_t lo, size_t hi) {      // stable: a window holds its records in list order
         uint64_t *c = cur.data() + (size_t)t * G;
-        for (size_t i = lo; i < hi; i++) idx[c[E[i].ref]++] = (uint32_t)i;
+        for (size_t i = lo; i < hi; i++) idx[c[group_of(E[i])]++] = (uint32_t)i;
     });
-    // inner order + filter, window by window; the kept indices stay at the front of their window
     std::vector<uint64_t> kept(ngroups + 1, 0);
     host_parallel_for(ngroups, T, [&](size_t g) {
-        static thread_local std::vector<uint64_t> keys;
-        static thread_local FxValMap inner;
-        uint32_t *w = idx.data() + group_begin[g];
-        const size_t k = (size_t)(group_begin[g + 1] - group_begin[g]);
-        keys.resize(k);
-        for (size_t j = 0; j < k; j++) keys[j] = (uint64_t)E[w[j]].query << 32 | w[j];
-        std::sort(keys.begin(), keys.end());                     // ascending Query (one record per pair; the index breaks no tie that matters)
-        inner.reset();
-        for (size_t j = 0; j < k; j++) inner.insert((uint32_t)(keys[j] >> 32), (uint32_t)keys[j]);
-        size_t out = 0;
-        for (uint32_t b = 0; b < inner.buckets; b++) {
-            const uint64_t kv = inner.slot[b];
-            if (kv == ~0ull) continue;
-            const uint32_t i = (uint32_t)kv;
-            if (passes_min_af(E[i], min_af_pct)) w[out++] = i;
-        }
-        kept[g] = out;
+        kept[g] = order_window(idx.data() + group_begin[g], (size_t)(group_begin[g + 1] - group_begin[g]));
     });
     uint64_t total = 0;
     for (size_t g = 0; g < ngroups; g++) { const uint64_t k = kept[g]; kept[g] = total; total += k; }
     kept[ngroups] = total;
-    if (total) {
-        skder_edge_t *R = static_cast<skder_edge_t *>(malloc((size_t)total * sizeof(skder_edge_t)));
-        if (!R) return false;                                    // (nothing has moved yet: the in-place version can still run)
-        host_parallel_for(ngroups, T, [&](size_t g) {
-            const uint32_t *w = idx.data() + group_begin[g];
-            skder_edge_t *o = R + kept[g];
-            const size_t k = (size_t)(kept[g + 1] - kept[g]);
-            for (size_t j = 0; j < k; j++) o[j] = E[w[j]];
-        });
-        host_parallel_ranges((size_t)total, T, [&](unsigned, size_t lo, size_t hi) {
-            if (hi > lo) memcpy(static_cast<void *>(E.data() + lo), R + lo, (hi - lo) * sizeof(skder_edge_t));
-        });
-        free(R);
+    // a window of a few records per job would be all overhead, one of 10^6 a straggler: jobs of consecutive windows, ~64 K records each
+    std::vector<size_t> job_first{0};
+    for (size_t g = 0, in_job = 0; g < ngroups; g++) {
+        in_job += (size_t)(kept[g + 1] - kept[g]);
+        if (in_job >= 65536 && g + 1 < ngroups) { job_first.push_back(g + 1); in_job = 0; }
     }
+    job_first.push_back(ngroups);
+    auto gather_into = [&](skder_edge_t *dst) {
+        host_parallel_for(job_first.size() - 1, T, [&](size_t j) {
+            for (size_t g = job_first[j]; g < job_first[j + 1]; g++) {
+                const uint32_t *w = idx.data() + group_begin[g];
+                skder_edge_t *o = dst + kept[g];
+                const size_t k = (size_t)(kept[g + 1] - kept[g]);
+                for (size_t i = 0; i < k; i++) o[i] = E[w[i]];
+            }
+        });
+    };
+    if ((size_t)total * sizeof(skder_edge_t) <= small_table_bytes) {
+        // SMALL tables (the searches of low_mem_greedy order ~50 MB every batch): gathered into a second list that is then SWAPPED with
+        // the caller's -- no copy back --, and the list that comes out of the swap is kept for the next call, so that no call after
+        // the first touches fresh memory
+        static std::mutex spare_mu;
+        static std::vector<skder_edge_t> spare;
+        std::vector<skder_edge_t> R;
+        {
+            std::lock_guard<std::mutex> lk(spare_mu);
+            R.swap(spare);
+        }
+        try {
+            if (R.size() < (size_t)total) R.resize((size_t)total);      // (only growth touches memory; the records are overwritten)
+        } catch (const std::bad_alloc &) { return false; }             // (nothing has moved yet: the in-place version can still run)
+        gather_into(R.data());
+        R.resize((size_t)total);
+        E.swap(R);
+        if (R.capacity() * sizeof(skder_edge_t) <= (256ull << 20)) {
+            std::lock_guard<std::mutex> lk(spare_mu);
+            if (spare.capacity() < R.capacity()) spare.swap(R);
+        }
+        return true;
+    }
+    // BIG tables (a triangle of 10^7 - 10^8 rows): a raw scratch block, first touched by all threads in the gather, copied back in
+    // parallel and released
+    skder_edge_t *R = static_cast<skder_edge_t *>(malloc((size_t)total * sizeof(skder_edge_t)));
+    if (!R) return false;                                           // (nothing has moved yet)
+    gather_into(R);
+    host_parallel_ranges((size_t)total, T, [&](unsigned, size_t lo, size_t hi) {
+        if (hi > lo) memcpy(static_cast<void *>(E.data() + lo), R + lo, (hi - lo) * sizeof(skder_edge_t));
+    });
+    free(R);
     E.resize((size_t)total);
     return true;
+}
+
+bool triangle_rows_order_parallel(std::vector<skder_edge_t> &E, double min_af_pct, unsigned T, size_t small_table_bytes)
+{
+    return rows_order_parallel(E, T, small_table_bytes, [](const skder_edge_t &e) { return e.ref; },
+        [](const std::vector<uint64_t> &cnt, std::vector<uint32_t> &groups) {
+            FxMap outer;                                             // distinct Refs enter in ascending order; rows leave in bucket order
+            for (size_t r = 0; r < cnt.size(); r++) if (cnt[r]) outer.insert(r);
+            for (uint32_t b = 0; b < outer.buckets; b++) if (outer.full[b]) groups.push_back((uint32_t)outer.key[b]);
+        },
+        [&](uint32_t *w, size_t k) -> size_t {
+            static thread_local std::vector<uint64_t> keys;
+            static thread_local FxValMap inner;
+            keys.resize(k);
+            for (size_t j = 0; j < k; j++) keys[j] = (uint64_t)E[w[j]].query << 32 | w[j];
+            std::sort(keys.begin(), keys.end());                     // ascending Query (one record per pair)
+            inner.reset();
+            for (size_t j = 0; j < k; j++) inner.insert((uint32_t)(keys[j] >> 32), (uint32_t)keys[j]);
+            size_t out = 0;
+            for (uint32_t b = 0; b < inner.buckets; b++) {
+                const uint64_t kv = inner.slot[b];
+                if (kv == ~0ull) continue;
+                const uint32_t i = (uint32_t)kv;
+                if (passes_min_af(E[i], min_af_pct)) w[out++] = i;
+            }
+            return out;
+        });
+}
+
+// search / dist tables on all host threads: windows = queries in ascending order; inside one, ANI descending (as a float, like rect_before),
+// then Ref -- a 64-bit key per record, sorted with its index
+bool rect_rows_order_parallel(std::vector<skder_edge_t> &E, double min_af_pct, unsigned T, size_t small_table_bytes)
+{
+    return rows_order_parallel(E, T, small_table_bytes, [](const skder_edge_t &e) { return e.query; },
+        [](const std::vector<uint64_t> &cnt, std::vector<uint32_t> &groups) {
+            for (size_t q = 0; q < cnt.size(); q++) if (cnt[q]) groups.push_back((uint32_t)q);
+        },
+        [&](uint32_t *w, size_t k) -> size_t {
+            struct KI { uint64_t key; uint32_t i; };
+            static thread_local std::vector<KI> ks;
+            ks.clear();
+            for (size_t j = 0; j < k; j++) {
+                const skder_edge_t &e = E[w[j]];
+                if (!passes_min_af(e, min_af_pct)) continue;
+                const float a = (float)e.ani;
+                uint32_t bits;
+                memcpy(&bits, &a, 4);
+                // floats order like their bit patterns once the sign is folded in: descending ANI = ascending ~ordered(bits)
+                const uint32_t ordered = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+                ks.push_back(KI{(uint64_t)(~ordered) << 32 | e.ref, w[j]});
+            }
+            std::sort(ks.begin(), ks.end(), [](const KI &x, const KI &y) { return x.key < y.key; });
+            for (size_t j = 0; j < ks.size(); j++) w[j] = ks[j].i;
+            return ks.size();
+        });
 }
 
 void triangle_rows_order_inplace(std::vector<skder_edge_t> &E, double min_af_pct)
@@ -1157,6 +1233,13 @@ static bool rect_before(const skder_edge_t &a, const skder_edge_t &b)
     return a.ref < b.ref;
 }
 void rect_rows_order_inplace(std::vector<skder_edge_t> &E, double min_af_pct)
+{
+    const unsigned T0 = (unsigned)std::min<size_t>(ingest_threads(), E.size() / 16384 + 1);
+    if (E.size() >= 65536 && rect_rows_order_parallel(E, min_af_pct, T0)) return;
+    rect_rows_order_serial(E, min_af_pct);
+}
+
+void rect_rows_order_serial(std::vector<skder_edge_t> &E, double min_af_pct)
 {
     E.erase(std::remove_if(E.begin(), E.end(), [&](const skder_edge_t &e) { return !passes_min_af(e, min_af_pct); }), E.end());
     const size_t n = E.size();

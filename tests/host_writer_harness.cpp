@@ -65,9 +65,9 @@ int main(int argc, char **argv)
             std::vector<skder_edge_t> ser(E);
             triangle_rows_order_serial(ser, min_af);
             if (!same(want, ser)) { printf("serial triangle order differs: round %u min_af %.1f\n", round, min_af); bad++; }
-            for (unsigned T : {2u, 5u}) {
+            for (unsigned T : {2u, 5u, 3u}) {       // (T == 3: the big-table branch -- raw scratch block, parallel copy back)
                 std::vector<skder_edge_t> par(E);
-                if (!triangle_rows_order_parallel(par, min_af, T)) { printf("parallel triangle order declined: round %u T %u\n", round, T); bad++; }
+                if (!triangle_rows_order_parallel(par, min_af, T, T == 3u ? 0 : (256ull << 20))) { printf("parallel triangle order declined: round %u T %u\n", round, T); bad++; }
                 else if (!same(want, par)) { printf("parallel triangle order differs: round %u min_af %.1f T %u (%zu / %zu rows)\n", round, min_af, T, want.size(), par.size()); bad++; }
             }
             std::vector<skder_edge_t> r(E), w(E);
@@ -80,6 +80,16 @@ int main(int argc, char **argv)
                 return a.ref < b.ref;
             });
             if (!same(r, w)) { printf("rectangle order differs: round %u min_af %.1f\n", round, min_af); bad++; }
+            {
+                std::vector<skder_edge_t> rs(E);
+                rect_rows_order_serial(rs, min_af);
+                if (!same(rs, w)) { printf("serial rectangle order differs: round %u min_af %.1f\n", round, min_af); bad++; }
+                for (unsigned T : {2u, 5u, 3u}) {
+                    std::vector<skder_edge_t> rp(E);
+                    if (!rect_rows_order_parallel(rp, min_af, T, T == 3u ? 0 : (256ull << 20))) { printf("parallel rectangle order declined: round %u T %u\n", round, T); bad++; }
+                    else if (!same(rp, w)) { printf("parallel rectangle order differs: round %u min_af %.1f T %u\n", round, min_af, T); bad++; }
+                }
+            }
             // text
             const std::string out = std::string(dir) + "/t.tsv", ref = std::string(dir) + "/t_ref.tsv";
             write_rows_tsv(out, want.data(), want.size(), names, names);
