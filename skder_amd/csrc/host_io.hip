@@ -1266,15 +1266,40 @@ std::vector<skder_edge_t> rect_rows_ordered(const std::vector<skder_edge_t> &edg
 }
 
 // one row of the table appended to `o`
+// "\t%.2f" of (double)(frac * 100.0f) appended to p: the hundredths come from skder_amd_pct2_cents (select.cpp: integer arithmetic on the
+// float's mantissa, ties to even like glibc's printf -- tests/test_selection_native.py holds it against printf), the digits from two
+// divisions; three of these per row were two thirds of a row's formatting time through snprintf.  Values a table never holds (negative,
+// NaN, beyond 10^7) take snprintf.
+static char *put_pct2(char *p, float frac)
+{
+    *p++ = '\t';
+    const float x = frac * 100.0f;
+    if (!(x >= 0.0f) || !(x < 1.0e7f)) return p + snprintf(p, 40, "%.2f", (double)x);
+    const uint64_t c = (uint64_t)skder_amd_pct2_cents(frac);
+    uint64_t ip = c / 100u;
+    const unsigned fr = (unsigned)(c % 100u);
+    char tmp[24];
+    int k = 0;
+    do { tmp[k++] = (char)('0' + ip % 10u); ip /= 10u; } while (ip);
+    while (k) *p++ = tmp[--k];
+    *p++ = '.';
+    *p++ = (char)('0' + fr / 10u);
+    *p++ = (char)('0' + fr % 10u);
+    return p;
+}
+
+// one row of the table appended to `o`
 static void format_row(std::string &o, const std::string &rf, const std::string &qf, const skder_edge_t &e, const std::string &rn,
                        const std::string &qn)
 {
     // skani keeps its results in single precision and prints percentages with two decimals
-    const float ani = (float)e.ani, afr = (float)e.af_ref, afq = (float)e.af_query;
-    char num[96];
-    const int k = snprintf(num, sizeof num, "\t%.2f\t%.2f\t%.2f\t", (double)(ani * 100.0f), (double)(afr * 100.0f), (double)(afq * 100.0f));
+    char num[160];
+    char *p = put_pct2(num, (float)e.ani);
+    p = put_pct2(p, (float)e.af_ref);
+    p = put_pct2(p, (float)e.af_query);
+    *p++ = '\t';
     o.append(rf); o.push_back('\t'); o.append(qf);
-    o.append(num, (size_t)k);
+    o.append(num, (size_t)(p - num));
     o.append(rn); o.push_back('\t'); o.append(qn); o.push_back('\n');
 }
 
