@@ -12,7 +12,7 @@
 
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-static std::vector<skder_edge_t> make_edges(uint32_t n_genomes, size_t n_edges, uint32_t seed, uint32_t block = 100)
+static std::vector<skder_edge_t> make_edges(uint32_t n_genomes, size_t n_edges, uint32_t seed, uint32_t block = 100, uint32_t ani_levels = 150000)
 {
     // species blocks of `block` genomes: dense rows inside a block, a few stray pairs across (thinned rows)
     std::mt19937_64 rng(seed);
@@ -28,7 +28,7 @@ static std::vector<skder_edge_t> make_edges(uint32_t n_genomes, size_t n_edges, 
         skder_edge_t e;
         memset(&e, 0, sizeof e);
         e.ref = a; e.query = b;
-        e.ani = 0.85 + (double)(rng() % 150000) / 1e6; e.af_ref = (double)(rng() % 100001) / 1e5; e.af_query = (double)(rng() % 100001) / 1e5;
+        e.ani = 0.85 + (double)(rng() % ani_levels) * (0.15 / ani_levels);   /* few levels: many rows of a search table tie on ANI, Ref decides */ e.af_ref = (double)(rng() % 100001) / 1e5; e.af_query = (double)(rng() % 100001) / 1e5;
         E.push_back(e);
     }
     // one record per pair
@@ -55,8 +55,13 @@ int main(int argc, char **argv)
         names.n50.push_back(1000 + g);
     }
     int bad = 0;
-    for (uint32_t round = 0; round < (big ? 0u : 6u); round++) {
-        const std::vector<skder_edge_t> E = make_edges(G, round == 0 ? 1 : (round == 1 ? 37 : 20000u * round), 17 + round);
+    for (uint32_t round = 0; round < (big ? 0u : 9u); round++) {
+        // rounds 0 - 5: species blocks of 100 genomes, 1 .. 100,000 edges; 6: ONE species (every row dense: 400 genomes, all pairs asked for);
+        // 7: the same with 12 ANI levels (ties); 8: 1,200 genomes in blocks of 3 (thousands of tiny rows)
+        const std::vector<skder_edge_t> E = round < 6 ? make_edges(G, round == 0 ? 1 : (round == 1 ? 37 : 20000u * round), 17 + round)
+                                          : round == 6 ? make_edges(400, 120000, 31, 400)
+                                          : round == 7 ? make_edges(400, 120000, 32, 400, 12)
+                                                       : make_edges(G, 30000, 33, 3);
         for (double min_af : {0.0, 50.0, 99.5}) {
             std::vector<skder_edge_t> want = triangle_rows_ordered(E, min_af), got(E);
             triangle_rows_order_inplace(got, min_af);
