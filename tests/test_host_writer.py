@@ -15,14 +15,16 @@ CSRC = os.path.join(ROOT, "skder_amd", "csrc")
 
 
 def _build(tmp_path, sanitize):
+    """sanitize: False (optimised), True (AddressSanitizer + UBSan) or "thread" (ThreadSanitizer)"""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     subprocess.check_call(["make", "-C", CSRC, "-j8"], stdout=subprocess.DEVNULL)
     # every object of the library except host_io.o, which the harness compiles from source under the sanitizers (list: csrc/Makefile)
     mk = open(os.path.join(CSRC, "Makefile")).read()
     srcs = re.search(r"^SRC = (.*)$", mk, re.M).group(1).split()
     objs = [os.path.join(CSRC, f[:-4] + ".o") for f in srcs if f != "host_io.hip"] + [os.path.join(CSRC, o) for o in ("gunzip.o", "select.o")]
-    exe = str(tmp_path / ("writer_harness" + ("_san" if sanitize else "")))
-    flags = ["-O1", "-g", "-Xarch_host", "-fsanitize=address,undefined", "-fno-omit-frame-pointer"] if sanitize else ["-O3"]
+    exe = str(tmp_path / ("writer_harness" + ("_tsan" if sanitize == "thread" else "_san" if sanitize else "")))
+    flags = (["-O1", "-g", "-Xarch_host", "-fsanitize=thread"] if sanitize == "thread" else
+             ["-O1", "-g", "-Xarch_host", "-fsanitize=address,undefined", "-fno-omit-frame-pointer"] if sanitize else ["-O3"])
     subprocess.check_call([hipcc, "--offload-arch=gfx950"] + flags + ["-std=c++17", "-I" + CSRC, "-x", "hip",
                            os.path.join(ROOT, "tests", "host_writer_harness.cpp"), os.path.join(CSRC, "host_io.hip"), "-x", "none"] + objs +
                           ["-o", exe, "-lz", "-lpthread"], stderr=subprocess.DEVNULL)
@@ -46,3 +48,14 @@ def test_two_million_rows_are_ordered_and_written(tmp_path):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     r = json.loads(out.stdout.splitlines()[0])
     assert r["rows_kept"] > 1_000_000 and r["table_bytes"] > 150 * r["rows_kept"]
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
+def test_row_order_and_writer_under_thread_sanitizer(tmp_path):
+    """the same harness under ThreadSanitizer: the parallel row orders (histograms, index scatter, window jobs, gather, the spare list
+    behind its mutex) and the block writer's hand-over of offsets run on several threads without a data race"""
+    exe = _build(tmp_path, "thread")
+    out = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=1500,
+                         env=dict(os.environ, SKDER_AMD_IO_THREADS="6", TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0"))
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:] + out.stderr[-3000:]
+    assert "ThreadSanitizer" not in out.stderr, out.stderr[-4000:]
