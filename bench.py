@@ -1176,7 +1176,7 @@ def main():
                 pm = allk[dom.split("+")[0]]
                 # counter values corrected by the calibration of profiles/calib (profiles/summarise.py)
                 traffic = sum(pm[c].get("corrected_bytes", pm[c]["sum_counter_kb"] * 1024.0) for c in ("FETCH_SIZE", "WRITE_SIZE"))
-                traffic_source = src + " (static: rocprofv3 --pmc passes of this build, not measured in this run)"
+                traffic_source = src + " (static: rocprofv3 --pmc passes, not measured in this run; " + str(allk.get("__source__", "of this build"))[:400] + ")"
                 step_traffic = allk.get("__step__", {}).get("bytes")
             except OSError:
                 traffic_source = "missing: %s (collect it with profiles/collect.sh)" % src       # an auxiliary field never costs the line
