@@ -265,3 +265,58 @@ def test_bench_cites_only_profile_files_that_exist():
     cited = set(re.findall(r"profiles/[A-Za-z0-9_./]+\.(?:json|txt|csv|hip|sh|py)", text))
     missing = sorted(c for c in cited if not os.path.isfile(os.path.join(ROOT, c)) and c != bench.PMC_TRAFFIC.replace(os.sep, "/"))
     assert not missing, missing
+
+
+def test_profile_summary_tool_on_a_synthetic_collection(tmp_path):
+    """profiles/summarise.py on a made-up collection directory (the layout profiles/collect.sh writes): per-kernel counters summed over
+    dispatches, calibration factors applied by pattern (the index kernel's FETCH_SIZE through gather16_random), kernels without a pattern
+    through the default (streaming reads x the read16 factor), the generator kernel left out of the step total, SQ summaries copied with
+    the round's prefix"""
+    import csv
+    import json
+    import shutil
+    import subprocess
+    import sys
+    root = tmp_path / "repo"
+    (root / "profiles").mkdir(parents=True)
+    shutil.copy(os.path.join(ROOT, "profiles", "summarise.py"), root / "profiles" / "summarise.py")
+    src = root / "gpurun_out" / "prof_roundX"
+
+    def counters(sub, rows):
+        d = src / sub / "x"
+        d.mkdir(parents=True)
+        with open(d / "1_counter_collection.csv", "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["Kernel_Name", "Counter_Name", "Counter_Value"])
+            for name, value in rows:
+                w.writerow([name, "X", value])
+
+    def stats(sub):
+        d = src / sub / "x"
+        d.mkdir(parents=True)
+        (d / "1_kernel_stats.csv").write_text("Name,Calls\nk,1\n")
+        (d / "1_domain_stats.csv").write_text("Name,Calls\nKERNEL_DISPATCH,1\n")
+    stats("stats")
+    kb = 1 << 20                                  # counter values are KB
+    counters("calib_fetch", [("read16_coalesced(...)", 3 * kb), ("read4_coalesced(...)", 3 * kb), ("gather16_random(...)", 12 * kb)])
+    counters("calib_write", [("write4_coalesced(...)", 6 * kb)])
+    (src / "calib_fetch.log").write_text("known_bytes read16_coalesced %d\nknown_bytes read4_coalesced %d\nknown_bytes gather16_random %d\n"
+                                         "known_bytes write4_coalesced %d\n" % (6 << 30, 6 << 30, 6 << 30, 6 << 30))
+    counters("fetch", [("void sketch_tiles_kernel<32781>(unsigned char*)", 100), ("void sketch_tiles_kernel<32781>(unsigned char*)", 50),
+                       ("index_genome_lds_kernel(GenomeMeta*)", 40), ("scan_apply_kernel(unsigned int*)", 10), ("synth_fill_kernel(x)", 1000)])
+    counters("write", [("void sketch_tiles_kernel<32781>(unsigned char*)", 20), ("index_genome_lds_kernel(GenomeMeta*)", 8),
+                       ("scan_apply_kernel(unsigned int*)", 4), ("synth_fill_kernel(x)", 5000)])
+    (src / "bench_line.json").write_text(json.dumps({"roofline": {"kernel": "sketch_tiles_kernel", "traffic": None}}) + "\n")
+    (src / "pmc_sketch_tiles_kernel.txt").write_text("SQ_WAVES 2 123\n")
+    subprocess.run([sys.executable, str(root / "profiles" / "summarise.py"), "roundX"], check=True, capture_output=True, cwd=str(root))
+    t = json.load(open(root / "profiles" / "roundX_pmc_traffic.json"))
+    sk, ix, sc = t["sketch_tiles_kernel"], t["index_genome_lds_kernel"], t["scan_apply_kernel"]
+    assert sk["FETCH_SIZE"]["launches"] == 2 and sk["FETCH_SIZE"]["corrected_bytes"] == 150 * 1024 * 2.0        # read16: the counter shows half
+    assert ix["FETCH_SIZE"]["pattern"] == "gather16_random" and ix["FETCH_SIZE"]["corrected_bytes"] == 40 * 1024 * 0.5
+    assert "pattern" not in sc["FETCH_SIZE"]
+    step = t["__step__"]
+    assert step["kernels"] == 3                                                                                    # the generator is not part of a step
+    assert step["FETCH_SIZE"] == 150 * 1024 * 2.0 + 40 * 1024 * 0.5 + 10 * 1024 * 2.0 and step["WRITE_SIZE"] == (20 + 8 + 4) * 1024
+    assert step["bytes"] == step["FETCH_SIZE"] + step["WRITE_SIZE"]
+    assert json.load(open(root / "profiles" / "roundX_bench_line.json"))["roofline"]["traffic"] == 150 * 1024 * 2.0 + 20 * 1024
+    assert (root / "profiles" / "roundX_pmc_sketch_tiles_kernel.txt").read_text() == "SQ_WAVES 2 123\n"
