@@ -162,6 +162,24 @@ def end_to_end_sample(tmp, paths, nbytes, device):
     return {"genomes": len(paths), "fasta_bytes": nbytes, "seconds": dt, "rows": rows, "ingest_MB_per_s": nbytes / dt / 1e6}
 
 
+def pmc_traffic(kernel, path=None):
+    """measured HBM traffic of `kernel` per step and of the whole step, from the committed summary of the rocprofv3 --pmc passes
+    (FETCH_SIZE / WRITE_SIZE in separate passes, corrected by the calibration of profiles/calib: profiles/summarise.py); only valid for the
+    default workload on one GPU.  -> (kernel bytes, where they come from, step bytes); (None, why, None) when the file is not there --
+    an auxiliary field never costs the line"""
+    src = path or PMC_TRAFFIC
+    try:
+        allk = json.load(open(os.path.join(ROOT, src)))
+        pm = allk[kernel]
+        traffic = sum(pm[c].get("corrected_bytes", pm[c]["sum_counter_kb"] * 1024.0) for c in ("FETCH_SIZE", "WRITE_SIZE"))
+        source = src + " (static: rocprofv3 --pmc passes, not measured in this run; " + str(allk.get("__source__", "of this build"))[:400] + ")"
+        return traffic, source, allk.get("__step__", {}).get("bytes")
+    except OSError:
+        return None, "missing: %s (collect it with profiles/collect.sh)" % src, None
+    except (KeyError, ValueError, TypeError) as ex:
+        return None, "unreadable: %s (%r)" % (src, ex), None
+
+
 def golden_compare(table):
     """a 7-column edge table of the reference's 34 genomes against the skani table the reference's own run holds (tests/golden/G5, two
     decimals): differences in percentage points and -- the distance to "bit-identical edge table" as integers -- how many golden values
@@ -1170,18 +1188,7 @@ def main():
         # separate passes, PMC_TRAFFIC; only valid for the default workload on 1 GPU)
         traffic, traffic_source, step_traffic = None, None, None
         if N == 5000 and world == 1 and args.len_range is None and args.genome_len == 3_000_000:
-            src = PMC_TRAFFIC
-            try:
-                allk = json.load(open(os.path.join(ROOT, src)))
-                pm = allk[dom.split("+")[0]]
-                # counter values corrected by the calibration of profiles/calib (profiles/summarise.py)
-                traffic = sum(pm[c].get("corrected_bytes", pm[c]["sum_counter_kb"] * 1024.0) for c in ("FETCH_SIZE", "WRITE_SIZE"))
-                traffic_source = src + " (static: rocprofv3 --pmc passes, not measured in this run; " + str(allk.get("__source__", "of this build"))[:400] + ")"
-                step_traffic = allk.get("__step__", {}).get("bytes")
-            except OSError:
-                traffic_source = "missing: %s (collect it with profiles/collect.sh)" % src       # an auxiliary field never costs the line
-            except (KeyError, ValueError) as ex:
-                traffic_source = "unreadable: %s (%r)" % (src, ex)
+            traffic, traffic_source, step_traffic = pmc_traffic(dom.split("+")[0])
         # the VALU-bound kernel against its own issue floor: the inner body alone (profiles/calib/sketch_body_bench.hip, the shipped
         # instruction selection, ns per position and wavefront per SIMD) over what the whole kernel takes per position and wavefront
         ns_pw = float(tm[0] * 1e6 * 1024 / (total_bases / 64.0)) if total_bases else 0.0

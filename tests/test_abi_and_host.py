@@ -320,3 +320,16 @@ def test_profile_summary_tool_on_a_synthetic_collection(tmp_path):
     assert step["bytes"] == step["FETCH_SIZE"] + step["WRITE_SIZE"]
     assert json.load(open(root / "profiles" / "roundX_bench_line.json"))["roofline"]["traffic"] == 150 * 1024 * 2.0 + 20 * 1024
     assert (root / "profiles" / "roundX_pmc_sketch_tiles_kernel.txt").read_text() == "SQ_WAVES 2 123\n"
+
+
+def test_bench_reads_its_traffic_figures_from_the_committed_summary():
+    """bench.pmc_traffic: the dominant kernel's measured bytes per step and the step total from profiles/round6_pmc_traffic.json; a missing
+    or unreadable file gives None and a reason, never an exception"""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    t, src, step = bench.pmc_traffic("sketch_tiles_kernel")
+    assert 16.5e9 < t < 17.5e9 and 160e9 < step < 175e9 and "round 5" in src.lower() or "ROUND 5" in src     # 1.07 x the 15.96 GB the algorithm moves
+    assert step > t
+    assert bench.pmc_traffic("sketch_tiles_kernel", "profiles/no_such_file.json")[::2] == (None, None)
+    assert bench.pmc_traffic("no_such_kernel")[0] is None
