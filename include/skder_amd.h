@@ -219,8 +219,8 @@ double skder_amd_last_runs_ms(skder_ctx_t *ctx);
  * unabridged (slow) chaining path */
 int skder_amd_last_counters(skder_ctx_t *ctx, uint64_t *out4);
 /* Memory the library keeps between calls on a device -- the ingest's pinned staging buffers with their device copies (about 0.6 GB of
- * pinned host memory and 1.2 GB of HBM at the default batch size) and the device allocator's cached blocks -- handed back to the
- * driver.  For long-lived host applications; 0: released, 1: the staging set is in use by a running call (the rest was released). */
+ * pinned host memory and 1.2 GB of HBM at the default batch size), the device allocator's cached blocks and the host list the table
+ * writers keep for the next small table (at most 256 MB) -- handed back.  For long-lived host applications; 0: released, 1: the staging set is in use by a running call (the rest was released). */
 int skder_amd_release_cached_buffers(int device);
 /* multi-GPU calls of one process (skder_amd_triangle_multi, skder_amd_sketch_multi): ordered device pairs found WITHOUT peer access so
  * far -- their copies are staged through host memory by the runtime (correct, an order of magnitude slower than xGMI).  0 on a healthy node. */

@@ -101,13 +101,14 @@ extern "C" int skder_amd_copy_d2d(skder_ctx_t *ctx, void *dst, const void *src, 
 }
 
 // memory the library keeps between calls (the ingest's pinned staging buffers and their device copies, the device
-// allocator's cached blocks): handed back to the driver.  Buffers in use by a running call stay.
+// allocator's cached blocks, the row orders' spare host list): handed back.  Buffers in use by a running call stay.
 extern "C" int skder_amd_release_cached_buffers(int device)
 {
     try {
         HIPCHECK(hipSetDevice(device));
         const bool ok = staging_release(device);
         pool_trim();
+        rows_order_release_spare();
         return ok ? 0 : 1;
     } catch (const std::exception &) { return 2; }
 }

@@ -76,4 +76,5 @@ void write_n50_tsv(const std::string &out, const GenomeNames &names);
 // sketch store
 void store_save(const std::string &out, skder_sketches *s, const GenomeNames &names);
 void store_load(const std::string &path, skder_sketches *s, GenomeNames &names);
+void rows_order_release_spare();       // the <= 256 MB list the row orders keep between calls goes back to the allocator
 bool staging_release(int device);      // free the device's cached ingest buffers (false: in use)

@@ -1004,6 +1004,15 @@ void host_parallel_chunks(size_t n, const std::function<void(size_t, size_t)> &f
 // (first touch on all threads) and copied back.  Needs the index array and room for one more copy of the kept records: taken when
 // the host has it (host_memory_available), else the in-place version runs.  Same rows in the same order: tests/host_writer_harness.cpp
 // holds both against triangle_rows_ordered under the sanitizers.
+// the list the parallel row orders keep between calls (at most 256 MB: a small table's ordered copy is built in it and swapped in)
+static std::mutex &rows_spare_mutex() { static std::mutex m; return m; }
+static std::vector<skder_edge_t> &rows_spare_list() { static std::vector<skder_edge_t> v; return v; }
+void rows_order_release_spare()
+{
+    std::lock_guard<std::mutex> lk(rows_spare_mutex());
+    std::vector<skder_edge_t>().swap(rows_spare_list());
+}
+
 // The common part of the parallel row orders: records grouped by a 32-bit GROUP id (Ref of a triangle row, Query of a search table),
 // the groups laid out in the order `window_order` gives them, every window ordered (and filtered) by `order_window`, which gets the
 // window's record indices, rewrites them in output order and returns how many stay.
@@ -1076,8 +1085,8 @@ static bool rows_order_parallel(std::vector<skder_edge_t> &E, unsigned T, size_t
         // SMALL tables (the searches of low_mem_greedy order ~50 MB every batch): gathered into a second list that is then SWAPPED with
         // the caller's -- no copy back --, and the list that comes out of the swap is kept for the next call, so that no call after
         // the first touches fresh memory
-        static std::mutex spare_mu;
-        static std::vector<skder_edge_t> spare;
+        std::mutex &spare_mu = rows_spare_mutex();
+        std::vector<skder_edge_t> &spare = rows_spare_list();
         std::vector<skder_edge_t> R;
         {
             std::lock_guard<std::mutex> lk(spare_mu);
