@@ -1336,7 +1336,13 @@ void write_rows_tsv(const std::string &out, const skder_edge_t *rows, size_t n, 
         std::string text, failure;
         const size_t lo = b * BLOCK, hi = std::min(n, lo + BLOCK);
         try {
-            text.reserve((hi - lo) * 160);
+            size_t need = 0;                          // the block's text in ONE allocation: paths and names are ~80 characters each, four per row
+            for (size_t i = lo; i < hi; i++) {
+                const skder_edge_t &e = rows[i];
+                need += ref_names.path[e.ref].size() + query_names.path[e.query].size() + ref_names.first_name[e.ref].size() +
+                        query_names.first_name[e.query].size() + 32;
+            }
+            text.reserve(need);
             for (size_t i = lo; i < hi; i++) {
                 const skder_edge_t &e = rows[i];
                 format_row(text, ref_names.path[e.ref], query_names.path[e.query], e, ref_names.first_name[e.ref], query_names.first_name[e.query]);
