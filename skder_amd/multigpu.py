@@ -18,7 +18,9 @@ MARKERS are all-gathered (8 B per 1000 bases), every rank screens its rows of th
 (8 B each), every connected component of the candidate-pair graph -- a species -- is given to ONE rank (heaviest first to the least
 loaded rank, weight = the seeds its pairs read), and each genome's seeds travel ONCE, to the rank that owns its component, by one
 all_to_all_single per array.  A rank then holds, indexes and chains only its components' genomes: 1/world of the seeds instead of all
-of them, and no genome of another rank is needed while chaining."""
+of them, and no genome of another rank is needed while chaining.  A component heavier than a rank's fair share (one species holding most
+of the genomes) is not an atom: `component_plan` shares it among several ranks, its pairs dealt by probed genome, and every sharing rank
+receives the seeds of the genomes its pairs touch (round 6)."""
 from typing import Dict, List
 
 import numpy as np
